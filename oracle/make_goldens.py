@@ -1,0 +1,241 @@
+"""Golden-vector generator — runs ONLY in the build container.
+
+Imports the real reference (/root/reference/inference/model_utils.py and
+/root/reference/na_model_utils.py), loads the seeded synthetic weights of
+``na_mpnn_amd.synth`` into it, runs the hot path on seeded synthetic inputs and
+stores inputs-that-cannot-be-regenerated + expected outputs under
+``tests/golden/``.  While doing so it asserts that ``oracle/cpu_ref.py`` is
+bit-identical to the reference on every case (that is the pin of the oracle).
+
+The reference source never leaves /root/reference: only arrays are written.
+
+    python oracle/make_goldens.py            # rewrites tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/inference")
+sys.path.insert(0, "/root/reference")
+
+import model_utils as ref_inf          # noqa: E402  (reference, inference copy)
+import na_model_utils as ref_train     # noqa: E402  (reference, training copy)
+
+from na_mpnn_amd import spec, synth    # noqa: E402
+from oracle import cpu_ref             # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)
+
+
+def tw(weights):
+    return {k: torch.from_numpy(v) for k, v in weights.items()}
+
+
+def ref_model(weights, k):
+    m = ref_inf.ProteinMPNN(node_features=128, edge_features=128, hidden_dim=128,
+                            num_encoder_layers=3, num_decoder_layers=3, k_neighbors=k,
+                            model_type="na_mpnn", vocab=33, num_letters=33,
+                            atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                            polytype_to_int=spec.polytype_to_int())
+    m.load_state_dict(tw(weights))
+    return m.eval()
+
+
+def ref_train_model(weights, k):
+    m = ref_train.ProteinMPNN(atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                              polytype_to_int=spec.polytype_to_int(), k_neighbors=k, dropout=0.0,
+                              protein_augment_eps=0.0, dna_augment_eps=0.0, rna_augment_eps=0.0)
+    m.load_state_dict(tw(weights))
+    return m.eval()
+
+
+def same(a, b, what):
+    d = float((a.float() - b.float()).abs().max()) if a.numel() else 0.0
+    assert a.shape == b.shape and d == 0.0, f"oracle != reference on {what}: max|d|={d}"
+
+
+def batchify(cx):
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+    return fd
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# ------------------------------------------------------------------------------------
+def g1_gather():
+    rng = np.random.default_rng(101)
+    nodes = rng.standard_normal((2, 64, 16)).astype(np.float32)
+    nbrs = rng.standard_normal((2, 64, 8, 16)).astype(np.float32)
+    idx = rng.integers(0, 64, (2, 64, 8)).astype(np.int64)
+    edges = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+    t = torch.from_numpy
+    gn = ref_inf.gather_nodes(t(nodes), t(idx))
+    ge = ref_inf.gather_edges(t(edges), t(idx))
+    cat = ref_inf.cat_neighbors_nodes(t(nodes), t(nbrs), t(idx))
+    same(cpu_ref.gather_nodes(t(nodes), t(idx)), gn, "gather_nodes")
+    same(cpu_ref.gather_edges(t(edges), t(idx)), ge, "gather_edges")
+    same(cpu_ref.cat_neighbors_nodes(t(nodes), t(nbrs), t(idx)), cat, "cat_neighbors_nodes")
+    same(ref_train.cat_neighbors_nodes(t(nodes), t(nbrs), t(idx)), cat, "train-copy cat")
+    save("g1_gather", nodes=nodes, nbrs=nbrs, idx=idx.astype(np.int16), edges=edges,
+         gather_nodes=gn.numpy(), gather_edges=ge.numpy(), cat=cat.numpy())
+
+
+def g2_layers(weights):
+    """Single EncLayer / DecLayer with partial masks, N=128 K=48."""
+    g = synth.make_graph(seed=202, batch=1, n=128, k=48, masked_frac=0.1)
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    m = ref_model(weights, 48)
+    w = tw(weights)
+    E_idx = t["E_idx"].long()
+    mask = t["mask"]
+    m_att = ref_inf.gather_nodes(mask.unsqueeze(-1), E_idx).squeeze(-1) * mask.unsqueeze(-1)
+    hV, hE = m.encoder_layers[1](t["V"], t["E"], E_idx, mask, m_att)
+    hV2, hE2 = cpu_ref.enc_layer(w, "encoder_layers.1.", t["V"], t["E"], E_idx, mask, m_att)
+    same(hV2, hV, "enc_layer h_V"); same(hE2, hE, "enc_layer h_E")
+    # decoder layer on a synthetic 384-wide context
+    rng = np.random.default_rng(203)
+    ctx = rng.standard_normal((1, 128, 48, 384)).astype(np.float32)
+    dV = m.decoder_layers[2](t["V"], torch.from_numpy(ctx), mask)
+    same(cpu_ref.dec_layer(w, "decoder_layers.2.", t["V"], torch.from_numpy(ctx), mask), dV, "dec_layer")
+    save("g2_layers", in_digest=digest(g["V"], g["E"], g["E_idx"], g["mask"]),
+         enc_hV=hV[0].numpy(), enc_hE_rows=hE[0, ::16].numpy(), dec_hV=dV[0].numpy())
+
+
+def g3_encdec(weights, n, tag, masked_frac=0.0, batch=1):
+    """encode-from-graph + score (the BASELINE metric scope), K=48."""
+    g = synth.make_graph(seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=masked_frac)
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    m = ref_model(weights, 48)
+    w = tw(weights)
+    E_idx = t["E_idx"].long()
+    mask = t["mask"]
+    # reference encoder from given (V,E,E_idx): replay model_utils.py:88-94 with its own modules
+    h_V = m.W_v(t["V"]); h_E = m.W_e(t["E"])
+    m_att = ref_inf.gather_nodes(mask.unsqueeze(-1), E_idx).squeeze(-1) * mask.unsqueeze(-1)
+    per_layer = []
+    for layer in m.encoder_layers:
+        h_V, h_E = layer(h_V, h_E, E_idx, mask, m_att)
+        per_layer.append(h_V)
+    o_hV, o_hE = cpu_ref.encode_from_graph(w, t["V"], t["E"], E_idx, mask)
+    same(o_hV, h_V, f"{tag} encoder h_V"); same(o_hE, h_E, f"{tag} encoder h_E")
+    # reference decoder: replay model_utils.py:388-421 through a patched encode()
+    m.encode = lambda fd: (h_V, h_E, E_idx)
+    outs, ords = [], []
+    for b in range(batch):   # score() is defined for B=1 inputs (run.py:345)
+        m.encode = lambda fd, b=b: (h_V[b:b + 1], h_E[b:b + 1], E_idx[b:b + 1])
+        fd = {"batch_size": 1, "S": t["S"][b:b + 1], "mask": mask[b:b + 1],
+              "chain_mask": t["chain_mask"][b:b + 1], "randn": t["randn"][b:b + 1]}
+        o = m.score(fd)
+        o2 = cpu_ref.score_from_encoded(w, h_V[b:b + 1], h_E[b:b + 1], E_idx[b:b + 1], fd["S"], fd["mask"],
+                                        fd["chain_mask"], fd["randn"])
+        same(o2["log_probs"], o["log_probs"], f"{tag} log_probs")
+        assert torch.equal(o2["decoding_order"], o["decoding_order"])
+        outs.append(o["log_probs"][0]); ords.append(o["decoding_order"])
+    logp = torch.stack(outs); order = torch.stack(ords)
+    stride = max(1, n // 64)
+    save(f"g3_encdec_{tag}", in_digest=digest(g["V"], g["E"], g["E_idx"], g["S"], g["mask"], g["randn"]),
+         enc_hV_layers=torch.stack(per_layer)[:, :, ::stride].numpy(),
+         enc_hE_rows=h_E[:, ::max(1, n // 16)].numpy()[:, :16],
+         log_probs=logp.numpy(), decoding_order=order.numpy().astype(np.int32),
+         argmax=logp.argmax(-1).numpy().astype(np.int8), row_stride=np.int32(stride))
+
+
+def g4_from_X(weights, n, k, tag, **kw):
+    """Full forward from coordinates incl. featurisation; also unconditional_probs (G6)
+    and the training copy's forward (F9: == score bit-exactly)."""
+    cx = synth.make_complex(seed=400 + n, n=n, **kw)
+    fd = batchify(cx)
+    fd["batch_size"] = 1
+    m = ref_model(weights, k)
+    w = tw(weights)
+    V, E, E_idx = m.features(fd)
+    oV, oE, oI = cpu_ref.features(w, fd, k)
+    same(oV, V, f"{tag} V"); same(oE, E, f"{tag} E"); assert torch.equal(oI, E_idx)
+    sc = m.score(fd)
+    osc = cpu_ref.score(w, fd, k)
+    same(osc["log_probs"], sc["log_probs"], f"{tag} score")
+    up = m.unconditional_probs(fd)
+    same(cpu_ref.unconditional_probs(w, fd, k)["log_probs"], up["log_probs"], f"{tag} uncond")
+    # training copy: same weights, same decoding-order noise through the global RNG
+    mt = ref_train_model(weights, k)
+    fdt = dict(fd); fdt["S"] = fd["S"].long()
+    torch.manual_seed(1234)
+    randn_train = torch.randn(fd["mask"].shape)
+    torch.manual_seed(1234)
+    lp_t, p_t = mt(fdt)
+    o_lp, o_p = cpu_ref.forward_train(w, fdt, k, randn_train)
+    same(o_lp, lp_t, f"{tag} train forward"); same(o_p, p_t, f"{tag} train probs")
+    save(f"g4_fromX_{tag}", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]),
+         E_idx=E_idx[0].numpy().astype(np.int16), V=V[0].numpy(),
+         E_rows=E[0, ::max(1, n // 8)].numpy()[:8],
+         log_probs=sc["log_probs"][0].numpy(), decoding_order=sc["decoding_order"].numpy().astype(np.int32),
+         uncond_log_probs=up["log_probs"][0].numpy(),
+         train_randn=randn_train.numpy(), train_log_probs=lp_t[0].numpy())
+
+
+def g5_sample(weights, n=60, k=16, bs=3):
+    """sample(): oracle reproduces the reference draw-for-draw under the same torch seed;
+    stores S / log_probs so the build can check score(S) == sample().log_probs (model_utils.py:367)."""
+    cx = synth.make_complex(seed=500, n=n, n_chains=2)
+    cx["chain_mask"][:7] = 0                      # some fixed positions
+    fd = batchify(cx)
+    fd.update({"batch_size": bs, "temperature": 0.5, "bias": torch.zeros(1, n, 33),
+               "symmetry_residues": [[]], "symmetry_weights": [[]]})
+    rng = np.random.default_rng(501)
+    fd["randn"] = torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32))
+    m = ref_model(weights, k)
+    w = tw(weights)
+    torch.manual_seed(77)
+    o = m.sample(fd)
+    torch.manual_seed(77)
+    o2 = cpu_ref.sample(w, fd, k)
+    assert torch.equal(o["S"], o2["S"]) and torch.equal(o["decoding_order"], o2["decoding_order"])
+    same(o2["log_probs"], o["log_probs"], "sample log_probs")
+    same(o2["sampling_probs"], o["sampling_probs"], "sample probs")
+    o3 = cpu_ref.sample(w, fd, k, S_forced=o["S"])            # teacher forcing reproduces it
+    same(o3["log_probs"], o["log_probs"], "teacher-forced sample")
+    save("g5_sample", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), randn=fd["randn"].numpy(),
+         S=o["S"].numpy().astype(np.int8), log_probs=o["log_probs"].numpy(),
+         sampling_probs=o["sampling_probs"].numpy(), decoding_order=o["decoding_order"].numpy().astype(np.int32))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    weights = synth.make_weights(0)
+    print("G1 gather"); g1_gather()
+    print("G2 layers"); g2_layers(weights)
+    print("G3 enc+dec from graph")
+    g3_encdec(weights, 256, "n256", masked_frac=0.05)
+    g3_encdec(weights, 1000, "n1000")
+    g3_encdec(weights, 40, "n40_LltK")                 # L < K  -> K' = L (model_utils.py:496)
+    g3_encdec(weights, 200, "b3_n200", masked_frac=0.1, batch=3)
+    print("G4 from coordinates (+G6 unconditional, +training-copy forward)")
+    g4_from_X(weights, 97, 32, "n97_k32", missing_atom_frac=0.05, masked_frac=0.04)
+    g4_from_X(weights, 150, 48, "n150_k48")
+    g4_from_X(weights, 32, 48, "n32_k48_LltK")
+    print("G5 sample"); g5_sample(weights)
+    print("all reference == oracle checks passed")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""The CPU oracle (oracle/cpu_ref.py) against the committed golden vectors.
+
+The goldens were produced by the real reference in the build container
+(oracle/make_goldens.py).  Bit-exact equality is required: the oracle performs
+the same ATen op sequence as the reference on CPU.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from na_mpnn_amd import synth
+from oracle import cpu_ref
+
+torch.set_grad_enabled(False)
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)
+
+
+def tw(weights):
+    return {k: torch.from_numpy(v) for k, v in weights.items()}
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def exact(a, b):
+    a = a.numpy() if isinstance(a, torch.Tensor) else a
+    assert a.shape == b.shape
+    assert np.array_equal(a, b), f"max|d|={np.abs(a.astype(np.float64) - b).max()}"
+
+
+def test_g1_gather(golden_dir):
+    g = load(golden_dir, "g1_gather")
+    t = torch.from_numpy
+    idx = t(g["idx"].astype(np.int64))
+    exact(cpu_ref.gather_nodes(t(g["nodes"]), idx), g["gather_nodes"])
+    exact(cpu_ref.gather_edges(t(g["edges"]), idx), g["gather_edges"])
+    exact(cpu_ref.cat_neighbors_nodes(t(g["nodes"]), t(g["nbrs"]), idx), g["cat"])
+
+
+def test_g2_layers(golden_dir, weights_np):
+    g = load(golden_dir, "g2_layers")
+    x = synth.make_graph(seed=202, batch=1, n=128, k=48, masked_frac=0.1)
+    assert np.array_equal(digest(x["V"], x["E"], x["E_idx"], x["mask"]), g["in_digest"]), \
+        "synthetic input generator drifted from the one the goldens were made with"
+    t = {k: torch.from_numpy(v) for k, v in x.items()}
+    w = tw(weights_np)
+    E_idx, mask = t["E_idx"].long(), t["mask"]
+    m_att = cpu_ref.gather_nodes(mask.unsqueeze(-1), E_idx).squeeze(-1) * mask.unsqueeze(-1)
+    hV, hE = cpu_ref.enc_layer(w, "encoder_layers.1.", t["V"], t["E"], E_idx, mask, m_att)
+    exact(hV[0], g["enc_hV"])
+    exact(hE[0, ::16], g["enc_hE_rows"])
+    ctx = np.random.default_rng(203).standard_normal((1, 128, 48, 384)).astype(np.float32)
+    exact(cpu_ref.dec_layer(w, "decoder_layers.2.", t["V"], torch.from_numpy(ctx), mask)[0], g["dec_hV"])
+
+
+@pytest.mark.parametrize("n,tag,mf,batch", [(256, "n256", 0.05, 1), (40, "n40_LltK", 0.0, 1),
+                                             (200, "b3_n200", 0.1, 3), (1000, "n1000", 0.0, 1)])
+def test_g3_encdec(golden_dir, weights_np, n, tag, mf, batch):
+    g = load(golden_dir, f"g3_encdec_{tag}")
+    x = synth.make_graph(seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=mf)
+    assert np.array_equal(digest(x["V"], x["E"], x["E_idx"], x["S"], x["mask"], x["randn"]), g["in_digest"])
+    t = {k: torch.from_numpy(v) for k, v in x.items()}
+    w = tw(weights_np)
+    E_idx = t["E_idx"].long()
+    h_V, h_E = cpu_ref.encode_from_graph(w, t["V"], t["E"], E_idx, t["mask"])
+    stride = int(g["row_stride"])
+    exact(h_V[:, ::stride], g["enc_hV_layers"][-1])
+    exact(h_E[:, ::max(1, n // 16)][:, :16], g["enc_hE_rows"])
+    for b in range(batch):
+        o = cpu_ref.score_from_encoded(w, h_V[b:b + 1], h_E[b:b + 1], E_idx[b:b + 1], t["S"][b:b + 1],
+                                       t["mask"][b:b + 1], t["chain_mask"][b:b + 1], t["randn"][b:b + 1])
+        exact(o["log_probs"][0], g["log_probs"][b])
+        assert np.array_equal(o["decoding_order"].numpy(), g["decoding_order"][b])
+        assert np.array_equal(o["log_probs"][0].argmax(-1).numpy(), g["argmax"][b])
+
+
+@pytest.mark.parametrize("n,k,tag,kw", [(97, 32, "n97_k32", dict(missing_atom_frac=0.05, masked_frac=0.04)),
+                                         (150, 48, "n150_k48", {}), (32, 48, "n32_k48_LltK", {})])
+def test_g4_from_coordinates(golden_dir, weights_np, n, k, tag, kw):
+    g = load(golden_dir, f"g4_fromX_{tag}")
+    cx = synth.make_complex(seed=400 + n, n=n, **kw)
+    assert np.array_equal(digest(*[cx[k_] for k_ in sorted(cx)]), g["in_digest"])
+    fd = {k_: torch.from_numpy(np.ascontiguousarray(v))[None] for k_, v in cx.items()}
+    fd["batch_size"] = 1
+    w = tw(weights_np)
+    V, E, E_idx = cpu_ref.features(w, fd, k)
+    assert np.array_equal(E_idx[0].numpy(), g["E_idx"].astype(np.int64))
+    exact(V[0], g["V"])
+    exact(E[0, ::max(1, n // 8)][:8], g["E_rows"])
+    sc = cpu_ref.score(w, fd, k)
+    exact(sc["log_probs"][0], g["log_probs"])
+    assert np.array_equal(sc["decoding_order"].numpy(), g["decoding_order"])
+    exact(cpu_ref.unconditional_probs(w, fd, k)["log_probs"][0], g["uncond_log_probs"])
+    fdt = dict(fd); fdt["S"] = fd["S"].long()
+    lp, _ = cpu_ref.forward_train(w, fdt, k, torch.from_numpy(g["train_randn"]))
+    exact(lp[0], g["train_log_probs"])
+
+
+def test_g5_sample_teacher_forced(golden_dir, weights_np):
+    """model_utils.py:367: score(S_sampled).log_probs == sample().log_probs on designed positions."""
+    g = load(golden_dir, "g5_sample")
+    n, k, bs = 60, 16, 3
+    cx = synth.make_complex(seed=500, n=n, n_chains=2)
+    cx["chain_mask"][:7] = 0
+    assert np.array_equal(digest(*[cx[k_] for k_ in sorted(cx)]), g["in_digest"])
+    fd = {k_: torch.from_numpy(np.ascontiguousarray(v))[None] for k_, v in cx.items()}
+    fd.update({"batch_size": bs, "temperature": 0.5, "bias": torch.zeros(1, n, 33),
+               "symmetry_residues": [[]], "symmetry_weights": [[]], "randn": torch.from_numpy(g["randn"])})
+    w = tw(weights_np)
+    S = torch.from_numpy(g["S"].astype(np.int64))
+    o = cpu_ref.sample(w, fd, k, S_forced=S)
+    exact(o["log_probs"], g["log_probs"])
+    exact(o["sampling_probs"], g["sampling_probs"])
+    assert np.array_equal(o["decoding_order"].numpy(), g["decoding_order"])
+    # the reference's own stated invariant, per sample row
+    cm = (fd["mask"] * fd["chain_mask"])[0].bool()
+    for b in range(bs):
+        fdb = dict(fd); fdb["batch_size"] = 1; fdb["S"] = S[b:b + 1]; fdb["randn"] = fd["randn"][b:b + 1]
+        sc = cpu_ref.score(w, fdb, k)
+        d = (sc["log_probs"][0][cm] - torch.from_numpy(g["log_probs"][b])[cm]).abs().max()
+        assert d < 2e-5, float(d)
+
+
+def test_rank_compare_equals_reference_einsum():
+    rng = np.random.default_rng(7)
+    L, K = 37, 9
+    order = torch.from_numpy(np.stack([rng.permutation(L) for _ in range(2)]))
+    E_idx = torch.from_numpy(rng.integers(0, L, (2, L, K)))
+    assert torch.equal(cpu_ref.backward_mask(order, E_idx), cpu_ref.backward_mask_einsum(order, E_idx))
