@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — residues/s of the NA-MPNN encoder+decoder forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path — (V, E, E_idx, S, mask, decoding ranks) -> log_probs, i.e.
+W_v/W_e + 3 x EncLayer + decoder context + 3 x DecLayer + W_out + log_softmax — over
+one batch of synthetic graphs already resident in HBM.  Default workload = BASELINE.json configs[1]
+("cfg2": B=1, N=1000, K=48, H=128, 3+3 layers, fp32).  Every rank runs its own independent
+complexes (weak scaling, no data-path collective); one RCCL all-gather of the arg-max sequences at
+the end collates results for reporting, outside the timed region.
+
+Rank 0 prints ONE JSON line with the driver's contract keys plus
+  roofline      – dominant kernel, algorithmic FLOPs / HIP-event-measured duration vs fp32-MFMA peak
+  gather        – the standalone neighbour-gather (cat_neighbors_nodes) HBM figure, cfg3-shaped
+  cpu_baseline  – the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from na_mpnn_amd import hip, spec, synth          # noqa: E402
+from na_mpnn_amd.pack import PackedWeights        # noqa: E402
+
+WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48)}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
+# algorithmic FLOP / residue of the dense reference formulation, K=48, H=128
+ALGO_FLOP = {"enc_message": 7_864_320, "enc_edge_update": 7_864_320, "dec_message": 9_437_184}
+ALGO_FLOP_TOTAL = 78_684_416
+# executed FLOP / residue of the hoisted formulation (three 128x128 GEMMs per edge)
+EXEC_FLOP_EDGE = 48 * 3 * 2 * 128 * 128
+
+
+class Runner:
+    """Owns the device tensors of one rank's batch and enqueues one step."""
+
+    def __init__(self, dev, B, N, K, seed):
+        self.L = hip.lib()
+        self.dev, self.B, self.N, self.K = dev, B, N, K
+        w = synth.make_weights(0)
+        self.w_np = w
+        self.packed = PackedWeights({k: torch.from_numpy(v).to(dev) for k, v in w.items()}, 3, 3, spec.VOCAB, dev)
+        # graphs are generated one at a time to bound host memory at B=64
+        parts = [synth.make_graph(seed=seed + b, batch=1, n=N, k=K) for b in range(B)]
+        self.g_np = {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+        d = {k: torch.from_numpy(v).to(dev) for k, v in self.g_np.items()}
+        self.d = d
+        order = torch.argsort((d["mask"] * d["chain_mask"] + 0.0001) * torch.abs(d["randn"]))
+        rank = torch.empty_like(order)
+        rank.scatter_(1, order, torch.arange(N, device=dev).expand(B, -1))
+        self.rank = rank.to(torch.int32).contiguous()
+        self.hV = torch.empty(B, N, 128, device=dev)
+        self.hE = torch.empty(B, N, K, 128, device=dev)
+        self.logp = torch.empty(B, N, spec.VOCAB, device=dev)
+        self.ws = torch.empty(self.L.namp_workspace_bytes(B, B, N, K), dtype=torch.uint8, device=dev)
+
+    def step(self):
+        d, L, s = self.d, self.L, hip.current_stream()
+        B, N, K = self.B, self.N, self.K
+        hip.check(L.namp_encoder_fwd(self.packed.model(), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
+                                     d["mask"].data_ptr(), self.hV.data_ptr(), self.hE.data_ptr(),
+                                     self.ws.data_ptr(), self.ws.numel(), B, N, K, s), "encoder_fwd")
+        hip.check(L.namp_decoder_fwd(self.packed.model(), self.hV.data_ptr(), self.hE.data_ptr(), d["E_idx"].data_ptr(),
+                                     d["S"].data_ptr(), d["mask"].data_ptr(), self.rank.data_ptr(),
+                                     self.logp.data_ptr(), None, None, self.ws.data_ptr(), self.ws.numel(),
+                                     B, B, N, K, s), "decoder_fwd")
+
+
+def gather_microbench(dev, reps=10):
+    """cat_neighbors_nodes at the cfg3 shape (B=64,N=1000,K=48,C=128|128): 1,540 B/edge algorithmic."""
+    L = hip.lib()
+    B, N, K = 64, 1000, 48
+    hE = torch.randn(B, N, K, 128, device=dev)
+    hV = torch.randn(B, N, 128, device=dev)
+    idx = torch.randint(0, N, (B, N, K), device=dev, dtype=torch.int32)
+    out = torch.empty(B, N, K, 256, device=dev)
+    s = hip.current_stream()
+    run = lambda: hip.check(L.namp_cat_neighbors_nodes_f32(hV.data_ptr(), hE.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                                           B, N, K, 128, 128, s))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = B * N * K * 1540 + B * N * 128 * 4
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    del hE, hV, idx, out
+    torch.cuda.empty_cache()
+    return {"kernel": "gather_cat_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4),
+            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": None}
+
+
+def cpu_baseline(runner, budget_s=25.0):
+    """The oracle on this box's host cores, same cfg2 inputs (bounded sample)."""
+    from oracle import cpu_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    w = {k: torch.from_numpy(v) for k, v in runner.w_np.items()}
+    g = {k: torch.from_numpy(v[:1]) for k, v in runner.g_np.items()}
+    E_idx = g["E_idx"].long()
+    f = lambda: cpu_ref.encdec_from_graph(w, g["V"], g["E"], E_idx, g["S"], g["mask"], g["chain_mask"], g["randn"])
+    with torch.no_grad():
+        out = f()                                           # warm-up
+        times, t_start = [], time.perf_counter()
+        while len(times) < 5 and time.perf_counter() - t_start < budget_s:
+            t0 = time.perf_counter(); out = f(); times.append(time.perf_counter() - t0)
+    n = g["V"].shape[1]
+    return out, {"value": round(n / min(times), 1), "unit": "residues/s", "cores": torch.get_num_threads(),
+                 "kind": "port", "sample": f"oracle/cpu_ref.py enc+dec forward, B=1 N={n} K={E_idx.shape[-1]} fp32, "
+                                           f"best of {len(times)} after 1 warm-up, eager PyTorch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+    torch.set_grad_enabled(False)
+
+    cfg = WORKLOADS[args.workload]
+    B, N, K = cfg["B"], cfg["N"], cfg["K"]
+    cfg_idx = 1 if args.workload == "cfg2" else 2
+    runner = Runner(dev, B, N, K, seed=1 + cfg_idx + 1000 * rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_gpus * B * N * args.steps / elapsed
+
+    # reporting-only collective: all-gather of the arg-max sequences (north_star: "RCCL all-gather ... only
+    # for throughput reporting"); outside the timed region.
+    seq = runner.logp.argmax(-1).to(torch.int8)
+    if dist is not None:
+        allseq = [torch.empty_like(seq) for _ in range(world)]
+        dist.all_gather(allseq, seq)
+        n_collated = sum(int(x.numel()) for x in allseq)
+    else:
+        n_collated = int(seq.numel())
+
+    # per-kernel durations: same steps again with the library's HIP-event hook on the launch stream
+    runner.L.namp_profile_enable(1)
+    for _ in range(args.steps):
+        runner.step()
+    prof = hip.profile_collect()
+    runner.L.namp_profile_enable(0)
+    per_kernel = {k: {"launches_per_step": c // args.steps, "avg_ms": round(ms / max(c, 1), 5),
+                      "ms_per_step": round(ms / args.steps, 5)} for k, (ms, c) in prof.items() if c}
+    dom = max((k for k in per_kernel if k in ALGO_FLOP), key=lambda k: per_kernel[k]["ms_per_step"])
+    avg_s = per_kernel[dom]["avg_ms"] * 1e-3
+    algo = ALGO_FLOP[dom] * B * N
+    roofline = {"kernel": f"edge_mlp_kernel<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": EXEC_FLOP_EDGE * B * N,
+                "executed_frac": round(EXEC_FLOP_EDGE * B * N / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+
+    out = {"metric": "residues/sec (enc+dec fwd), N~1000 K=48 h=128", "value": round(value, 1), "unit": "residues/s",
+           "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: B={B} x N={N} residues, K={K}, H=128, 3 enc + 3 dec layers, "
+                                  "fp32 MFMA, seeded random-init weights, per-rank independent complexes",
+                      "global_batch": B * n_gpus, "seq_len": N, "parallelism": f"replicas x{n_gpus}"},
+           "roofline": roofline, "per_kernel": per_kernel,
+           "whole_path": {"algorithmic_tflops": round(ALGO_FLOP_TOTAL * B * N / (ms_per_step * 1e-3) / 1e12, 3),
+                          "collated_residues": n_collated}}
+
+    if rank == 0:
+        if not args.no_gather and n_gpus == 1:
+            out["gather"] = gather_microbench(dev)
+        if not args.no_cpu_baseline and n_gpus == 1:
+            ref_out, cb = cpu_baseline(runner)
+            out["cpu_baseline"] = cb
+            lp = runner.logp[:1].cpu()
+            d = float((lp - ref_out["log_probs"]).abs().max())
+            out["parity"] = {"max_abs_dlogp_vs_cpu": round(d, 7),
+                             "argmax_equal": bool(torch.equal(lp.argmax(-1), ref_out["log_probs"].argmax(-1)))}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * namp.h — C ABI of libnamp_hip.so: the MI355X (gfx950) implementation of the NA-MPNN
+ * message-passing encoder/decoder hot path.
+ *
+ * The reference (baker-laboratory/NA-MPNN) has no FFI of its own: the path lives in Python
+ * (inference/model_utils.py, na_model_utils.py) and runs on stock ATen kernels.  This header
+ * is therefore the boundary a maintainer would bind with ctypes; every
+ * entry point cites the reference function it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / HIP types.  `stream` is a hipStream_t passed as void*.
+ *   - every pointer is a DEVICE pointer owned by the caller, 16-byte aligned, dense row-major.
+ *   - hidden width is fixed at H = 128 (the only width the reference instantiates).
+ *   - index tensors are int32 (the wrapper converts the reference's int64 once per forward).
+ *   - calls are asynchronous on `stream`, re-entrant across streams, hold no device memory.
+ *   - return 0 on success, negative NAMP_E* on error; text via namp_last_error() (thread local).
+ *   - a "weight image" is the 64 KiB MFMA-fragment permutation of a [128 x 128] block of an
+ *     nn.Linear weight ([out,in] row-major) produced by namp_pack_image().
+ */
+#ifndef NAMP_H_
+#define NAMP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAMP_ABI_VERSION 1
+#define NAMP_HIDDEN 128
+#define NAMP_MAX_LAYERS 8
+#define NAMP_MAX_K 192
+
+#define NAMP_OK 0
+#define NAMP_EINVAL (-1)   /* bad argument (null / misaligned pointer, unsupported size) */
+#define NAMP_ELAUNCH (-2)  /* HIP launch or runtime failure */
+#define NAMP_EWORKSPACE (-3)
+
+int namp_abi_version(void);
+const char* namp_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------- */
+
+/* Permute the block W[0:out_f, col0:col0+in_f] of an nn.Linear weight (leading dimension ld)
+ * into fragment-image order.  out_f, in_f multiples of 16.  img: out_f*in_f floats. */
+int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float* img, void* stream);
+
+/* EncLayer parameters (inference/model_utils.py:659-679).  W1/W11 are split by input block:
+ * a = h_V_i columns [0,128), b = h_E_ik [128,256), c = h_V_j [256,384). */
+typedef struct NampEncLayerW {
+  const float *W1a_img, *W1b_img, *W1c_img, *b1;
+  const float *W2_img, *b2, *W3_img, *b3;
+  const float *W11a_img, *W11b_img, *W11c_img, *b11;
+  const float *W12_img, *b12, *W13_img, *b13;
+  const float *Win_img, *b_in, *Wout_img, *b_out;   /* dense.W_in [512x128], dense.W_out [128x512] */
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+} NampEncLayerW;
+
+/* DecLayer parameters (inference/model_utils.py:619-634).  W1 [128x512] split by input block:
+ * a = h_V_i [0,128), e = h_E_ik [128,256), s = h_S_j [256,384), v = h_V_j [384,512).
+ * tok = W_s.weight . W1s^T  ([vocab x 128]), the per-token image of the sequence embedding. */
+typedef struct NampDecLayerW {
+  const float *W1a_img, *W1e_img, *W1s_img, *W1v_img, *b1, *tok;
+  const float *W2_img, *b2, *W3_img, *b3;
+  const float *Win_img, *b_in, *Wout_img, *b_out;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} NampDecLayerW;
+
+typedef struct NampModelW {
+  int32_t n_enc, n_dec, vocab, reserved;
+  const float *Wv_img, *Wv_b;      /* W_v (model_utils.py:35,88) */
+  const float *We_img, *We_b;      /* W_e (model_utils.py:48,89) */
+  const float *Wout_w, *Wout_b;    /* W_out [vocab x 128] plain layout (model_utils.py:65) */
+  NampEncLayerW enc[NAMP_MAX_LAYERS];
+  NampDecLayerW dec[NAMP_MAX_LAYERS];
+} NampModelW;
+
+/* ---- a1/a3: neighbour gather ----------------------------------------------------------- */
+
+/* gather_nodes (model_utils.py:713-721): out[b,i,k,:] = nodes[b, idx[b,i,k], :]   (C floats) */
+int namp_gather_nodes_f32(const float* nodes, const int32_t* idx, float* out,
+                          int B, int N, int K, int C, void* stream);
+/* cat_neighbors_nodes (model_utils.py:729-732): out = [h_neighbors (C1) | h_nodes[idx] (C2)] */
+int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors, const int32_t* idx,
+                                 float* out, int B, int N, int K, int C1, int C2, void* stream);
+
+/* ---- building blocks (also what bench.py times per kernel) ----------------------------- */
+
+/* out_p = X . W_p^T + bias_p (+ tok_p[S]) for nproj <= 8 blocks; X has G_src = B_src*N rows and
+ * is broadcast over output batches (row n reads batch (n / N) % B_src). */
+typedef struct NampProj { const float* img; const float* bias; const float* tok; float* out; } NampProj;
+int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int N,
+                     const NampProj* proj, int nproj, void* stream);
+
+/* h_E = W_e . E + b_e (model_utils.py:89) */
+int namp_edge_embed(const float* We_img, const float* We_b, const float* E, float* h_E,
+                    int B, int N, int K, void* stream);
+
+/* Message phase of EncLayer (model_utils.py:684-690): partial[n][t][:] = sum over the t-th
+ * 16-neighbour tile of mask_i*mask_j/30 * W3.gelu(W2.gelu(W1.[h_V_i|h_E_ik|h_V_j])).
+ * Pa = W1a.h_V + b1 and Pc = W1c.h_V come from namp_node_linear.  partial: [B*N][ceil(K/16)][128].
+ * mask_attend may be NULL (then mask_i*mask_j, as every reference call site passes). */
+int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
+                     const int32_t* mask_attend, const float* Pa, const float* Pc, float* partial,
+                     int B, int N, int K, void* stream);
+/* Edge update of EncLayer (model_utils.py:699-703): h_E' = LN3(h_E + MLP'([h_V'_i|h_E|h_V'_j])).
+ * h_E_out may alias h_E. */
+int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx,
+                         const float* Pa, const float* Pc, float* h_E_out, int B, int N, int K, void* stream);
+/* Residue tail shared by EncLayer / DecLayer (model_utils.py:690-697, 646-656):
+ * h_V' = mask * LN2(x + FFN(x)),  x = LN1(h_V + sum_t partial[n][t]). */
+int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+                     const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
+                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
+                     int G, int K, void* stream);
+/* Message phase of DecLayer on the implicit context h_ESV (model_utils.py:416-418, 640-646):
+ * first layer = W1e.h_E_ik + Pa[i] + (rank[j]<rank[i] ? Pbw[j] : Pfw[j]).  Decoder batch b uses
+ * encoder batch b % B_enc (the reference's .repeat(B_decoder, ...), model_utils.py:399-404). */
+int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
+                     const float* Pa, const float* Pbw, const float* Pfw, float* partial,
+                     int B_dec, int B_enc, int N, int K, void* stream);
+/* log_softmax(W_out . h_V + b) (model_utils.py:420-421); logits may be NULL. */
+int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const float* h_V,
+                            float* log_probs, float* logits, int G, int vocab, void* stream);
+
+/* ---- a4 / a7 / a8 / a10: layer- and model-level operators -------------------------------- */
+
+size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K);
+
+/* EncLayer.forward (model_utils.py:681-704) with dropout inactive.  h_V_out / h_E_out may alias
+ * the inputs.  mask_attend NULL -> mask_i*mask_j. */
+int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_E, const int32_t* E_idx,
+                       const int32_t* mask, const int32_t* mask_attend, float* h_V_out, float* h_E_out,
+                       void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
+
+/* ProteinMPNN.encode after featurisation (model_utils.py:88-94): (V, E, E_idx, mask) -> h_V, h_E. */
+int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
+                     const int32_t* mask, float* h_V, float* h_E,
+                     void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
+
+/* Parallel decoder of score() / training forward() (model_utils.py:406-421 ==
+ * na_model_utils.py:610-642): encoder outputs + S + decoding ranks -> log_probs [B_dec,N,vocab].
+ * rank[b][i] = position of residue i in decoding order of decoder batch b; rank all-zero gives
+ * unconditional_probs (model_utils.py:343-361: nothing is "backward").
+ * S / mask / rank: [B_dec, N] int32.  logits may be NULL.  h_V_dec (optional, [B_dec*N,128])
+ * receives the last decoder layer's h_V. */
+int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                     const int32_t* S, const int32_t* mask, const int32_t* rank,
+                     float* log_probs, float* logits, float* h_V_dec,
+                     void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
+
+/* ---- measurement hook (bench.py) ------------------------------------------------------------
+ * When enabled (thread-local), every kernel launch made through this ABI is bracketed by HIP
+ * events on the launch stream; namp_profile_collect() waits for them and returns the summed
+ * milliseconds and launch counts per kernel kind, then clears the records.  Off by default. */
+#define NAMP_KIND_GATHER 0
+#define NAMP_KIND_NODE_LINEAR 1
+#define NAMP_KIND_EDGE_EMBED 2
+#define NAMP_KIND_ENC_MESSAGE 3
+#define NAMP_KIND_ENC_EDGE 4
+#define NAMP_KIND_NODE_UPDATE 5
+#define NAMP_KIND_DEC_MESSAGE 6
+#define NAMP_KIND_LOGITS 7
+#define NAMP_NUM_KINDS 8
+int namp_profile_enable(int on);
+int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nkinds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAMP_H_ */

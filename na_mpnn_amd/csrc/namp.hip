@@ -1,0 +1,498 @@
+// libnamp_hip.so — C ABI (include/namp.h) over the gfx950 kernels in namp_kernels.h.
+// Host code here only validates arguments, carves the caller's workspace and enqueues
+// launches on the caller's stream; it owns no device memory and never synchronises.
+#include "../../include/namp.h"
+#include "namp_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- optional per-kernel timing (bench.py): thread-local, off by default --------------------
+struct ProfRec { int kind; hipEvent_t a, b; };
+thread_local bool g_prof_on = false;
+thread_local std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+  hipStream_t s; ProfRec r; bool on;
+  ProfScope(int kind, hipStream_t st) : s(st), on(g_prof_on) {
+    if (!on) return;
+    r.kind = kind;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    g_prof.push_back(r);
+  }
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define REQUIRE_PTR(p)                                                                         \
+  do {                                                                                         \
+    if ((p) == nullptr) return fail(NAMP_EINVAL, "%s: null pointer argument '%s'", __func__, #p); \
+    if (!aligned16(p)) return fail(NAMP_EINVAL, "%s: '%s' is not 16-byte aligned", __func__, #p); \
+  } while (0)
+#define OPTIONAL_PTR(p)                                                                        \
+  do {                                                                                         \
+    if ((p) != nullptr && !aligned16(p))                                                       \
+      return fail(NAMP_EINVAL, "%s: '%s' is not 16-byte aligned", __func__, #p);               \
+  } while (0)
+#define REQUIRE(cond, ...)                                   \
+  do {                                                       \
+    if (!(cond)) return fail(NAMP_EINVAL, __VA_ARGS__);      \
+  } while (0)
+#define CHECK_LAUNCH()                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = hipGetLastError();                                                          \
+    if (e_ != hipSuccess) return fail(NAMP_ELAUNCH, "%s: %s", __func__, hipGetErrorString(e_)); \
+  } while (0)
+
+int check_dims(const char* fn, long B, long N, long K) {
+  if (B < 1 || N < 1 || K < 1) return fail(NAMP_EINVAL, "%s: B, N, K must be >= 1 (got %ld, %ld, %ld)", fn, B, N, K);
+  if (K > NAMP_MAX_K) return fail(NAMP_EINVAL, "%s: K=%ld exceeds NAMP_MAX_K=%d", fn, K, NAMP_MAX_K);
+  if (B * N * K > (1L << 31) / NAMP_HIDDEN * 4) return fail(NAMP_EINVAL, "%s: B*N*K=%ld too large", fn, B * N * K);
+  return NAMP_OK;
+}
+
+std::once_flag g_attr_once;
+hipError_t g_attr_err = hipSuccess;
+
+void set_lds_attributes() {
+  auto set = [](const void* f, int bytes) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) g_attr_err = e;
+  };
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_EMBED>, NAMP_IMG_BYTES);
+  set((const void*)node_ffn_kernel, (16 + 8 * 16) * FFN_LD * 4);
+}
+
+int ensure_attributes() {
+  std::call_once(g_attr_once, set_lds_attributes);
+  if (g_attr_err != hipSuccess)
+    return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
+  return NAMP_OK;
+}
+
+struct EdgeGeom { int tpn, nwaves, npw, grid; };
+EdgeGeom edge_geom(int G, int K) {
+  EdgeGeom e;
+  e.tpn = (K + 15) / 16;
+  e.nwaves = e.tpn * (12 / e.tpn > 0 ? 12 / e.tpn : 1);
+  e.npw = e.nwaves / e.tpn;
+  e.grid = (G + e.npw - 1) / e.npw;
+  return e;
+}
+
+template <int MODE>
+int launch_edge(EdgeArgs a, hipStream_t s) {
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  a.TPN = e.tpn;
+  const int lds = (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
+  hipLaunchKernelGGL(edge_mlp_kernel<MODE>, dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  return NAMP_OK;
+}
+
+int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
+                       const NampProj* proj, int nproj, hipStream_t s) {
+  NodeLinearArgs a;
+  a.X = X; a.S = S; a.G_out = G_out; a.G_src = G_src; a.N = N; a.nproj = nproj;
+  for (int i = 0; i < 8; ++i) {
+    const NampProj& p = proj[i < nproj ? i : 0];
+    a.p[i].img = p.img; a.p[i].bias = p.bias; a.p[i].tok = p.tok; a.p[i].out = p.out;
+  }
+  const int units = ((G_out + 15) / 16) * nproj;
+  hipLaunchKernelGGL(node_linear_kernel, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  return NAMP_OK;
+}
+
+int launch_node_ffn(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+                    const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
+                    const float* hV, const float* partial, const int32_t* mask, float* hV_out,
+                    int G, int TPN, hipStream_t s) {
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  NodeFfnArgs a;
+  a.hV = hV; a.partial = partial; a.mask = mask; a.ln1_g = ln1_g; a.ln1_b = ln1_b;
+  a.Win_img = Win_img; a.b_in = b_in; a.Wout_img = Wout_img; a.b_out = b_out;
+  a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.hV_out = hV_out; a.G = G; a.TPN = TPN;
+  hipLaunchKernelGGL(node_ffn_kernel, dim3((G + 15) / 16), dim3(512), (16 + 8 * 16) * FFN_LD * 4, s, a);
+  return NAMP_OK;
+}
+
+int launch_gather(const float* nodes, const float* nbrs, const int32_t* idx, float* out,
+                  long B, int N, int K, int C1, int C2, hipStream_t s) {
+  const long rows = B * N * K;
+  if (((C1 | C2) & 3) == 0) {
+    const long total = rows * ((C1 + C2) >> 2);
+    long blocks = (total + 256L * 4 - 1) / (256L * 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gather_cat_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
+                       N * K, N, C1, C2);
+  } else {
+    const long total = rows * (C1 + C2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gather_cat_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
+                       N * K, N, C1, C2);
+  }
+  return NAMP_OK;
+}
+
+// bump allocator over the caller's workspace
+struct Carver {
+  char* base; size_t size, off;
+  Carver(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  float* take(size_t floats) {
+    size_t bytes = (floats * 4 + 255) & ~size_t(255);
+    if (off + bytes > size) return nullptr;
+    float* r = (float*)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+size_t tbl(size_t G) { return ((G * NAMP_HIDDEN * 4 + 255) & ~size_t(255)); }
+
+}  // namespace
+
+extern "C" {
+
+int namp_abi_version(void) { return NAMP_ABI_VERSION; }
+const char* namp_last_error(void) { return g_err; }
+
+int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float* img, void* stream) {
+  if (!W || !img) return fail(NAMP_EINVAL, "namp_pack_image: null pointer");
+  REQUIRE(out_f > 0 && in_f > 0 && (out_f % 16) == 0 && (in_f % 16) == 0 && col0 >= 0 && ld >= col0 + in_f,
+          "namp_pack_image: out_f=%d in_f=%d must be multiples of 16 inside ld=%d (col0=%d)", out_f, in_f, ld, col0);
+  const int total = out_f * in_f;
+  hipLaunchKernelGGL(pack_image_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, col0,
+                     out_f, in_f, img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_gather_nodes_f32(const float* nodes, const int32_t* idx, float* out, int B, int N, int K, int C,
+                          void* stream) {
+  if (!nodes || !idx || !out) return fail(NAMP_EINVAL, "namp_gather_nodes_f32: null pointer");
+  REQUIRE(B >= 0 && N >= 0 && K >= 0 && C >= 1, "namp_gather_nodes_f32: bad dims B=%d N=%d K=%d C=%d", B, N, K, C);
+  if ((long)B * N * K == 0) return NAMP_OK;               // empty input: nothing to do
+  if ((C & 3) == 0) { REQUIRE_PTR(nodes); REQUIRE_PTR(out); }
+  ProfScope prof_(NAMP_KIND_GATHER, (hipStream_t)stream);
+  launch_gather(nodes, nullptr, idx, out, B, N, K, 0, C, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors, const int32_t* idx, float* out,
+                                 int B, int N, int K, int C1, int C2, void* stream) {
+  if (!h_nodes || !h_neighbors || !idx || !out) return fail(NAMP_EINVAL, "namp_cat_neighbors_nodes_f32: null pointer");
+  REQUIRE(B >= 0 && N >= 0 && K >= 0 && C1 >= 1 && C2 >= 1, "namp_cat_neighbors_nodes_f32: bad dims");
+  if ((long)B * N * K == 0) return NAMP_OK;
+  if (((C1 | C2) & 3) == 0) { REQUIRE_PTR(h_nodes); REQUIRE_PTR(h_neighbors); REQUIRE_PTR(out); }
+  ProfScope prof_(NAMP_KIND_GATHER, (hipStream_t)stream);
+  launch_gather(h_nodes, h_neighbors, idx, out, B, N, K, C1, C2, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int N, const NampProj* proj,
+                     int nproj, void* stream) {
+  REQUIRE_PTR(X);
+  REQUIRE(proj != nullptr && nproj >= 1 && nproj <= 8, "namp_node_linear: nproj=%d must be in [1,8]", nproj);
+  REQUIRE(B_out >= 1 && B_src >= 1 && N >= 1, "namp_node_linear: bad dims");
+  for (int i = 0; i < nproj; ++i) {
+    REQUIRE_PTR(proj[i].img); REQUIRE_PTR(proj[i].out); OPTIONAL_PTR(proj[i].bias); OPTIONAL_PTR(proj[i].tok);
+    REQUIRE(!(proj[i].tok && !S), "namp_node_linear: proj[%d].tok given but S is null", i);
+  }
+  ProfScope prof_(NAMP_KIND_NODE_LINEAR, (hipStream_t)stream);
+  launch_node_linear(X, S, B_out * N, B_src * N, N, proj, nproj, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_edge_embed(const float* We_img, const float* We_b, const float* E, float* h_E, int B, int N, int K,
+                    void* stream) {
+  REQUIRE_PTR(We_img); REQUIRE_PTR(We_b); REQUIRE_PTR(E); REQUIRE_PTR(h_E);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = E; a.hE_out = h_E; a.W1_img = We_img; a.b1 = We_b;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_EDGE_EMBED, (hipStream_t)stream);
+  rc = launch_edge<MODE_EMBED>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
+                     const int32_t* mask_attend, const float* Pa, const float* Pc, float* partial, int B, int N,
+                     int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_enc_message: null weights");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(partial);
+  REQUIRE_PTR(w->W1b_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_enc_message: null E_idx");
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
+  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.partial = partial; a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
+  rc = launch_edge<MODE_ENC_MSG>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const float* Pa,
+                         const float* Pc, float* h_E_out, int B, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_enc_edge_update: null weights");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(h_E_out);
+  REQUIRE_PTR(w->W11b_img); REQUIRE_PTR(w->W12_img); REQUIRE_PTR(w->W13_img); REQUIRE_PTR(w->b12); REQUIRE_PTR(w->b13);
+  REQUIRE_PTR(w->ln3_g); REQUIRE_PTR(w->ln3_b);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_enc_edge_update: null E_idx");
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = h_E; a.hE_out = h_E_out; a.E_idx = E_idx; a.Pa = Pa; a.Pj0 = Pc;
+  a.W1_img = w->W11b_img; a.W2_img = w->W12_img; a.W3_img = w->W13_img; a.b2 = w->b12; a.b3 = w->b13;
+  a.ln_g = w->ln3_g; a.ln_b = w->ln3_b; a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_ENC_EDGE, (hipStream_t)stream);
+  rc = launch_edge<MODE_ENC_EDGE>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+                     const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
+                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out, int G, int K,
+                     void* stream) {
+  REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_img); REQUIRE_PTR(b_in); REQUIRE_PTR(Wout_img);
+  REQUIRE_PTR(b_out); REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
+  OPTIONAL_PTR(partial);
+  REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_node_update: bad dims G=%d K=%d", G, K);
+  ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
+  int rc = launch_node_ffn(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
+                           G, (K + 15) / 16, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
+                     const float* Pa, const float* Pbw, const float* Pfw, float* partial, int B_dec, int B_enc,
+                     int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_dec_message: null weights");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pbw); REQUIRE_PTR(Pfw); REQUIRE_PTR(partial);
+  REQUIRE_PTR(w->W1e_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  if (!E_idx || !rank) return fail(NAMP_EINVAL, "namp_dec_message: null E_idx / rank");
+  int rc = check_dims(__func__, B_dec, N, K);
+  if (rc) return rc;
+  REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_dec_message: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
+  EdgeArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
+  a.W1_img = w->W1e_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.partial = partial; a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
+  rc = launch_edge<MODE_DEC_MSG>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const float* h_V, float* log_probs,
+                            float* logits, int G, int vocab, void* stream) {
+  REQUIRE_PTR(Wout_w); REQUIRE_PTR(h_V);
+  if (!Wout_b || !log_probs) return fail(NAMP_EINVAL, "namp_logits_log_softmax: null pointer");
+  REQUIRE(G >= 1 && vocab >= 1 && vocab <= 64, "namp_logits_log_softmax: vocab=%d must be in [1,64]", vocab);
+  ProfScope prof_(NAMP_KIND_LOGITS, (hipStream_t)stream);
+  hipLaunchKernelGGL(logits_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, h_V, Wout_w, Wout_b,
+                     log_probs, logits, G, vocab);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_profile_enable(int on) {
+  g_prof_on = (on != 0);
+  return NAMP_OK;
+}
+
+int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nkinds) {
+  if (!ms_per_kind || !launches_per_kind || nkinds < NAMP_NUM_KINDS)
+    return fail(NAMP_EINVAL, "namp_profile_collect: need arrays of at least %d entries", NAMP_NUM_KINDS);
+  for (int i = 0; i < nkinds; ++i) { ms_per_kind[i] = 0.f; launches_per_kind[i] = 0; }
+  int rc = NAMP_OK;
+  for (ProfRec& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+      rc = fail(NAMP_ELAUNCH, "namp_profile_collect: event query failed");
+    else { ms_per_kind[r.kind] += ms; launches_per_kind[r.kind] += 1; }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return rc;
+}
+
+size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
+  if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
+  const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N, tpn = (K + 15) / 16;
+  const size_t enc = (2 + 4 + tpn) * tbl(Ge);
+  const size_t dec = (2 + 2 + tpn) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
+  return (enc > dec ? enc : dec) + 4096;
+}
+
+int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_E, const int32_t* E_idx,
+                       const int32_t* mask, const int32_t* mask_attend, float* h_V_out, float* h_E_out, void* ws,
+                       size_t ws_bytes, int B, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_enc_layer_fwd: null weights");
+  REQUIRE_PTR(h_V); REQUIRE_PTR(h_E); REQUIRE_PTR(h_V_out); REQUIRE_PTR(h_E_out); REQUIRE_PTR(ws);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  const int G = B * N, tpn = (K + 15) / 16;
+  Carver c(ws, ws_bytes);
+  float* Pa = c.take((size_t)G * NAMP_HIDDEN);
+  float* Pc = c.take((size_t)G * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  if (!partial) return fail(NAMP_EWORKSPACE, "namp_enc_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
+  NampProj p1[2] = {{w->W1a_img, w->b1, nullptr, Pa}, {w->W1c_img, nullptr, nullptr, Pc}};
+  if ((rc = namp_node_linear(h_V, nullptr, B, B, N, p1, 2, stream))) return rc;
+  if ((rc = namp_enc_message(w, h_E, E_idx, mask, mask_attend, Pa, Pc, partial, B, N, K, stream))) return rc;
+  if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
+                             partial, mask, h_V_out, G, K, stream)))
+    return rc;
+  NampProj p2[2] = {{w->W11a_img, w->b11, nullptr, Pa}, {w->W11c_img, nullptr, nullptr, Pc}};
+  if ((rc = namp_node_linear(h_V_out, nullptr, B, B, N, p2, 2, stream))) return rc;
+  return namp_enc_edge_update(w, h_E, E_idx, Pa, Pc, h_E_out, B, N, K, stream);
+}
+
+int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
+                     const int32_t* mask, float* h_V, float* h_E, void* ws, size_t ws_bytes, int B, int N, int K,
+                     void* stream) {
+  REQUIRE(w != nullptr, "namp_encoder_fwd: null weights");
+  REQUIRE(w->n_enc >= 1 && w->n_enc <= NAMP_MAX_LAYERS, "namp_encoder_fwd: n_enc=%d out of range", w->n_enc);
+  REQUIRE_PTR(V); REQUIRE_PTR(E); REQUIRE_PTR(h_V); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  const int G = B * N, tpn = (K + 15) / 16;
+  Carver c(ws, ws_bytes);
+  float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* P[4];
+  for (int i = 0; i < 4; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  if (!partial) return fail(NAMP_EWORKSPACE, "namp_encoder_fwd: workspace too small (%zu bytes)", ws_bytes);
+
+  NampProj pv[1] = {{w->Wv_img, w->Wv_b, nullptr, hv[0]}};
+  if ((rc = namp_node_linear(V, nullptr, B, B, N, pv, 1, stream))) return rc;
+  if ((rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
+  const NampEncLayerW* L0 = &w->enc[0];
+  NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
+  if ((rc = namp_node_linear(hv[0], nullptr, B, B, N, p0, 2, stream))) return rc;
+  int cur = 0;     // hv[cur] holds the layer input
+  int tb = 0;      // P[tb], P[tb+1] hold this layer's Pa, Pc for the message phase
+  for (int l = 0; l < w->n_enc; ++l) {
+    const NampEncLayerW* L = &w->enc[l];
+    const bool last = (l + 1 == w->n_enc);
+    float* out = last ? h_V : hv[cur ^ 1];
+    if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[tb], P[tb + 1], partial, B, N, K, stream))) return rc;
+    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
+                               hv[cur], partial, mask, out, G, K, stream)))
+      return rc;
+    const int te = tb ^ 2;   // tables for the edge update (and, above them, for the next layer)
+    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[te]}, {L->W11c_img, nullptr, nullptr, P[te + 1]}, {}, {}};
+    int np = 2;
+    if (!last) {
+      const NampEncLayerW* Ln = &w->enc[l + 1];
+      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[tb]};
+      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[tb + 1]};
+      np = 4;
+    }
+    if ((rc = namp_node_linear(out, nullptr, B, B, N, pe, np, stream))) return rc;
+    if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[te], P[te + 1], h_E, B, N, K, stream))) return rc;
+    cur ^= 1;
+  }
+  return NAMP_OK;
+}
+
+int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                     const int32_t* S, const int32_t* mask, const int32_t* rank, float* log_probs, float* logits,
+                     float* h_V_dec, void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_decoder_fwd: null weights");
+  REQUIRE(w->n_dec >= 1 && w->n_dec <= NAMP_MAX_LAYERS, "namp_decoder_fwd: n_dec=%d out of range", w->n_dec);
+  REQUIRE_PTR(h_V_enc); REQUIRE_PTR(h_E); REQUIRE_PTR(ws); OPTIONAL_PTR(h_V_dec);
+  if (!E_idx || !S || !rank || !log_probs) return fail(NAMP_EINVAL, "namp_decoder_fwd: null E_idx / S / rank / log_probs");
+  int rc = check_dims(__func__, B_dec, N, K);
+  if (rc) return rc;
+  REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_decoder_fwd: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
+  const int Gd = B_dec * N, Ge = B_enc * N, tpn = (K + 15) / 16;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(ws, ws_bytes);
+  float* hv[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
+  float* Pa = c.take((size_t)Gd * NAMP_HIDDEN);
+  float* Pbw = c.take((size_t)Gd * NAMP_HIDDEN);
+  float* partial = c.take((size_t)Gd * tpn * NAMP_HIDDEN);
+  float* Pfw[NAMP_MAX_LAYERS];
+  for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
+  if (!Pfw[w->n_dec - 1] || !partial) return fail(NAMP_EWORKSPACE, "namp_decoder_fwd: workspace too small (%zu bytes)", ws_bytes);
+
+  // encoder-context tables Pfw_l = W1v_l . h_V_enc (h_EXV_encoder of model_utils.py:410-413)
+  NampProj pf[NAMP_MAX_LAYERS];
+  for (int l = 0; l < w->n_dec; ++l) pf[l] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
+  if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, w->n_dec, stream))) return rc;
+  // layer-0 residue tables from h_V^(0) = h_V_enc broadcast over decoder batches
+  const NampDecLayerW* D0 = &w->dec[0];
+  NampProj p0[2] = {{D0->W1a_img, D0->b1, nullptr, Pa}, {D0->W1v_img, nullptr, D0->tok, Pbw}};
+  if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, p0, 2, stream))) return rc;
+  const float* hin = h_V_enc;
+  if (B_dec != B_enc) {
+    for (int b = 0; b < B_dec; b += B_enc) {
+      hipError_t e = hipMemcpyAsync(hv[0] + (size_t)b * N * NAMP_HIDDEN, h_V_enc, (size_t)Ge * NAMP_HIDDEN * 4,
+                                    hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_fwd: hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+    hin = hv[0];
+  }
+  int cur = 0;
+  for (int l = 0; l < w->n_dec; ++l) {
+    const NampDecLayerW* D = &w->dec[l];
+    const bool last = (l + 1 == w->n_dec);
+    float* out = (last && h_V_dec) ? h_V_dec : hv[cur ^ 1];
+    if ((rc = namp_dec_message(D, h_E, E_idx, rank, Pa, Pbw, Pfw[l], partial, B_dec, B_enc, N, K, stream))) return rc;
+    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
+                               partial, mask, out, Gd, K, stream)))
+      return rc;
+    if (!last) {
+      const NampDecLayerW* Dn = &w->dec[l + 1];
+      NampProj pn[2] = {{Dn->W1a_img, Dn->b1, nullptr, Pa}, {Dn->W1v_img, nullptr, Dn->tok, Pbw}};
+      if ((rc = namp_node_linear(out, S, B_dec, B_dec, N, pn, 2, stream))) return rc;
+    }
+    hin = out;
+    cur ^= 1;
+  }
+  return namp_logits_log_softmax(w->Wout_w, w->Wout_b, hin, log_probs, logits, Gd, w->vocab, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// Device-side building blocks for the NA-MPNN encoder/decoder path on gfx950.
+//
+// Everything here is written for one shape family: hidden width H = 128,
+// 64-lane wavefronts, fp32 MFMA v_mfma_f32_16x16x4_f32.  A "tile" is 16 rows
+// (16 edges of one residue, or 16 residues); one wavefront owns one tile and
+// carries its activations through a whole MLP *in registers*:
+//
+//   D = mfma_16x16x4(a, b, C):  lane l supplies a = A[i=l&15][k=l>>4],
+//                               b = B[k=l>>4][j=l&15];
+//                               lane l receives D[i = 4*(l>>4)+r][j = l&15], r=0..3.
+//
+//   "T" orientation (A = weights, B = activations):  D[n_local][m] -> lane
+//   (m = l&15, g = l>>4) ends up with output channels 16*tn + 4*g + r of ITS row m.
+//   That is exactly the operand layout the next layer wants if the reduction
+//   index is enumerated as  k = 16*tk + 4*g + r  — a permutation of k that the
+//   weight image (pack_image_kernel) bakes in.  So a 3-layer MLP never leaves
+//   the register file and needs no LDS round trip for activations.
+//
+//   "F" orientation (A = activations, B = weights): D[m][n_local] -> lane
+//   (n_local = l&15, g) holds rows m = 4*g + r of channel 16*tn + n_local, which
+//   is what the K-neighbour sum wants (4 in-lane adds + 2 cross-lane steps).
+//
+// Weight image of a [OUT x IN] block W (row-major, leading dimension ld):
+//   img[tk][tn][lane][r] = W[16*tn + (lane&15)][16*tk + 4*(lane>>4) + r]
+// one float4 per lane per (tk,tn): a wave reads 1 KiB contiguous, conflict-free
+// from LDS (ds_read_b128) or fully coalesced from L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define NAMP_H 128
+#define NAMP_TN 8                 // 128 / 16 output-channel tiles
+#define NAMP_IMG_FLOATS 16384     // one 128x128 image
+#define NAMP_IMG_BYTES 65536
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// exact-erf GELU (torch.nn.GELU default; reference model_utils.py:600,633,678)
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ f4 gelu4(f4 v) {
+  f4 o;
+  o.x = gelu_erf(v.x); o.y = gelu_erf(v.y); o.z = gelu_erf(v.z); o.w = gelu_erf(v.w);
+  return o;
+}
+
+// acc[tn] (+)= W . x  over TK k-tiles.  `w` points at img[tk0][0][lane]; consecutive
+// tn are 64 f4 apart, consecutive tk are 64*TNW f4 apart (TNW = tn extent of the image).
+//   FLIP=false: "T" orientation, FLIP=true: "F" orientation (see header comment).
+template <int TK, int NTN, bool FLIP>
+__device__ __forceinline__ void chain_gemm(f4 (&acc)[NTN], const f4 (&x)[TK], const f4* w, const int tn_stride_img) {
+#pragma unroll
+  for (int tk = 0; tk < TK; ++tk) {
+    f4 wf[NTN];
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn) wf[tn] = w[(tk * tn_stride_img + tn) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int tn = 0; tn < NTN; ++tn) {
+        if (FLIP) acc[tn] = mfma4(x[tk][r], wf[tn][r], acc[tn]);
+        else      acc[tn] = mfma4(wf[tn][r], x[tk][r], acc[tn]);
+      }
+    }
+  }
+}
+
+// Asynchronous global -> LDS copy of `nchunks` KiB-sized chunks (one wave-instruction each,
+// 64 lanes x 16 B).  The LDS image is the global image verbatim (lane-linear), which is all
+// global_load_lds can do.  Completion: s_waitcnt vmcnt(0) in every issuing wave + a barrier.
+__device__ __forceinline__ void dma_to_lds(char* lds_dst, const float* gsrc, int nchunks, int wave, int nwaves, int lane) {
+  for (int c = wave; c < nchunks; c += nwaves) {
+    const char* g = (const char*)gsrc + (size_t)c * 1024 + lane * 16;
+    char* d = lds_dst + c * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void wait_dma_and_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// sum over the 4 lane groups g (lanes l, l^16, l^32, l^48 hold the same column)
+__device__ __forceinline__ float xg_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// LayerNorm over the 128 channels of one row held as v[8] (f4 each) by the 4 lanes
+// (m, g=0..3); gamma/beta are read at channel 16*tn + 4*g.  eps = 1e-5, biased variance
+// (torch.nn.LayerNorm; reference model_utils.py:627-628,668-670).
+__device__ __forceinline__ void layernorm_row_T(f4 (&v)[8], const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+  const float mean = xg_sum(s) * (1.0f / 128.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    v[t] -= mean;
+    q += (v[t].x * v[t].x + v[t].y * v[t].y) + (v[t].z * v[t].z + v[t].w * v[t].w);
+  }
+  const float rstd = rsqrtf(xg_sum(q) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f4 ga = *(const f4*)(gamma + 16 * t + 4 * g);
+    const f4 be = *(const f4*)(beta + 16 * t + 4 * g);
+    v[t] = v[t] * rstd * ga + be;
+  }
+}

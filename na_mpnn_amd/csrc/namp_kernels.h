@@ -1,0 +1,440 @@
+// Kernels of the NA-MPNN encoder/decoder path (gfx950).  See namp_device.h for the register
+// layout conventions and DESIGN.md for the per-kernel roofline accounting.
+#pragma once
+#include "namp_device.h"
+
+// ------------------------------------------------------------------------------------------
+// pack_image_kernel: nn.Linear weight block -> MFMA fragment image (see namp_device.h).
+//   W: [OUT x *] row-major with leading dimension ld; the block is columns [col0, col0+IN).
+//   img[tk][tn][lane][r], tk < IN/16, tn < OUT/16.
+// ------------------------------------------------------------------------------------------
+__global__ void pack_image_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN,
+                                  float* __restrict__ img) {
+  const int total = OUT * IN;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int r = e & 3, lane = (e >> 2) & 63, t = e >> 8;
+    const int ntn = OUT >> 4;
+    const int tn = t % ntn, tk = t / ntn;
+    const int n = 16 * tn + (lane & 15), k = 16 * tk + 4 * (lane >> 4) + r;
+    img[e] = W[(size_t)n * ld + col0 + k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather_cat_kernel — a1 + a3: out[row] = [ nbrs[row][0:C1] | nodes[b*N + idx[row]][0:C2] ]
+// (reference gather_nodes / cat_neighbors_nodes, inference/model_utils.py:713-732).
+// One float4 per thread, flat over the output so stores are perfectly coalesced; with
+// C1 = C2 = 128 a wave moves exactly one output row (512 B streamed + 512 B gathered).
+// C1 may be 0 (pure gather_nodes).  C1, C2 multiples of 4.
+// ------------------------------------------------------------------------------------------
+template <int UNROLL>
+__global__ void gather_cat_kernel(const float* __restrict__ nodes, const float* __restrict__ nbrs,
+                                  const int32_t* __restrict__ idx, float* __restrict__ out,
+                                  long rows, int NK /* N*K rows per batch */, int N, int C1, int C2) {
+  const int s1 = C1 >> 2, slots = (C1 + C2) >> 2;
+  const long total = rows * slots;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e0 < total; e0 += stride * UNROLL) {
+    f4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) {
+        const long row = e / slots;
+        const int s = (int)(e - row * slots);
+        if (s < s1) {
+          v[u] = *(const f4*)(nbrs + row * C1 + 4 * s);
+        } else {
+          const long b = row / NK;
+          const long j = b * N + idx[row];
+          v[u] = *(const f4*)(nodes + j * C2 + 4 * (s - s1));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) *(f4*)(out + 4 * e) = v[u];
+    }
+  }
+}
+
+// scalar fallback for channel counts that are not multiples of 4 (e.g. the C=1 mask gather)
+__global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes, const float* __restrict__ nbrs,
+                                         const int32_t* __restrict__ idx, float* __restrict__ out,
+                                         long rows, int NK, int N, int C1, int C2) {
+  const int ct = C1 + C2;
+  const long total = rows * ct;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / ct;
+    const int c = (int)(e - row * ct);
+    out[e] = (c < C1) ? nbrs[row * C1 + c] : nodes[((row / NK) * N + idx[row]) * C2 + (c - C1)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// edge_mlp_kernel — the hot kernel.  One wave = one 16-row tile = 16 of the K neighbours of
+// one residue; a workgroup = (blockDim/64)/TPN residues, TPN = ceil(K/16) tiles per residue.
+// The 128x128 weight images of the three layers are DMA'd into a 2 x 64 KiB LDS ring and
+// shared by all waves; activations stay in registers (namp_device.h).
+//
+// With W1 = [W1a | W1b | W1c] applied to [h_V_i | h_E_ik | h_V_j]  (EncLayer,
+// model_utils.py:684-687,699-702) the first layer is evaluated as
+//      W1b . h_E_ik  +  (W1a . h_V_i + b1)  +  W1c . h_V_j
+//      \_ MFMA here _/   \__ Pa[i] table __/    \_ Pj[j] table _/
+// i.e. the two node-only products are hoisted into per-residue tables computed once by
+// node_linear_kernel and *gathered* here; no [N,K,384] concatenation is ever materialised.
+// The decoder (DecLayer on h_ESV, model_utils.py:416-418,636-646) is the same with
+//      first layer = W1e . h_E_ik + Pa[i] + (bw ? Pbw[j] : Pfw[j]),
+//      Pbw[j] = W1s . W_s[S_j] + W1v . h_V_j ,  Pfw[j] = W1v . h_V^enc_j ,
+//      bw = [rank(j) < rank(i)]   (the order mask of model_utils.py:391-396 as a rank compare).
+//
+//   MODE_ENC_MSG : partial[i][kt][:] = sum_{k in tile} mask_i mask_j / 30 * MLP(...)
+//   MODE_DEC_MSG : partial[i][kt][:] = sum_{k in tile}           1 / 30 * MLP(...)
+//   MODE_ENC_EDGE: h_E'[i,k,:] = LayerNorm3(h_E[i,k,:] + MLP(...))           (in place allowed)
+//   MODE_EMBED   : h_E[i,k,:]  = W_e . E[i,k,:] + b_e   (single layer; model_utils.py:89)
+// ------------------------------------------------------------------------------------------
+enum { MODE_ENC_MSG = 0, MODE_DEC_MSG = 1, MODE_ENC_EDGE = 2, MODE_EMBED = 3 };
+
+struct EdgeArgs {
+  const float* hE;             // [G_enc*K][128] input edge rows
+  float* hE_out;               // ENC_EDGE / EMBED output rows
+  const int32_t* E_idx;        // [G_enc][K] neighbour ids, local to the complex
+  const int32_t* mask;         // [G] residue mask (may be null = all ones)
+  const int32_t* mask_attend;  // optional explicit [G_enc][K] (ENC_MSG); null -> mask_i*mask_j
+  const int32_t* rank;         // DEC_MSG: [G] decoding rank of every residue
+  const float* Pa;             // [G][128] per-residue first-layer term (bias folded in)
+  const float* Pj0;            // ENC: Pc [G][128];   DEC: Pbw [G][128]
+  const float* Pj1;            // DEC: Pfw [G_enc][128]
+  const float* W1_img;         // 64 KiB images
+  const float* W2_img;
+  const float* W3_img;
+  const float* b1;             // EMBED only (otherwise folded into Pa)
+  const float* b2;
+  const float* b3;
+  const float* ln_g;           // ENC_EDGE
+  const float* ln_b;
+  float* partial;              // MSG modes: [G][TPN][128]
+  int G;                       // residues processed by this launch (decoder: B_dec*N)
+  int G_enc;                   // residues on the encoder side (B_enc*N); decoder batch b maps to b % B_enc
+  int N, K, TPN;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;
+  char* buf1 = smem + NAMP_IMG_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+
+  dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
+  if (MODE != MODE_EMBED) dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
+
+  const int m = lane & 15, g = lane >> 4;
+  const int npw = nwaves / a.TPN;                      // residues per workgroup
+  const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
+  int node = blockIdx.x * npw + node_l;
+  const bool wave_active = (node_l < npw) && (node < a.G);
+  if (!wave_active) node = 0;
+  // encoder-side residue (decoder batches are replicas of encoder batches: h_V.repeat(B_decoder,..))
+  const int b_dec = node / a.N;
+  const int i_loc = node - b_dec * a.N;
+  const int node_enc = (MODE == MODE_DEC_MSG) ? ((b_dec % (a.G_enc / a.N)) * a.N + i_loc) : node;
+  const int k = 16 * kt + m;
+  const bool valid = wave_active && (k < a.K);
+  const long erow = (long)node_enc * a.K + (valid ? k : 0);
+
+  // ---- per-row operands: the h_E row (B operand of layer 1) and the hoisted first-layer terms
+  f4 x[8];
+  {
+    const float* src = a.hE + erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+  }
+  f4 acc[8];
+  float w_row = 0.f;
+  if (MODE == MODE_EMBED) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g);
+  } else {
+    const int j_loc = a.E_idx[erow];
+    const float* pj;
+    if (MODE == MODE_DEC_MSG) {
+      const int j_dec = b_dec * a.N + j_loc;
+      const bool bw = a.rank[j_dec] < a.rank[node];
+      pj = bw ? (a.Pj0 + (long)j_dec * NAMP_H) : (a.Pj1 + (long)(node_enc - i_loc + j_loc) * NAMP_H);
+      w_row = valid ? (1.0f / 30.0f) : 0.f;
+    } else {
+      const int j = node - i_loc + j_loc;
+      pj = a.Pj0 + (long)j * NAMP_H;
+      if (MODE == MODE_ENC_MSG) {
+        int ma;
+        if (a.mask_attend) ma = a.mask_attend[erow];
+        else ma = a.mask ? (a.mask[node] * a.mask[j]) : 1;
+        w_row = valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
+      }
+    }
+    const float* pa = a.Pa + (long)node * NAMP_H + 4 * g;
+    pj += 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(pa + 16 * t) + *(const f4*)(pj + 16 * t);
+  }
+
+  const f4* w0 = (const f4*)buf0 + lane;
+  const f4* w1 = (const f4*)buf1 + lane;
+
+  // ---- layer 1 (T): acc += W1b . h_E
+  wait_dma_and_sync();
+  chain_gemm<8, 8, false>(acc, x, w0, 8);
+
+  if (MODE == MODE_EMBED) {
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
+  __syncthreads();                                   // every wave is done with buf0
+  dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);
+
+  // ---- layer 2 (T)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+  chain_gemm<8, 8, false>(acc, x, w1, 8);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
+  wait_dma_and_sync();
+
+  if (MODE == MODE_ENC_EDGE) {
+    // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+    chain_gemm<8, 8, false>(acc, x, w0, 8);
+    const float* src = a.hE + erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
+    layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+    }
+  } else {
+    // ---- layer 3 (F): lane (n_local=m, g) gets rows 4g..4g+3 of channel 16*tn + m
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float b = a.b3[16 * t + m];
+      acc[t] = (f4){b, b, b, b};
+    }
+    chain_gemm<8, 8, true>(acc, x, w0, 8);
+    // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
+    float wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
+    float* dst = a.partial + ((long)node * a.TPN + kt) * NAMP_H + m;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+      s = xg_sum(s);
+      if (wave_active && g == 0) dst[16 * t] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// node_linear_kernel — residue-level projections  out_p[n] = W_p . X[src(n)] + bias_p (+ tok_p[S[n]])
+// for up to 8 weight blocks p at once.  One wave per (16-residue tile, p); weights stream
+// straight from L2 as coalesced fragment loads (each element is used once per wave, so LDS
+// staging would buy nothing).  Produces the Pa / Pc / Pbw / Pfw tables, h_V = W_v.V + b
+// (model_utils.py:88) and the per-token table W1s . W_s (33 rows).
+// ------------------------------------------------------------------------------------------
+struct ProjDesc {
+  const float* img;    // 64 KiB image of the [128x128] block
+  const float* bias;   // [128] or null
+  const float* tok;    // [vocab][128] table added per residue by token S[n], or null
+  float* out;          // [G_out][128]
+};
+struct NodeLinearArgs {
+  const float* X;      // [G_src][128]
+  const int32_t* S;    // [G_out] tokens (only if some tok != null)
+  int G_out, G_src, N; // output row n reads source row ((n / N) % (G_src / N)) * N + n % N
+  int nproj;
+  ProjDesc p[8];
+};
+
+__global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int unit = blockIdx.x * 4 + wave;
+  const int ntiles = (a.G_out + 15) >> 4;
+  if (unit >= ntiles * a.nproj) return;
+  const int tile = unit / a.nproj, pi = unit - tile * a.nproj;
+  const int m = lane & 15, g = lane >> 4;
+  const int row = tile * 16 + m;
+  const bool valid = row < a.G_out;
+  const int rr = valid ? row : 0;
+  const int b = rr / a.N;
+  const int src_row = (b % (a.G_src / a.N)) * a.N + (rr - b * a.N);
+  // select the descriptor without dynamic indexing of the kernarg struct
+  ProjDesc d = a.p[0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) if (pi == q) d = a.p[q];
+
+  f4 x[8], acc[8];
+  const float* src = a.X + (long)src_row * NAMP_H + 4 * g;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = d.bias ? *(const f4*)(d.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
+  if (d.tok) {
+    const float* tk = d.tok + (long)a.S[rr] * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(tk + 16 * t);
+  }
+  if (valid) {
+    float* dst = d.out + (long)row * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// node_ffn_kernel — the per-residue tail of EncLayer / DecLayer (model_utils.py:690-697,646-656):
+//      x  = LayerNorm1(h_V + sum_t partial[n][t])          (partial already carries mask / 30)
+//      y  = LayerNorm2(x + W_out . gelu(W_in . x + b_in) + b_out)
+//      h_V' = mask * y
+// 16 residues per workgroup, 8 waves; wave w owns hidden units [64w, 64w+64) of the 512-wide
+// FFN: W_in slice (T) -> gelu -> W_out slice (T) gives a partial [16 x 128] per wave, reduced
+// through LDS.  Weight fragments stream from L2 (each is used once per workgroup).
+// ------------------------------------------------------------------------------------------
+struct NodeFfnArgs {
+  const float* hV;        // [G][128]
+  const float* partial;   // [G][TPN][128] or null (no message term)
+  const int32_t* mask;    // [G] or null
+  const float* ln1_g; const float* ln1_b;
+  const float* Win_img;   // image of W_in  [512 x 128]: img[tk 8][tn 32][lane]
+  const float* b_in;      // [512]
+  const float* Wout_img;  // image of W_out [128 x 512]: img[tk 32][tn 8][lane]
+  const float* b_out;     // [128]
+  const float* ln2_g; const float* ln2_b;
+  float* hV_out;          // [G][128]
+  int G, TPN;
+};
+
+#define FFN_LD 132   // padded row stride (floats) of the LDS tiles: conflict-free ds_write_b128
+
+__global__ __launch_bounds__(512) void node_ffn_kernel(const NodeFfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                 // [16][FFN_LD]   x = LN1(...)
+  float* ps = xs + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial outputs
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int row = blockIdx.x * 16 + m;
+  const int rr = row < a.G ? row : 0;
+
+  // LN1 in the T layout, redundantly per wave (cheap, avoids a barrier)
+  f4 x[8];
+  {
+    const float* src = a.hV + (long)rr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+    if (a.partial) {
+      for (int p = 0; p < a.TPN; ++p) {
+        const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(ps_ + 16 * t);
+      }
+    }
+    layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(xs + m * FFN_LD + 16 * t + 4 * g) = x[t];
+  }
+  // hidden slice: 4 tn tiles of W_in
+  f4 hacc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) hacc[t] = *(const f4*)(a.b_in + 64 * wave + 16 * t + 4 * g);
+  chain_gemm<8, 4, false>(hacc, x, (const f4*)a.Win_img + (4 * wave) * 64 + lane, 32);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) hacc[t] = gelu4(hacc[t]);
+  // partial output over this wave's 64 hidden units: k tiles 4w..4w+3 of W_out
+  f4 oacc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) oacc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<4, 8, false>(oacc, hacc, (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane, 8);
+  {
+    float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = oacc[t];
+  }
+  __syncthreads();
+  // LN2: thread -> (row = tid/32, 4 channels)
+  {
+    const int r = tid >> 5, c = (tid & 31) * 4;
+    f4 v = *(const f4*)(xs + r * FFN_LD + c) + *(const f4*)(a.b_out + c);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += *(const f4*)(ps + (w * 16 + r) * FFN_LD + c);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / 128.0f);
+    v -= mean;
+    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / 128.0f) + 1e-5f);
+    const int orow = blockIdx.x * 16 + r;
+    if (orow < a.G) {
+      const float mk = a.mask ? (float)a.mask[orow] : 1.0f;
+      f4 y = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
+      *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// logits_kernel — log_softmax(W_out . h_V + b) over the 33-letter vocabulary
+// (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ hV, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ log_probs,
+                                                     float* __restrict__ logits_out, int G, int V) {
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= G) return;
+  const float* h = hV + (long)node * NAMP_H;
+  float z = -INFINITY;
+  if (lane < V) {
+    const float* w = W + (long)lane * NAMP_H;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < NAMP_H; c += 4) {
+      const f4 wv = *(const f4*)(w + c);
+      const f4 hv = *(const f4*)(h + c);
+      s0 = fmaf(wv.x, hv.x, s0); s1 = fmaf(wv.y, hv.y, s1);
+      s2 = fmaf(wv.z, hv.z, s2); s3 = fmaf(wv.w, hv.w, s3);
+    }
+    z = (s0 + s1) + (s2 + s3) + bias[lane];
+  }
+  float mx = z;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float e = (lane < V) ? expf(z - mx) : 0.f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+  if (lane < V) {
+    log_probs[(long)node * V + lane] = (z - mx) - logf(e);
+    if (logits_out) logits_out[(long)node * V + lane] = z;
+  }
+}

@@ -1,0 +1,135 @@
+"""ctypes binding of libnamp_hip.so (include/namp.h).
+
+The library is built in-tree by ``na_mpnn_amd.build`` (hipcc, gfx950).  There is no
+fallback: if the shared object is missing or a symbol is absent, importing callers get
+a RuntimeError that says how to build it.  Raw device pointers (``tensor.data_ptr()``)
+and the current HIP stream handle cross the boundary; no torch types do.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnamp_hip.so")
+
+NAMP_ABI_VERSION = 1
+NAMP_MAX_LAYERS = 8
+
+c_fp = C.c_void_p   # const float*  (device)
+c_ip = C.c_void_p   # const int32_t* (device)
+
+
+def _fields(names):
+    return [(n, c_fp) for n in names]
+
+
+class NampEncLayerW(C.Structure):
+    _fields_ = _fields(["W1a_img", "W1b_img", "W1c_img", "b1", "W2_img", "b2", "W3_img", "b3",
+                        "W11a_img", "W11b_img", "W11c_img", "b11", "W12_img", "b12", "W13_img", "b13",
+                        "Win_img", "b_in", "Wout_img", "b_out",
+                        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"])
+
+
+class NampDecLayerW(C.Structure):
+    _fields_ = _fields(["W1a_img", "W1e_img", "W1s_img", "W1v_img", "b1", "tok",
+                        "W2_img", "b2", "W3_img", "b3", "Win_img", "b_in", "Wout_img", "b_out",
+                        "ln1_g", "ln1_b", "ln2_g", "ln2_b"])
+
+
+class NampModelW(C.Structure):
+    _fields_ = [("n_enc", C.c_int32), ("n_dec", C.c_int32), ("vocab", C.c_int32), ("reserved", C.c_int32),
+                ("Wv_img", c_fp), ("Wv_b", c_fp), ("We_img", c_fp), ("We_b", c_fp),
+                ("Wout_w", c_fp), ("Wout_b", c_fp),
+                ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS)]
+
+
+class NampProj(C.Structure):
+    _fields_ = [("img", c_fp), ("bias", c_fp), ("tok", c_fp), ("out", c_fp)]
+
+
+i32, vp, sz = C.c_int, C.c_void_p, C.c_size_t
+_PROTOTYPES = {
+    # name: (restype, argtypes)      — must list every symbol include/namp.h declares
+    "namp_abi_version": (i32, []),
+    "namp_last_error": (C.c_char_p, []),
+    "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
+    "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
+    "namp_cat_neighbors_nodes_f32": (i32, [c_fp, c_fp, c_ip, c_fp, i32, i32, i32, i32, i32, vp]),
+    "namp_node_linear": (i32, [c_fp, c_ip, i32, i32, i32, C.POINTER(NampProj), i32, vp]),
+    "namp_edge_embed": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
+    "namp_enc_message": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
+    "namp_enc_edge_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
+    "namp_node_update": (i32, [c_fp] * 8 + [c_fp, c_fp, c_ip, c_fp, i32, i32, vp]),
+    "namp_dec_message": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
+                               i32, i32, i32, i32, vp]),
+    "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
+    "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_profile_enable": (i32, [i32]),
+    "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),
+    "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,
+                                 vp, sz, i32, i32, i32, vp]),
+    "namp_encoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_fp, c_fp,
+                               vp, sz, i32, i32, i32, vp]),
+    "namp_decoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp,
+                               vp, sz, i32, i32, i32, i32, vp]),
+}
+
+KERNEL_KINDS = ["gather", "node_linear", "edge_embed", "enc_message", "enc_edge_update", "node_update",
+                "dec_message", "logits"]
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def lib():
+    """The loaded library with prototypes set.  Raises (never falls back) if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -m na_mpnn_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _PROTOTYPES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild with `python -m na_mpnn_amd.build`") from e
+        fn.restype, fn.argtypes = res, args
+    v = L.namp_abi_version()
+    if v != NAMP_ABI_VERSION:
+        raise RuntimeError(f"libnamp_hip.so ABI version {v} != expected {NAMP_ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().namp_last_error().decode(errors="replace")
+        raise RuntimeError(f"libnamp_hip {what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def profile_collect():
+    """{kind: (total_ms, launches)} recorded since namp_profile_enable(1)."""
+    n = len(KERNEL_KINDS)
+    ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+    check(lib().namp_profile_collect(ms, cnt, n), "profile_collect")
+    return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}

@@ -1,0 +1,323 @@
+"""Drop-in ``ProteinMPNN`` for NA-MPNN on MI355X.
+
+Mirrors the reference module surface — constructor keywords, ``state_dict`` key set and the
+``feature_dict`` methods ``encode / score / unconditional_probs / sample / forward``
+(/root/reference/inference/model_utils.py:8-424 and /root/reference/na_model_utils.py:519-646) —
+while every encoder/decoder op runs in hand-written HIP kernels reached through the C ABI of
+``libnamp_hip.so`` (include/namp.h).  The ``nn.Linear`` / ``nn.LayerNorm`` / ``nn.Embedding``
+children are parameter containers only (they give the reference's key names and initialisers);
+their ``forward`` is never called on the hot path.
+
+There is no CPU path: tensors must live on a HIP device and the extension must be built,
+otherwise a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip, spec
+from .pack import PackedWeights
+
+H = spec.H
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (names = reference state_dict keys)
+# --------------------------------------------------------------------------------------------
+class _FFN(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.W_in = nn.Linear(h, 4 * h, bias=True)
+        self.W_out = nn.Linear(4 * h, h, bias=True)
+
+
+class _EncLayerParams(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(h), nn.LayerNorm(h), nn.LayerNorm(h)
+        self.W1, self.W2, self.W3 = nn.Linear(3 * h, h), nn.Linear(h, h), nn.Linear(h, h)
+        self.W11, self.W12, self.W13 = nn.Linear(3 * h, h), nn.Linear(h, h), nn.Linear(h, h)
+        self.dense = _FFN(h)
+
+
+class _DecLayerParams(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.norm1, self.norm2 = nn.LayerNorm(h), nn.LayerNorm(h)
+        self.W1, self.W2, self.W3 = nn.Linear(4 * h, h), nn.Linear(h, h), nn.Linear(h, h)
+        self.dense = _FFN(h)
+
+
+class _PosEmb(nn.Module):
+    def __init__(self, n_emb, max_rel):
+        super().__init__()
+        self.linear = nn.Linear(2 * max_rel + 2, n_emb)
+
+
+class _FeatureParams(nn.Module):
+    def __init__(self, edge_features, node_features, n_polytypes, n_atoms_aug):
+        super().__init__()
+        self.embeddings = _PosEmb(spec.NUM_POS, spec.MAX_REL)
+        self.node_embedding = nn.Linear(n_polytypes, node_features, bias=False)
+        self.norm_nodes = nn.LayerNorm(node_features)
+        self.edge_embedding = nn.Linear(spec.NUM_POS + spec.NUM_RBF * n_atoms_aug * n_atoms_aug, edge_features, bias=False)
+        self.norm_edges = nn.LayerNorm(edge_features)
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"na_mpnn_amd: '{what}' is on {t.device}; this implementation runs only on a HIP device "
+                           "(no CPU fallback — use the reference or oracle/cpu_ref.py for CPU checks)")
+
+
+class ProteinMPNN(nn.Module):
+    """Same constructor keywords as the inference copy (model_utils.py:9-23); the training copy's
+    extra keywords (na_model_utils.py:520-539) are accepted as well."""
+
+    def __init__(self, num_letters=21, node_features=128, edge_features=128, hidden_dim=128,
+                 num_encoder_layers=3, num_decoder_layers=3, vocab=21, k_neighbors=48,
+                 augment_eps=0.0, dropout=0.0, model_type="na_mpnn",
+                 atom_dict=None, restype_to_int=None, polytype_to_int=None,
+                 protein_augment_eps=None, dna_augment_eps=None, rna_augment_eps=None,
+                 decode_protein_first=0, na_ref_atom="C1'", include_pred_na_N=1, device=None):
+        super().__init__()
+        if model_type != "na_mpnn":
+            # reference behaviour (model_utils.py:44-46)
+            print("Choose --model_type flag from currently available models")
+            sys.exit()
+        if atom_dict is None:
+            raise Exception("atom_dict is necessary for featurization!")
+        if polytype_to_int is None:
+            raise Exception("polytype_to_int is necessary for featurization!")
+        if (node_features, edge_features, hidden_dim) != (H, H, H):
+            raise ValueError("the HIP kernels are specialised for node/edge/hidden width 128 "
+                             "(the only configuration the reference instantiates)")
+        if not include_pred_na_N:
+            raise NotImplementedError("include_pred_na_N=0 is not supported")
+        self.model_type = model_type
+        self.node_features, self.edge_features, self.hidden_dim = node_features, edge_features, hidden_dim
+        self.vocab, self.num_letters = vocab, num_letters
+        self.k_neighbors = k_neighbors
+        self.restype_to_int = restype_to_int
+        self.atom_dict = dict(atom_dict)
+        self.na_ref_atom = na_ref_atom
+        self.decode_protein_first = decode_protein_first
+        self.mask_token = restype_to_int["MAS"] if restype_to_int else None
+        eps = lambda v: augment_eps if v is None else v
+        self.protein_augment_eps, self.dna_augment_eps, self.rna_augment_eps = \
+            eps(protein_augment_eps), eps(dna_augment_eps), eps(rna_augment_eps)
+
+        self.W_v = nn.Linear(node_features, hidden_dim, bias=True)
+        self.features = _FeatureParams(edge_features, node_features, len(polytype_to_int), len(atom_dict) + 2)
+        self.W_e = nn.Linear(edge_features, hidden_dim, bias=True)
+        self.W_s = nn.Embedding(vocab, hidden_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.encoder_layers = nn.ModuleList([_EncLayerParams(hidden_dim) for _ in range(num_encoder_layers)])
+        self.decoder_layers = nn.ModuleList([_DecLayerParams(hidden_dim) for _ in range(num_decoder_layers)])
+        self.W_out = nn.Linear(hidden_dim, num_letters, bias=True)
+        for p in self.parameters():          # model_utils.py:67-69
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self._packed = None
+        self._packed_sig = None
+        self._ws = None
+
+    # ---------------------------------------------------------------------------------------
+    # packed weights / workspace plumbing
+    # ---------------------------------------------------------------------------------------
+    def _weights(self):
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or sig != self._packed_sig:
+            dev = self.W_v.weight.device
+            _require_device(self.W_v.weight, "model parameters")
+            sd = {k: v for k, v in self.state_dict().items()}
+            if self._packed is None or self._packed.flat.device != dev:
+                self._packed = PackedWeights(sd, len(self.encoder_layers), len(self.decoder_layers), self.num_letters, dev)
+            else:
+                self._packed.repack(sd)
+            self._packed_sig = sig
+        return self._packed
+
+    def _workspace(self, B_enc, B_dec, N, K, device):
+        need = hip.lib().namp_workspace_bytes(B_enc, B_dec, N, K)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---------------------------------------------------------------------------------------
+    # a11: featurisation (ProteinFeaturesNA.forward, model_utils.py:528-593).  First build: stock
+    # PyTorch-ROCm tensor ops, chunked over residues so the [.,K,18,18,16] RBF block stays small
+    # (the fused HIP featuriser is the next widening step).
+    # ---------------------------------------------------------------------------------------
+    def _virtual(self, p0, p1, p2, wa, wb, wc):
+        b, c = p1 - p0, p2 - p1
+        return wa * torch.cross(b, c, dim=-1) + wb * b + wc * c + p1
+
+    @torch.no_grad()
+    def featurize(self, fd, chunk=128):
+        X, mask = fd["X"], fd["mask"]
+        _require_device(X, "X")
+        ad = self.atom_dict
+        if self.training and max(self.protein_augment_eps, self.dna_augment_eps, self.rna_augment_eps) > 0:
+            eps = fd["protein_mask"] * self.protein_augment_eps + fd["dna_mask"] * self.dna_augment_eps + \
+                fd["rna_mask"] * self.rna_augment_eps
+            X = X + fd["X_m"][:, :, :, None] * eps[:, :, None, None] * torch.randn_like(X)
+        B, L = X.shape[:2]
+        K = int(min(self.k_neighbors, L))
+        Ca = X[:, :, ad["CA"]]
+        Cb = self._virtual(X[:, :, ad["N"]], Ca, X[:, :, ad["C"]], -0.58273431, 0.56802827, -0.54067466)
+        C1p = X[:, :, ad["C1'"]]
+        Nna = self._virtual(X[:, :, ad["O4'"]], C1p, X[:, :, ad["C2'"]], -0.56967352, 0.51055973, -0.53122153)
+        X18 = torch.cat((X, Cb[:, :, None], Nna[:, :, None]), -2)
+        M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (fd["rna_mask"] + fd["dna_mask"])[:, :, None]), -1).float()
+        P = Ca + X[:, :, ad[self.na_ref_atom]]
+        mf = mask.float()
+        m2 = mf[:, None, :] * mf[:, :, None]
+        D = m2 * torch.sqrt(((P[:, None] - P[:, :, None]) ** 2).sum(-1) + 1e-6)
+        D = D + (1. - m2) * D.max(-1, keepdim=True)[0]
+        E_idx = torch.topk(D, K, dim=-1, largest=False)[1]
+        del D, m2
+        fp = self.features
+        mu = torch.linspace(2., 22., spec.NUM_RBF, device=X.device)
+        R_idx, chain = fd["R_idx"].long(), fd["chain_labels"].long()
+        bidx = torch.arange(B, device=X.device)[:, None, None]
+        Wpos, bpos = fp.embeddings.linear.weight, fp.embeddings.linear.bias
+        E = torch.empty(B, L, K, self.edge_features, device=X.device)
+        for i0 in range(0, L, chunk):
+            i1 = min(L, i0 + chunk)
+            j = E_idx[:, i0:i1]                                        # [B,c,K]
+            Xj, Mj = X18[bidx, j], M18[bidx, j]                         # [B,c,K,18,3], [B,c,K,18]
+            Dab = torch.sqrt(((X18[:, i0:i1, None, :, None, :] - Xj[:, :, :, None, :, :]) ** 2).sum(-1) + 1e-6)
+            rbf = torch.exp(-(((Dab[..., None] - mu) / 1.25) ** 2))
+            rbf = rbf * M18[:, i0:i1, None, :, None, None] * Mj[:, :, :, None, :, None]
+            off = R_idx[:, i0:i1, None] - R_idx[bidx, j]
+            same = (chain[:, i0:i1, None] == chain[bidx, j]).long()
+            d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
+            pos = Wpos.t()[d] + bpos                                   # one-hot @ W^T == column select
+            feat = torch.cat((pos, rbf.reshape(B, i1 - i0, K, -1)), -1)
+            E[:, i0:i1] = nn.functional.layer_norm(feat @ fp.edge_embedding.weight.t(), (self.edge_features,),
+                                                   fp.norm_edges.weight, fp.norm_edges.bias, 1e-5)
+        V = fp.node_embedding.weight.t()[fd["R_polymer_type"].long()]
+        V = nn.functional.layer_norm(V, (self.node_features,), fp.norm_nodes.weight, fp.norm_nodes.bias, 1e-5)
+        return V, E, E_idx
+
+    # ---------------------------------------------------------------------------------------
+    # a7: encoder
+    # ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_graph(self, V, E, E_idx, mask):
+        """(V [B,N,128], E [B,N,K,128], E_idx [B,N,K], mask [B,N]) -> h_V, h_E  (model_utils.py:88-94)."""
+        _require_device(V, "V")
+        W = self._weights()
+        B, N, K = E_idx.shape
+        V, E = V.float().contiguous(), E.float().contiguous()
+        E_idx32, mask32 = _i32(E_idx), _i32(mask)
+        h_V = torch.empty(B, N, H, device=V.device)
+        h_E = torch.empty(B, N, K, H, device=V.device)
+        ws = self._workspace(B, B, N, K, V.device)
+        hip.check(hip.lib().namp_encoder_fwd(W.model(), V.data_ptr(), E.data_ptr(), E_idx32.data_ptr(), mask32.data_ptr(),
+                                             h_V.data_ptr(), h_E.data_ptr(), ws.data_ptr(), ws.numel(), B, N, K,
+                                             hip.current_stream()), "encoder_fwd")
+        return h_V, h_E
+
+    @torch.no_grad()
+    def encode(self, feature_dict):
+        """ProteinMPNN.encode (model_utils.py:71-99)."""
+        V, E, E_idx = self.featurize(feature_dict)
+        h_V, h_E = self.encode_graph(V, E, E_idx, feature_dict["mask"])
+        return h_V, h_E, E_idx
+
+    # ---------------------------------------------------------------------------------------
+    # a8 / a10: parallel decoder
+    # ---------------------------------------------------------------------------------------
+    @staticmethod
+    def decoding_order(chain_mask, randn):
+        """argsort((chain_mask + 1e-4) * |randn|)  (model_utils.py:389; na_model_utils.py:623)."""
+        return torch.argsort((chain_mask + 0.0001) * torch.abs(randn))
+
+    @staticmethod
+    def ranks_of(order):
+        rank = torch.empty_like(order)
+        rank.scatter_(1, order, torch.arange(order.shape[1], device=order.device).expand_as(order))
+        return rank
+
+    @torch.no_grad()
+    def decode_graph(self, h_V, h_E, E_idx, S, mask, rank, want_logits=False):
+        """Teacher-forced decoder (model_utils.py:406-421).  S / mask / rank: [B_dec, N];
+        h_V / h_E / E_idx carry B_enc batches with B_dec % B_enc == 0."""
+        _require_device(h_V, "h_V")
+        W = self._weights()
+        B_enc, N, K = E_idx.shape
+        B_dec = S.shape[0]
+        h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
+        E32, S32, m32, r32 = _i32(E_idx), _i32(S), _i32(mask), _i32(rank)
+        log_probs = torch.empty(B_dec, N, self.num_letters, device=h_V.device)
+        logits = torch.empty_like(log_probs) if want_logits else None
+        ws = self._workspace(B_enc, B_dec, N, K, h_V.device)
+        hip.check(hip.lib().namp_decoder_fwd(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), S32.data_ptr(),
+                                             m32.data_ptr(), r32.data_ptr(), log_probs.data_ptr(), hip.ptr(logits), None,
+                                             ws.data_ptr(), ws.numel(), B_dec, B_enc, N, K, hip.current_stream()),
+                  "decoder_fwd")
+        return (log_probs, logits) if want_logits else log_probs
+
+    @torch.no_grad()
+    def score(self, feature_dict):
+        """ProteinMPNN.score (model_utils.py:366-424)."""
+        bs = feature_dict["batch_size"]
+        S_true, mask = feature_dict["S"], feature_dict["mask"]
+        B, L = S_true.shape
+        h_V, h_E, E_idx = self.encode(feature_dict)
+        chain_mask = mask * feature_dict["chain_mask"]
+        order = self.decoding_order(chain_mask, feature_dict["randn"])
+        rank = self.ranks_of(order)[:B]          # the reference's gather keeps only E_idx's batch rows (:393)
+        rep = lambda t: t.repeat(bs, *([1] * (t.dim() - 1)))
+        log_probs = self.decode_graph(h_V, h_E, E_idx, rep(S_true), rep(mask), rep(rank))
+        return {"S": rep(S_true), "log_probs": log_probs, "decoding_order": order[0]}
+
+    @torch.no_grad()
+    def unconditional_probs(self, feature_dict):
+        """ProteinMPNN.unconditional_probs (model_utils.py:329-364): nothing is decoded 'before'."""
+        bs = feature_dict["batch_size"]
+        mask = feature_dict["mask"]
+        h_V, h_E, E_idx = self.encode(feature_dict)
+        rep = lambda t: t.repeat(bs, *([1] * (t.dim() - 1)))
+        m = rep(mask)
+        zeros = torch.zeros_like(m, dtype=torch.int32)
+        return {"log_probs": self.decode_graph(h_V, h_E, E_idx, zeros, m, zeros)}
+
+    def forward(self, feature_dict, decoding_randn=None):
+        """Training-copy surface (na_model_utils.py:589-646): feature_dict -> (log_probs, probs).
+        ``decoding_randn`` replaces the internal torch.randn (:623) when reproducibility is needed."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("HIP backward kernels are not built yet: call under torch.no_grad()")
+        with torch.no_grad():
+            mask = feature_dict["mask"]
+            h_V, h_E, E_idx = self.encode(feature_dict)
+            chain_M = mask
+            if self.decode_protein_first:
+                chain_M = chain_M.masked_fill(feature_dict["protein_mask"].to(torch.bool), 0.0)
+            if decoding_randn is None:
+                decoding_randn = torch.randn(chain_M.shape, device=mask.device)
+            rank = self.ranks_of(self.decoding_order(chain_M, decoding_randn))
+            log_probs, logits = self.decode_graph(h_V, h_E, E_idx, feature_dict["S"], mask, rank, want_logits=True)
+            return log_probs, torch.softmax(logits, dim=-1)
+
+    def sample(self, feature_dict):
+        raise NotImplementedError("autoregressive sampler (SURVEY §8 f2) is not built yet")
+
+    # positional convenience wrapper in the upstream ProteinMPNN argument order
+    def forward_positional(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, randn, *, X_m,
+                           protein_mask, dna_mask, rna_mask, R_polymer_type):
+        fd = {"X": X, "S": S, "mask": mask, "chain_mask": chain_M, "R_idx": residue_idx,
+              "chain_labels": chain_encoding_all, "randn": randn, "X_m": X_m, "protein_mask": protein_mask,
+              "dna_mask": dna_mask, "rna_mask": rna_mask, "R_polymer_type": R_polymer_type, "batch_size": 1}
+        return self.score(fd)["log_probs"]

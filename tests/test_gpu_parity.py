@@ -1,0 +1,261 @@
+"""GPU parity tests: HIP kernels (through the C ABI of libnamp_hip.so) vs the CPU oracle and the
+committed goldens.  Run on an MI355X with  python -m pytest tests -m gpu.
+
+Tolerances (BASELINE.json north_star): argmax sequences identical; logits / log-probs within
+1e-3 in fp32 mode.  Copy kernels (gather) are bit-exact.  Intermediate activations are
+checked at 2e-4 (observed ~1e-5: fp32 MFMA with a different but fixed summation order).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from na_mpnn_amd import hip, spec, synth
+from na_mpnn_amd.pack import PackedWeights, image_index
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TOL_LOGP = 1e-3
+TOL_ACT = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    return hip.lib()
+
+
+@pytest.fixture(scope="module")
+def wt(weights_np):
+    return {k: torch.from_numpy(v) for k, v in weights_np.items()}
+
+
+@pytest.fixture(scope="module")
+def packed(wt, dev):
+    return PackedWeights({k: v.to(dev) for k, v in wt.items()}, 3, 3, 33, dev)
+
+
+def stream():
+    return hip.current_stream()
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def graph(dev, **kw):
+    g = synth.make_graph(**kw)
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    d = {k: v.to(dev) for k, v in t.items()}
+    return t, d
+
+
+# ------------------------------------------------------------------------------------------
+def test_pack_image_matches_host_permutation(L, dev):
+    rng = np.random.default_rng(5)
+    for out_f, in_f, ld, col0 in [(128, 128, 384, 128), (512, 128, 128, 0), (128, 512, 512, 0)]:
+        W = rng.standard_normal((out_f, ld)).astype(np.float32)
+        Wd = torch.from_numpy(W).to(dev)
+        img = torch.empty(out_f * in_f, device=dev)
+        hip.check(L.namp_pack_image(Wd.data_ptr(), ld, col0, out_f, in_f, img.data_ptr(), stream()))
+        n, k = image_index(out_f, in_f)
+        assert np.array_equal(img.cpu().numpy(), W[n, col0 + k])
+
+
+def test_gather_and_cat_bit_exact(L, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_gather.npz"))
+    nodes, nbrs = torch.from_numpy(g["nodes"]).to(dev), torch.from_numpy(g["nbrs"]).to(dev)
+    idx = torch.from_numpy(g["idx"].astype(np.int32)).to(dev)
+    B, N, K = idx.shape
+    out = torch.empty(B, N, K, 16, device=dev)
+    hip.check(L.namp_gather_nodes_f32(nodes.data_ptr(), idx.data_ptr(), out.data_ptr(), B, N, K, 16, stream()))
+    assert np.array_equal(out.cpu().numpy(), g["gather_nodes"])
+    cat = torch.empty(B, N, K, 32, device=dev)
+    hip.check(L.namp_cat_neighbors_nodes_f32(nodes.data_ptr(), nbrs.data_ptr(), idx.data_ptr(), cat.data_ptr(),
+                                             B, N, K, 16, 16, stream()))
+    assert np.array_equal(cat.cpu().numpy(), g["cat"])
+    # channel counts that are not multiples of 4 (the reference gathers C=1 masks and C=54 coordinates)
+    for c in (1, 54, 18):
+        x = torch.randn(B, N, c, device=dev)
+        o = torch.empty(B, N, K, c, device=dev)
+        hip.check(L.namp_gather_nodes_f32(x.data_ptr(), idx.data_ptr(), o.data_ptr(), B, N, K, c, stream()))
+        ref = cpu_ref.gather_nodes(x.cpu(), idx.cpu().long())
+        assert torch.equal(o.cpu(), ref)
+    # empty input is a no-op, not an error
+    hip.check(L.namp_gather_nodes_f32(nodes.data_ptr(), idx.data_ptr(), out.data_ptr(), 0, N, K, 16, stream()))
+
+
+def test_gather_cat_full_size(L, dev):
+    """cfg2-sized [1,1000,48,128|128] concat, bit-exact vs torch on the same device data."""
+    t, d = graph(dev, seed=11, batch=2, n=1000, k=48)
+    hV = torch.randn(2, 1000, 128, device=dev)
+    out = torch.empty(2, 1000, 48, 256, device=dev)
+    hip.check(L.namp_cat_neighbors_nodes_f32(hV.data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(), out.data_ptr(),
+                                             2, 1000, 48, 128, 128, stream()))
+    ref = cpu_ref.cat_neighbors_nodes(hV.cpu(), t["E"], t["E_idx"].long())
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_node_linear_and_token_table(L, dev, wt, packed):
+    t, d = graph(dev, seed=12, batch=2, n=77, k=16)
+    X = d["V"]
+    outs = [torch.empty(2, 77, 128, device=dev) for _ in range(3)]
+    S = d["S"]
+    proj = (hip.NampProj * 3)(
+        hip.NampProj(packed.addr("enc0.W1a_img"), packed.addr("enc0.b1"), None, outs[0].data_ptr()),
+        hip.NampProj(packed.addr("enc0.W1c_img"), None, None, outs[1].data_ptr()),
+        hip.NampProj(packed.addr("dec1.W1v_img"), None, packed.addr("dec1.tok"), outs[2].data_ptr()))
+    hip.check(L.namp_node_linear(X.data_ptr(), S.data_ptr(), 2, 2, 77, proj, 3, stream()))
+    W1, W1d = wt["encoder_layers.0.W1.weight"], wt["decoder_layers.1.W1.weight"]
+    r0 = t["V"] @ W1[:, :128].T + wt["encoder_layers.0.W1.bias"]
+    r1 = t["V"] @ W1[:, 256:384].T
+    tok = wt["W_s.weight"] @ W1d[:, 256:384].T
+    r2 = t["V"] @ W1d[:, 384:].T + tok[t["S"].long()]
+    assert maxdiff(outs[0], r0) < 1e-5 and maxdiff(outs[1], r1) < 1e-5 and maxdiff(outs[2], r2) < 1e-5
+    assert maxdiff(packed.view("dec1.tok").view(33, 128), tok) < 1e-5
+
+
+def test_edge_embed(L, dev, wt, packed):
+    for n, k in [(50, 48), (33, 30), (20, 7)]:
+        t, d = graph(dev, seed=13 + n, batch=2, n=n, k=k)
+        kk = t["E_idx"].shape[-1]
+        out = torch.empty_like(d["E"])
+        hip.check(L.namp_edge_embed(packed.addr("We_img"), packed.addr("We_b"), d["E"].data_ptr(), out.data_ptr(),
+                                    2, n, kk, stream()))
+        ref = torch.nn.functional.linear(t["E"], wt["W_e.weight"], wt["W_e.bias"])
+        assert maxdiff(out, ref) < 1e-5, (n, k)
+
+
+def test_enc_layer_golden(L, dev, wt, packed, golden_dir):
+    """a4: EncLayer.forward with partial masks vs the reference golden (G2)."""
+    g = np.load(os.path.join(golden_dir, "g2_layers.npz"))
+    t, d = graph(dev, seed=202, batch=1, n=128, k=48, masked_frac=0.1)
+    hV, hE = torch.empty_like(d["V"]), torch.empty_like(d["E"])
+    ws = torch.empty(L.namp_workspace_bytes(1, 1, 128, 48), dtype=torch.uint8, device=dev)
+    hip.check(L.namp_enc_layer_fwd(packed.enc_layer(1), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
+                                   d["mask"].data_ptr(), None, hV.data_ptr(), hE.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   1, 128, 48, stream()))
+    dv = maxdiff(hV[0], torch.from_numpy(g["enc_hV"]))
+    de = maxdiff(hE[0, ::16], torch.from_numpy(g["enc_hE_rows"]))
+    assert dv < TOL_ACT and de < TOL_ACT, (dv, de)
+    # explicit mask_attend (arbitrary 0/1 pattern) is honoured too
+    rng = np.random.default_rng(3)
+    ma = torch.from_numpy(rng.integers(0, 2, (1, 128, 48)).astype(np.int32))
+    hip.check(L.namp_enc_layer_fwd(packed.enc_layer(1), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
+                                   d["mask"].data_ptr(), ma.to(dev).data_ptr(), hV.data_ptr(), hE.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), 1, 128, 48, stream()))
+    rV, rE = cpu_ref.enc_layer(wt, "encoder_layers.1.", t["V"], t["E"], t["E_idx"].long(), t["mask"], ma)
+    assert maxdiff(hV, rV) < TOL_ACT and maxdiff(hE, rE) < TOL_ACT
+
+
+def run_encdec(L, dev, packed, d, B, N, K):
+    hV = torch.empty(B, N, 128, device=dev)
+    hE = torch.empty(B, N, K, 128, device=dev)
+    ws = torch.empty(L.namp_workspace_bytes(B, B, N, K), dtype=torch.uint8, device=dev)
+    hip.check(L.namp_encoder_fwd(packed.model(), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
+                                 d["mask"].data_ptr(), hV.data_ptr(), hE.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 B, N, K, stream()))
+    order = torch.argsort((d["mask"] * d["chain_mask"] + 0.0001) * torch.abs(d["randn"]))
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(N, device=dev).expand(B, -1))
+    rank = rank.to(torch.int32)
+    logp = torch.empty(B, N, 33, device=dev)
+    hip.check(L.namp_decoder_fwd(packed.model(), hV.data_ptr(), hE.data_ptr(), d["E_idx"].data_ptr(), d["S"].data_ptr(),
+                                 d["mask"].data_ptr(), rank.data_ptr(), logp.data_ptr(), None, None,
+                                 ws.data_ptr(), ws.numel(), B, B, N, K, stream()))
+    torch.cuda.synchronize()
+    return hV, hE, logp, order
+
+
+@pytest.mark.parametrize("n,tag,mf,batch", [(256, "n256", 0.05, 1), (40, "n40_LltK", 0.0, 1),
+                                             (200, "b3_n200", 0.1, 3), (1000, "n1000", 0.0, 1)])
+def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch):
+    """a7+a8, the BASELINE metric scope: (V,E,E_idx) -> log_probs vs reference goldens (G3)."""
+    g = np.load(os.path.join(golden_dir, f"g3_encdec_{tag}.npz"))
+    t, d = graph(dev, seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=mf)
+    K = t["E_idx"].shape[-1]
+    hV, hE, logp, order = run_encdec(L, dev, packed, d, batch, n, K)
+    stride = int(g["row_stride"])
+    d_hv = maxdiff(hV[:, ::stride], torch.from_numpy(g["enc_hV_layers"][-1]))
+    d_he = maxdiff(hE[:, ::max(1, n // 16)][:, :16], torch.from_numpy(g["enc_hE_rows"]))
+    assert np.array_equal(order.cpu().numpy(), g["decoding_order"]), "decoding order differs from the reference"
+    d_lp = maxdiff(logp, torch.from_numpy(g["log_probs"]))
+    assert d_hv < TOL_ACT and d_he < TOL_ACT, (d_hv, d_he)
+    assert d_lp < TOL_LOGP, d_lp
+    valid = t["mask"].bool().numpy()
+    assert np.array_equal(logp.argmax(-1).cpu().numpy()[valid], g["argmax"].astype(np.int64)[valid]), \
+        "argmax sequence differs from the reference"
+
+
+def test_decoder_batch_replication_and_unconditional(L, dev, wt, packed):
+    """B_dec = 3 x B_enc with different sequences / orders per decoder batch; rank = 0 -> unconditional."""
+    t, d = graph(dev, seed=21, batch=1, n=90, k=32)
+    hV_r, hE_r = cpu_ref.encode_from_graph(wt, t["V"], t["E"], t["E_idx"].long(), t["mask"])
+    hV, hE = hV_r.to(dev), hE_r.to(dev)
+    rng = np.random.default_rng(22)
+    S = torch.from_numpy(rng.integers(0, 25, (3, 90)).astype(np.int32))
+    randn = torch.from_numpy(rng.standard_normal((3, 90)).astype(np.float32))
+    mask3 = t["mask"].repeat(3, 1)
+    order = torch.argsort((mask3 + 0.0001) * randn.abs())
+    rank = torch.empty_like(order); rank.scatter_(1, order, torch.arange(90).expand(3, -1))
+    logp = torch.empty(3, 90, 33, device=dev)
+    ws = torch.empty(L.namp_workspace_bytes(1, 3, 90, 32), dtype=torch.uint8, device=dev)
+    hip.check(L.namp_decoder_fwd(packed.model(), hV.data_ptr(), hE.data_ptr(), d["E_idx"].data_ptr(),
+                                 S.to(dev).data_ptr(), mask3.to(dev).data_ptr(), rank.to(torch.int32).to(dev).data_ptr(),
+                                 logp.data_ptr(), None, None, ws.data_ptr(), ws.numel(), 3, 1, 90, 32, stream()))
+    E3 = t["E_idx"].long().repeat(3, 1, 1)
+    ref, _ = cpu_ref.decode_parallel(wt, hV_r.repeat(3, 1, 1), hE_r.repeat(3, 1, 1, 1), E3, S.long(), mask3,
+                                     cpu_ref.backward_mask(order, E3))
+    assert maxdiff(logp, ref) < TOL_LOGP
+    assert torch.equal(logp.argmax(-1).cpu(), ref.argmax(-1))
+    zeros = torch.zeros(3, 90, dtype=torch.int32, device=dev)
+    hip.check(L.namp_decoder_fwd(packed.model(), hV.data_ptr(), hE.data_ptr(), d["E_idx"].data_ptr(),
+                                 zeros.data_ptr(), mask3.to(dev).data_ptr(), zeros.data_ptr(),
+                                 logp.data_ptr(), None, None, ws.data_ptr(), ws.numel(), 3, 1, 90, 32, stream()))
+    refu, _ = cpu_ref.decode_parallel(wt, hV_r.repeat(3, 1, 1), hE_r.repeat(3, 1, 1, 1), E3,
+                                      torch.zeros(3, 90, dtype=torch.long), mask3, torch.zeros(3, 90, 32, 1))
+    assert maxdiff(logp, refu) < TOL_LOGP
+
+
+def test_full_size_invariants(L, dev, packed):
+    """cfg2-sized (N=1000,K=48) size-independent properties: (i) neighbour-order permutation
+    invariance of the message sums, (ii) batch independence (a complex scored alone == inside a batch)."""
+    t, d = graph(dev, seed=31, batch=2, n=1000, k=48)
+    _, _, logp, _ = run_encdec(L, dev, packed, d, 2, 1000, 48)
+    # (ii) first complex alone
+    d1 = {k: v[:1].contiguous() for k, v in d.items()}
+    _, _, logp1, _ = run_encdec(L, dev, packed, d1, 1, 1000, 48)
+    assert torch.equal(logp1[0], logp[0]), "batched and single-complex results differ (should be bit-identical)"
+    # (i) permute the neighbour slots of every residue consistently in E and E_idx
+    perm = torch.stack([torch.randperm(48, device=dev) for _ in range(2000)]).view(2, 1000, 48)
+    dp = dict(d)
+    dp["E_idx"] = torch.gather(d["E_idx"], 2, perm).contiguous()
+    dp["E"] = torch.gather(d["E"], 2, perm[..., None].expand(-1, -1, -1, 128)).contiguous()
+    _, _, logp_p, _ = run_encdec(L, dev, packed, dp, 2, 1000, 48)
+    assert maxdiff(logp_p, logp) < 2e-4
+    assert torch.isfinite(logp).all()
+    assert maxdiff(torch.logsumexp(logp, -1), torch.zeros(2, 1000)) < 1e-5     # rows are normalised
+
+
+def test_abi_error_reporting(L, dev, packed):
+    x = torch.zeros(64 * 128 + 4, device=dev)
+    out = torch.zeros(64 * 128, device=dev)
+    proj = hip.NampProj(packed.addr("Wv_img"), None, None, out.data_ptr())
+    rc = L.namp_node_linear(x.data_ptr() + 4, None, 1, 1, 64, C.byref(proj), 1, stream())     # misaligned
+    assert rc == -1 and b"aligned" in L.namp_last_error()
+    rc = L.namp_edge_embed(packed.addr("We_img"), packed.addr("We_b"), x.data_ptr(), out.data_ptr(), 1, 1, 500, stream())
+    assert rc == -1 and b"NAMP_MAX_K" in L.namp_last_error()
+    rc = L.namp_encoder_fwd(packed.model(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), out.data_ptr(),
+                            out.data_ptr(), out.data_ptr(), 16, 1, 4, 2, stream())                   # tiny workspace
+    assert rc == -3
+    with pytest.raises(RuntimeError):
+        hip.check(rc, "encoder_fwd")

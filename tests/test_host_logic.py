@@ -1,0 +1,94 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/namp.h declares,
+host-side planning logic, the drop-in module's parameter surface, and loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from na_mpnn_amd import hip, spec, synth
+from na_mpnn_amd.model import ProteinMPNN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "namp.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(namp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
+    L = hip.lib()                       # loads on a CPU-only box (no compute calls are made)
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.namp_abi_version() == hip.NAMP_ABI_VERSION
+    assert L.namp_workspace_bytes(1, 1, 1000, 48) > 0
+    assert L.namp_workspace_bytes(0, 1, 10, 4) == 0
+
+
+def test_argument_validation_needs_no_gpu():
+    L = hip.lib()
+    rc = L.namp_edge_embed(None, None, None, None, 1, 10, 4, None)
+    assert rc == -1 and b"null pointer" in L.namp_last_error()
+    rc = L.namp_pack_image(16, 100, 0, 24, 16, 32, None)          # out_f not a multiple of 16
+    assert rc == -1 and b"multiples of 16" in L.namp_last_error()
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        hip.check(rc, "pack_image")
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of the weight structs: one pointer per field, in header order."""
+    header = open(os.path.join(ROOT, "include", "namp.h")).read()
+    for cls in (hip.NampEncLayerW, hip.NampDecLayerW):
+        body = re.search(r"typedef struct %s \{(.*?)\}" % cls.__name__, header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"\*\s*([A-Za-z0-9_]+)", body)
+        assert names == [f for f, _ in cls._fields_]
+
+
+def test_module_surface_and_state_dict():
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=48, atom_dict=spec.atom_dict(),
+                    restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
+    sd, sp = m.state_dict(), spec.state_dict_spec()
+    assert list(sd) and set(sd) == set(sp)
+    assert all(tuple(sd[k].shape) == tuple(sp[k]) for k in sp)
+    assert sum(v.numel() for v in sd.values()) == 2_293_457
+    w = synth.make_weights(0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    for name in ("encode", "score", "sample", "unconditional_probs", "forward"):
+        assert callable(getattr(m, name))
+    with pytest.raises(Exception, match="atom_dict"):
+        ProteinMPNN(polytype_to_int=spec.polytype_to_int())
+
+
+def test_cpu_tensors_fail_loudly():
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=8, atom_dict=spec.atom_dict(),
+                    restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
+    cx = synth.make_complex(seed=1, n=20)
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+    fd["batch_size"] = 1
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.score(fd)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.encode_graph(torch.zeros(1, 4, 128), torch.zeros(1, 4, 2, 128), torch.zeros(1, 4, 2, dtype=torch.long),
+                       torch.ones(1, 4))
+
+
+def test_decoding_rank_helpers():
+    order = torch.tensor([[2, 0, 3, 1], [1, 2, 3, 0]])
+    rank = ProteinMPNN.ranks_of(order)
+    assert rank.tolist() == [[1, 3, 0, 2], [3, 0, 1, 2]]
+    cm = torch.tensor([[1, 0, 1, 1]])
+    rn = torch.tensor([[0.5, -3.0, -0.1, 2.0]])
+    assert ProteinMPNN.decoding_order(cm, rn).tolist() == [[1, 2, 0, 3]]     # fixed position first
+
+
+def test_synthetic_generators_are_deterministic():
+    a, b = synth.make_graph(seed=3, batch=2, n=50, k=16), synth.make_graph(seed=3, batch=2, n=50, k=16)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert (a["E_idx"][:, :, 0] == np.arange(50)).all()              # self is neighbour 0
+    g = synth.make_graph(seed=3, batch=1, n=10, k=48)
+    assert g["E_idx"].shape == (1, 10, 10)                          # L < K -> K' = L
+    w1, w2 = synth.make_weights(0), synth.make_weights(0)
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
