@@ -111,20 +111,33 @@ def gather_microbench(dev, reps=10):
 def cpu_baseline(runner, budget_s=25.0):
     """The oracle on this box's host cores, same cfg2 inputs (bounded sample)."""
     from oracle import cpu_ref
-    torch.set_num_threads(os.cpu_count() or 1)
     w = {k: torch.from_numpy(v) for k, v in runner.w_np.items()}
     g = {k: torch.from_numpy(v[:1]) for k, v in runner.g_np.items()}
     E_idx = g["E_idx"].long()
     f = lambda: cpu_ref.encdec_from_graph(w, g["V"], g["E"], E_idx, g["S"], g["mask"], g["chain_mask"], g["randn"])
-    with torch.no_grad():
-        out = f()                                           # warm-up
-        times, t_start = [], time.perf_counter()
-        while len(times) < 5 and time.perf_counter() - t_start < budget_s:
-            t0 = time.perf_counter(); out = f(); times.append(time.perf_counter() - t0)
     n = g["V"].shape[1]
-    return out, {"value": round(n / min(times), 1), "unit": "residues/s", "cores": torch.get_num_threads(),
-                 "kind": "port", "sample": f"oracle/cpu_ref.py enc+dec forward, B=1 N={n} K={E_idx.shape[-1]} fp32, "
-                                           f"best of {len(times)} after 1 warm-up, eager PyTorch CPU"}
+    ncpu = os.cpu_count() or 1
+    # eager PyTorch on a many-core host is fastest well below the core count at this problem size:
+    # try a few intra-op thread counts inside the time budget and report the best one.
+    best, out, tried, t_start = None, None, [], time.perf_counter()
+    with torch.no_grad():
+        for nt in [t for t in (8, 16, 32, 64) if t <= max(ncpu, 8)]:
+            if time.perf_counter() - t_start > budget_s:
+                break
+            torch.set_num_threads(min(nt, ncpu))
+            out = f()                                       # warm-up at this thread count
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter(); out = f(); times.append(time.perf_counter() - t0)
+                if time.perf_counter() - t_start > budget_s:
+                    break
+            tried.append((min(nt, ncpu), min(times)))
+            if best is None or min(times) < best[1]:
+                best = (min(nt, ncpu), min(times))
+    return out, {"value": round(n / best[1], 1), "unit": "residues/s", "cores": best[0], "kind": "port",
+                 "sample": f"oracle/cpu_ref.py enc+dec forward, B=1 N={n} K={E_idx.shape[-1]} fp32, eager PyTorch CPU, "
+                           f"best of <=3 after 1 warm-up per thread count; tried (threads, s): "
+                           + ", ".join(f"({a}, {b:.3f})" for a, b in tried) + f"; host has {ncpu} logical cores"}
 
 
 def main():
