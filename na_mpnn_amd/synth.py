@@ -72,7 +72,10 @@ def make_complex(seed: int, n: int, *, n_chains: int = 4, frac_protein: float = 
     X_m[poly == 0, :4] = 1
     X_m[poly != 0, 4:] = 1
     if missing_atom_frac > 0:
+        # never the kNN reference atoms CA / C1': the reference's parser masks such residues out
+        # (data_utils.py), and zeroed reference points would create exact distance ties in topk
         drop = rng.random((n, spec.N_ATOMS)) < missing_atom_frac
+        drop[:, [1, 15]] = False
         X_m[drop] = 0
     X = (X * X_m[:, :, None]).astype(np.float32)   # absent atoms are stored as 0 (data_utils.py zero-fills)
 

@@ -150,8 +150,9 @@ def test_enc_layer_golden(L, dev, wt, packed, golden_dir):
     # explicit mask_attend (arbitrary 0/1 pattern) is honoured too
     rng = np.random.default_rng(3)
     ma = torch.from_numpy(rng.integers(0, 2, (1, 128, 48)).astype(np.int32))
+    ma_d = ma.to(dev)
     hip.check(L.namp_enc_layer_fwd(packed.enc_layer(1), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
-                                   d["mask"].data_ptr(), ma.to(dev).data_ptr(), hV.data_ptr(), hE.data_ptr(),
+                                   d["mask"].data_ptr(), ma_d.data_ptr(), hV.data_ptr(), hE.data_ptr(),
                                    ws.data_ptr(), ws.numel(), 1, 128, 48, stream()))
     rV, rE = cpu_ref.enc_layer(wt, "encoder_layers.1.", t["V"], t["E"], t["E_idx"].long(), t["mask"], ma)
     assert maxdiff(hV, rV) < TOL_ACT and maxdiff(hE, rE) < TOL_ACT
@@ -209,8 +210,9 @@ def test_decoder_batch_replication_and_unconditional(L, dev, wt, packed):
     rank = torch.empty_like(order); rank.scatter_(1, order, torch.arange(90).expand(3, -1))
     logp = torch.empty(3, 90, 33, device=dev)
     ws = torch.empty(L.namp_workspace_bytes(1, 3, 90, 32), dtype=torch.uint8, device=dev)
+    S_d, mask_d, rank_d = S.to(dev), mask3.to(dev), rank.to(torch.int32).to(dev)   # keep the device buffers alive
     hip.check(L.namp_decoder_fwd(packed.model(), hV.data_ptr(), hE.data_ptr(), d["E_idx"].data_ptr(),
-                                 S.to(dev).data_ptr(), mask3.to(dev).data_ptr(), rank.to(torch.int32).to(dev).data_ptr(),
+                                 S_d.data_ptr(), mask_d.data_ptr(), rank_d.data_ptr(),
                                  logp.data_ptr(), None, None, ws.data_ptr(), ws.numel(), 3, 1, 90, 32, stream()))
     E3 = t["E_idx"].long().repeat(3, 1, 1)
     ref, _ = cpu_ref.decode_parallel(wt, hV_r.repeat(3, 1, 1), hE_r.repeat(3, 1, 1, 1), E3, S.long(), mask3,
@@ -219,7 +221,7 @@ def test_decoder_batch_replication_and_unconditional(L, dev, wt, packed):
     assert torch.equal(logp.argmax(-1).cpu(), ref.argmax(-1))
     zeros = torch.zeros(3, 90, dtype=torch.int32, device=dev)
     hip.check(L.namp_decoder_fwd(packed.model(), hV.data_ptr(), hE.data_ptr(), d["E_idx"].data_ptr(),
-                                 zeros.data_ptr(), mask3.to(dev).data_ptr(), zeros.data_ptr(),
+                                 zeros.data_ptr(), mask_d.data_ptr(), zeros.data_ptr(),
                                  logp.data_ptr(), None, None, ws.data_ptr(), ws.numel(), 3, 1, 90, 32, stream()))
     refu, _ = cpu_ref.decode_parallel(wt, hV_r.repeat(3, 1, 1), hE_r.repeat(3, 1, 1, 1), E3,
                                       torch.zeros(3, 90, dtype=torch.long), mask3, torch.zeros(3, 90, 32, 1))
