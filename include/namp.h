@@ -90,8 +90,10 @@ int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors,
 /* out_p = X . W_p^T + bias_p (+ tok_p[S]) for nproj <= 8 blocks; X has G_src = B_src*N rows and
  * is broadcast over output batches (row n reads batch (n / N) % B_src). */
 typedef struct NampProj { const float* img; const float* bias; const float* tok; float* out; } NampProj;
+/* pre (nullable, needs B_out == B_src): h = pre->img . X + pre->bias is computed first, stored to
+ * pre->out, and the projections apply to h — W_v followed by the first layer's tables in one launch. */
 int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int N,
-                     const NampProj* proj, int nproj, void* stream);
+                     const NampProj* proj, int nproj, const NampProj* pre, void* stream);
 
 /* h_E = W_e . E + b_e (model_utils.py:89) */
 int namp_edge_embed(const float* We_img, const float* We_b, const float* E, float* h_E,
@@ -109,11 +111,12 @@ int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_
 int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx,
                          const float* Pa, const float* Pc, float* h_E_out, int B, int N, int K, void* stream);
 /* Residue tail shared by EncLayer / DecLayer (model_utils.py:690-697, 646-656):
- * h_V' = mask * LN2(x + FFN(x)),  x = LN1(h_V + sum_t partial[n][t]). */
+ * h_V' = mask * LN2(x + FFN(x)),  x = LN1(h_V + sum_t partial[n][t]),
+ * fused with nproj (0..8) projections of h_V' (as namp_node_linear) that the next edge kernels gather. */
 int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                      const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
                      const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
-                     int G, int K, void* stream);
+                     const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream);
 /* Message phase of DecLayer on the implicit context h_ESV (model_utils.py:416-418, 640-646):
  * first layer = W1e.h_E_ik + Pa[i] + (rank[j]<rank[i] ? Pbw[j] : Pfw[j]).  Decoder batch b uses
  * encoder batch b % B_enc (the reference's .repeat(B_decoder, ...), model_utils.py:399-404). */

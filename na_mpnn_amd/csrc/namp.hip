@@ -81,8 +81,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_EMBED>, NAMP_IMG_BYTES);
-  set((const void*)node_ffn_kernel, (16 + 8 * 16) * FFN_LD * 4);
+  set((const void*)node_update_kernel, NODE_UPDATE_LDS);
 }
 
 int ensure_attributes() {
@@ -108,15 +107,17 @@ int launch_edge(EdgeArgs a, hipStream_t s) {
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
-  const int lds = (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
+  const int lds = (MODE == MODE_EMBED) ? 0 : 2 * NAMP_IMG_BYTES;
   hipLaunchKernelGGL(edge_mlp_kernel<MODE>, dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
 }
 
 int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
-                       const NampProj* proj, int nproj, hipStream_t s) {
+                       const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s) {
   NodeLinearArgs a;
   a.X = X; a.S = S; a.G_out = G_out; a.G_src = G_src; a.N = N; a.nproj = nproj;
+  a.pre.img = pre ? pre->img : nullptr; a.pre.bias = pre ? pre->bias : nullptr;
+  a.pre.tok = nullptr; a.pre.out = pre ? pre->out : nullptr;
   for (int i = 0; i < 8; ++i) {
     const NampProj& p = proj[i < nproj ? i : 0];
     a.p[i].img = p.img; a.p[i].bias = p.bias; a.p[i].tok = p.tok; a.p[i].out = p.out;
@@ -126,17 +127,21 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
   return NAMP_OK;
 }
 
-int launch_node_ffn(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
-                    const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                    const float* hV, const float* partial, const int32_t* mask, float* hV_out,
-                    int G, int TPN, hipStream_t s) {
+int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+                       const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
+                       const float* hV, const float* partial, const int32_t* mask, float* hV_out,
+                       const NampProj* proj, int nproj, const int32_t* S, int G, int TPN, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
-  NodeFfnArgs a;
+  NodeUpdateArgs a;
   a.hV = hV; a.partial = partial; a.mask = mask; a.ln1_g = ln1_g; a.ln1_b = ln1_b;
   a.Win_img = Win_img; a.b_in = b_in; a.Wout_img = Wout_img; a.b_out = b_out;
-  a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.hV_out = hV_out; a.G = G; a.TPN = TPN;
-  hipLaunchKernelGGL(node_ffn_kernel, dim3((G + 15) / 16), dim3(512), (16 + 8 * 16) * FFN_LD * 4, s, a);
+  a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.hV_out = hV_out; a.S = S; a.G = G; a.TPN = TPN; a.nproj = nproj;
+  for (int i = 0; i < 8; ++i) {
+    if (i < nproj) { a.p[i].img = proj[i].img; a.p[i].bias = proj[i].bias; a.p[i].tok = proj[i].tok; a.p[i].out = proj[i].out; }
+    else { a.p[i].img = nullptr; a.p[i].bias = nullptr; a.p[i].tok = nullptr; a.p[i].out = nullptr; }
+  }
+  hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_UPDATE_LDS, s, a);
   return NAMP_OK;
 }
 
@@ -218,8 +223,10 @@ int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors,
 }
 
 int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int N, const NampProj* proj,
-                     int nproj, void* stream) {
+                     int nproj, const NampProj* pre, void* stream) {
   REQUIRE_PTR(X);
+  if (pre) { REQUIRE_PTR(pre->img); OPTIONAL_PTR(pre->bias); OPTIONAL_PTR(pre->out);
+             REQUIRE(B_out == B_src, "namp_node_linear: a pre-linear stage needs B_out == B_src"); }
   REQUIRE(proj != nullptr && nproj >= 1 && nproj <= 8, "namp_node_linear: nproj=%d must be in [1,8]", nproj);
   REQUIRE(B_out >= 1 && B_src >= 1 && N >= 1, "namp_node_linear: bad dims");
   for (int i = 0; i < nproj; ++i) {
@@ -227,7 +234,7 @@ int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int
     REQUIRE(!(proj[i].tok && !S), "namp_node_linear: proj[%d].tok given but S is null", i);
   }
   ProfScope prof_(NAMP_KIND_NODE_LINEAR, (hipStream_t)stream);
-  launch_node_linear(X, S, B_out * N, B_src * N, N, proj, nproj, (hipStream_t)stream);
+  launch_node_linear(X, S, B_out * N, B_src * N, N, proj, nproj, pre, (hipStream_t)stream);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -289,15 +296,20 @@ int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t
 
 int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                      const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out, int G, int K,
-                     void* stream) {
+                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
+                     const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
   REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_img); REQUIRE_PTR(b_in); REQUIRE_PTR(Wout_img);
   REQUIRE_PTR(b_out); REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
   OPTIONAL_PTR(partial);
   REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_node_update: bad dims G=%d K=%d", G, K);
+  REQUIRE(nproj >= 0 && nproj <= 8 && (nproj == 0 || proj != nullptr), "namp_node_update: nproj=%d must be in [0,8]", nproj);
+  for (int i = 0; i < nproj; ++i) {
+    REQUIRE_PTR(proj[i].img); REQUIRE_PTR(proj[i].out); OPTIONAL_PTR(proj[i].bias); OPTIONAL_PTR(proj[i].tok);
+    REQUIRE(!(proj[i].tok && !S), "namp_node_update: proj[%d].tok given but S is null", i);
+  }
   ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
-  int rc = launch_node_ffn(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
-                           G, (K + 15) / 16, (hipStream_t)stream);
+  int rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
+                              proj, nproj, S, G, (K + 15) / 16, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -379,13 +391,13 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
   float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_enc_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
   NampProj p1[2] = {{w->W1a_img, w->b1, nullptr, Pa}, {w->W1c_img, nullptr, nullptr, Pc}};
-  if ((rc = namp_node_linear(h_V, nullptr, B, B, N, p1, 2, stream))) return rc;
+  if ((rc = namp_node_linear(h_V, nullptr, B, B, N, p1, 2, nullptr, stream))) return rc;
   if ((rc = namp_enc_message(w, h_E, E_idx, mask, mask_attend, Pa, Pc, partial, B, N, K, stream))) return rc;
-  if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
-                             partial, mask, h_V_out, G, K, stream)))
-    return rc;
+  // Pa / Pc are free again once the message kernel has run (stream order): reuse them for W11a / W11c
   NampProj p2[2] = {{w->W11a_img, w->b11, nullptr, Pa}, {w->W11c_img, nullptr, nullptr, Pc}};
-  if ((rc = namp_node_linear(h_V_out, nullptr, B, B, N, p2, 2, stream))) return rc;
+  if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
+                             partial, mask, h_V_out, p2, 2, nullptr, G, K, stream)))
+    return rc;
   return namp_enc_edge_update(w, h_E, E_idx, Pa, Pc, h_E_out, B, N, K, stream);
 }
 
@@ -405,33 +417,32 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_encoder_fwd: workspace too small (%zu bytes)", ws_bytes);
 
-  NampProj pv[1] = {{w->Wv_img, w->Wv_b, nullptr, hv[0]}};
-  if ((rc = namp_node_linear(V, nullptr, B, B, N, pv, 1, stream))) return rc;
-  if ((rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
+  // h_V = W_v.V + b (model_utils.py:88) chained with enc[0]'s Pa / Pc tables in one launch
   const NampEncLayerW* L0 = &w->enc[0];
+  NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
-  if ((rc = namp_node_linear(hv[0], nullptr, B, B, N, p0, 2, stream))) return rc;
+  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  if ((rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
   int cur = 0;     // hv[cur] holds the layer input
-  int tb = 0;      // P[tb], P[tb+1] hold this layer's Pa, Pc for the message phase
   for (int l = 0; l < w->n_enc; ++l) {
     const NampEncLayerW* L = &w->enc[l];
     const bool last = (l + 1 == w->n_enc);
     float* out = last ? h_V : hv[cur ^ 1];
-    if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[tb], P[tb + 1], partial, B, N, K, stream))) return rc;
-    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
-                               hv[cur], partial, mask, out, G, K, stream)))
-      return rc;
-    const int te = tb ^ 2;   // tables for the edge update (and, above them, for the next layer)
-    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[te]}, {L->W11c_img, nullptr, nullptr, P[te + 1]}, {}, {}};
+    // P[0],P[1]: this layer's message tables; P[2],P[3]: its edge-update tables.  The node update
+    // writes P[2],P[3] and, for the next layer, P[0],P[1] again (free once the message kernel ran).
+    if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[0], P[1], partial, B, N, K, stream))) return rc;
+    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[2]}, {L->W11c_img, nullptr, nullptr, P[3]}, {}, {}};
     int np = 2;
     if (!last) {
       const NampEncLayerW* Ln = &w->enc[l + 1];
-      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[tb]};
-      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[tb + 1]};
+      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[0]};
+      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[1]};
       np = 4;
     }
-    if ((rc = namp_node_linear(out, nullptr, B, B, N, pe, np, stream))) return rc;
-    if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[te], P[te + 1], h_E, B, N, K, stream))) return rc;
+    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
+                               hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
+      return rc;
+    if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[2], P[3], h_E, B, N, K, stream))) return rc;
     cur ^= 1;
   }
   return NAMP_OK;
@@ -459,13 +470,20 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
   if (!Pfw[w->n_dec - 1] || !partial) return fail(NAMP_EWORKSPACE, "namp_decoder_fwd: workspace too small (%zu bytes)", ws_bytes);
 
   // encoder-context tables Pfw_l = W1v_l . h_V_enc (h_EXV_encoder of model_utils.py:410-413)
-  NampProj pf[NAMP_MAX_LAYERS];
-  for (int l = 0; l < w->n_dec; ++l) pf[l] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
-  if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, w->n_dec, stream))) return rc;
-  // layer-0 residue tables from h_V^(0) = h_V_enc broadcast over decoder batches
+  // layer-0 residue tables from h_V^(0) = h_V_enc broadcast over decoder batches, and the encoder-context
+  // tables; one launch when decoder and encoder batches coincide (<= 8 blocks), two otherwise
   const NampDecLayerW* D0 = &w->dec[0];
+  NampProj pf[NAMP_MAX_LAYERS + 2];
+  int nf = 0;
+  for (int l = 0; l < w->n_dec; ++l) pf[nf++] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
   NampProj p0[2] = {{D0->W1a_img, D0->b1, nullptr, Pa}, {D0->W1v_img, nullptr, D0->tok, Pbw}};
-  if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, p0, 2, stream))) return rc;
+  if (B_dec == B_enc && nf + 2 <= 8) {
+    pf[nf++] = p0[0]; pf[nf++] = p0[1];
+    if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, pf, nf, nullptr, stream))) return rc;
+  } else {
+    if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, nf, nullptr, stream))) return rc;
+    if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, p0, 2, nullptr, stream))) return rc;
+  }
   const float* hin = h_V_enc;
   if (B_dec != B_enc) {
     for (int b = 0; b < B_dec; b += B_enc) {
@@ -481,14 +499,17 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
     const bool last = (l + 1 == w->n_dec);
     float* out = (last && h_V_dec) ? h_V_dec : hv[cur ^ 1];
     if ((rc = namp_dec_message(D, h_E, E_idx, rank, Pa, Pbw, Pfw[l], partial, B_dec, B_enc, N, K, stream))) return rc;
-    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
-                               partial, mask, out, Gd, K, stream)))
-      return rc;
-    if (!last) {
+    NampProj pn[2] = {{}, {}};
+    int np = 0;
+    if (!last) {     // next layer's Pa / Pbw (free once this layer's message kernel ran)
       const NampDecLayerW* Dn = &w->dec[l + 1];
-      NampProj pn[2] = {{Dn->W1a_img, Dn->b1, nullptr, Pa}, {Dn->W1v_img, nullptr, Dn->tok, Pbw}};
-      if ((rc = namp_node_linear(out, S, B_dec, B_dec, N, pn, 2, stream))) return rc;
+      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, Pa};
+      pn[1] = {Dn->W1v_img, nullptr, Dn->tok, Pbw};
+      np = 2;
     }
+    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
+                               partial, mask, out, pn, np, S, Gd, K, stream)))
+      return rc;
     hin = out;
     cur ^= 1;
   }

@@ -76,8 +76,11 @@ __global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes, const 
 // ------------------------------------------------------------------------------------------
 // edge_mlp_kernel — the hot kernel.  One wave = one 16-row tile = 16 of the K neighbours of
 // one residue; a workgroup = (blockDim/64)/TPN residues, TPN = ceil(K/16) tiles per residue.
-// The 128x128 weight images of the three layers are DMA'd into a 2 x 64 KiB LDS ring and
-// shared by all waves; activations stay in registers (namp_device.h).
+// Weights: the first layer's 128x128 image streams from L2 (prefetched fragment loads) while the
+// images of layers 2 and 3 are DMA'd (global_load_lds) into 2 x 64 KiB of LDS shared by all waves;
+// one barrier after layer 1 is the only workgroup synchronisation, so from there on the 3 waves of
+// a SIMD drift apart and one wave's GELU (VALU) overlaps another's MFMAs.  Activations stay in
+// registers (namp_device.h).
 //
 // With W1 = [W1a | W1b | W1c] applied to [h_V_i | h_E_ik | h_V_j]  (EncLayer,
 // model_utils.py:684-687,699-702) the first layer is evaluated as
@@ -130,9 +133,6 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = blockDim.x >> 6;
-
-  dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
-  if (MODE != MODE_EMBED) dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
 
   const int m = lane & 15, g = lane >> 4;
   const int npw = nwaves / a.TPN;                      // residues per workgroup
@@ -187,9 +187,51 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
 
-  // ---- layer 1 (T): acc += W1b . h_E
-  wait_dma_and_sync();
-  chain_gemm<8, 8, false>(acc, x, w0, 8);
+  // ---- layer 1 (T): acc += W1b . h_E.  Weight fragments stream from L2 one k-step ahead of their
+  // MFMAs; the LDS-DMA of the W2 / W3 images is issued in small pieces between them (the VM counter
+  // retires in order, so a bulk DMA issued up front would stall every later fragment load behind it).
+  {
+    const f4* w = (const f4*)a.W1_img + lane;
+    f4 cur[8], nxt[8];
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) cur[tn] = w[tn * 64];
+    int dma_c = wave;                                  // chunk ids 0..63 -> buf0 (W2), 64..127 -> buf1 (W3)
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk) {
+      if (tk + 1 < 8) {
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) nxt[tn] = w[((tk + 1) * 8 + tn) * 64];
+      }
+      if (MODE != MODE_EMBED) {
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep) {
+          if (dma_c < 128) {
+            const float* gsrc = (dma_c < 64) ? a.W2_img : a.W3_img;
+            dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
+            dma_c += nwaves;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(cur[tn][r], x[tk][r], acc[tn]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tk + 1 < 8) {
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) cur[tn] = nxt[tn];
+      }
+    }
+    if (MODE != MODE_EMBED) {
+      while (dma_c < 128) {                            // only for very small workgroups (< 6 waves)
+        const float* gsrc = (dma_c < 64) ? a.W2_img : a.W3_img;
+        dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
+        dma_c += nwaves;
+      }
+    }
+  }
 
   if (MODE == MODE_EMBED) {
     if (valid) {
@@ -202,22 +244,20 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
-  __syncthreads();                                   // every wave is done with buf0
-  dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);
+  wait_dma_and_sync();                               // W2 / W3 images have landed in LDS
 
   // ---- layer 2 (T)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false>(acc, x, w1, 8);
+  chain_gemm<8, 8, false>(acc, x, w0, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
-  wait_dma_and_sync();
 
   if (MODE == MODE_ENC_EDGE) {
     // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false>(acc, x, w0, 8);
+    chain_gemm<8, 8, false>(acc, x, w1, 8);
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const float b = a.b3[16 * t + m];
       acc[t] = (f4){b, b, b, b};
     }
-    chain_gemm<8, 8, true>(acc, x, w0, 8);
+    chain_gemm<8, 8, true>(acc, x, w1, 8);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll
@@ -267,6 +307,8 @@ struct NodeLinearArgs {
   const int32_t* S;    // [G_out] tokens (only if some tok != null)
   int G_out, G_src, N; // output row n reads source row ((n / N) % (G_src / N)) * N + n % N
   int nproj;
+  ProjDesc pre;        // optional first stage: h = pre.img . X + pre.bias (stored to pre.out), the
+                       // projections then apply to h (h_V = W_v.V + b feeding enc0's tables in one launch)
   ProjDesc p[8];
 };
 
@@ -292,9 +334,21 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   const float* src = a.X + (long)src_row * NAMP_H + 4 * g;
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+  if (a.pre.img) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = a.pre.bias ? *(const f4*)(a.pre.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+    chain_gemm_global<8, 8, false>(acc, x, (const f4*)a.pre.img + lane, 8);
+    if (pi == 0 && valid && a.pre.out) {
+      float* dst = a.pre.out + (long)row * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = acc[t];
+  }
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = d.bias ? *(const f4*)(d.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
+  chain_gemm_global<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
   if (d.tok) {
     const float* tk = d.tok + (long)a.S[rr] * NAMP_H + 4 * g;
 #pragma unroll
@@ -308,15 +362,20 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// node_ffn_kernel — the per-residue tail of EncLayer / DecLayer (model_utils.py:690-697,646-656):
-//      x  = LayerNorm1(h_V + sum_t partial[n][t])          (partial already carries mask / 30)
-//      y  = LayerNorm2(x + W_out . gelu(W_in . x + b_in) + b_out)
+// node_update_kernel — the per-residue tail of EncLayer / DecLayer (model_utils.py:690-697,646-656)
+// fused with the residue-level projections the NEXT edge kernels gather:
+//      x    = LayerNorm1(h_V + sum_t partial[n][t])          (partial already carries mask / 30)
+//      y    = LayerNorm2(x + W_out . gelu(W_in . x + b_in) + b_out)
 //      h_V' = mask * y
-// 16 residues per workgroup, 8 waves; wave w owns hidden units [64w, 64w+64) of the 512-wide
-// FFN: W_in slice (T) -> gelu -> W_out slice (T) gives a partial [16 x 128] per wave, reduced
-// through LDS.  Weight fragments stream from L2 (each is used once per workgroup).
+//      out_p = W_p . h_V' + bias_p (+ tok_p[S])               p < nproj <= 8
+// 16 residues per workgroup, 8 waves (2 per SIMD, up to 256 VGPRs each).  Wave w owns hidden units
+// [64w, 64w+64) of the 512-wide FFN: W_in slice (T) -> gelu -> W_out slice (T) gives a partial
+// [16 x 128] per wave, reduced through LDS; then wave w computes output channels [16w,16w+16) of
+// every projection.  At B=1 this kernel is latency-bound (63 workgroups), so every weight
+// fragment of a phase is requested up front (explicit register arrays + sched_barrier) instead of
+// leaving it to the compiler's one-deep pipelining.
 // ------------------------------------------------------------------------------------------
-struct NodeFfnArgs {
+struct NodeUpdateArgs {
   const float* hV;        // [G][128]
   const float* partial;   // [G][TPN][128] or null (no message term)
   const int32_t* mask;    // [G] or null
@@ -327,21 +386,74 @@ struct NodeFfnArgs {
   const float* b_out;     // [128]
   const float* ln2_g; const float* ln2_b;
   float* hV_out;          // [G][128]
-  int G, TPN;
+  const int32_t* S;       // [G] tokens for tok tables (or null)
+  int G, TPN, nproj;
+  ProjDesc p[8];
 };
 
 #define FFN_LD 132   // padded row stride (floats) of the LDS tiles: conflict-free ds_write_b128
+#define NODE_UPDATE_LDS ((16 + 16 + 8 * 16) * FFN_LD * 4)
 
-__global__ __launch_bounds__(512) void node_ffn_kernel(const NodeFfnArgs a) {
+template <int NP>
+__device__ __forceinline__ void node_proj_group(const NodeUpdateArgs& a, const int p0, const f4 (&x)[8], const int wave,
+                                                const int lane, const int row, const bool valid) {
+  const int g = lane >> 4;
+  ProjDesc d[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    d[q] = a.p[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (p0 + q == k) d[q] = a.p[k];
+  }
+  const int np = a.nproj - p0;             // projections live in this group (wave-uniform)
+  f4 wf[8][NP];
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (q < np) wf[tk][q] = ((const f4*)d[q].img)[(tk * 8 + wave) * 64 + lane];
+  __builtin_amdgcn_sched_barrier(0);
+  f4 acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    acc[q] = (q < np && d[q].bias) ? *(const f4*)(d[q].bias + 16 * wave + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        if (q < np) acc[q] = mfma4(wf[tk][q][r], x[tk][r], acc[q]);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    if (q < np) {
+      if (d[q].tok) acc[q] += *(const f4*)(d[q].tok + (long)a.S[row] * NAMP_H + 16 * wave + 4 * g);
+      if (valid) *(f4*)(d[q].out + (long)row * NAMP_H + 16 * wave + 4 * g) = acc[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = (float*)smem;                 // [16][FFN_LD]   x = LN1(...)
-  float* ps = xs + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial outputs
+  float* xs = (float*)smem;                 // [16][FFN_LD]    x = LN1(...)
+  float* ys = xs + 16 * FFN_LD;             // [16][FFN_LD]    h_V' tile for the projections
+  float* ps = ys + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial FFN outputs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
   const int row = blockIdx.x * 16 + m;
-  const int rr = row < a.G ? row : 0;
+  const bool valid = row < a.G;
+  const int rr = valid ? row : 0;
 
+  // all W_in fragments of this wave's hidden slice: 8 tk x 4 tn
+  f4 win[8][4];
+  {
+    const f4* w = (const f4*)a.Win_img + (4 * wave) * 64 + lane;
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) win[tk][tn] = w[(tk * 32 + tn) * 64];
+  }
   // LN1 in the T layout, redundantly per wave (cheap, avoids a barrier)
   f4 x[8];
   {
@@ -355,8 +467,9 @@ __global__ __launch_bounds__(512) void node_ffn_kernel(const NodeFfnArgs a) {
         for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(ps_ + 16 * t);
       }
     }
-    layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
   if (wave == 0) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(xs + m * FFN_LD + 16 * t + 4 * g) = x[t];
@@ -365,14 +478,33 @@ __global__ __launch_bounds__(512) void node_ffn_kernel(const NodeFfnArgs a) {
   f4 hacc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) hacc[t] = *(const f4*)(a.b_in + 64 * wave + 16 * t + 4 * g);
-  chain_gemm<8, 4, false>(hacc, x, (const f4*)a.Win_img + (4 * wave) * 64 + lane, 32);
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) hacc[tn] = mfma4(win[tk][tn][r], x[tk][r], hacc[tn]);
+  // all W_out fragments over this wave's 64 hidden units: k tiles 4w..4w+3, 8 tn  (reuses win's registers)
+  f4 wo[4][8];
+  {
+    const f4* w = (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane;
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) wo[tk][tn] = w[(tk * 8 + tn) * 64];
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) hacc[t] = gelu4(hacc[t]);
-  // partial output over this wave's 64 hidden units: k tiles 4w..4w+3 of W_out
   f4 oacc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) oacc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<4, 8, false>(oacc, hacc, (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane, 8);
+#pragma unroll
+  for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[tk][tn][r], hacc[tk][r], oacc[tn]);
   {
     float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
 #pragma unroll
@@ -395,12 +527,18 @@ __global__ __launch_bounds__(512) void node_ffn_kernel(const NodeFfnArgs a) {
     for (int o = 1; o < 32; o <<= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q * (1.0f / 128.0f) + 1e-5f);
     const int orow = blockIdx.x * 16 + r;
-    if (orow < a.G) {
-      const float mk = a.mask ? (float)a.mask[orow] : 1.0f;
-      f4 y = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
-      *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
-    }
+    const float mk = (a.mask && orow < a.G) ? (float)a.mask[orow] : 1.0f;
+    const f4 y = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
+    *(f4*)(ys + r * FFN_LD + c) = y;
+    if (orow < a.G) *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
   }
+  if (a.nproj == 0) return;
+  __syncthreads();
+  // projections of h_V': wave w -> output channels [16w, 16w+16) of every block
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
+  node_proj_group<4>(a, 0, x, wave, lane, rr, valid);
+  if (a.nproj > 4) node_proj_group<4>(a, 4, x, wave, lane, rr, valid);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -132,7 +132,7 @@ class PackedWeights:
         ws = src("W_s.weight")
         for l in range(self.n_dec):
             proj = hip.NampProj(self.addr(f"dec{l}.W1s_img"), None, None, self.addr(f"dec{l}.tok"))
-            hip.check(L.namp_node_linear(ws.data_ptr(), None, 1, 1, self.vocab, C.byref(proj), 1, stream),
+            hip.check(L.namp_node_linear(ws.data_ptr(), None, 1, 1, self.vocab, C.byref(proj), 1, None, stream),
                       f"tok table {l}")
         torch.cuda.current_stream().synchronize()
         del keep

@@ -114,7 +114,7 @@ def test_node_linear_and_token_table(L, dev, wt, packed):
         hip.NampProj(packed.addr("enc0.W1a_img"), packed.addr("enc0.b1"), None, outs[0].data_ptr()),
         hip.NampProj(packed.addr("enc0.W1c_img"), None, None, outs[1].data_ptr()),
         hip.NampProj(packed.addr("dec1.W1v_img"), None, packed.addr("dec1.tok"), outs[2].data_ptr()))
-    hip.check(L.namp_node_linear(X.data_ptr(), S.data_ptr(), 2, 2, 77, proj, 3, stream()))
+    hip.check(L.namp_node_linear(X.data_ptr(), S.data_ptr(), 2, 2, 77, proj, 3, None, stream()))
     W1, W1d = wt["encoder_layers.0.W1.weight"], wt["decoder_layers.1.W1.weight"]
     r0 = t["V"] @ W1[:, :128].T + wt["encoder_layers.0.W1.bias"]
     r1 = t["V"] @ W1[:, 256:384].T
@@ -252,7 +252,7 @@ def test_abi_error_reporting(L, dev, packed):
     x = torch.zeros(64 * 128 + 4, device=dev)
     out = torch.zeros(64 * 128, device=dev)
     proj = hip.NampProj(packed.addr("Wv_img"), None, None, out.data_ptr())
-    rc = L.namp_node_linear(x.data_ptr() + 4, None, 1, 1, 64, C.byref(proj), 1, stream())     # misaligned
+    rc = L.namp_node_linear(x.data_ptr() + 4, None, 1, 1, 64, C.byref(proj), 1, None, stream())     # misaligned
     assert rc == -1 and b"aligned" in L.namp_last_error()
     rc = L.namp_edge_embed(packed.addr("We_img"), packed.addr("We_b"), x.data_ptr(), out.data_ptr(), 1, 1, 500, stream())
     assert rc == -1 and b"NAMP_MAX_K" in L.namp_last_error()
