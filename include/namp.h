@@ -123,6 +123,18 @@ int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_im
 int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
                      const float* Pa, const float* Pbw, const float* Pfw, float* partial,
                      int B_dec, int B_enc, int N, int K, void* stream);
+/* Fused forms: message phase + residue tail + projections in ONE launch (the workgroup that summed a
+ * residue's messages also updates it).  Same results as namp_enc_message + namp_node_update resp.
+ * namp_dec_message + namp_node_update; preferred while B*N <= namp_fused_tail_max_residues().
+ * The projection outputs must not alias Pa / Pc / Pbw (other workgroups are still gathering those). */
+int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
+                            const int32_t* mask_attend, const float* Pa, const float* Pc, const float* h_V,
+                            float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream);
+int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
+                            const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
+                            float* h_V_out, const NampProj* proj, int nproj, const int32_t* S,
+                            int B_dec, int B_enc, int N, int K, void* stream);
+int namp_fused_tail_max_residues(void);
 /* log_softmax(W_out . h_V + b) (model_utils.py:420-421); logits may be NULL. */
 int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const float* h_V,
                             float* log_probs, float* logits, int G, int vocab, void* stream);

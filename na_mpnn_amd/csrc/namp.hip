@@ -78,10 +78,13 @@ void set_lds_attributes() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) g_attr_err = e;
   };
-  set((const void*)edge_mlp_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
-  set((const void*)node_update_kernel, NODE_UPDATE_LDS);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, false>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, false>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, true>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, true>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_ENC_EDGE, false>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_EMBED, false>, NAMP_IMG_BYTES);
+  set((const void*)node_update_kernel, NODE_TAIL_LDS);
 }
 
 int ensure_attributes() {
@@ -90,6 +93,11 @@ int ensure_attributes() {
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
   return NAMP_OK;
 }
+
+// The message kernels update their own residues in-launch (fused tail) while the batch is small enough
+// that this beats a separate 16-residue-per-workgroup node_update launch: every workgroup of the fused
+// form re-streams the 768 KiB of FFN + projection weights for <= 12 residues.
+#define NAMP_FUSED_TAIL_MAX_RESIDUES 4096
 
 struct EdgeGeom { int tpn, nwaves, npw, grid; };
 EdgeGeom edge_geom(int G, int K) {
@@ -101,14 +109,37 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE>
+template <int MODE, bool TAIL = false>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
-  const int lds = (MODE == MODE_EMBED) ? 0 : 2 * NAMP_IMG_BYTES;
-  hipLaunchKernelGGL(edge_mlp_kernel<MODE>, dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
+  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  return NAMP_OK;
+}
+
+void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+               const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b, const float* hV,
+               const int32_t* mask, float* hV_out, const NampProj* proj, int nproj, const int32_t* S) {
+  t.hV = hV; t.mask = mask; t.ln1_g = ln1_g; t.ln1_b = ln1_b; t.Win_img = Win_img; t.b_in = b_in;
+  t.Wout_img = Wout_img; t.b_out = b_out; t.ln2_g = ln2_g; t.ln2_b = ln2_b; t.hV_out = hV_out; t.S = S;
+  t.nproj = nproj;
+  for (int i = 0; i < 8; ++i) {
+    if (i < nproj) { t.p[i].img = proj[i].img; t.p[i].bias = proj[i].bias; t.p[i].tok = proj[i].tok; t.p[i].out = proj[i].out; }
+    else { t.p[i].img = nullptr; t.p[i].bias = nullptr; t.p[i].tok = nullptr; t.p[i].out = nullptr; }
+  }
+}
+
+int check_proj(const char* fn, const NampProj* proj, int nproj, const int32_t* S) {
+  if (nproj < 0 || nproj > 8 || (nproj > 0 && !proj)) return fail(NAMP_EINVAL, "%s: nproj=%d must be in [0,8]", fn, nproj);
+  for (int i = 0; i < nproj; ++i) {
+    if (!proj[i].img || !proj[i].out) return fail(NAMP_EINVAL, "%s: proj[%d] has a null image / output", fn, i);
+    if (!aligned16(proj[i].img) || !aligned16(proj[i].out) || !aligned16(proj[i].bias) || !aligned16(proj[i].tok))
+      return fail(NAMP_EINVAL, "%s: proj[%d] pointers must be 16-byte aligned", fn, i);
+    if (proj[i].tok && !S) return fail(NAMP_EINVAL, "%s: proj[%d].tok given but S is null", fn, i);
+  }
   return NAMP_OK;
 }
 
@@ -134,14 +165,9 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   int rc = ensure_attributes();
   if (rc) return rc;
   NodeUpdateArgs a;
-  a.hV = hV; a.partial = partial; a.mask = mask; a.ln1_g = ln1_g; a.ln1_b = ln1_b;
-  a.Win_img = Win_img; a.b_in = b_in; a.Wout_img = Wout_img; a.b_out = b_out;
-  a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.hV_out = hV_out; a.S = S; a.G = G; a.TPN = TPN; a.nproj = nproj;
-  for (int i = 0; i < 8; ++i) {
-    if (i < nproj) { a.p[i].img = proj[i].img; a.p[i].bias = proj[i].bias; a.p[i].tok = proj[i].tok; a.p[i].out = proj[i].out; }
-    else { a.p[i].img = nullptr; a.p[i].bias = nullptr; a.p[i].tok = nullptr; a.p[i].out = nullptr; }
-  }
-  hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_UPDATE_LDS, s, a);
+  fill_tail(a.t, ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, hV, mask, hV_out, proj, nproj, S);
+  a.partial = partial; a.G = G; a.TPN = TPN;
+  hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_TAIL_LDS, s, a);
   return NAMP_OK;
 }
 
@@ -302,13 +328,10 @@ int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_im
   REQUIRE_PTR(b_out); REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
   OPTIONAL_PTR(partial);
   REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_node_update: bad dims G=%d K=%d", G, K);
-  REQUIRE(nproj >= 0 && nproj <= 8 && (nproj == 0 || proj != nullptr), "namp_node_update: nproj=%d must be in [0,8]", nproj);
-  for (int i = 0; i < nproj; ++i) {
-    REQUIRE_PTR(proj[i].img); REQUIRE_PTR(proj[i].out); OPTIONAL_PTR(proj[i].bias); OPTIONAL_PTR(proj[i].tok);
-    REQUIRE(!(proj[i].tok && !S), "namp_node_update: proj[%d].tok given but S is null", i);
-  }
+  int rc = check_proj(__func__, proj, nproj, S);
+  if (rc) return rc;
   ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
-  int rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
+  rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
                               proj, nproj, S, G, (K + 15) / 16, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
@@ -331,6 +354,58 @@ int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_
   a.partial = partial; a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
   rc = launch_edge<MODE_DEC_MSG>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
+                            const int32_t* mask_attend, const float* Pa, const float* Pc, const float* h_V,
+                            float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_enc_message_update: null weights");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
+  REQUIRE_PTR(w->W1b_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  REQUIRE_PTR(w->Win_img); REQUIRE_PTR(w->Wout_img); REQUIRE_PTR(w->b_in); REQUIRE_PTR(w->b_out);
+  REQUIRE_PTR(w->ln1_g); REQUIRE_PTR(w->ln1_b); REQUIRE_PTR(w->ln2_g); REQUIRE_PTR(w->ln2_b);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_enc_message_update: null E_idx");
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  if ((rc = check_proj(__func__, proj, nproj, nullptr))) return rc;
+  EdgeArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
+  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
+            h_V_out, proj, nproj, nullptr);
+  ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
+  rc = launch_edge<MODE_ENC_MSG, true>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
+                            const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
+                            float* h_V_out, const NampProj* proj, int nproj, const int32_t* S, int B_dec, int B_enc,
+                            int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_dec_message_update: null weights");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pbw); REQUIRE_PTR(Pfw); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
+  REQUIRE_PTR(w->W1e_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  REQUIRE_PTR(w->Win_img); REQUIRE_PTR(w->Wout_img); REQUIRE_PTR(w->b_in); REQUIRE_PTR(w->b_out);
+  REQUIRE_PTR(w->ln1_g); REQUIRE_PTR(w->ln1_b); REQUIRE_PTR(w->ln2_g); REQUIRE_PTR(w->ln2_b);
+  if (!E_idx || !rank) return fail(NAMP_EINVAL, "namp_dec_message_update: null E_idx / rank");
+  int rc = check_dims(__func__, B_dec, N, K);
+  if (rc) return rc;
+  REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_dec_message_update: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
+  if ((rc = check_proj(__func__, proj, nproj, S))) return rc;
+  EdgeArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
+  a.W1_img = w->W1e_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
+  fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
+            h_V_out, proj, nproj, S);
+  ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
+  rc = launch_edge<MODE_DEC_MSG, true>(a, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -372,10 +447,12 @@ int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nki
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N, tpn = (K + 15) / 16;
-  const size_t enc = (2 + 4 + tpn) * tbl(Ge);
-  const size_t dec = (2 + 2 + tpn) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
+  const size_t enc = (2 + 6 + tpn) * tbl(Ge);
+  const size_t dec = (2 + 4 + tpn) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
   return (enc > dec ? enc : dec) + 4096;
 }
+
+int namp_fused_tail_max_residues(void) { return NAMP_FUSED_TAIL_MAX_RESIDUES; }
 
 int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_E, const int32_t* E_idx,
                        const int32_t* mask, const int32_t* mask_attend, float* h_V_out, float* h_E_out, void* ws,
@@ -392,13 +469,20 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_enc_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
   NampProj p1[2] = {{w->W1a_img, w->b1, nullptr, Pa}, {w->W1c_img, nullptr, nullptr, Pc}};
   if ((rc = namp_node_linear(h_V, nullptr, B, B, N, p1, 2, nullptr, stream))) return rc;
-  if ((rc = namp_enc_message(w, h_E, E_idx, mask, mask_attend, Pa, Pc, partial, B, N, K, stream))) return rc;
-  // Pa / Pc are free again once the message kernel has run (stream order): reuse them for W11a / W11c
-  NampProj p2[2] = {{w->W11a_img, w->b11, nullptr, Pa}, {w->W11c_img, nullptr, nullptr, Pc}};
-  if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
-                             partial, mask, h_V_out, p2, 2, nullptr, G, K, stream)))
-    return rc;
-  return namp_enc_edge_update(w, h_E, E_idx, Pa, Pc, h_E_out, B, N, K, stream);
+  float* Pa2 = c.take((size_t)G * NAMP_HIDDEN);
+  float* Pc2 = c.take((size_t)G * NAMP_HIDDEN);
+  if (!Pc2) return fail(NAMP_EWORKSPACE, "namp_enc_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
+  NampProj p2[2] = {{w->W11a_img, w->b11, nullptr, Pa2}, {w->W11c_img, nullptr, nullptr, Pc2}};
+  if (G <= NAMP_FUSED_TAIL_MAX_RESIDUES) {
+    if ((rc = namp_enc_message_update(w, h_E, E_idx, mask, mask_attend, Pa, Pc, h_V, h_V_out, p2, 2, B, N, K, stream)))
+      return rc;
+  } else {
+    if ((rc = namp_enc_message(w, h_E, E_idx, mask, mask_attend, Pa, Pc, partial, B, N, K, stream))) return rc;
+    if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
+                               partial, mask, h_V_out, p2, 2, nullptr, G, K, stream)))
+      return rc;
+  }
+  return namp_enc_edge_update(w, h_E, E_idx, Pa2, Pc2, h_E_out, B, N, K, stream);
 }
 
 int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
@@ -412,10 +496,11 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   const int G = B * N, tpn = (K + 15) / 16;
   Carver c(ws, ws_bytes);
   float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
-  float* P[4];
-  for (int i = 0; i < 4; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
+  float* P[6];
+  for (int i = 0; i < 6; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
   float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_encoder_fwd: workspace too small (%zu bytes)", ws_bytes);
+  const bool fused = G <= NAMP_FUSED_TAIL_MAX_RESIDUES;
 
   // h_V = W_v.V + b (model_utils.py:88) chained with enc[0]'s Pa / Pc tables in one launch
   const NampEncLayerW* L0 = &w->enc[0];
@@ -428,20 +513,28 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
     const NampEncLayerW* L = &w->enc[l];
     const bool last = (l + 1 == w->n_enc);
     float* out = last ? h_V : hv[cur ^ 1];
-    // P[0],P[1]: this layer's message tables; P[2],P[3]: its edge-update tables.  The node update
-    // writes P[2],P[3] and, for the next layer, P[0],P[1] again (free once the message kernel ran).
-    if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[0], P[1], partial, B, N, K, stream))) return rc;
+    // message tables of layer l live in P[tm], P[tm+1] (ping-pong {0,1} / {4,5}: with the fused tail the
+    // next layer's tables are written while other workgroups still gather this layer's); the
+    // edge-update tables in P[2], P[3].
+    const int tm = (l & 1) ? 4 : 0, tn = (l & 1) ? 0 : 4;
     NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[2]}, {L->W11c_img, nullptr, nullptr, P[3]}, {}, {}};
     int np = 2;
     if (!last) {
       const NampEncLayerW* Ln = &w->enc[l + 1];
-      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[0]};
-      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[1]};
+      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[tn]};
+      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[tn + 1]};
       np = 4;
     }
-    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
-                               hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
-      return rc;
+    if (fused) {
+      if ((rc = namp_enc_message_update(L, h_E, E_idx, mask, nullptr, P[tm], P[tm + 1], hv[cur], out, pe, np, B, N, K,
+                                        stream)))
+        return rc;
+    } else {
+      if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[tm], P[tm + 1], partial, B, N, K, stream))) return rc;
+      if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
+                                 hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
+        return rc;
+    }
     if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[2], P[3], h_E, B, N, K, stream))) return rc;
     cur ^= 1;
   }
@@ -462,9 +555,12 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
   hipStream_t s = (hipStream_t)stream;
   Carver c(ws, ws_bytes);
   float* hv[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
-  float* Pa = c.take((size_t)Gd * NAMP_HIDDEN);
-  float* Pbw = c.take((size_t)Gd * NAMP_HIDDEN);
+  float* PA[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};   // ping-pong per layer
+  float* PB[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
+  float* Pa = PA[0];
+  float* Pbw = PB[0];
   float* partial = c.take((size_t)Gd * tpn * NAMP_HIDDEN);
+  const bool fused = Gd <= NAMP_FUSED_TAIL_MAX_RESIDUES;
   float* Pfw[NAMP_MAX_LAYERS];
   for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
   if (!Pfw[w->n_dec - 1] || !partial) return fail(NAMP_EWORKSPACE, "namp_decoder_fwd: workspace too small (%zu bytes)", ws_bytes);
@@ -498,18 +594,25 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
     const NampDecLayerW* D = &w->dec[l];
     const bool last = (l + 1 == w->n_dec);
     float* out = (last && h_V_dec) ? h_V_dec : hv[cur ^ 1];
-    if ((rc = namp_dec_message(D, h_E, E_idx, rank, Pa, Pbw, Pfw[l], partial, B_dec, B_enc, N, K, stream))) return rc;
     NampProj pn[2] = {{}, {}};
     int np = 0;
-    if (!last) {     // next layer's Pa / Pbw (free once this layer's message kernel ran)
+    if (!last) {     // next layer's Pa / Pbw go to the other ping-pong slot
       const NampDecLayerW* Dn = &w->dec[l + 1];
-      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, Pa};
-      pn[1] = {Dn->W1v_img, nullptr, Dn->tok, Pbw};
+      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, PA[(l + 1) & 1]};
+      pn[1] = {Dn->W1v_img, nullptr, Dn->tok, PB[(l + 1) & 1]};
       np = 2;
     }
-    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
-                               partial, mask, out, pn, np, S, Gd, K, stream)))
-      return rc;
+    if (fused) {
+      if ((rc = namp_dec_message_update(D, h_E, E_idx, rank, PA[l & 1], PB[l & 1], Pfw[l], hin, mask, out, pn, np, S,
+                                        B_dec, B_enc, N, K, stream)))
+        return rc;
+    } else {
+      if ((rc = namp_dec_message(D, h_E, E_idx, rank, PA[l & 1], PB[l & 1], Pfw[l], partial, B_dec, B_enc, N, K, stream)))
+        return rc;
+      if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
+                                 partial, mask, out, pn, np, S, Gd, K, stream)))
+        return rc;
+    }
     hin = out;
     cur ^= 1;
   }

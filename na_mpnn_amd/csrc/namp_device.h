@@ -59,7 +59,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(fabsf(h), y, h);                                  // h + h * sign(x) * |erf|
 }
 
+// Ablation switches for tools/kbench.py (never defined in the shipped build).
+//   NAMP_ABL_NOGELU   : GELU -> identity          NAMP_ABL_LAYERS=n : stop the edge MLP after layer n
+//   NAMP_ABL_NOPROLOG : edge kernel reads no per-row operands (constants instead)
 __device__ __forceinline__ f4 gelu4(f4 v) {
+#ifdef NAMP_ABL_NOGELU
+  return v;
+#endif
   f4 o;
   o.x = gelu_erf(v.x); o.y = gelu_erf(v.y); o.z = gelu_erf(v.z); o.w = gelu_erf(v.w);
   return o;

@@ -74,12 +74,165 @@ __global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Residue-level tail of EncLayer / DecLayer (model_utils.py:690-697,646-656) and the projections the
+// next edge kernels gather, as a workgroup-cooperative device function over ONE 16-row tile:
+//      x    = LayerNorm1(pre)            pre = h_V + sum_k messages / 30  (caller supplies it, T layout)
+//      y    = LayerNorm2(x + W_out . gelu(W_in . x + b_in) + b_out)
+//      h_V' = mask * y
+//      out_p = W_p . h_V' + bias_p (+ tok_p[S])               p < nproj <= 8
+// Waves 0..7 each own 64 of the 512 hidden units (W_in slice (T) -> gelu -> W_out slice (T)); their
+// partial [16 x 128] outputs are reduced through LDS.  Projection work is dealt out in (block p,
+// channel tile tn) units over all waves.  Used by node_update_kernel (16 residues per workgroup) and
+// as the fused tail of the message kernels (the workgroup's own <= 12 residues).
+// ------------------------------------------------------------------------------------------
+struct ProjDesc {
+  const float* img;    // 64 KiB image of the [128x128] block
+  const float* bias;   // [128] or null
+  const float* tok;    // [vocab][128] table added per residue by token S[n], or null
+  float* out;          // [G_out][128]
+};
+
+struct NodeTail {
+  const float* hV;        // [G][128] layer input
+  const int32_t* mask;    // [G] or null
+  const float* ln1_g; const float* ln1_b;
+  const float* Win_img;   // image of W_in  [512 x 128]: img[tk 8][tn 32][lane]
+  const float* b_in;      // [512]
+  const float* Wout_img;  // image of W_out [128 x 512]: img[tk 32][tn 8][lane]
+  const float* b_out;     // [128]
+  const float* ln2_g; const float* ln2_b;
+  float* hV_out;          // [G][128]
+  const int32_t* S;       // [G] tokens for tok tables (or null)
+  int nproj;
+  ProjDesc p[8];
+};
+
+#define FFN_LD 132   // padded row stride (floats) of the LDS tiles: conflict-free ds_write_b128
+#define NODE_TAIL_LDS ((16 + 16 + 8 * 16) * FFN_LD * 4)
+
+// x: pre-LayerNorm1 rows in the T layout (lane (m,g) holds channels 16t+4g+r of tile row m).
+// row0: first residue of the tile, nrows: rows of the tile that are real residues, G: total residues.
+// lds: NODE_TAIL_LDS bytes.  DEEP: request every weight fragment of a phase up front (256-VGPR budget).
+template <bool DEEP>
+__device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const int row0, const int nrows, const int G,
+                                          float* lds, const int tid, const int wave, const int nwaves, const int lane) {
+  float* xs = lds;                          // [16][FFN_LD]    x = LN1(...)
+  float* ys = xs + 16 * FFN_LD;             // [16][FFN_LD]    h_V' tile for the projections
+  float* ps = ys + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial FFN outputs
+  const int m = lane & 15, g = lane >> 4;
+
+  f4 win[DEEP ? 8 : 1][4];
+  if (DEEP && wave < 8) {
+    const f4* w = (const f4*)a.Win_img + (4 * wave) * 64 + lane;
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) win[DEEP ? tk : 0][tn] = w[(tk * 32 + tn) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(xs + m * FFN_LD + 16 * t + 4 * g) = x[t];
+  }
+  if (wave < 8) {
+    f4 hacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hacc[t] = *(const f4*)(a.b_in + 64 * wave + 16 * t + 4 * g);
+    f4 oacc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) oacc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (DEEP) {
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) hacc[tn] = mfma4(win[DEEP ? tk : 0][tn][r], x[tk][r], hacc[tn]);
+      f4 wo[4][8];
+      const f4* w = (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane;
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) wo[tk][tn] = w[(tk * 8 + tn) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hacc[t] = gelu4(hacc[t]);
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[tk][tn][r], hacc[tk][r], oacc[tn]);
+    } else {
+      chain_gemm_global<8, 4, false>(hacc, x, (const f4*)a.Win_img + (4 * wave) * 64 + lane, 32);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hacc[t] = gelu4(hacc[t]);
+      chain_gemm_global<4, 8, false>(oacc, hacc, (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane, 8);
+    }
+    float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = oacc[t];
+  }
+  __syncthreads();
+  // LN2: thread -> (row = tid/32, 4 channels)
+  if (tid < 512) {
+    const int r = tid >> 5, c = (tid & 31) * 4;
+    f4 v = *(const f4*)(xs + r * FFN_LD + c) + *(const f4*)(a.b_out + c);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += *(const f4*)(ps + (w * 16 + r) * FFN_LD + c);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / 128.0f);
+    v -= mean;
+    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / 128.0f) + 1e-5f);
+    const int orow = row0 + r;
+    const bool ok = (r < nrows) && (orow < G);
+    const float mk = (a.mask && ok) ? (float)a.mask[orow] : 1.0f;
+    const f4 y = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
+    *(f4*)(ys + r * FFN_LD + c) = y;
+    if (ok) *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
+  }
+  if (a.nproj == 0) return;
+  __syncthreads();
+  // projections of h_V': unit u = (block p, channel tile tn)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
+  const int row = row0 + m;
+  const bool valid = (m < nrows) && (row < G);
+  const int rr = valid ? row : row0;
+  // unit u = 8*pi + tn goes to wave u % nwaves.  The block loop is unrolled so that a.p[pi] is a static
+  // index (a dynamic index into the kernarg struct makes hipcc spill the whole struct to scratch).
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) {
+    if (pi >= a.nproj) break;
+    const ProjDesc d = a.p[pi];
+    for (int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn < 8; tn += nwaves) {
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)d.img)[(tk * 8 + tn) * 64 + lane];
+      f4 acc = d.bias ? *(const f4*)(d.bias + 16 * tn + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+      if (d.tok) acc += *(const f4*)(d.tok + (long)a.S[rr] * NAMP_H + 16 * tn + 4 * g);
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(wf[tk][r], x[tk][r], acc);
+      if (valid) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // edge_mlp_kernel — the hot kernel.  One wave = one 16-row tile = 16 of the K neighbours of
 // one residue; a workgroup = (blockDim/64)/TPN residues, TPN = ceil(K/16) tiles per residue.
-// Weights: the first layer's 128x128 image streams from L2 (prefetched fragment loads) while the
-// images of layers 2 and 3 are DMA'd (global_load_lds) into 2 x 64 KiB of LDS shared by all waves;
-// one barrier after layer 1 is the only workgroup synchronisation, so from there on the 3 waves of
-// a SIMD drift apart and one wave's GELU (VALU) overlaps another's MFMAs.  Activations stay in
+// Weights: the three 128x128 images go through a 2 x 64 KiB LDS ring shared by all waves, filled by
+// LDS-DMA (global_load_lds): W1 and W2 up front, W3 into W1's slot while layer 2 computes.  (Streaming
+// an image per wave from L2 instead was measured 10 us slower per launch: 12 waves x 64 KiB per CU and
+// layer exceeds what the CU's L1 path sustains — profiles/r01_ablation.md.)  Activations stay in
 // registers (namp_device.h).
 //
 // With W1 = [W1a | W1b | W1c] applied to [h_V_i | h_E_ik | h_V_j]  (EncLayer,
@@ -118,13 +271,19 @@ struct EdgeArgs {
   const float* b3;
   const float* ln_g;           // ENC_EDGE
   const float* ln_b;
-  float* partial;              // MSG modes: [G][TPN][128]
+  float* partial;              // MSG modes without the fused tail: [G][TPN][128]
+  NodeTail tail;               // MSG modes with the fused tail (TAIL = true)
   int G;                       // residues processed by this launch (decoder: B_dec*N)
   int G_enc;                   // residues on the encoder side (B_enc*N); decoder batch b maps to b % B_enc
   int N, K, TPN;
 };
 
-template <int MODE>
+// TAIL (message modes only): the workgroup goes on to update its own residues (node_tail) instead of
+// writing partial sums — one launch per layer half instead of two, worth it while the whole batch is
+// a single wave of workgroups (every workgroup re-streams the 768 KiB of FFN / projection weights).
+#define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4)
+
+template <int MODE, bool TAIL>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
@@ -150,14 +309,22 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 
   // ---- per-row operands: the h_E row (B operand of layer 1) and the hoisted first-layer terms
   f4 x[8];
+  f4 acc[8];
+  float w_row = 0.f;
+#ifdef NAMP_ABL_NOPROLOG
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { x[t] = (f4){0.1f * lane, 0.2f, 0.3f, 0.4f * t}; acc[t] = x[t]; }
+  w_row = valid ? 1.f : 0.f;
+  if (true) {
+  } else if (MODE == MODE_EMBED) {
+#else
   {
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
   }
-  f4 acc[8];
-  float w_row = 0.f;
   if (MODE == MODE_EMBED) {
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g);
   } else {
@@ -187,15 +354,14 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
 
-  // ---- layer 1 (T): acc += W1b . h_E.  Weight fragments stream from L2 one k-step ahead of their
-  // MFMAs; the LDS-DMA of the W2 / W3 images is issued in small pieces between them (the VM counter
-  // retires in order, so a bulk DMA issued up front would stall every later fragment load behind it).
+#ifdef NAMP_ABL_W1_FROM_L2
+  // (ablation) first-layer fragments straight from L2, W2 / W3 DMA'd in pieces between the k-steps
   {
     const f4* w = (const f4*)a.W1_img + lane;
     f4 cur[8], nxt[8];
 #pragma unroll
     for (int tn = 0; tn < 8; ++tn) cur[tn] = w[tn * 64];
-    int dma_c = wave;                                  // chunk ids 0..63 -> buf0 (W2), 64..127 -> buf1 (W3)
+    int dma_c = wave;
 #pragma unroll
     for (int tk = 0; tk < 8; ++tk) {
       if (tk + 1 < 8) {
@@ -206,7 +372,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
         for (int rep = 0; rep < 3; ++rep) {
           if (dma_c < 128) {
-            const float* gsrc = (dma_c < 64) ? a.W2_img : a.W3_img;
+            const float* gsrc = (dma_c < 64) ? a.W3_img : a.W2_img;
             dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
             dma_c += nwaves;
           }
@@ -225,13 +391,22 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       }
     }
     if (MODE != MODE_EMBED) {
-      while (dma_c < 128) {                            // only for very small workgroups (< 6 waves)
-        const float* gsrc = (dma_c < 64) ? a.W2_img : a.W3_img;
+      while (dma_c < 128) {
+        const float* gsrc = (dma_c < 64) ? a.W3_img : a.W2_img;
         dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
         dma_c += nwaves;
       }
     }
   }
+#else
+  // ---- weight staging: W1 -> buf0 and W2 -> buf1 by LDS-DMA.  Issued AFTER the per-row operand loads
+  // above (the VM counter retires in order: loads queued behind a bulk DMA could not be consumed before it).
+  dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
+  if (MODE != MODE_EMBED) dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
+  wait_dma_and_sync();
+  // ---- layer 1 (T): acc += W1b . h_E
+  chain_gemm<8, 8, false>(acc, x, w0, 8);
+#endif
 
   if (MODE == MODE_EMBED) {
     if (valid) {
@@ -244,20 +419,36 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
-  wait_dma_and_sync();                               // W2 / W3 images have landed in LDS
+#ifdef NAMP_ABL_W1_FROM_L2
+  wait_dma_and_sync();
+#else
+  __syncthreads();                                   // every wave is done with buf0 (W1)
+  dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);   // lands while layer 2 runs out of buf1
+#endif
+#if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 1
+  if (valid && x[0].x == 123.456f) a.partial[0] = x[1].x + x[2].y + x[3].z + x[4].w + x[5].x + x[6].y + x[7].z;
+  return;
+#endif
 
   // ---- layer 2 (T)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false>(acc, x, w0, 8);
+  chain_gemm<8, 8, false>(acc, x, w1, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
+#if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 2
+  if (valid && x[0].x == 123.456f) a.partial[0] = x[1].x + x[2].y + x[3].z + x[4].w + x[5].x + x[6].y + x[7].z;
+  return;
+#endif
+#ifndef NAMP_ABL_W1_FROM_L2
+  wait_dma_and_sync();                               // W3 has landed in buf0
+#endif
 
   if (MODE == MODE_ENC_EDGE) {
     // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false>(acc, x, w1, 8);
+    chain_gemm<8, 8, false>(acc, x, w0, 8);
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
@@ -274,17 +465,43 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const float b = a.b3[16 * t + m];
       acc[t] = (f4){b, b, b, b};
     }
-    chain_gemm<8, 8, true>(acc, x, w1, 8);
+    chain_gemm<8, 8, true>(acc, x, w0, 8);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
-    float* dst = a.partial + ((long)node * a.TPN + kt) * NAMP_H + m;
+    if (!TAIL) {
+      float* dst = a.partial + ((long)node * a.TPN + kt) * NAMP_H + m;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
-      s = xg_sum(s);
-      if (wave_active && g == 0) dst[16 * t] = s;
+      for (int t = 0; t < 8; ++t) {
+        float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        s = xg_sum(s);
+        if (wave_active && g == 0) dst[16 * t] = s;
+      }
+    } else {
+      // per-tile sums -> LDS (beyond the weight ring, which slower waves may still be reading)
+      float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);       // [nwaves][128]
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        s = xg_sum(s);
+        if (g == 0) dpart[wave * NAMP_H + 16 * t + m] = s;
+      }
+      __syncthreads();                                          // all tiles summed; weight ring is free
+      // tile rows = this workgroup's residues: row m -> residue row0 + m
+      const int row0 = blockIdx.x * npw;
+      const int trow = row0 + m;
+      const bool tvalid = (m < npw) && (trow < a.G);
+      const int mm = tvalid ? m : 0;
+      const float* hsrc = a.tail.hV + (long)(row0 + mm) * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(hsrc + 16 * t);
+      for (int q = 0; q < a.TPN; ++q) {
+        const float* dp = dpart + (mm * a.TPN + q) * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(dp + 16 * t);
+      }
+      node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
     }
   }
 }
@@ -296,12 +513,6 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 // staging would buy nothing).  Produces the Pa / Pc / Pbw / Pfw tables, h_V = W_v.V + b
 // (model_utils.py:88) and the per-token table W1s . W_s (33 rows).
 // ------------------------------------------------------------------------------------------
-struct ProjDesc {
-  const float* img;    // 64 KiB image of the [128x128] block
-  const float* bias;   // [128] or null
-  const float* tok;    // [vocab][128] table added per residue by token S[n], or null
-  float* out;          // [G_out][128]
-};
 struct NodeLinearArgs {
   const float* X;      // [G_src][128]
   const int32_t* S;    // [G_out] tokens (only if some tok != null)
@@ -362,183 +573,36 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// node_update_kernel — the per-residue tail of EncLayer / DecLayer (model_utils.py:690-697,646-656)
-// fused with the residue-level projections the NEXT edge kernels gather:
-//      x    = LayerNorm1(h_V + sum_t partial[n][t])          (partial already carries mask / 30)
-//      y    = LayerNorm2(x + W_out . gelu(W_in . x + b_in) + b_out)
-//      h_V' = mask * y
-//      out_p = W_p . h_V' + bias_p (+ tok_p[S])               p < nproj <= 8
-// 16 residues per workgroup, 8 waves (2 per SIMD, up to 256 VGPRs each).  Wave w owns hidden units
-// [64w, 64w+64) of the 512-wide FFN: W_in slice (T) -> gelu -> W_out slice (T) gives a partial
-// [16 x 128] per wave, reduced through LDS; then wave w computes output channels [16w,16w+16) of
-// every projection.  At B=1 this kernel is latency-bound (63 workgroups), so every weight
-// fragment of a phase is requested up front (explicit register arrays + sched_barrier) instead of
-// leaving it to the compiler's one-deep pipelining.
+// node_update_kernel — node_tail over 16 residues per workgroup (8 waves, 2 per SIMD, up to 256 VGPRs
+// so that every weight fragment of a phase is in flight at once).  The unfused path: used for large
+// batches, where 16 real rows per weight pass beat the message kernels' <= 12.
+//      pre = h_V + sum_t partial[n][t]      (partial already carries mask / 30)
 // ------------------------------------------------------------------------------------------
 struct NodeUpdateArgs {
-  const float* hV;        // [G][128]
+  NodeTail t;
   const float* partial;   // [G][TPN][128] or null (no message term)
-  const int32_t* mask;    // [G] or null
-  const float* ln1_g; const float* ln1_b;
-  const float* Win_img;   // image of W_in  [512 x 128]: img[tk 8][tn 32][lane]
-  const float* b_in;      // [512]
-  const float* Wout_img;  // image of W_out [128 x 512]: img[tk 32][tn 8][lane]
-  const float* b_out;     // [128]
-  const float* ln2_g; const float* ln2_b;
-  float* hV_out;          // [G][128]
-  const int32_t* S;       // [G] tokens for tok tables (or null)
-  int G, TPN, nproj;
-  ProjDesc p[8];
+  int G, TPN;
 };
-
-#define FFN_LD 132   // padded row stride (floats) of the LDS tiles: conflict-free ds_write_b128
-#define NODE_UPDATE_LDS ((16 + 16 + 8 * 16) * FFN_LD * 4)
-
-template <int NP>
-__device__ __forceinline__ void node_proj_group(const NodeUpdateArgs& a, const int p0, const f4 (&x)[8], const int wave,
-                                                const int lane, const int row, const bool valid) {
-  const int g = lane >> 4;
-  ProjDesc d[NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    d[q] = a.p[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) if (p0 + q == k) d[q] = a.p[k];
-  }
-  const int np = a.nproj - p0;             // projections live in this group (wave-uniform)
-  f4 wf[8][NP];
-#pragma unroll
-  for (int tk = 0; tk < 8; ++tk)
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-      if (q < np) wf[tk][q] = ((const f4*)d[q].img)[(tk * 8 + wave) * 64 + lane];
-  __builtin_amdgcn_sched_barrier(0);
-  f4 acc[NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q)
-    acc[q] = (q < np && d[q].bias) ? *(const f4*)(d[q].bias + 16 * wave + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tk = 0; tk < 8; ++tk)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-        if (q < np) acc[q] = mfma4(wf[tk][q][r], x[tk][r], acc[q]);
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    if (q < np) {
-      if (d[q].tok) acc[q] += *(const f4*)(d[q].tok + (long)a.S[row] * NAMP_H + 16 * wave + 4 * g);
-      if (valid) *(f4*)(d[q].out + (long)row * NAMP_H + 16 * wave + 4 * g) = acc[q];
-    }
-  }
-}
 
 __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = (float*)smem;                 // [16][FFN_LD]    x = LN1(...)
-  float* ys = xs + 16 * FFN_LD;             // [16][FFN_LD]    h_V' tile for the projections
-  float* ps = ys + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial FFN outputs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
-  const int row = blockIdx.x * 16 + m;
-  const bool valid = row < a.G;
-  const int rr = valid ? row : 0;
-
-  // all W_in fragments of this wave's hidden slice: 8 tk x 4 tn
-  f4 win[8][4];
-  {
-    const f4* w = (const f4*)a.Win_img + (4 * wave) * 64 + lane;
-#pragma unroll
-    for (int tk = 0; tk < 8; ++tk)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) win[tk][tn] = w[(tk * 32 + tn) * 64];
-  }
-  // LN1 in the T layout, redundantly per wave (cheap, avoids a barrier)
+  const int row0 = blockIdx.x * 16;
+  const int rr = (row0 + m < a.G) ? row0 + m : row0;
   f4 x[8];
-  {
-    const float* src = a.hV + (long)rr * NAMP_H + 4 * g;
+  const float* src = a.t.hV + (long)rr * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
-    if (a.partial) {
-      for (int p = 0; p < a.TPN; ++p) {
-        const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
+  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+  if (a.partial) {
+    for (int p = 0; p < a.TPN; ++p) {
+      const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(ps_ + 16 * t);
-      }
+      for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(ps_ + 16 * t);
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
-  if (wave == 0) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(xs + m * FFN_LD + 16 * t + 4 * g) = x[t];
-  }
-  // hidden slice: 4 tn tiles of W_in
-  f4 hacc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) hacc[t] = *(const f4*)(a.b_in + 64 * wave + 16 * t + 4 * g);
-#pragma unroll
-  for (int tk = 0; tk < 8; ++tk)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) hacc[tn] = mfma4(win[tk][tn][r], x[tk][r], hacc[tn]);
-  // all W_out fragments over this wave's 64 hidden units: k tiles 4w..4w+3, 8 tn  (reuses win's registers)
-  f4 wo[4][8];
-  {
-    const f4* w = (const f4*)a.Wout_img + (4 * wave) * 8 * 64 + lane;
-#pragma unroll
-    for (int tk = 0; tk < 4; ++tk)
-#pragma unroll
-      for (int tn = 0; tn < 8; ++tn) wo[tk][tn] = w[(tk * 8 + tn) * 64];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) hacc[t] = gelu4(hacc[t]);
-  f4 oacc[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) oacc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tk = 0; tk < 4; ++tk)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[tk][tn][r], hacc[tk][r], oacc[tn]);
-  {
-    float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = oacc[t];
-  }
-  __syncthreads();
-  // LN2: thread -> (row = tid/32, 4 channels)
-  {
-    const int r = tid >> 5, c = (tid & 31) * 4;
-    f4 v = *(const f4*)(xs + r * FFN_LD + c) + *(const f4*)(a.b_out + c);
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += *(const f4*)(ps + (w * 16 + r) * FFN_LD + c);
-    float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / 128.0f);
-    v -= mean;
-    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q * (1.0f / 128.0f) + 1e-5f);
-    const int orow = blockIdx.x * 16 + r;
-    const float mk = (a.mask && orow < a.G) ? (float)a.mask[orow] : 1.0f;
-    const f4 y = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
-    *(f4*)(ys + r * FFN_LD + c) = y;
-    if (orow < a.G) *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
-  }
-  if (a.nproj == 0) return;
-  __syncthreads();
-  // projections of h_V': wave w -> output channels [16w, 16w+16) of every block
-#pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
-  node_proj_group<4>(a, 0, x, wave, lane, rr, valid);
-  if (a.nproj > 4) node_proj_group<4>(a, 4, x, wave, lane, rr, valid);
+  node_tail<true>(a.t, x, row0, 16, a.G, (float*)smem, tid, wave, 8, lane);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnamp_hip.so")
+LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnamp_hip.so")   # env: tools/kbench.py ablations
 
 NAMP_ABI_VERSION = 1
 NAMP_MAX_LAYERS = 8
@@ -63,6 +63,11 @@ _PROTOTYPES = {
     "namp_node_update": (i32, [c_fp] * 8 + [c_fp, c_fp, c_ip, c_fp, C.POINTER(NampProj), i32, c_ip, i32, i32, vp]),
     "namp_dec_message": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
                                i32, i32, i32, i32, vp]),
+    "namp_enc_message_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
+                                      C.POINTER(NampProj), i32, i32, i32, i32, vp]),
+    "namp_dec_message_update": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp,
+                                      C.POINTER(NampProj), i32, c_ip, i32, i32, i32, i32, vp]),
+    "namp_fused_tail_max_residues": (i32, []),
     "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
     "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "namp_profile_enable": (i32, [i32]),

@@ -248,6 +248,76 @@ def test_full_size_invariants(L, dev, packed):
     assert maxdiff(torch.logsumexp(logp, -1), torch.zeros(2, 1000)) < 1e-5     # rows are normalised
 
 
+@pytest.mark.parametrize("n,k,bdec", [(300, 48, 1), (130, 30, 1), (75, 16, 2)])
+def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
+    """namp_{enc,dec}_message_update (one launch) == namp_*_message + namp_node_update (two launches)."""
+    t, d = graph(dev, seed=41 + n, batch=1, n=n, k=k, masked_frac=0.1)
+    K = t["E_idx"].shape[-1]
+    tpn = (K + 15) // 16
+    G = n
+    a = lambda nm: packed.addr("enc1." + nm)
+    Pa, Pc = torch.randn(G, 128, device=dev), torch.randn(G, 128, device=dev)
+    outs = [[torch.empty(G, 128, device=dev) for _ in range(3)] for _ in range(2)]
+    hv = [torch.empty(G, 128, device=dev) for _ in range(2)]
+    partial = torch.empty(G, tpn, 128, device=dev)
+    def projs(o):
+        return (hip.NampProj * 3)(hip.NampProj(a("W11a_img"), a("b11"), None, o[0].data_ptr()),
+                                  hip.NampProj(a("W11c_img"), None, None, o[1].data_ptr()),
+                                  hip.NampProj(a("W1a_img"), a("b1"), None, o[2].data_ptr()))
+    s = stream()
+    hip.check(L.namp_enc_message_update(packed.enc_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(),
+                                        None, Pa.data_ptr(), Pc.data_ptr(), d["V"].data_ptr(), hv[0].data_ptr(),
+                                        projs(outs[0]), 3, 1, n, K, s))
+    hip.check(L.namp_enc_message(packed.enc_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(), None,
+                                 Pa.data_ptr(), Pc.data_ptr(), partial.data_ptr(), 1, n, K, s))
+    hip.check(L.namp_node_update(a("ln1_g"), a("ln1_b"), a("Win_img"), a("b_in"), a("Wout_img"), a("b_out"), a("ln2_g"),
+                                 a("ln2_b"), d["V"].data_ptr(), partial.data_ptr(), d["mask"].data_ptr(), hv[1].data_ptr(),
+                                 projs(outs[1]), 3, None, G, K, s))
+    assert torch.equal(hv[0], hv[1])
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    # decoder form, with decoder-batch replication and token tables
+    Gd = bdec * n
+    b = lambda nm: packed.addr("dec1." + nm)
+    rng = np.random.default_rng(n)
+    S = torch.from_numpy(rng.integers(0, 33, (Gd,)).astype(np.int32)).to(dev)
+    rank = torch.from_numpy(np.concatenate([rng.permutation(n) for _ in range(bdec)]).astype(np.int32)).to(dev)
+    maskd = d["mask"].repeat(bdec, 1).contiguous()
+    hVd = torch.randn(Gd, 128, device=dev)
+    Pa, Pbw, Pfw = torch.randn(Gd, 128, device=dev), torch.randn(Gd, 128, device=dev), torch.randn(G, 128, device=dev)
+    outs = [[torch.empty(Gd, 128, device=dev) for _ in range(2)] for _ in range(2)]
+    hv = [torch.empty(Gd, 128, device=dev) for _ in range(2)]
+    partial = torch.empty(Gd, tpn, 128, device=dev)
+    def dprojs(o):
+        return (hip.NampProj * 2)(hip.NampProj(b("W1a_img"), b("b1"), None, o[0].data_ptr()),
+                                  hip.NampProj(b("W1v_img"), None, b("tok"), o[1].data_ptr()))
+    hip.check(L.namp_dec_message_update(packed.dec_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), rank.data_ptr(),
+                                        Pa.data_ptr(), Pbw.data_ptr(), Pfw.data_ptr(), hVd.data_ptr(), maskd.data_ptr(),
+                                        hv[0].data_ptr(), dprojs(outs[0]), 2, S.data_ptr(), bdec, 1, n, K, s))
+    hip.check(L.namp_dec_message(packed.dec_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), rank.data_ptr(),
+                                 Pa.data_ptr(), Pbw.data_ptr(), Pfw.data_ptr(), partial.data_ptr(), bdec, 1, n, K, s))
+    hip.check(L.namp_node_update(b("ln1_g"), b("ln1_b"), b("Win_img"), b("b_in"), b("Wout_img"), b("b_out"), b("ln2_g"),
+                                 b("ln2_b"), hVd.data_ptr(), partial.data_ptr(), maskd.data_ptr(), hv[1].data_ptr(),
+                                 dprojs(outs[1]), 2, S.data_ptr(), Gd, K, s))
+    assert torch.equal(hv[0], hv[1])
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+
+
+def test_unfused_path_large_batch(L, dev, wt, packed):
+    """B*N above namp_fused_tail_max_residues() takes the two-launch path; same parity bar."""
+    B, N = 6, 800
+    assert B * N > L.namp_fused_tail_max_residues()
+    t, d = graph(dev, seed=51, batch=B, n=N, k=32)
+    _, _, logp, _ = run_encdec(L, dev, packed, d, B, N, 32)
+    b = 4
+    hV_r, hE_r = cpu_ref.encode_from_graph(wt, t["V"][b:b + 1], t["E"][b:b + 1], t["E_idx"][b:b + 1].long(), t["mask"][b:b + 1])
+    ref = cpu_ref.score_from_encoded(wt, hV_r, hE_r, t["E_idx"][b:b + 1].long(), t["S"][b:b + 1], t["mask"][b:b + 1],
+                                     t["chain_mask"][b:b + 1], t["randn"][b:b + 1])
+    assert maxdiff(logp[b:b + 1], ref["log_probs"]) < TOL_LOGP
+    assert torch.equal(logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1))
+
+
 def test_abi_error_reporting(L, dev, packed):
     x = torch.zeros(64 * 128 + 4, device=dev)
     out = torch.zeros(64 * 128, device=dev)
