@@ -227,6 +227,142 @@ __device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const i
 }
 
 // ------------------------------------------------------------------------------------------
+// node_tail_rows4 — the same residue tail for a tile of <= 4 real residues (the fused message kernel
+// at K > 32 owns 3-4 residues per workgroup).  A 16-row MFMA tile would spend 75 % of its issue slots
+// on padding, which made the tail MFMA-bound (12 us of a 21 us tail); with only 4 rows the work is
+// bound by streaming the 768 KiB of weights through the CU anyway, so it runs on the VALU instead:
+// lane (n_local, g) of fragment (tk, tn) holds W[16tn + n_local][16tk + 4g + r], multiplies it with
+// the 4 residues' activations x[.][16tk + 4g + r] (broadcast LDS reads of a [k][4] transposed tile) and
+// the four g-lanes of a channel are summed at the end — the existing MFMA weight images are reused as is.
+// ------------------------------------------------------------------------------------------
+#define ROWS4_LDS_FLOATS (128 * 4 + 512 * 4 + 4 * 128 * 4 + 128 * 4 + 16)
+
+__device__ __forceinline__ void rows4_fma(float (&acc)[4], const f4 (&wf)[8], const float* xT, const int g) {
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f4 xv = *(const f4*)(xT + (16 * tk + 4 * g + r) * 4);      // 4 residues at this k
+      acc[0] = fmaf(wf[tk][r], xv.x, acc[0]);
+      acc[1] = fmaf(wf[tk][r], xv.y, acc[1]);
+      acc[2] = fmaf(wf[tk][r], xv.z, acc[2]);
+      acc[3] = fmaf(wf[tk][r], xv.w, acc[3]);
+    }
+  }
+}
+
+__device__ __forceinline__ void node_tail_rows4(const NodeTail& a, f4 (&x)[8], const int row0, const int nrows,
+                                                const int G, float* lds, const int tid, const int wave,
+                                                const int nwaves, const int lane) {
+  float* xT = lds;                    // [128][4]   x = LN1(...)          (k-major, residue-minor)
+  float* hT = xT + 128 * 4;           // [512][4]   gelu(W_in x + b_in)
+  float* oP = hT + 512 * 4;           // [4][128][4] W_out partials over k-quarters
+  float* yT = oP + 4 * 128 * 4;       // [128][4]   h_V'
+  float* red = yT + 128 * 4;          // [16]       LayerNorm2 cross-wave sums
+  const int m = lane & 15, g = lane >> 4;
+
+  layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
+  if (wave == 0 && m < 4) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      xT[(16 * t + 4 * g + 0) * 4 + m] = x[t].x; xT[(16 * t + 4 * g + 1) * 4 + m] = x[t].y;
+      xT[(16 * t + 4 * g + 2) * 4 + m] = x[t].z; xT[(16 * t + 4 * g + 3) * 4 + m] = x[t].w;
+    }
+  }
+  __syncthreads();
+  // ---- hidden = gelu(W_in x + b_in): 32 channel tiles dealt over the waves
+  for (int tn = wave; tn < 32; tn += nwaves) {
+    f4 wf[8];
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Win_img)[(tk * 32 + tn) * 64 + lane];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    rows4_fma(acc, wf, xT, g);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
+    if (g == 0) {
+      const float b = a.b_in[16 * tn + m];
+      *(f4*)(hT + (16 * tn + m) * 4) = (f4){gelu_erf(acc[0] + b), gelu_erf(acc[1] + b), gelu_erf(acc[2] + b), gelu_erf(acc[3] + b)};
+    }
+  }
+  __syncthreads();
+  // ---- W_out: units (channel tile tn, k-quarter kq); partials reduced in the LayerNorm2 pass
+  for (int u = wave; u < 32; u += nwaves) {
+    const int tn = u & 7, kq = u >> 3;
+    f4 wf[8];
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Wout_img)[((8 * kq + tk) * 8 + tn) * 64 + lane];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    rows4_fma(acc, wf, hT + 128 * kq * 4, g);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
+    if (g == 0) *(f4*)(oP + (kq * 128 + 16 * tn + m) * 4) = (f4){acc[0], acc[1], acc[2], acc[3]};
+  }
+  __syncthreads();
+  // ---- LayerNorm2 over channels: thread -> (residue n = tid / 128, channel c = tid % 128)
+  const int n_ = (tid >> 7) & 3, c_ = tid & 127;
+  float v = 0.f;
+  if (tid < 512) {
+    v = xT[c_ * 4 + n_] + a.b_out[c_];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) v += oP[(kq * 128 + c_) * 4 + n_];
+    float s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+  }
+  __syncthreads();
+  float d = 0.f;
+  if (tid < 512) {
+    const float mean = (red[2 * n_] + red[2 * n_ + 1]) * (1.0f / 128.0f);
+    d = v - mean;
+    float q = d * d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[8 + wave] = q;
+  }
+  __syncthreads();
+  if (tid < 512) {
+    const float rstd = rsqrtf((red[8 + 2 * n_] + red[8 + 2 * n_ + 1]) * (1.0f / 128.0f) + 1e-5f);
+    const int orow = row0 + n_;
+    const bool ok = (n_ < nrows) && (orow < G);
+    const float mk = (a.mask && ok) ? (float)a.mask[orow] : 1.0f;
+    const float y = (d * rstd * a.ln2_g[c_] + a.ln2_b[c_]) * mk;
+    yT[c_ * 4 + n_] = y;
+    if (ok) a.hV_out[(long)orow * NAMP_H + c_] = y;
+  }
+  if (a.nproj == 0) return;
+  __syncthreads();
+  // ---- projections of h_V': unit (block pi, channel tile tn) -> wave (8 pi + tn) % nwaves
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) {
+    if (pi >= a.nproj) break;
+    const ProjDesc pd = a.p[pi];
+    for (int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn < 8; tn += nwaves) {
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)pd.img)[(tk * 8 + tn) * 64 + lane];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      rows4_fma(acc, wf, yT, g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
+      if (g == 0) {
+        const int c = 16 * tn + m;
+        const float b = pd.bias ? pd.bias[c] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int orow = row0 + n;
+          if (n < nrows && orow < G) {
+            float o = acc[n] + b;
+            if (pd.tok) o += pd.tok[(long)a.S[orow] * NAMP_H + c];
+            pd.out[(long)orow * NAMP_H + c] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // edge_mlp_kernel — the hot kernel.  One wave = one 16-row tile = 16 of the K neighbours of
 // one residue; a workgroup = (blockDim/64)/TPN residues, TPN = ceil(K/16) tiles per residue.
 // Weights: the three 128x128 images go through a 2 x 64 KiB LDS ring shared by all waves, filled by
@@ -501,7 +637,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(dp + 16 * t);
       }
-      node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+      if (npw <= 4) node_tail_rows4(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+      else          node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
     }
   }
 }

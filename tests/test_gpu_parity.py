@@ -273,9 +273,12 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_node_update(a("ln1_g"), a("ln1_b"), a("Win_img"), a("b_in"), a("Wout_img"), a("b_out"), a("ln2_g"),
                                  a("ln2_b"), d["V"].data_ptr(), partial.data_ptr(), d["mask"].data_ptr(), hv[1].data_ptr(),
                                  projs(outs[1]), 3, None, G, K, s))
-    assert torch.equal(hv[0], hv[1])
+    # K <= 32: both forms run the same 16-row MFMA tail (bit-identical); K > 32: the fused form's tile has
+    # <= 4 residues and uses the VALU tail (same math, different fp32 summation order)
+    tol = 0.0 if K <= 32 else 2e-5
+    assert maxdiff(hv[0], hv[1]) <= tol
     for x, y in zip(outs[0], outs[1]):
-        assert torch.equal(x, y)
+        assert maxdiff(x, y) <= tol
     # decoder form, with decoder-batch replication and token tables
     Gd = bdec * n
     b = lambda nm: packed.addr("dec1." + nm)
@@ -299,9 +302,9 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_node_update(b("ln1_g"), b("ln1_b"), b("Win_img"), b("b_in"), b("Wout_img"), b("b_out"), b("ln2_g"),
                                  b("ln2_b"), hVd.data_ptr(), partial.data_ptr(), maskd.data_ptr(), hv[1].data_ptr(),
                                  dprojs(outs[1]), 2, S.data_ptr(), Gd, K, s))
-    assert torch.equal(hv[0], hv[1])
+    assert maxdiff(hv[0], hv[1]) <= tol
     for x, y in zip(outs[0], outs[1]):
-        assert torch.equal(x, y)
+        assert maxdiff(x, y) <= tol
 
 
 def test_unfused_path_large_batch(L, dev, wt, packed):
