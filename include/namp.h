@@ -133,7 +133,10 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
 int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
                             const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
                             float* h_V_out, const NampProj* proj, int nproj, const int32_t* S,
+                            const float* head_w, const float* head_b, float* log_probs, float* logits, int vocab,
                             int B_dec, int B_enc, int N, int K, void* stream);
+/* head_w (nullable): when given, the launch also writes log_softmax(head_w . h_V' + head_b) — the W_out
+ * head of model_utils.py:420-421 — for the residues it updates (logits optional). */
 int namp_fused_tail_max_residues(void);
 /* log_softmax(W_out . h_V + b) (model_utils.py:420-421); logits may be NULL. */
 int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const float* h_V,

@@ -125,6 +125,7 @@ void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float*
                const int32_t* mask, float* hV_out, const NampProj* proj, int nproj, const int32_t* S) {
   t.hV = hV; t.mask = mask; t.ln1_g = ln1_g; t.ln1_b = ln1_b; t.Win_img = Win_img; t.b_in = b_in;
   t.Wout_img = Wout_img; t.b_out = b_out; t.ln2_g = ln2_g; t.ln2_b = ln2_b; t.hV_out = hV_out; t.S = S;
+  t.head_w = nullptr; t.head_b = nullptr; t.log_probs = nullptr; t.logits = nullptr; t.vocab = 0;
   t.nproj = nproj;
   for (int i = 0; i < 8; ++i) {
     if (i < nproj) { t.p[i].img = proj[i].img; t.p[i].bias = proj[i].bias; t.p[i].tok = proj[i].tok; t.p[i].out = proj[i].out; }
@@ -386,9 +387,14 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
 
 int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
                             const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
-                            float* h_V_out, const NampProj* proj, int nproj, const int32_t* S, int B_dec, int B_enc,
-                            int N, int K, void* stream) {
+                            float* h_V_out, const NampProj* proj, int nproj, const int32_t* S,
+                            const float* head_w, const float* head_b, float* log_probs, float* logits, int vocab,
+                            int B_dec, int B_enc, int N, int K, void* stream) {
   REQUIRE(w != nullptr, "namp_dec_message_update: null weights");
+  if (head_w) {
+    REQUIRE_PTR(head_w);
+    REQUIRE(head_b && log_probs && vocab >= 1 && vocab <= 64, "namp_dec_message_update: output head needs head_b, log_probs and 1 <= vocab <= 64");
+  }
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pbw); REQUIRE_PTR(Pfw); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
   REQUIRE_PTR(w->W1e_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
   REQUIRE_PTR(w->Win_img); REQUIRE_PTR(w->Wout_img); REQUIRE_PTR(w->b_in); REQUIRE_PTR(w->b_out);
@@ -404,6 +410,7 @@ int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int3
   a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, S);
+  a.tail.head_w = head_w; a.tail.head_b = head_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = vocab;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
   rc = launch_edge<MODE_DEC_MSG, true>(a, (hipStream_t)stream);
   if (rc) return rc;
@@ -603,7 +610,9 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
       np = 2;
     }
     if (fused) {
+      // the last layer's launch also evaluates the output head on the residues it has just updated
       if ((rc = namp_dec_message_update(D, h_E, E_idx, rank, PA[l & 1], PB[l & 1], Pfw[l], hin, mask, out, pn, np, S,
+                                        last ? w->Wout_w : nullptr, w->Wout_b, log_probs, logits, w->vocab,
                                         B_dec, B_enc, N, K, stream)))
         return rc;
     } else {
@@ -616,6 +625,7 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
     hin = out;
     cur ^= 1;
   }
+  if (fused) return NAMP_OK;
   return namp_logits_log_softmax(w->Wout_w, w->Wout_b, hin, log_probs, logits, Gd, w->vocab, stream);
 }
 

@@ -74,19 +74,22 @@ __device__ __forceinline__ f4 gelu4(f4 v) {
 // acc[tn] (+)= W . x  over TK k-tiles.  `w` points at img[tk0][0][lane]; consecutive
 // tn are 64 f4 apart, consecutive tk are 64*TNW f4 apart (TNW = tn extent of the image).
 //   FLIP=false: "T" orientation, FLIP=true: "F" orientation (see header comment).
-template <int TK, int NTN, bool FLIP>
+//   ACT=true: x holds PRE-activations; GELU of k-tile tk is evaluated right before its MFMAs, so the VALU
+//   work of tile tk+1 issues in the shadow of tile tk's 4*NTN MFMAs instead of in a separate phase.
+template <int TK, int NTN, bool FLIP, bool ACT = false>
 __device__ __forceinline__ void chain_gemm(f4 (&acc)[NTN], const f4 (&x)[TK], const f4* w, const int tn_stride_img) {
 #pragma unroll
   for (int tk = 0; tk < TK; ++tk) {
     f4 wf[NTN];
 #pragma unroll
     for (int tn = 0; tn < NTN; ++tn) wf[tn] = w[(tk * tn_stride_img + tn) * 64];
+    const f4 xk = ACT ? gelu4(x[tk]) : x[tk];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int tn = 0; tn < NTN; ++tn) {
-        if (FLIP) acc[tn] = mfma4(x[tk][r], wf[tn][r], acc[tn]);
-        else      acc[tn] = mfma4(wf[tn][r], x[tk][r], acc[tn]);
+        if (FLIP) acc[tn] = mfma4(xk[r], wf[tn][r], acc[tn]);
+        else      acc[tn] = mfma4(wf[tn][r], xk[r], acc[tn]);
       }
     }
   }

@@ -103,9 +103,48 @@ struct NodeTail {
   const float* ln2_g; const float* ln2_b;
   float* hV_out;          // [G][128]
   const int32_t* S;       // [G] tokens for tok tables (or null)
+  // optional output head on h_V' (last decoder layer): log_softmax(W_out . h_V' + b), model_utils.py:420-421
+  const float* head_w;    // [vocab][128] plain layout, or null
+  const float* head_b;    // [vocab]
+  float* log_probs;       // [G][vocab]
+  float* logits;          // [G][vocab] or null
+  int vocab;
   int nproj;
   ProjDesc p[8];
 };
+
+// log_softmax head over the tile's residues; y[n][c] = ybase[n * sn + c * sc] lives in LDS.
+// One wave per residue (round-robin), lane t < vocab owns logit t.
+__device__ __forceinline__ void tail_head(const NodeTail& a, const float* ybase, const int sn, const int sc,
+                                          const int row0, const int nrows, const int G, const int wave,
+                                          const int nwaves, const int lane) {
+  for (int n = wave; n < nrows; n += nwaves) {
+    const int orow = row0 + n;
+    if (orow >= G) break;
+    float z = -INFINITY;
+    if (lane < a.vocab) {
+      const float* w = a.head_w + (long)lane * NAMP_H;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < NAMP_H; c += 4) {
+        const f4 wv = *(const f4*)(w + c);
+        s0 = fmaf(wv.x, ybase[n * sn + (c + 0) * sc], s0); s1 = fmaf(wv.y, ybase[n * sn + (c + 1) * sc], s1);
+        s2 = fmaf(wv.z, ybase[n * sn + (c + 2) * sc], s2); s3 = fmaf(wv.w, ybase[n * sn + (c + 3) * sc], s3);
+      }
+      z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
+    }
+    float mx = z;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = (lane < a.vocab) ? expf(z - mx) : 0.f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+    if (lane < a.vocab) {
+      a.log_probs[(long)orow * a.vocab + lane] = (z - mx) - logf(e);
+      if (a.logits) a.logits[(long)orow * a.vocab + lane] = z;
+    }
+  }
+}
 
 #define FFN_LD 132   // padded row stride (floats) of the LDS tiles: conflict-free ds_write_b128
 #define NODE_TAIL_LDS ((16 + 16 + 8 * 16) * FFN_LD * 4)
@@ -197,8 +236,9 @@ __device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const i
     *(f4*)(ys + r * FFN_LD + c) = y;
     if (ok) *(f4*)(a.hV_out + (long)orow * NAMP_H + c) = y;
   }
-  if (a.nproj == 0) return;
+  if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
+  if (a.head_w) tail_head(a, ys, FFN_LD, 1, row0, nrows, G, wave, nwaves, lane);
   // projections of h_V': unit u = (block p, channel tile tn)
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
@@ -330,8 +370,9 @@ __device__ __forceinline__ void node_tail_rows4(const NodeTail& a, f4 (&x)[8], c
     yT[c_ * 4 + n_] = y;
     if (ok) a.hV_out[(long)orow * NAMP_H + c_] = y;
   }
-  if (a.nproj == 0) return;
+  if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
+  if (a.head_w) tail_head(a, yT, 1, 4, row0, nrows, G, wave, nwaves, lane);
   // ---- projections of h_V': unit (block pi, channel tile tn) -> wave (8 pi + tn) % nwaves
 #pragma unroll
   for (int pi = 0; pi < 8; ++pi) {
@@ -446,10 +487,11 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   // ---- per-row operands: the h_E row (B operand of layer 1) and the hoisted first-layer terms
   f4 x[8];
   f4 acc[8];
+  f4 pjv[8];                       // gathered neighbour term, added after layer 1 (its latency hides under the MFMAs)
   float w_row = 0.f;
 #ifdef NAMP_ABL_NOPROLOG
 #pragma unroll
-  for (int t = 0; t < 8; ++t) { x[t] = (f4){0.1f * lane, 0.2f, 0.3f, 0.4f * t}; acc[t] = x[t]; }
+  for (int t = 0; t < 8; ++t) { x[t] = (f4){0.1f * lane, 0.2f, 0.3f, 0.4f * t}; acc[t] = x[t]; pjv[t] = x[t]; }
   w_row = valid ? 1.f : 0.f;
   if (true) {
   } else if (MODE == MODE_EMBED) {
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   if (MODE == MODE_EMBED) {
 #endif
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g);
+    for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g); pjv[t] = (f4){0.f, 0.f, 0.f, 0.f}; }
   } else {
     const int j_loc = a.E_idx[erow];
     const float* pj;
@@ -484,65 +526,19 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     const float* pa = a.Pa + (long)node * NAMP_H + 4 * g;
     pj += 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(pa + 16 * t) + *(const f4*)(pj + 16 * t);
+    for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
   }
 
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
 
-#ifdef NAMP_ABL_W1_FROM_L2
-  // (ablation) first-layer fragments straight from L2, W2 / W3 DMA'd in pieces between the k-steps
-  {
-    const f4* w = (const f4*)a.W1_img + lane;
-    f4 cur[8], nxt[8];
-#pragma unroll
-    for (int tn = 0; tn < 8; ++tn) cur[tn] = w[tn * 64];
-    int dma_c = wave;
-#pragma unroll
-    for (int tk = 0; tk < 8; ++tk) {
-      if (tk + 1 < 8) {
-#pragma unroll
-        for (int tn = 0; tn < 8; ++tn) nxt[tn] = w[((tk + 1) * 8 + tn) * 64];
-      }
-      if (MODE != MODE_EMBED) {
-#pragma unroll
-        for (int rep = 0; rep < 3; ++rep) {
-          if (dma_c < 128) {
-            const float* gsrc = (dma_c < 64) ? a.W3_img : a.W2_img;
-            dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
-            dma_c += nwaves;
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(cur[tn][r], x[tk][r], acc[tn]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (tk + 1 < 8) {
-#pragma unroll
-        for (int tn = 0; tn < 8; ++tn) cur[tn] = nxt[tn];
-      }
-    }
-    if (MODE != MODE_EMBED) {
-      while (dma_c < 128) {
-        const float* gsrc = (dma_c < 64) ? a.W3_img : a.W2_img;
-        dma_to_lds(smem + dma_c * 1024, gsrc + (dma_c & 63) * 256, 1, 0, 1, lane);
-        dma_c += nwaves;
-      }
-    }
-  }
-#else
   // ---- weight staging: W1 -> buf0 and W2 -> buf1 by LDS-DMA.  Issued AFTER the per-row operand loads
   // above (the VM counter retires in order: loads queued behind a bulk DMA could not be consumed before it).
   dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
   if (MODE != MODE_EMBED) dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
   wait_dma_and_sync();
-  // ---- layer 1 (T): acc += W1b . h_E
+  // ---- layer 1 (T): acc = Pa + W1b . h_E (+ Pj afterwards)
   chain_gemm<8, 8, false>(acc, x, w0, 8);
-#endif
 
   if (MODE == MODE_EMBED) {
     if (valid) {
@@ -552,39 +548,30 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     }
     return;
   }
-
 #pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
-#ifdef NAMP_ABL_W1_FROM_L2
-  wait_dma_and_sync();
-#else
-  __syncthreads();                                   // every wave is done with buf0 (W1)
-  dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);   // lands while layer 2 runs out of buf1
-#endif
+  for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
+  __syncthreads();                                        // every wave is done with buf0 (W1)
+  dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);     // lands while layer 2 runs out of buf1
 #if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 1
-  if (valid && x[0].x == 123.456f) a.partial[0] = x[1].x + x[2].y + x[3].z + x[4].w + x[5].x + x[6].y + x[7].z;
+  if (valid && acc[0].x == 123.456f) a.partial[0] = acc[1].x + acc[2].y + acc[3].z + acc[4].w + acc[5].x + acc[6].y + acc[7].z;
   return;
 #endif
 
-  // ---- layer 2 (T)
+  // ---- layer 2 (T); GELU of layer 1 is applied k-tile by k-tile inside the MFMA loop
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false>(acc, x, w1, 8);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = gelu4(acc[t]);
+  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+  chain_gemm<8, 8, false, true>(x, acc, w1, 8);           // x = layer-2 pre-activations
 #if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 2
   if (valid && x[0].x == 123.456f) a.partial[0] = x[1].x + x[2].y + x[3].z + x[4].w + x[5].x + x[6].y + x[7].z;
   return;
 #endif
-#ifndef NAMP_ABL_W1_FROM_L2
-  wait_dma_and_sync();                               // W3 has landed in buf0
-#endif
+  wait_dma_and_sync();                                    // W3 has landed in buf0
 
   if (MODE == MODE_ENC_EDGE) {
     // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false>(acc, x, w0, 8);
+    chain_gemm<8, 8, false, true>(acc, x, w0, 8);
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
@@ -601,7 +588,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const float b = a.b3[16 * t + m];
       acc[t] = (f4){b, b, b, b};
     }
-    chain_gemm<8, 8, true>(acc, x, w0, 8);
+    chain_gemm<8, 8, true, true>(acc, x, w0, 8);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll

@@ -66,7 +66,8 @@ _PROTOTYPES = {
     "namp_enc_message_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
                                       C.POINTER(NampProj), i32, i32, i32, i32, vp]),
     "namp_dec_message_update": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp,
-                                      C.POINTER(NampProj), i32, c_ip, i32, i32, i32, i32, vp]),
+                                      C.POINTER(NampProj), i32, c_ip, c_fp, c_fp, c_fp, c_fp, i32,
+                                      i32, i32, i32, i32, vp]),
     "namp_fused_tail_max_residues": (i32, []),
     "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
     "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),

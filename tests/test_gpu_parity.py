@@ -291,12 +291,15 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     outs = [[torch.empty(Gd, 128, device=dev) for _ in range(2)] for _ in range(2)]
     hv = [torch.empty(Gd, 128, device=dev) for _ in range(2)]
     partial = torch.empty(Gd, tpn, 128, device=dev)
+    lp = [torch.empty(Gd, 33, device=dev) for _ in range(2)]
     def dprojs(o):
         return (hip.NampProj * 2)(hip.NampProj(b("W1a_img"), b("b1"), None, o[0].data_ptr()),
                                   hip.NampProj(b("W1v_img"), None, b("tok"), o[1].data_ptr()))
     hip.check(L.namp_dec_message_update(packed.dec_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), rank.data_ptr(),
                                         Pa.data_ptr(), Pbw.data_ptr(), Pfw.data_ptr(), hVd.data_ptr(), maskd.data_ptr(),
-                                        hv[0].data_ptr(), dprojs(outs[0]), 2, S.data_ptr(), bdec, 1, n, K, s))
+                                        hv[0].data_ptr(), dprojs(outs[0]), 2, S.data_ptr(),
+                                        packed.addr("Wout_w"), packed.addr("Wout_b"), lp[0].data_ptr(), None, 33,
+                                        bdec, 1, n, K, s))
     hip.check(L.namp_dec_message(packed.dec_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), rank.data_ptr(),
                                  Pa.data_ptr(), Pbw.data_ptr(), Pfw.data_ptr(), partial.data_ptr(), bdec, 1, n, K, s))
     hip.check(L.namp_node_update(b("ln1_g"), b("ln1_b"), b("Win_img"), b("b_in"), b("Wout_img"), b("b_out"), b("ln2_g"),
@@ -305,6 +308,10 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     assert maxdiff(hv[0], hv[1]) <= tol
     for x, y in zip(outs[0], outs[1]):
         assert maxdiff(x, y) <= tol
+    # fused output head == separate logits kernel on the same h_V'
+    hip.check(L.namp_logits_log_softmax(packed.addr("Wout_w"), packed.addr("Wout_b"), hv[0].data_ptr(), lp[1].data_ptr(),
+                                        None, Gd, 33, s))
+    assert maxdiff(lp[0], lp[1]) <= 2e-6
 
 
 def test_unfused_path_large_batch(L, dev, wt, packed):
