@@ -31,7 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from na_mpnn_amd import hip, spec, synth          # noqa: E402
+from na_mpnn_amd import hip, shard, spec, synth   # noqa: E402
 from na_mpnn_amd.pack import PackedWeights        # noqa: E402
 
 WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48)}
@@ -103,9 +103,15 @@ def gather_microbench(dev, reps=10):
     gbs = nbytes / (ms * 1e-3) / 1e9
     del hE, hV, idx, out
     torch.cuda.empty_cache()
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get("gather_cfg3")
+    except OSError:
+        pass
     return {"kernel": "gather_cat_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4),
-            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": None}
+            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": traffic}
 
 
 def cpu_baseline(runner, budget_s=25.0):
@@ -193,13 +199,10 @@ def main():
 
     # reporting-only collective: all-gather of the arg-max sequences (north_star: "RCCL all-gather ... only
     # for throughput reporting"); outside the timed region.
-    seq = runner.logp.argmax(-1).to(torch.int8)
-    if dist is not None:
-        allseq = [torch.empty_like(seq) for _ in range(world)]
-        dist.all_gather(allseq, seq)
-        n_collated = sum(int(x.numel()) for x in allseq)
-    else:
-        n_collated = int(seq.numel())
+    seq = runner.logp.argmax(-1)
+    local = {rank * B + b: seq[b] for b in range(B)}              # complex id -> designed sequence
+    collated = shard.all_gather_ragged(local, world * B, device=dev)
+    n_collated = sum(int(x.numel()) for x in collated if x is not None)
 
     # per-kernel durations: same steps again with the library's HIP-event hook on the launch stream
     runner.L.namp_profile_enable(1)
@@ -212,9 +215,16 @@ def main():
     dom = max((k for k in per_kernel if k in ALGO_FLOP), key=lambda k: per_kernel[k]["ms_per_step"])
     avg_s = per_kernel[dom]["avg_ms"] * 1e-3
     algo = ALGO_FLOP[dom] * B * N
+    # HBM-side bytes per launch from the committed PMC pass (profiles/r01_pmc.md); bench.py cannot run rocprofv3 on itself
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(args.workload, {}).get(dom)
+    except OSError:
+        pass
     roofline = {"kernel": f"edge_mlp_kernel<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": EXEC_FLOP_EDGE * B * N,
+                "traffic": traffic, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": EXEC_FLOP_EDGE * B * N,
                 "executed_frac": round(EXEC_FLOP_EDGE * B * N / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "avg_launch_ms": per_kernel[dom]["avg_ms"]}
 
