@@ -78,12 +78,16 @@ void set_lds_attributes() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) g_attr_err = e;
   };
-  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, false>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, false>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, true>, EDGE_TAIL_LDS);
-  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, true>, EDGE_TAIL_LDS);
-  set((const void*)edge_mlp_kernel<MODE_ENC_EDGE, false>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_mlp_kernel<MODE_EMBED, false>, NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, 0>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, 0>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, 4>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, 4>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, 8>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, 8>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_ENC_MSG, 16>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_DEC_MSG, 16>, EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_kernel<MODE_ENC_EDGE, 0>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
 }
 
@@ -109,7 +113,7 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE, bool TAIL = false>
+template <int MODE, int TAIL = 0>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
@@ -118,6 +122,16 @@ int launch_edge(EdgeArgs a, hipStream_t s) {
   const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
   hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
+}
+
+// fused-tail flavour by residues per workgroup: <= 4 and <= 6 take the VALU tails (the latter needs 128
+// LayerNorm threads per residue: 2*npw <= waves), more take the 16-row MFMA tail
+template <int MODE>
+int launch_edge_tail(EdgeArgs a, hipStream_t s) {
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  if (e.npw <= 4) return launch_edge<MODE, 4>(a, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8>(a, s);
+  return launch_edge<MODE, 16>(a, s);
 }
 
 void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
@@ -379,7 +393,7 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge<MODE_ENC_MSG, true>(a, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_ENC_MSG>(a, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -412,7 +426,7 @@ int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int3
             h_V_out, proj, nproj, S);
   a.tail.head_w = head_w; a.tail.head_b = head_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = vocab;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge<MODE_DEC_MSG, true>(a, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_DEC_MSG>(a, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -113,36 +113,30 @@ struct NodeTail {
   ProjDesc p[8];
 };
 
-// log_softmax head over the tile's residues; y[n][c] = ybase[n * sn + c * sc] lives in LDS.
-// One wave per residue (round-robin), lane t < vocab owns logit t.
-__device__ __forceinline__ void tail_head(const NodeTail& a, const float* ybase, const int sn, const int sc,
-                                          const int row0, const int nrows, const int G, const int wave,
-                                          const int nwaves, const int lane) {
-  for (int n = wave; n < nrows; n += nwaves) {
-    const int orow = row0 + n;
-    if (orow >= G) break;
-    float z = -INFINITY;
-    if (lane < a.vocab) {
-      const float* w = a.head_w + (long)lane * NAMP_H;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// log_softmax head for one residue: y[c] = ybase[c * sc] lives in LDS; lane t < vocab owns logit t.
+__device__ __forceinline__ void tail_head_row(const NodeTail& a, const float* ybase, const int sc, const int orow,
+                                              const int lane) {
+  float z = -INFINITY;
+  if (lane < a.vocab) {
+    const float* w = a.head_w + (long)lane * NAMP_H;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-      for (int c = 0; c < NAMP_H; c += 4) {
-        const f4 wv = *(const f4*)(w + c);
-        s0 = fmaf(wv.x, ybase[n * sn + (c + 0) * sc], s0); s1 = fmaf(wv.y, ybase[n * sn + (c + 1) * sc], s1);
-        s2 = fmaf(wv.z, ybase[n * sn + (c + 2) * sc], s2); s3 = fmaf(wv.w, ybase[n * sn + (c + 3) * sc], s3);
-      }
-      z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
+    for (int c = 0; c < NAMP_H; c += 4) {
+      const f4 wv = *(const f4*)(w + c);
+      s0 = fmaf(wv.x, ybase[(c + 0) * sc], s0); s1 = fmaf(wv.y, ybase[(c + 1) * sc], s1);
+      s2 = fmaf(wv.z, ybase[(c + 2) * sc], s2); s3 = fmaf(wv.w, ybase[(c + 3) * sc], s3);
     }
-    float mx = z;
+    z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
+  }
+  float mx = z;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float e = (lane < a.vocab) ? expf(z - mx) : 0.f;
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float e = (lane < a.vocab) ? expf(z - mx) : 0.f;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
-    if (lane < a.vocab) {
-      a.log_probs[(long)orow * a.vocab + lane] = (z - mx) - logf(e);
-      if (a.logits) a.logits[(long)orow * a.vocab + lane] = z;
-    }
+  for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+  if (lane < a.vocab) {
+    a.log_probs[(long)orow * a.vocab + lane] = (z - mx) - logf(e);
+    if (a.logits) a.logits[(long)orow * a.vocab + lane] = z;
   }
 }
 
@@ -238,7 +232,10 @@ __device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const i
   }
   if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
-  if (a.head_w) tail_head(a, ys, FFN_LD, 1, row0, nrows, G, wave, nwaves, lane);
+  if (a.head_w) {
+    for (int n = wave; n < nrows; n += nwaves)
+      if (row0 + n < G) tail_head_row(a, ys + n * FFN_LD, 1, row0 + n, lane);
+  }
   // projections of h_V': unit u = (block p, channel tile tn)
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
@@ -267,84 +264,109 @@ __device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const i
 }
 
 // ------------------------------------------------------------------------------------------
-// node_tail_rows4 — the same residue tail for a tile of <= 4 real residues (the fused message kernel
-// at K > 32 owns 3-4 residues per workgroup).  A 16-row MFMA tile would spend 75 % of its issue slots
-// on padding, which made the tail MFMA-bound (12 us of a 21 us tail); with only 4 rows the work is
-// bound by streaming the 768 KiB of weights through the CU anyway, so it runs on the VALU instead:
-// lane (n_local, g) of fragment (tk, tn) holds W[16tn + n_local][16tk + 4g + r], multiplies it with
-// the 4 residues' activations x[.][16tk + 4g + r] (broadcast LDS reads of a [k][4] transposed tile) and
-// the four g-lanes of a channel are summed at the end — the existing MFMA weight images are reused as is.
+// node_tail_rows<R> — the same residue tail for a tile of <= R (4 or 8) real residues: the fused message
+// kernel owns 12/TPN residues per workgroup (4 at K=48, 6 at K=32), and the sampler's workgroup owns one
+// residue per sample stream.  A 16-row MFMA tile would spend most of its issue slots on padding, which
+// made the tail MFMA-bound (12 us of a 21 us tail at 4 rows); with few rows the work is bound by
+// streaming the 768 KiB of weights through the CU anyway, so it runs on the VALU instead: lane
+// (n_local, g) of fragment (tk, tn) holds W[16tn + n_local][16tk + 4g + r], multiplies it with the R
+// residues' activations x[.][16tk + 4g + r] (broadcast LDS reads of a [k][R] transposed tile) and the four
+// g-lanes of a channel are summed at the end — the existing MFMA weight images are reused as is.
+// Tile row n is residue orow[n] (global row, < 0 = padding); rows need not be consecutive.
 // ------------------------------------------------------------------------------------------
-#define ROWS4_LDS_FLOATS (128 * 4 + 512 * 4 + 4 * 128 * 4 + 128 * 4 + 16)
-
-__device__ __forceinline__ void rows4_fma(float (&acc)[4], const f4 (&wf)[8], const float* xT, const int g) {
+template <int R>
+__device__ __forceinline__ void rows_fma(float (&acc)[R], const f4 (&wf)[8], const float* xT, const int g) {
 #pragma unroll
   for (int tk = 0; tk < 8; ++tk) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const f4 xv = *(const f4*)(xT + (16 * tk + 4 * g + r) * 4);      // 4 residues at this k
-      acc[0] = fmaf(wf[tk][r], xv.x, acc[0]);
-      acc[1] = fmaf(wf[tk][r], xv.y, acc[1]);
-      acc[2] = fmaf(wf[tk][r], xv.z, acc[2]);
-      acc[3] = fmaf(wf[tk][r], xv.w, acc[3]);
+      const float* xp = xT + (16 * tk + 4 * g + r) * R;                 // R residues at this k
+#pragma unroll
+      for (int q = 0; q < R; q += 4) {
+        const f4 xv = *(const f4*)(xp + q);
+        acc[q + 0] = fmaf(wf[tk][r], xv.x, acc[q + 0]);
+        acc[q + 1] = fmaf(wf[tk][r], xv.y, acc[q + 1]);
+        acc[q + 2] = fmaf(wf[tk][r], xv.z, acc[q + 2]);
+        acc[q + 3] = fmaf(wf[tk][r], xv.w, acc[q + 3]);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later k-tiles from being hoisted (register pressure)
   }
 }
 
-__device__ __forceinline__ void node_tail_rows4(const NodeTail& a, f4 (&x)[8], const int row0, const int nrows,
-                                                const int G, float* lds, const int tid, const int wave,
-                                                const int nwaves, const int lane) {
-  float* xT = lds;                    // [128][4]   x = LN1(...)          (k-major, residue-minor)
-  float* hT = xT + 128 * 4;           // [512][4]   gelu(W_in x + b_in)
-  float* oP = hT + 512 * 4;           // [4][128][4] W_out partials over k-quarters
-  float* yT = oP + 4 * 128 * 4;       // [128][4]   h_V'
-  float* red = yT + 128 * 4;          // [16]       LayerNorm2 cross-wave sums
+#define ROWS_TAIL_LDS_FLOATS(R) ((128 + 512 + 4 * 128 + 128) * (R) + 64)
+
+// RowFn: int operator()(int n) -> global row of tile row n (any runtime n in [0,R)), < 0 for padding.
+struct ConsecutiveRows {
+  int row0, nrows, G;
+  __device__ __forceinline__ int operator()(int n) const { return (n < nrows && row0 + n < G) ? row0 + n : -1; }
+};
+
+template <int R, typename RowFn>
+__device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const RowFn orow, float* lds,
+                                               const int tid, const int wave, const int nwaves, const int lane) {
+  float* xT = lds;                    // [128][R]    x = LN1(...)          (k-major, residue-minor)
+  float* hT = xT + 128 * R;           // [512][R]    gelu(W_in x + b_in)
+  float* oP = hT + 512 * R;           // [4][128][R] W_out partials over k-quarters
+  float* yT = oP + 4 * 128 * R;       // [128][R]    h_V'
+  float* red = yT + 128 * R;          // [2][32]     LayerNorm2 cross-wave sums
   const int m = lane & 15, g = lane >> 4;
 
   layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
-  if (wave == 0 && m < 4) {
+  if (wave == 0 && m < R) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      xT[(16 * t + 4 * g + 0) * 4 + m] = x[t].x; xT[(16 * t + 4 * g + 1) * 4 + m] = x[t].y;
-      xT[(16 * t + 4 * g + 2) * 4 + m] = x[t].z; xT[(16 * t + 4 * g + 3) * 4 + m] = x[t].w;
+      xT[(16 * t + 4 * g + 0) * R + m] = x[t].x; xT[(16 * t + 4 * g + 1) * R + m] = x[t].y;
+      xT[(16 * t + 4 * g + 2) * R + m] = x[t].z; xT[(16 * t + 4 * g + 3) * R + m] = x[t].w;
     }
   }
   __syncthreads();
   // ---- hidden = gelu(W_in x + b_in): 32 channel tiles dealt over the waves
+#pragma unroll 1
   for (int tn = wave; tn < 32; tn += nwaves) {
     f4 wf[8];
 #pragma unroll
     for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Win_img)[(tk * 32 + tn) * 64 + lane];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    rows4_fma(acc, wf, xT, g);
+    float acc[R];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
+    for (int n = 0; n < R; ++n) acc[n] = 0.f;
+    rows_fma<R>(acc, wf, xT, g);
+#pragma unroll
+    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
     if (g == 0) {
       const float b = a.b_in[16 * tn + m];
-      *(f4*)(hT + (16 * tn + m) * 4) = (f4){gelu_erf(acc[0] + b), gelu_erf(acc[1] + b), gelu_erf(acc[2] + b), gelu_erf(acc[3] + b)};
+#pragma unroll
+      for (int n = 0; n < R; ++n) hT[(16 * tn + m) * R + n] = gelu_erf(acc[n] + b);
     }
   }
   __syncthreads();
   // ---- W_out: units (channel tile tn, k-quarter kq); partials reduced in the LayerNorm2 pass
+#pragma unroll 1
   for (int u = wave; u < 32; u += nwaves) {
     const int tn = u & 7, kq = u >> 3;
     f4 wf[8];
 #pragma unroll
     for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Wout_img)[((8 * kq + tk) * 8 + tn) * 64 + lane];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    rows4_fma(acc, wf, hT + 128 * kq * 4, g);
+    float acc[R];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
-    if (g == 0) *(f4*)(oP + (kq * 128 + 16 * tn + m) * 4) = (f4){acc[0], acc[1], acc[2], acc[3]};
+    for (int n = 0; n < R; ++n) acc[n] = 0.f;
+    rows_fma<R>(acc, wf, hT + 128 * kq * R, g);
+#pragma unroll
+    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
+    if (g == 0) {
+#pragma unroll
+      for (int n = 0; n < R; ++n) oP[(kq * 128 + 16 * tn + m) * R + n] = acc[n];
+    }
   }
   __syncthreads();
-  // ---- LayerNorm2 over channels: thread -> (residue n = tid / 128, channel c = tid % 128)
-  const int n_ = (tid >> 7) & 3, c_ = tid & 127;
+  // ---- LayerNorm2 over channels: thread -> (residue n = tid / 128, channel c = tid % 128), 128*R threads
+  const int n_ = tid >> 7, c_ = tid & 127;
+  const bool ln_thr = tid < 128 * R;
   float v = 0.f;
-  if (tid < 512) {
-    v = xT[c_ * 4 + n_] + a.b_out[c_];
+  if (ln_thr) {
+    v = xT[c_ * R + n_] + a.b_out[c_];
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) v += oP[(kq * 128 + c_) * 4 + n_];
+    for (int kq = 0; kq < 4; ++kq) v += oP[(kq * 128 + c_) * R + n_];
     float s = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
@@ -352,50 +374,57 @@ __device__ __forceinline__ void node_tail_rows4(const NodeTail& a, f4 (&x)[8], c
   }
   __syncthreads();
   float d = 0.f;
-  if (tid < 512) {
+  if (ln_thr) {
     const float mean = (red[2 * n_] + red[2 * n_ + 1]) * (1.0f / 128.0f);
     d = v - mean;
     float q = d * d;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o);
-    if (lane == 0) red[8 + wave] = q;
+    if (lane == 0) red[32 + wave] = q;
   }
   __syncthreads();
-  if (tid < 512) {
-    const float rstd = rsqrtf((red[8 + 2 * n_] + red[8 + 2 * n_ + 1]) * (1.0f / 128.0f) + 1e-5f);
-    const int orow = row0 + n_;
-    const bool ok = (n_ < nrows) && (orow < G);
-    const float mk = (a.mask && ok) ? (float)a.mask[orow] : 1.0f;
+  if (ln_thr) {
+    const float rstd = rsqrtf((red[32 + 2 * n_] + red[32 + 2 * n_ + 1]) * (1.0f / 128.0f) + 1e-5f);
+    const int orw = orow(n_);
+    const float mk = (a.mask && orw >= 0) ? (float)a.mask[orw] : 1.0f;
     const float y = (d * rstd * a.ln2_g[c_] + a.ln2_b[c_]) * mk;
-    yT[c_ * 4 + n_] = y;
-    if (ok) a.hV_out[(long)orow * NAMP_H + c_] = y;
+    yT[c_ * R + n_] = y;
+    if (orw >= 0) a.hV_out[(long)orw * NAMP_H + c_] = y;
   }
   if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
-  if (a.head_w) tail_head(a, yT, 1, 4, row0, nrows, G, wave, nwaves, lane);
+  if (a.head_w) {
+    for (int n = wave; n < R; n += nwaves) {
+      const int orw = orow(n);
+      if (orw >= 0) tail_head_row(a, yT + n, R, orw, lane);
+    }
+  }
   // ---- projections of h_V': unit (block pi, channel tile tn) -> wave (8 pi + tn) % nwaves
 #pragma unroll
   for (int pi = 0; pi < 8; ++pi) {
     if (pi >= a.nproj) break;
     const ProjDesc pd = a.p[pi];
+#pragma unroll 1
     for (int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn < 8; tn += nwaves) {
       f4 wf[8];
 #pragma unroll
       for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)pd.img)[(tk * 8 + tn) * 64 + lane];
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      rows4_fma(acc, wf, yT, g);
+      float acc[R];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] = xg_sum(acc[n]);
+      for (int n = 0; n < R; ++n) acc[n] = 0.f;
+      rows_fma<R>(acc, wf, yT, g);
+#pragma unroll
+      for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
       if (g == 0) {
         const int c = 16 * tn + m;
         const float b = pd.bias ? pd.bias[c] : 0.f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const int orow = row0 + n;
-          if (n < nrows && orow < G) {
+        for (int n = 0; n < R; ++n) {
+          const int orw = orow(n);
+          if (orw >= 0) {
             float o = acc[n] + b;
-            if (pd.tok) o += pd.tok[(long)a.S[orow] * NAMP_H + c];
-            pd.out[(long)orow * NAMP_H + c] = o;
+            if (pd.tok) o += pd.tok[(long)a.S[orw] * NAMP_H + c];
+            pd.out[(long)orw * NAMP_H + c] = o;
           }
         }
       }
@@ -460,7 +489,9 @@ struct EdgeArgs {
 // a single wave of workgroups (every workgroup re-streams the 768 KiB of FFN / projection weights).
 #define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4)
 
-template <int MODE, bool TAIL>
+// TAIL: 0 = write partial sums; 4 / 8 = node_tail_rows<4/8> (the workgroup owns <= 4 / <= 6 residues);
+// 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
+template <int MODE, int TAIL>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
@@ -624,8 +655,13 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(dp + 16 * t);
       }
-      if (npw <= 4) node_tail_rows4(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
-      else          node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+      if (TAIL == 4 || TAIL == 8) {
+        constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
+        const ConsecutiveRows orow = {row0, npw, a.G};
+        node_tail_rows<R>(a.tail, x, orow, (float*)smem, tid, wave, nwaves, lane);
+      } else {
+        node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+      }
     }
   }
 }

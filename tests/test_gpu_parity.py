@@ -273,9 +273,9 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_node_update(a("ln1_g"), a("ln1_b"), a("Win_img"), a("b_in"), a("Wout_img"), a("b_out"), a("ln2_g"),
                                  a("ln2_b"), d["V"].data_ptr(), partial.data_ptr(), d["mask"].data_ptr(), hv[1].data_ptr(),
                                  projs(outs[1]), 3, None, G, K, s))
-    # K <= 32: both forms run the same 16-row MFMA tail (bit-identical); K > 32: the fused form's tile has
-    # <= 4 residues and uses the VALU tail (same math, different fp32 summation order)
-    tol = 0.0 if K <= 32 else 2e-5
+    # K <= 16: both forms run the same 16-row MFMA tail (bit-identical); K > 16: the fused form's tile has
+    # <= 8 residues and uses the VALU tail (same math, different fp32 summation order)
+    tol = 0.0 if K <= 16 else 2e-5
     assert maxdiff(hv[0], hv[1]) <= tol
     for x, y in zip(outs[0], outs[1]):
         assert maxdiff(x, y) <= tol
