@@ -168,6 +168,26 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
                      float* log_probs, float* logits, float* h_V_dec,
                      void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 
+/* ---- a9: autoregressive sampler ------------------------------------------------------------
+ * ProteinMPNN.sample, non-symmetric branch (model_utils.py:126-218), after encode(): B_dec independent sample
+ * streams over B_enc encoded complexes (stream b uses complex b % B_enc), one persistent launch.
+ *   mask_dec    [B_dec,N]  residue mask per stream (the caller may reproduce the reference's use of stream 0's
+ *                          mask at every step, model_utils.py:186 — see na_mpnn_amd/model.py)
+ *   chain_mask  [B_enc,N]  mask*chain_mask: 1 = design, 0 = keep S_true       S_true [B_enc,N]
+ *   bias        [B_enc,N,vocab] added to the logits before the temperature softmax (model_utils.py:196)
+ *   order, rank [B_dec,N]  decoding order and its inverse                       uniform [B_dec,N] in [0,1),
+ *                          consumed one per step by an inverse-CDF draw (replaces torch.multinomial, :209)
+ *   S_forced    [B_dec,N]  optional: use this token instead of the draw (teacher forcing)
+ *   special_tokens  bit t set = token t is never drawn (UNK, DX, RX, MAS, PAD: model_utils.py:199-203)
+ * Outputs: S_out int32 [B_dec,N]; probs_out / logp_out [B_dec,N,vocab] = chain_mask * (sampling
+ * distribution / log_softmax(logits)) as model_utils.py:211-212. */
+size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K);
+int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                        const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                        float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                        void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
+
 /* ---- measurement hook (bench.py) ------------------------------------------------------------
  * When enabled (thread-local), every kernel launch made through this ABI is bracketed by HIP
  * events on the launch stream; namp_profile_collect() waits for them and returns the summed

@@ -89,6 +89,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_ENC_EDGE, 0>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
+  set((const void*)dec_sample_kernel, SAMPLE_LDS);
 }
 
 int ensure_attributes() {
@@ -463,6 +464,78 @@ int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nki
   }
   g_prof.clear();
   return rc;
+}
+
+size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
+  if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
+  const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N;
+  // Pfw[3] + Pa0 on the encoder side; Pa[2] + Pv[2] + h[3] on the sample-stream side
+  return (3 + 1) * tbl(Ge) + (2 + 2 + 3) * tbl(Gd) + 4096;
+}
+
+int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                        const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                        float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                        void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_decoder_sample: null weights");
+  REQUIRE(w->n_dec >= 1 && w->n_dec <= 3, "namp_decoder_sample: supports 1..3 decoder layers (got %d)", w->n_dec);
+  REQUIRE(w->vocab >= 1 && w->vocab <= 64, "namp_decoder_sample: vocab=%d must be in [1,64]", w->vocab);
+  REQUIRE_PTR(h_V_enc); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
+  if (!E_idx || !chain_mask || !S_true || !bias || !order || !rank || !uniform || !S_out || !probs_out || !logp_out)
+    return fail(NAMP_EINVAL, "namp_decoder_sample: null pointer argument");
+  REQUIRE(temperature > 0.f, "namp_decoder_sample: temperature must be > 0");
+  int rc = check_dims(__func__, B_dec, N, K);
+  if (rc) return rc;
+  REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_decoder_sample: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
+  if ((rc = ensure_attributes())) return rc;
+  const int Gd = B_dec * N, Ge = B_enc * N;
+  Carver c(ws, ws_bytes);
+  float* Pfw[3]; for (int l = 0; l < 3; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
+  float* Pa0 = c.take((size_t)Ge * NAMP_HIDDEN);
+  float* Pa[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
+  float* Pv[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
+  float* hs[3] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
+  if (!hs[2]) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
+  // static tables from the encoder output: Pfw_l = W1v_l . h_V^enc, Pa_0 = W1a_0 . h_V^enc + b1
+  NampProj pf[4];
+  int nf = 0;
+  for (int l = 0; l < w->n_dec; ++l) pf[nf++] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
+  pf[nf++] = {w->dec[0].W1a_img, w->dec[0].b1, nullptr, Pa0};
+  if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, nf, nullptr, stream))) return rc;
+
+  SampleArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
+  a.uniform = uniform; a.S_forced = S_forced; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
+  a.probs_out = probs_out; a.logp_out = logp_out; a.special = special_tokens; a.inv_T = 1.0f / temperature;
+  a.B_dec = B_dec; a.B_enc = B_enc; a.N = N; a.K = K; a.TPN = (K + 15) / 16; a.n_layers = w->n_dec; a.vocab = w->vocab;
+  int slots = 12 / a.TPN; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;
+  a.slots = slots;
+  int nwaves = slots * a.TPN; if (nwaves < 8) nwaves = 8;
+  REQUIRE(nwaves <= 12, "namp_decoder_sample: K=%d needs %d waves per workgroup (max 12)", K, nwaves);
+  for (int l = 0; l < w->n_dec; ++l) {
+    const NampDecLayerW* D = &w->dec[l];
+    SampleLayer& L = a.l[l];
+    L.W1e_img = D->W1e_img; L.W2_img = D->W2_img; L.W3_img = D->W3_img; L.b2 = D->b2; L.b3 = D->b3; L.tok = D->tok;
+    L.Pfw = Pfw[l];
+    L.Pa = (l == 0) ? Pa0 : Pa[l - 1];
+    L.Pv = (l == 0) ? Pfw[0] : Pv[l - 1];
+    NampProj pn[2] = {{}, {}};
+    int np = 0;
+    if (l + 1 < w->n_dec) {
+      const NampDecLayerW* Dn = &w->dec[l + 1];
+      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, Pa[l]};
+      pn[1] = {Dn->W1v_img, nullptr, nullptr, Pv[l]};
+      np = 2;
+    }
+    fill_tail(L.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b,
+              (l == 0) ? h_V_enc : hs[l - 1], mask_dec, hs[l], pn, np, nullptr);
+  }
+  ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
+  hipLaunchKernelGGL(dec_sample_kernel, dim3((B_dec + slots - 1) / slots), dim3(nwaves * 64), SAMPLE_LDS,
+                     (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
 }
 
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {

@@ -583,19 +583,11 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
   __syncthreads();                                        // every wave is done with buf0 (W1)
   dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);     // lands while layer 2 runs out of buf1
-#if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 1
-  if (valid && acc[0].x == 123.456f) a.partial[0] = acc[1].x + acc[2].y + acc[3].z + acc[4].w + acc[5].x + acc[6].y + acc[7].z;
-  return;
-#endif
 
   // ---- layer 2 (T); GELU of layer 1 is applied k-tile by k-tile inside the MFMA loop
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
   chain_gemm<8, 8, false, true>(x, acc, w1, 8);           // x = layer-2 pre-activations
-#if defined(NAMP_ABL_LAYERS) && NAMP_ABL_LAYERS == 2
-  if (valid && x[0].x == 123.456f) a.partial[0] = x[1].x + x[2].y + x[3].z + x[4].w + x[5].x + x[6].y + x[7].z;
-  return;
-#endif
   wait_dma_and_sync();                                    // W3 has landed in buf0
 
   if (MODE == MODE_ENC_EDGE) {
@@ -663,6 +655,228 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
         node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dec_sample_kernel — the autoregressive sampler (ProteinMPNN.sample, non-symmetric branch,
+// inference/model_utils.py:126-218) as ONE persistent launch.  Sample streams are independent, so
+// there is no inter-workgroup traffic: a workgroup owns up to 4 streams (tile rows of the residue tail)
+// and walks their decoding orders; at step t stream b visits residue i = order[b][t] and runs, per
+// decoder layer l, exactly the message MLP + residue tail of the parallel decoder restricted to that
+// residue (the three-term first layer of edge_mlp_kernel, with Pbw[j] = Pv_l[j] + tok_l[S[j]] gathered for
+// neighbours already decoded in this stream and the static encoder-context table Pfw_l[j] for the rest),
+// then the W_out head, temperature softmax with the special tokens removed (model_utils.py:194-205),
+// an inverse-CDF draw from a caller-supplied uniform (torch.multinomial's stream is not reproducible
+// off-device; the caller seeds torch.rand instead) and the table updates for the sampled token.
+// State written by a stream is only ever read by the same workgroup (barrier + workgroup fence); words
+// that share cache lines with not-yet-written neighbours (S) are read with L1-bypassing loads.
+// ------------------------------------------------------------------------------------------
+#define NAMP_SAMPLE_SLOTS 4
+#define SAMPLE_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)
+
+struct SampleLayer {
+  const float* W1e_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
+  const float* tok;        // [vocab][128]  W1s . W_s
+  const float* Pfw;        // [G_enc][128]  W1v_l . h_V^enc            (static)
+  float* Pa;               // layer 0: [G_enc][128] static; else [G_dec][128], written at the residue's step
+  float* Pv;               // layer 0: == Pfw;                 else [G_dec][128]  W1v_l . h_V^(l)
+  NodeTail tail;           // LN1/FFN/LN2 of this layer; hV = h^(l), hV_out = h^(l+1); projections -> next layer's Pa / Pv
+};
+
+struct SampleArgs {
+  const float* hE; const int32_t* E_idx;
+  const int32_t* chain_mask;   // [G_enc]  mask * chain_mask
+  const int32_t* S_true;       // [G_enc]
+  const float* bias;           // [G_enc][vocab]
+  const int32_t* order;        // [B_dec][N]
+  const int32_t* rank;         // [B_dec][N]
+  const float* uniform;        // [B_dec][N] indexed by step
+  const int32_t* S_forced;     // optional [B_dec][N] indexed by residue (teacher forcing)
+  const float* head_w; const float* head_b;
+  int32_t* S_out;              // [B_dec][N]   (also the running sequence read back for decoded neighbours)
+  float* probs_out;            // [B_dec][N][vocab]
+  float* logp_out;             // [B_dec][N][vocab]
+  unsigned long long special;  // bit t set -> token t can never be drawn
+  float inv_T;
+  int B_dec, B_enc, N, K, TPN, n_layers, vocab, slots;
+  SampleLayer l[3];
+};
+
+struct SampleRows {             // tile row n -> residue of stream (b0 + n) at this step, or -1
+  const int* node_lds;
+  __device__ __forceinline__ int operator()(int n) const { return node_lds[n]; }
+};
+
+__global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;
+  char* buf1 = smem + NAMP_IMG_BYTES;
+  float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);            // [12 waves][128]
+  int* node_lds = (int*)(dpart + 12 * NAMP_H);                   // [4] residue (dec-global) per slot, -1 idle
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int slot = wave / a.TPN, kt = wave - slot * a.TPN;
+  const int b = blockIdx.x * a.slots + slot;
+  const bool wave_active = (slot < a.slots) && (b < a.B_dec);
+  const int bb = wave_active ? b : 0;
+  const int b_enc = bb % a.B_enc;
+  const f4* w0 = (const f4*)buf0 + lane;
+  const f4* w1 = (const f4*)buf1 + lane;
+  const SampleRows rows = {node_lds};
+
+  for (int t = 0; t < a.N; ++t) {
+    const int i_loc = a.order[(long)bb * a.N + t];
+    const int node = bb * a.N + i_loc;                   // stream-global residue
+    const int node_enc = b_enc * a.N + i_loc;
+    if (tid < NAMP_SAMPLE_SLOTS) {
+      const int bs = blockIdx.x * a.slots + tid;
+      node_lds[tid] = (tid < a.slots && bs < a.B_dec) ? bs * a.N + a.order[(long)bs * a.N + t] : -1;
+    }
+    const int k = 16 * kt + m;
+    const bool valid = wave_active && (k < a.K);
+    const long erow = (long)node_enc * a.K + (valid ? k : 0);
+    const int j_loc = a.E_idx[erow];
+    const bool bw = a.rank[(long)bb * a.N + j_loc] < a.rank[(long)bb * a.N + i_loc];
+    const int j_dec = bb * a.N + j_loc, j_enc = b_enc * a.N + j_loc;
+    int S_j = 0;
+    if (bw) S_j = __hip_atomic_load(a.S_out + j_dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypass L1
+    const float w_row = valid ? (1.0f / 30.0f) : 0.f;
+
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {          // unrolled: a.l[l] must be a static index into the kernarg struct
+      if (l >= a.n_layers) break;
+      const SampleLayer& L = a.l[l];
+      f4 x[8], acc[8], pjv[8];
+      {
+        const float* src = a.hE + erow * NAMP_H + 4 * g;
+        const float* pa = L.Pa + (long)(l == 0 ? node_enc : node) * NAMP_H + 4 * g;
+        const float* pj = (bw ? L.Pv + (long)(l == 0 ? j_enc : j_dec) * NAMP_H : L.Pfw + (long)j_enc * NAMP_H) + 4 * g;
+        const float* tk = L.tok + (long)S_j * NAMP_H + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          x[q] = *(const f4*)(src + 16 * q);
+          acc[q] = *(const f4*)(pa + 16 * q);
+          pjv[q] = *(const f4*)(pj + 16 * q);
+          if (bw) pjv[q] += *(const f4*)(tk + 16 * q);
+        }
+      }
+      dma_to_lds(buf0, L.W1e_img, 64, wave, nwaves, lane);
+      dma_to_lds(buf1, L.W2_img, 64, wave, nwaves, lane);
+      wait_dma_and_sync();
+      chain_gemm<8, 8, false>(acc, x, w0, 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
+      __syncthreads();
+      dma_to_lds(buf0, L.W3_img, 64, wave, nwaves, lane);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(L.b2 + 16 * q + 4 * g);
+      chain_gemm<8, 8, false, true>(x, acc, w1, 8);
+      wait_dma_and_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float bq = L.b3[16 * q + m];
+        acc[q] = (f4){bq, bq, bq, bq};
+      }
+      chain_gemm<8, 8, true, true>(acc, x, w0, 8);
+      float wr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float sres = (acc[q].x * wr[0] + acc[q].y * wr[1]) + (acc[q].z * wr[2] + acc[q].w * wr[3]);
+        sres = xg_sum(sres);
+        if (g == 0) dpart[wave * NAMP_H + 16 * q + m] = sres;
+      }
+      __syncthreads();
+      // residue tail over the workgroup's <= 4 streams: tile row m -> stream slot m
+      {
+        const int nd = (m < NAMP_SAMPLE_SLOTS) ? node_lds[m] : -1;
+        const int ms = nd >= 0 ? m : 0;
+        const int ndc = nd >= 0 ? nd : node_lds[0];
+        // h^(l) of the residue: layer 0 reads the (stream-shared) encoder output
+        long hrow = ndc;
+        if (l == 0) { const int bq = ndc / a.N; hrow = (long)(bq % a.B_enc) * a.N + (ndc - bq * a.N); }
+        const float* hsrc = L.tail.hV + hrow * NAMP_H + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(hsrc + 16 * q);
+        for (int q2 = 0; q2 < a.TPN; ++q2) {
+          const float* dp = dpart + (ms * a.TPN + q2) * NAMP_H + 4 * g;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * q);
+        }
+        node_tail_rows<NAMP_SAMPLE_SLOTS>(L.tail, x, rows, (float*)smem, tid, wave, nwaves, lane);
+      }
+      __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
+    }
+
+    // ---- output head + draw, one wave per stream slot.  h^(n_layers) row of slot n is yT[c * R + n].
+    {
+      const float* yT = (const float*)smem + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
+      for (int n = wave; n < NAMP_SAMPLE_SLOTS; n += nwaves) {
+        const int nd = node_lds[n];
+        if (nd < 0) continue;
+        const int bq = nd / a.N, iq = nd - bq * a.N;
+        const int ne = (bq % a.B_enc) * a.N + iq;
+        float z = -INFINITY;
+        if (lane < a.vocab) {
+          const float* w = a.head_w + (long)lane * NAMP_H;
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+          for (int c = 0; c < NAMP_H; c += 4) {
+            const f4 wv = *(const f4*)(w + c);
+            s0 = fmaf(wv.x, yT[(c + 0) * NAMP_SAMPLE_SLOTS + n], s0); s1 = fmaf(wv.y, yT[(c + 1) * NAMP_SAMPLE_SLOTS + n], s1);
+            s2 = fmaf(wv.z, yT[(c + 2) * NAMP_SAMPLE_SLOTS + n], s2); s3 = fmaf(wv.w, yT[(c + 3) * NAMP_SAMPLE_SLOTS + n], s3);
+          }
+          z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
+        }
+        // log_softmax(logits)                                         (model_utils.py:190)
+        float mx = z;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float e = (lane < a.vocab) ? expf(z - mx) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+        const float logp = (z - mx) - logf(e);
+        // softmax((logits + bias) / T), special tokens removed, renormalised   (model_utils.py:196-205)
+        float zt = (lane < a.vocab) ? (z + a.bias[(long)ne * a.vocab + lane]) * a.inv_T : -INFINITY;
+        float mt = zt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
+        float p = (lane < a.vocab) ? expf(zt - mt) : 0.f;
+        float ps = p;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ps += __shfl_xor(ps, o);
+        p = p / ps;
+        if ((a.special >> lane) & 1ull) p = 0.f;
+        float pr = p;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) pr += __shfl_xor(pr, o);
+        p = p / pr;
+        // inverse CDF: first token whose inclusive prefix sum exceeds u
+        float cdf = p;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float up = __shfl_up(cdf, o);
+          if (lane >= o) cdf += up;
+        }
+        const float u = a.uniform[(long)bq * a.N + t];
+        const unsigned long long hit = __ballot(p > 0.f && cdf > u);
+        const unsigned long long any = __ballot(p > 0.f);
+        int S_t = hit ? (int)__builtin_ctzll(hit) : (any ? 63 - (int)__builtin_clzll(any) : 0);
+        if (a.S_forced) S_t = a.S_forced[(long)bq * a.N + iq];
+        const int cm = a.chain_mask[ne];
+        if (!cm) S_t = a.S_true[ne];
+        if (lane < a.vocab) {
+          a.probs_out[(long)nd * a.vocab + lane] = cm ? p : 0.f;
+          a.logp_out[(long)nd * a.vocab + lane] = cm ? logp : 0.f;
+        }
+        if (lane == 0) __hip_atomic_store(a.S_out + nd, S_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();              // S of this step is published before the next step's neighbours read it
   }
 }
 

@@ -71,6 +71,9 @@ _PROTOTYPES = {
     "namp_fused_tail_max_residues": (i32, []),
     "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
     "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_sample_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+                                  C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),
     "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,

@@ -311,8 +311,61 @@ class ProteinMPNN(nn.Module):
             log_probs, logits = self.decode_graph(h_V, h_E, E_idx, feature_dict["S"], mask, rank, want_logits=True)
             return log_probs, torch.softmax(logits, dim=-1)
 
+    # reference quirk (model_utils.py:186): DecLayer receives mask_t of shape [B], which broadcasts so that
+    # every stream is masked with STREAM 0's mask at that step.  True reproduces it; it only matters when
+    # batch_size > 1 and masked residues coexist with fixed (chain_mask = 0) ones.
+    reference_sample_mask_quirk = True
+
+    @torch.no_grad()
     def sample(self, feature_dict):
-        raise NotImplementedError("autoregressive sampler (SURVEY §8 f2) is not built yet")
+        """ProteinMPNN.sample, non-symmetric branch (model_utils.py:101-218), as one persistent HIP launch.
+        The categorical draw uses torch.rand on the device (seed with torch.manual_seed) through an inverse
+        CDF instead of torch.multinomial; ``feature_dict["S_forced"]`` (optional, [batch,L]) teacher-forces."""
+        fd = feature_dict
+        bs = fd["batch_size"]
+        S_true, mask, bias = fd["S"], fd["mask"], fd["bias"]
+        sym = fd.get("symmetry_residues", [[]])
+        if not (len(sym) == 1 and len(sym[0]) == 0):
+            raise NotImplementedError("symmetry-tied sampling (model_utils.py:219-326) is not built yet")
+        if "pair_bias" in fd:
+            raise NotImplementedError("pair_bias sampling is not built yet")
+        B, L = S_true.shape
+        dev = S_true.device
+        h_V, h_E, E_idx = self.encode(fd)
+        K = E_idx.shape[-1]
+        chain_mask = mask * fd["chain_mask"]
+        order = self.decoding_order(chain_mask, fd["randn"])                  # [max(B, bs), L]
+        B_dec = B * bs
+        if order.shape[0] != B_dec:
+            raise ValueError(f"randn has {fd['randn'].shape[0]} rows; expected batch_size*B = {B_dec}")
+        rank = self.ranks_of(order)
+        mask_dec = mask.repeat(bs, 1)
+        if self.reference_sample_mask_quirk and B == 1 and bs > 1:
+            m0 = mask[0][order[0]]                                             # stream 0's mask along the steps
+            mask_dec = torch.empty_like(mask_dec).scatter_(1, order, m0.expand(B_dec, L).contiguous())
+        uniform = torch.rand(B_dec, L, device=dev)
+        special = 0
+        for name in ("UNK", "DX", "RX", "MAS", "PAD"):                        # model_utils.py:199-203
+            special |= 1 << int(self.restype_to_int[name])
+        W = self._weights()
+        Lb = hip.lib()
+        S_out = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
+        probs = torch.empty(B_dec, L, self.num_letters, device=dev)
+        logp = torch.empty_like(probs)
+        ws = torch.empty(Lb.namp_sample_workspace_bytes(B, B_dec, L, K), dtype=torch.uint8, device=dev)
+        E32, cm32, St32 = _i32(E_idx), _i32(chain_mask), _i32(S_true)
+        md32, o32, r32 = _i32(mask_dec), _i32(order), _i32(rank)
+        bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
+        forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
+        h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
+        hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
+                                         cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(),
+                                         uniform.data_ptr(), hip.ptr(forced), float(fd["temperature"]), special,
+                                         S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         B_dec, B, L, K, hip.current_stream()), "decoder_sample")
+        torch.cuda.current_stream().synchronize()        # temporaries above must outlive the launch
+        return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
+                "uniform": uniform}
 
     # positional convenience wrapper in the upstream ProteinMPNN argument order (SURVEY §0 F3)
     def forward_positional(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, randn, *, X_m,
