@@ -67,6 +67,12 @@ typedef struct NampDecLayerW {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 } NampDecLayerW;
 
+/* ProteinFeaturesNA parameters (inference/model_utils.py:470-486): edge_embedding.weight [128 x 5200] as a
+ * 325-k-tile fragment image, embeddings.linear [16 x 66] + bias in plain layout, norm_edges. */
+typedef struct NampFeatW {
+  const float *Wedge_img, *pos_w, *pos_b, *ln_g, *ln_b;
+} NampFeatW;
+
 typedef struct NampModelW {
   int32_t n_enc, n_dec, vocab, reserved;
   const float *Wv_img, *Wv_b;      /* W_v (model_utils.py:35,88) */
@@ -74,6 +80,7 @@ typedef struct NampModelW {
   const float *Wout_w, *Wout_b;    /* W_out [vocab x 128] plain layout (model_utils.py:65) */
   NampEncLayerW enc[NAMP_MAX_LAYERS];
   NampDecLayerW dec[NAMP_MAX_LAYERS];
+  NampFeatW feat;
 } NampModelW;
 
 /* ---- a1/a3: neighbour gather ----------------------------------------------------------- */
@@ -152,7 +159,20 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
                        const int32_t* mask, const int32_t* mask_attend, float* h_V_out, float* h_E_out,
                        void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
 
-/* ProteinMPNN.encode after featurisation (model_utils.py:88-94): (V, E, E_idx, mask) -> h_V, h_E. */
+/* ---- a11: graph construction + edge features ------------------------------------------------
+ * ProteinFeaturesNA.forward, eval mode (model_utils.py:528-593) without the node one-hot (a 6-row table lookup
+ * the caller does): virtual atoms, kNN on CA + ref atom with the reference's masking (E_idx int32 [B,L,K],
+ * K = min(top_k, L), ascending distance, ties by index), and E = LayerNorm(edge_embedding([positional | RBF])).
+ * X [B,L,16,3] f32, X_m / masks / R_idx / chain_labels int32 [B,L(,16)]; atom order of run.py:15-19; ref_atom =
+ * index of na_ref_atom (15 = C1').  E and/or h_E = W_e.E + b_e [B,L,K,128] are written (pass NULL to skip one). */
+size_t namp_featurize_workspace_bytes(int B, int L);
+int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                   const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                   const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E,
+                   void* ws, size_t ws_bytes, int B, int L, void* stream);
+
+/* ProteinMPNN.encode after featurisation (model_utils.py:88-94): (V, E, E_idx, mask) -> h_V, h_E.
+ * E may be NULL when h_E already holds W_e.E + b_e (written by namp_featurize). */
 int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
                      const int32_t* mask, float* h_V, float* h_E,
                      void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
@@ -200,7 +220,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
 #define NAMP_KIND_NODE_UPDATE 5
 #define NAMP_KIND_DEC_MESSAGE 6
 #define NAMP_KIND_LOGITS 7
-#define NAMP_NUM_KINDS 8
+#define NAMP_KIND_FEATURES 8
+#define NAMP_NUM_KINDS 9
 int namp_profile_enable(int on);
 int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nkinds);
 

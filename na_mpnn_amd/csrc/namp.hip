@@ -90,6 +90,8 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel, SAMPLE_LDS);
+  set((const void*)edge_features_kernel, FEAT_LDS);
+  set((const void*)knn_kernel, 8192 * 8 + 64);
 }
 
 int ensure_attributes() {
@@ -466,6 +468,57 @@ int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nki
   return rc;
 }
 
+size_t namp_featurize_workspace_bytes(int B, int L) {
+  if (B < 1 || L < 1) return 0;
+  const size_t G = (size_t)B * L;
+  return ((G * 54 * 4 + 255) & ~size_t(255)) + ((G * 4 + 255) & ~size_t(255)) + ((G * 3 * 4 + 255) & ~size_t(255)) + 4096;
+}
+
+int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                   const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                   const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
+                   size_t ws_bytes, int B, int L, void* stream) {
+  REQUIRE(w != nullptr, "namp_featurize: null weights");
+  REQUIRE_PTR(X); REQUIRE_PTR(ws); OPTIONAL_PTR(E); OPTIONAL_PTR(h_E);
+  REQUIRE_PTR(w->feat.Wedge_img); REQUIRE_PTR(w->feat.pos_w); REQUIRE_PTR(w->feat.pos_b);
+  REQUIRE_PTR(w->feat.ln_g); REQUIRE_PTR(w->feat.ln_b);
+  if (!X_m || !mask || !R_idx || !chain_labels || !protein_mask || !dna_mask || !rna_mask || !E_idx)
+    return fail(NAMP_EINVAL, "namp_featurize: null pointer argument");
+  REQUIRE(E || h_E, "namp_featurize: at least one of E / h_E must be requested");
+  REQUIRE(B >= 1 && L >= 1 && top_k >= 1, "namp_featurize: bad dims B=%d L=%d top_k=%d", B, L, top_k);
+  REQUIRE(L <= 8192, "namp_featurize: L=%d exceeds the 8192 residues the in-LDS neighbour sort handles", L);
+  REQUIRE(ref_atom >= 0 && ref_atom < 16, "namp_featurize: ref_atom=%d out of range", ref_atom);
+  const int K = top_k < L ? top_k : L;
+  int rc = check_dims(__func__, B, L, K);
+  if (rc) return rc;
+  if ((rc = ensure_attributes())) return rc;
+  if (h_E) { REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }
+  const int G = B * L;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(ws, ws_bytes);
+  float* X18 = c.take((size_t)G * 54);
+  uint32_t* M18 = (uint32_t*)c.take((size_t)G);
+  float* P = c.take((size_t)G * 3);
+  if (!P) return fail(NAMP_EWORKSPACE, "namp_featurize: workspace too small (%zu bytes)", ws_bytes);
+  {
+    ProfScope prof_(NAMP_KIND_FEATURES, s);
+    hipLaunchKernelGGL(prep_atoms_kernel, dim3((G + 255) / 256), dim3(256), 0, s, X, X_m, protein_mask, dna_mask, rna_mask,
+                       X18, M18, P, G, ref_atom);
+    int Lp2 = 1; while (Lp2 < L) Lp2 <<= 1;
+    hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);
+    FeatArgs a = {};
+    a.X18 = X18; a.M18 = M18; a.E_idx = E_idx; a.R_idx = R_idx; a.chain = chain_labels;
+    a.Wedge_img = w->feat.Wedge_img; a.pos_w = w->feat.pos_w; a.pos_b = w->feat.pos_b; a.ln_g = w->feat.ln_g; a.ln_b = w->feat.ln_b;
+    a.We_img = h_E ? w->We_img : nullptr; a.We_b = h_E ? w->We_b : nullptr; a.E_out = E; a.hE_out = h_E;
+    a.G = G; a.L = L; a.K = K;
+    const EdgeGeom e = edge_geom(G, K);
+    a.TPN = e.tpn;
+    hipLaunchKernelGGL(edge_features_kernel, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+  }
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N;
@@ -584,7 +637,7 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
                      void* stream) {
   REQUIRE(w != nullptr, "namp_encoder_fwd: null weights");
   REQUIRE(w->n_enc >= 1 && w->n_enc <= NAMP_MAX_LAYERS, "namp_encoder_fwd: n_enc=%d out of range", w->n_enc);
-  REQUIRE_PTR(V); REQUIRE_PTR(E); REQUIRE_PTR(h_V); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
+  REQUIRE_PTR(V); OPTIONAL_PTR(E); REQUIRE_PTR(h_V); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
   int rc = check_dims(__func__, B, N, K);
   if (rc) return rc;
   const int G = B * N, tpn = (K + 15) / 16;
@@ -601,7 +654,7 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
   if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
-  if ((rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
+  if (E && (rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;   // E == NULL: h_E already = W_e.E + b
   int cur = 0;     // hv[cur] holds the layer input
   for (int l = 0; l < w->n_enc; ++l) {
     const NampEncLayerW* L = &w->enc[l];

@@ -1014,3 +1014,227 @@ __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ h
     if (logits_out) logits_out[(long)node * V + lane] = z;
   }
 }
+
+// ==========================================================================================
+// a11 — graph construction + edge featurisation (ProteinFeaturesNA.forward, model_utils.py:528-593)
+// ==========================================================================================
+
+// prep_atoms_kernel: per residue, the 18-atom frame (16 real + virtual Cb + virtual N_na, model_utils.py:548-569),
+// its 0/1 atom mask as a bit field, and the kNN reference point P = CA + C1' (model_utils.py:573).
+// Atom order is the reference's atom_dict (run.py:15-19): N, CA, C, O, OP1, OP2, P, O5', C5', C4', O4', C3', O3', C2', O2', C1'.
+__global__ void prep_atoms_kernel(const float* __restrict__ X, const int32_t* __restrict__ X_m,
+                                  const int32_t* __restrict__ protein_mask, const int32_t* __restrict__ dna_mask,
+                                  const int32_t* __restrict__ rna_mask, float* __restrict__ X18,
+                                  uint32_t* __restrict__ M18, float* __restrict__ P, int G, int ref_atom) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= G) return;
+  const float* x = X + (long)n * 48;
+  float* o = X18 + (long)n * 54;
+  uint32_t bits = 0;
+  for (int a = 0; a < 16; ++a) {
+    o[3 * a] = x[3 * a]; o[3 * a + 1] = x[3 * a + 1]; o[3 * a + 2] = x[3 * a + 2];
+    if (X_m[(long)n * 16 + a]) bits |= 1u << a;
+  }
+  auto virt = [&](int i0, int i1, int i2, float wa, float wb, float wc, float* dst) {      // get_Cb, model_utils.py:521-526
+    const float bx = x[3 * i1] - x[3 * i0], by = x[3 * i1 + 1] - x[3 * i0 + 1], bz = x[3 * i1 + 2] - x[3 * i0 + 2];
+    const float cx = x[3 * i2] - x[3 * i1], cy = x[3 * i2 + 1] - x[3 * i1 + 1], cz = x[3 * i2 + 2] - x[3 * i1 + 2];
+    const float ax = by * cz - bz * cy, ay = bz * cx - bx * cz, az = bx * cy - by * cx;
+    dst[0] = wa * ax + wb * bx + wc * cx + x[3 * i1];
+    dst[1] = wa * ay + wb * by + wc * cy + x[3 * i1 + 1];
+    dst[2] = wa * az + wb * bz + wc * cz + x[3 * i1 + 2];
+  };
+  virt(0, 1, 2, -0.58273431f, 0.56802827f, -0.54067466f, o + 48);        // Cb from N, CA, C
+  virt(10, 15, 13, -0.56967352f, 0.51055973f, -0.53122153f, o + 51);     // N_na from O4', C1', C2'
+  if (protein_mask[n]) bits |= 1u << 16;
+  if (rna_mask[n] + dna_mask[n]) bits |= 1u << 17;
+  M18[n] = bits;
+  P[3 * n] = x[3] + x[3 * ref_atom]; P[3 * n + 1] = x[4] + x[3 * ref_atom + 1]; P[3 * n + 2] = x[5] + x[3 * ref_atom + 2];
+}
+
+// knn_kernel: _dist (model_utils.py:489-497).  One workgroup per residue row: masked distances to all L
+// residues, row maximum, then a bitonic sort of 64-bit keys (distance bits << 32 | index) in LDS and the K
+// smallest are written in ascending order (ties resolved by index; torch.topk leaves them unspecified).
+// The distance uses the reference's operation order with contraction off so that near-ties round identically.
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
+                                                  int32_t* __restrict__ E_idx, int L, int Lp2, int K) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;            // [Lp2]
+  float* red = (float*)(keys + Lp2);                               // [4]
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int b = row / L;
+  const float* Pb = P + (long)b * L * 3;
+  const int32_t* mb = mask + (long)b * L;
+  const float px = P[3 * (long)row], py = P[3 * (long)row + 1], pz = P[3 * (long)row + 2];
+  const float mi = (float)mask[row];
+  float dmax = 0.f;
+  for (int j = tid; j < L; j += 256) {
+    const float dx = px - Pb[3 * j], dy = py - Pb[3 * j + 1], dz = pz - Pb[3 * j + 2];
+    float s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    const float d = (mi * (float)mb[j]) * sqrtf(s + 1e-6f);
+    dmax = fmaxf(dmax, d);
+    keys[j] = (unsigned long long)__float_as_uint(d) << 32;       // provisional: distance only
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+  if ((tid & 63) == 0) red[tid >> 6] = dmax;
+  __syncthreads();
+  dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int j = tid; j < Lp2; j += 256) {
+    if (j < L) {
+      const float m2 = mi * (float)mb[j];
+      const float d = __uint_as_float((unsigned)(keys[j] >> 32)) + (1.0f - m2) * dmax;
+      keys[j] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+    } else {
+      keys[j] = ~0ull;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= Lp2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int idx = tid; idx < Lp2; idx += 256) {
+        const int ixj = idx ^ j;
+        if (ixj > idx) {
+          const unsigned long long a = keys[idx], c = keys[ixj];
+          const bool up = (idx & k) == 0;
+          if ((a > c) == up) { keys[idx] = c; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int k = tid; k < K; k += 256) E_idx[(long)row * K + k] = (int32_t)(keys[k] & 0xffffffffu);
+}
+
+// edge_features_kernel: RBF + positional features -> edge_embedding (5200 -> 128, no bias) -> LayerNorm
+// (model_utils.py:499-519, 577-585), optionally followed by W_e (model_utils.py:89).  Same tiling as
+// edge_mlp_kernel (one wave = 16 neighbours of one residue, activations in registers); the GEMM's 5200-long
+// reduction never exists in memory: k-tile 0 is the 16 positional features, k-tile 1 + 18a + b is the 16 RBFs of
+// atom pair (a of residue i, b of neighbour j), generated in registers right before their MFMAs.  The 2.66 MB
+// weight image streams through a 2 x 48 KiB LDS ring in chunks of 6 k-tiles (one (a, b-group)); 63.9 MFLOP per
+// residue, MFMA-bound.
+struct FeatArgs {
+  const float* X18; const uint32_t* M18;          // [G][54], [G]
+  const int32_t* E_idx;                           // [G][K]
+  const int32_t* R_idx; const int32_t* chain;     // [G]
+  const float* Wedge_img;                         // image of edge_embedding.weight [128 x 5200]: 325 k-tiles
+  const float* pos_w; const float* pos_b;         // embeddings.linear [16 x 66], [16]
+  const float* ln_g; const float* ln_b;           // norm_edges
+  const float* We_img; const float* We_b;         // optional fused W_e
+  float* E_out;                                   // [G][K][128] or null
+  float* hE_out;                                  // [G][K][128] or null (needs We_img)
+  int G, L, K, TPN;
+};
+
+#define FEAT_CHUNK_BYTES (6 * 8 * 64 * 16)        // 6 k-tiles x 8 tn x 1 KiB
+#define FEAT_LDS (2 * NAMP_IMG_BYTES)
+
+__global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int npw = nwaves / a.TPN;
+  const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
+  int node = blockIdx.x * npw + node_l;
+  const bool wave_active = (node_l < npw) && (node < a.G);
+  if (!wave_active) node = 0;
+  const int bq = node / a.L;
+  const int k = 16 * kt + m;
+  const bool valid = wave_active && (k < a.K);
+  const long erow = (long)node * a.K + (valid ? k : 0);
+  const int j = bq * a.L + a.E_idx[erow];
+
+  // neighbour frame in registers (static indices below), own frame read per atom from L1/L2
+  float xj[54];
+  {
+    const float* src = a.X18 + (long)j * 54;
+#pragma unroll
+    for (int q = 0; q < 54; ++q) xj[q] = src[q];
+  }
+  const uint32_t mj = a.M18[j], mi = a.M18[node];
+  const float* xi_base = a.X18 + (long)node * 54;
+
+  f4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- chunk 0: positional k-tile (weights: first 8 KiB of the image, read straight from L2)
+  {
+    const int off = a.R_idx[node] - a.R_idx[j];
+    const int same = (a.chain[node] == a.chain[j]) ? 1 : 0;
+    int d = off + 32; d = d < 0 ? 0 : (d > 64 ? 64 : d);
+    d = d * same + (1 - same) * 65;                                  // PositionalEncodings, model_utils.py:613-616
+    f4 xk;
+    xk.x = a.pos_w[(4 * g + 0) * 66 + d] + a.pos_b[4 * g + 0];
+    xk.y = a.pos_w[(4 * g + 1) * 66 + d] + a.pos_b[4 * g + 1];
+    xk.z = a.pos_w[(4 * g + 2) * 66 + d] + a.pos_b[4 * g + 2];
+    xk.w = a.pos_w[(4 * g + 3) * 66 + d] + a.pos_b[4 * g + 3];
+    const f4* w = (const f4*)a.Wedge_img + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(w[tn * 64][r], xk[r], acc[tn]);
+  }
+
+  // ---- RBF chunks: c = 3a + bg, 6 k-tiles each, through the LDS ring
+  const float* img1 = a.Wedge_img + 8 * 64 * 4;                    // k-tile 1 onwards
+  const int chunk_kb = FEAT_CHUNK_BYTES / 1024;
+  dma_to_lds(smem, img1, chunk_kb, wave, nwaves, lane);
+  // RBF centres of this lane: mu = 2 + (4g + r) * 20/15, sigma = 1.25  (model_utils.py:499-507)
+  const float mu0 = 2.0f + (4 * g + 0) * (20.0f / 15.0f), mu1 = 2.0f + (4 * g + 1) * (20.0f / 15.0f);
+  const float mu2 = 2.0f + (4 * g + 2) * (20.0f / 15.0f), mu3 = 2.0f + (4 * g + 3) * (20.0f / 15.0f);
+#pragma unroll 1
+  for (int aa = 0; aa < 18; ++aa) {
+    const float xi0 = xi_base[3 * aa], xi1 = xi_base[3 * aa + 1], xi2 = xi_base[3 * aa + 2];
+    const float mia = (float)((mi >> aa) & 1u);
+#pragma unroll
+    for (int bg = 0; bg < 3; ++bg) {
+      const int c = 3 * aa + bg;
+      wait_dma_and_sync();                                           // chunk c has landed; everyone is done with c-1
+      if (c + 1 < 54) dma_to_lds(smem + ((c + 1) & 1) * NAMP_IMG_BYTES, img1 + (long)(c + 1) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
+      const f4* w = (const f4*)(smem + (c & 1) * NAMP_IMG_BYTES) + lane;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int bb = 6 * bg + q;
+        const float dx = xi0 - xj[3 * bb], dy = xi1 - xj[3 * bb + 1], dz = xi2 - xj[3 * bb + 2];
+        const float D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);
+        const float mk = mia * (float)((mj >> bb) & 1u);
+        const float t0 = (D - mu0) * 0.8f, t1 = (D - mu1) * 0.8f, t2 = (D - mu2) * 0.8f, t3 = (D - mu3) * 0.8f;
+        f4 xk;
+        xk.x = __expf(-(t0 * t0)) * mk; xk.y = __expf(-(t1 * t1)) * mk;
+        xk.z = __expf(-(t2 * t2)) * mk; xk.w = __expf(-(t3 * t3)) * mk;
+        f4 wf[8];
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) wf[tn] = w[(q * 8 + tn) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(wf[tn][r], xk[r], acc[tn]);
+      }
+    }
+  }
+  // ---- LayerNorm (norm_edges) -> E; optional W_e embed -> h_E
+  layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+  if (a.E_out && valid) {
+    float* dst = a.E_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+  }
+  if (a.hE_out) {
+    __syncthreads();                                                 // ring free
+    dma_to_lds(smem, a.We_img, 64, wave, nwaves, lane);
+    f4 out[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[t] = *(const f4*)(a.We_b + 16 * t + 4 * g);
+    wait_dma_and_sync();
+    chain_gemm<8, 8, false>(out, acc, (const f4*)smem + lane, 8);
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = out[t];
+    }
+  }
+}

@@ -37,11 +37,16 @@ class NampDecLayerW(C.Structure):
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b"])
 
 
+class NampFeatW(C.Structure):
+    _fields_ = _fields(["Wedge_img", "pos_w", "pos_b", "ln_g", "ln_b"])
+
+
 class NampModelW(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("n_dec", C.c_int32), ("vocab", C.c_int32), ("reserved", C.c_int32),
                 ("Wv_img", c_fp), ("Wv_b", c_fp), ("We_img", c_fp), ("We_b", c_fp),
                 ("Wout_w", c_fp), ("Wout_b", c_fp),
-                ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS)]
+                ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS),
+                ("feat", NampFeatW)]
 
 
 class NampProj(C.Structure):
@@ -72,6 +77,9 @@ _PROTOTYPES = {
     "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
     "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "namp_sample_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_featurize_workspace_bytes": (sz, [i32, i32]),
+    "namp_featurize": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
+                             vp, sz, i32, i32, vp]),
     "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                   C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),
@@ -85,7 +93,7 @@ _PROTOTYPES = {
 }
 
 KERNEL_KINDS = ["gather", "node_linear", "edge_embed", "enc_message", "enc_edge_update", "node_update",
-                "dec_message", "logits"]
+                "dec_message", "logits", "features"]
 
 _lib = None
 

@@ -162,15 +162,61 @@ class ProteinMPNN(nn.Module):
         b, c = p1 - p0, p2 - p1
         return wa * torch.cross(b, c, dim=-1) + wb * b + wc * c + p1
 
-    @torch.no_grad()
-    def featurize(self, fd, chunk=128):
-        X, mask = fd["X"], fd["mask"]
-        _require_device(X, "X")
-        ad = self.atom_dict
-        if self.training and max(self.protein_augment_eps, self.dna_augment_eps, self.rna_augment_eps) > 0:
+    def _hip_featuriser_ok(self):
+        """The HIP featuriser hard-codes the reference's atom order (run.py:15-19)."""
+        return [self.atom_dict.get(a) for a in spec.ATOM_TYPES] == list(range(spec.N_ATOMS)) and \
+            self.na_ref_atom in self.atom_dict
+
+    def _noised_X(self, fd):
+        X = fd["X"]
+        if self.training and max(self.protein_augment_eps, self.dna_augment_eps, self.rna_augment_eps) > 0:   # :539-546
             eps = fd["protein_mask"] * self.protein_augment_eps + fd["dna_mask"] * self.dna_augment_eps + \
                 fd["rna_mask"] * self.rna_augment_eps
             X = X + fd["X_m"][:, :, :, None] * eps[:, :, None, None] * torch.randn_like(X)
+        return X
+
+    def _node_features(self, fd):
+        fp = self.features
+        V = fp.node_embedding.weight.t()[fd["R_polymer_type"].long()]      # one-hot @ W^T == row select (6 rows)
+        return nn.functional.layer_norm(V, (self.node_features,), fp.norm_nodes.weight, fp.norm_nodes.bias, 1e-5)
+
+    @torch.no_grad()
+    def _featurize_hip(self, fd, want_E=True, want_hE=False):
+        """a11 on the HIP kernels (prep_atoms, knn, edge_features): returns V, E (or None), h_E0 (or None), E_idx."""
+        X = self._noised_X(fd).float().contiguous()
+        _require_device(X, "X")
+        W = self._weights()
+        Lb = hip.lib()
+        B, L = X.shape[:2]
+        K = int(min(self.k_neighbors, L))
+        dev = X.device
+        E_idx = torch.empty(B, L, K, dtype=torch.int32, device=dev)
+        E = torch.empty(B, L, K, self.edge_features, device=dev) if want_E else None
+        hE = torch.empty(B, L, K, self.hidden_dim, device=dev) if want_hE else None
+        ws = torch.empty(Lb.namp_featurize_workspace_bytes(B, L), dtype=torch.uint8, device=dev)
+        t = [_i32(fd[k]) for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask")]
+        hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
+                                    int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
+                                    ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
+        torch.cuda.current_stream().synchronize()      # int32 temporaries / workspace must outlive the launches
+        return self._node_features(fd), E, hE, E_idx
+
+    @torch.no_grad()
+    def featurize(self, fd):
+        """ProteinFeaturesNA.forward (model_utils.py:528-593) -> V, E, E_idx (int64 like the reference)."""
+        if not self._hip_featuriser_ok():
+            return self.featurize_torch(fd)
+        V, E, _, E_idx = self._featurize_hip(fd, want_E=True, want_hE=False)
+        return V, E, E_idx.long()
+
+    @torch.no_grad()
+    def featurize_torch(self, fd, chunk=128):
+        """The same featurisation as stock PyTorch-ROCm ops, chunked over residues (used for non-standard atom
+        orders and as an on-device cross-check of the HIP featuriser)."""
+        X, mask = fd["X"], fd["mask"]
+        _require_device(X, "X")
+        ad = self.atom_dict
+        X = self._noised_X(fd)
         B, L = X.shape[:2]
         K = int(min(self.k_neighbors, L))
         Ca = X[:, :, ad["CA"]]
@@ -206,35 +252,40 @@ class ProteinMPNN(nn.Module):
             feat = torch.cat((pos, rbf.reshape(B, i1 - i0, K, -1)), -1)
             E[:, i0:i1] = nn.functional.layer_norm(feat @ fp.edge_embedding.weight.t(), (self.edge_features,),
                                                    fp.norm_edges.weight, fp.norm_edges.bias, 1e-5)
-        V = fp.node_embedding.weight.t()[fd["R_polymer_type"].long()]
-        V = nn.functional.layer_norm(V, (self.node_features,), fp.norm_nodes.weight, fp.norm_nodes.bias, 1e-5)
-        return V, E, E_idx
+        return self._node_features(fd), E, E_idx
 
     # ---------------------------------------------------------------------------------------
     # a7: encoder
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def encode_graph(self, V, E, E_idx, mask):
-        """(V [B,N,128], E [B,N,K,128], E_idx [B,N,K], mask [B,N]) -> h_V, h_E  (model_utils.py:88-94)."""
+    def encode_graph(self, V, E, E_idx, mask, h_E_embedded=None):
+        """(V [B,N,128], E [B,N,K,128], E_idx [B,N,K], mask [B,N]) -> h_V, h_E  (model_utils.py:88-94).
+        ``h_E_embedded`` (= W_e.E + b, updated in place) may be given instead of E."""
         _require_device(V, "V")
         W = self._weights()
         B, N, K = E_idx.shape
-        V, E = V.float().contiguous(), E.float().contiguous()
+        V = V.float().contiguous()
+        E = E.float().contiguous() if E is not None else None
         E_idx32, mask32 = _i32(E_idx), _i32(mask)
         h_V = torch.empty(B, N, H, device=V.device)
-        h_E = torch.empty(B, N, K, H, device=V.device)
+        h_E = h_E_embedded if h_E_embedded is not None else torch.empty(B, N, K, H, device=V.device)
         ws = self._workspace(B, B, N, K, V.device)
-        hip.check(hip.lib().namp_encoder_fwd(W.model(), V.data_ptr(), E.data_ptr(), E_idx32.data_ptr(), mask32.data_ptr(),
+        hip.check(hip.lib().namp_encoder_fwd(W.model(), V.data_ptr(), hip.ptr(E), E_idx32.data_ptr(), mask32.data_ptr(),
                                              h_V.data_ptr(), h_E.data_ptr(), ws.data_ptr(), ws.numel(), B, N, K,
                                              hip.current_stream()), "encoder_fwd")
         return h_V, h_E
 
     @torch.no_grad()
     def encode(self, feature_dict):
-        """ProteinMPNN.encode (model_utils.py:71-99)."""
-        V, E, E_idx = self.featurize(feature_dict)
-        h_V, h_E = self.encode_graph(V, E, E_idx, feature_dict["mask"])
-        return h_V, h_E, E_idx
+        """ProteinMPNN.encode (model_utils.py:71-99).  With the HIP featuriser W_e is applied inside the feature
+        kernel, so E itself is never written."""
+        if not self._hip_featuriser_ok():
+            V, E, E_idx = self.featurize_torch(feature_dict)
+            h_V, h_E = self.encode_graph(V, E, E_idx, feature_dict["mask"])
+            return h_V, h_E, E_idx
+        V, _, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
+        h_V, h_E = self.encode_graph(V, None, E_idx, feature_dict["mask"], h_E_embedded=h_E)
+        return h_V, h_E, E_idx.long()
 
     # ---------------------------------------------------------------------------------------
     # a8 / a10: parallel decoder

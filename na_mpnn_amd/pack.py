@@ -46,6 +46,11 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
+    # featuriser (ProteinFeaturesNA): 5200-wide edge embedding as a 325-k-tile image
+    img("feat.Wedge_img", "features.edge_embedding.weight", 0, H, spec.EDGE_IN)
+    vec("feat.pos_w", "features.embeddings.linear.weight", spec.NUM_POS * (2 * spec.MAX_REL + 2))
+    vec("feat.pos_b", "features.embeddings.linear.bias", spec.NUM_POS)
+    vec("feat.ln_g", "features.norm_edges.weight", H); vec("feat.ln_b", "features.norm_edges.bias", H)
     for l in range(n_enc):
         p, q = f"enc{l}.", f"encoder_layers.{l}."
         for nm, c0 in (("W1a", 0), ("W1b", H), ("W1c", 2 * H)):
@@ -149,6 +154,8 @@ class PackedWeights:
         for l in range(self.n_dec):
             for f, _ in hip.NampDecLayerW._fields_:
                 setattr(m.dec[l], f, self.addr(f"dec{l}.{f}"))
+        for f, _ in hip.NampFeatW._fields_:
+            setattr(m.feat, f, self.addr(f"feat.{f}"))
         self.struct = m
 
     def enc_layer(self, l):

@@ -47,6 +47,15 @@ def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw):
     ref_idx = np.sort(g["E_idx"].astype(np.int64), -1)
     assert np.array_equal(np.sort(E_idx[0].cpu().numpy(), -1)[valid], ref_idx[valid])
     assert maxdiff(V[0], g["V"]) < 1e-5
+    # a11: edge features of the HIP featuriser vs the reference rows stored in the golden (same neighbour ORDER
+    # wherever distances are distinct) and vs the stock-PyTorch featuriser on the same device
+    same_order = np.array_equal(E_idx[0].cpu().numpy()[::max(1, n // 8)][:8], g["E_idx"].astype(np.int64)[::max(1, n // 8)][:8])
+    if same_order:
+        assert maxdiff(E[0, ::max(1, n // 8)][:8], g["E_rows"]) < 2e-4
+    Vt, Et, It = m.featurize_torch(fd)
+    assert torch.equal(torch.sort(It[0][valid], -1)[0], torch.sort(E_idx[0][valid], -1)[0])
+    if torch.equal(It[0][valid], E_idx[0][valid]):
+        assert maxdiff(E[0][valid], Et[0][valid].cpu()) < 2e-4
     out = m.score(fd)
     assert np.array_equal(out["decoding_order"].cpu().numpy(), g["decoding_order"])
     d = maxdiff(out["log_probs"][0], g["log_probs"])
