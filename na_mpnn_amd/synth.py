@@ -71,6 +71,7 @@ def make_complex(seed: int, n: int, *, n_chains: int = 4, frac_protein: float = 
     X_m = np.zeros((n, spec.N_ATOMS), np.int32)
     X_m[poly == 0, :4] = 1
     X_m[poly != 0, 4:] = 1
+    X_m[poly == 1, 14] = 0           # DNA has no O2' (that is how the reference's parser tells DNA from RNA)
     if missing_atom_frac > 0:
         # never the kNN reference atoms CA / C1': the reference's parser masks such residues out
         # (data_utils.py), and zeroed reference points would create exact distance ties in topk

@@ -179,3 +179,32 @@ def test_cpu_tensors_are_rejected(weights_np):
     fd["batch_size"] = 1
     with pytest.raises(RuntimeError, match="HIP device"):
         m.score(fd)
+
+
+def test_cli_design_and_specificity(tmp_path, weights_np):
+    """f3: run.py-compatible CLI end to end on a synthetic PDB (seeded synthetic weights): FASTA header/sequence
+    format of run.py:445-455,501-511 and the specificity .npz keys of run.py:426-443."""
+    from na_mpnn_amd import cli, pdbio
+    cx = synth.make_complex(seed=31, n=64, n_chains=3)
+    int_to_res = {v: k for k, v in spec.restype_to_int().items()}
+    letters = ["ABC"[c] for c in cx["chain_labels"]]
+    pdb = os.path.join(str(tmp_path), "toy.pdb")
+    pdbio.write_pdb(pdb, cx["X"], cx["X_m"], [int_to_res[int(s)] for s in cx["S"]], letters, cx["R_idx"])
+    out = os.path.join(str(tmp_path), "out")
+    cli.main(["--mode", "design", "--pdb_path", pdb, "--out_folder", out, "--random_init_seed", "0", "--seed", "7",
+              "--fixed_residues", f"A{cx['R_idx'][0]} A{cx['R_idx'][1]}", "--number_of_batches", "2"])
+    lines = open(os.path.join(out, "seqs", "toy.fa")).read().splitlines()
+    assert len(lines) == 2 * (1 + 2)
+    assert lines[0].startswith(">toy, T=0.1, seed=7, num_res=62, batch_size=1, number_of_batches=2, model_path=")
+    assert lines[2].startswith(">toy, id=1, T=0.1, seed=7, overall_confidence=") and " seq_rec=" in lines[2]
+    native, designed = lines[1], lines[3]
+    assert len(native) == 64 + 2 and native.count("/") == 2 and len(designed) == len(native)
+    assert designed[:2] == native[:2]                       # the two fixed residues keep their identity
+    assert not set(designed) & set("Xxy-+")                 # omitted / special tokens never appear
+    cli.main(["--mode", "specificity", "--pdb_path", pdb, "--out_folder", out, "--random_init_seed", "0", "--seed", "7",
+              "--design_na_only", "1", "--output_specificity", "1", "--batch_size", "6"])
+    z = np.load(os.path.join(out, "specificity", "toy.npz"), allow_pickle=True)
+    assert z["predicted_ppm"].shape == (64, 33)
+    na = (cx["dna_mask"] + cx["rna_mask"]).astype(bool)
+    assert np.allclose(z["predicted_ppm"][na].sum(-1), 1.0, atol=1e-5) and np.all(z["predicted_ppm"][~na] == 0)
+    assert list(z["encoded_residues"][:2]) == [f"A{cx['R_idx'][0]}", f"A{cx['R_idx'][1]}"]
