@@ -190,7 +190,7 @@ def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bia
 
     rna_flag = P["rna_mask_for_token_conversion"]
     entries = ['>{}, T={}, seed={}, num_res={}, batch_size={}, number_of_batches={}, model_path={}\n{}'.format(
-        name, args.temperature, seed, cmask.sum().cpu().numpy(), args.batch_size, args.number_of_batches, ckpt_name,
+        name, args.temperature, seed, (fd["mask"] * fd["chain_mask"]).sum().cpu().numpy(), args.batch_size, args.number_of_batches, ckpt_name,
         seq_string(P["S"], rna_flag, int_to_str, dna_to_rna, P["chain_letters"]))]
     for ix in range(S_stack.shape[0]):
         conf = np.format_float_positional(np.exp(-loss_stack[ix].cpu().numpy()), unique=False, precision=4)
