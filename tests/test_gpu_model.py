@@ -206,5 +206,7 @@ def test_cli_design_and_specificity(tmp_path, weights_np):
     z = np.load(os.path.join(out, "specificity", "toy.npz"), allow_pickle=True)
     assert z["predicted_ppm"].shape == (64, 33)
     na = (cx["dna_mask"] + cx["rna_mask"]).astype(bool)
-    assert np.allclose(z["predicted_ppm"][na].sum(-1), 1.0, atol=1e-5) and np.all(z["predicted_ppm"][~na] == 0)
+    na_chains = {l for l, f in zip(letters, na) if f}       # --design_na_only works per chain (run.py:296-301)
+    des = np.array([l in na_chains for l in letters])
+    assert np.allclose(z["predicted_ppm"][des].sum(-1), 1.0, atol=1e-5) and np.all(z["predicted_ppm"][~des] == 0)
     assert list(z["encoded_residues"][:2]) == [f"A{cx['R_idx'][0]}", f"A{cx['R_idx'][1]}"]
