@@ -107,6 +107,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must bring in ITS HIP runtime first: the process may hold only one libamdhip64, and the device
+    # pointers / streams handed to this library come from torch's.  (Loading this .so first binds /opt/rocm's
+    # runtime instead and every call then fails with "no ROCm-capable device is detected".)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"HIP extension not built: {LIB_PATH} is missing. Run `python -m na_mpnn_amd.build` "
