@@ -341,3 +341,45 @@ def test_abi_error_reporting(L, dev, packed):
     assert rc == -3
     with pytest.raises(RuntimeError):
         hip.check(rc, "encoder_fwd")
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 2), (5, 3), (17, 16), (70, 64), (90, 80), (120, 100), (200, 130)])
+def test_small_and_wide_neighbourhoods(L, dev, wt, packed, n, k):
+    """Edge cases of the tiling: single-residue graphs, K below one tile, K = 64 / 80 / 100 / 130 (4..9 tiles per
+    residue, i.e. 3 / 2 / 1 / 1 residues per workgroup) — encoder + decoder against the oracle."""
+    t, d = graph(dev, seed=900 + n, batch=2, n=n, k=k, masked_frac=0.1 if n > 10 else 0.0)
+    K = t["E_idx"].shape[-1]
+    hV, hE, logp, order = run_encdec(L, dev, packed, d, 2, n, K)
+    for b in range(2):
+        sl = slice(b, b + 1)
+        rV, rE = cpu_ref.encode_from_graph(wt, t["V"][sl], t["E"][sl], t["E_idx"][sl].long(), t["mask"][sl])
+        ref = cpu_ref.score_from_encoded(wt, rV, rE, t["E_idx"][sl].long(), t["S"][sl], t["mask"][sl],
+                                         t["chain_mask"][sl], t["randn"][sl])
+        assert torch.equal(order[b].cpu(), ref["decoding_order"])
+        assert maxdiff(hV[sl], rV) < TOL_ACT and maxdiff(hE[sl], rE) < TOL_ACT
+        assert maxdiff(logp[sl], ref["log_probs"]) < TOL_LOGP
+        valid = t["mask"][b].bool()
+        assert torch.equal(logp[b].argmax(-1).cpu()[valid], ref["log_probs"][0].argmax(-1)[valid])
+
+
+def test_cfg3_sized_batch(L, dev, wt, packed):
+    """BASELINE configs[2] shape in fp32: B=64 x N=1000, K=48 (3.07 M edges, unfused large-batch path).  Spot-check
+    three complexes against the oracle and the whole batch for normalisation / batch independence."""
+    B, N, K = 64, 1000, 48
+    parts = [synth.make_graph(seed=7000 + b, batch=1, n=N, k=K) for b in range(B)]
+    g = {k_: np.concatenate([p[k_] for p in parts], 0) for k_ in parts[0]}
+    t = {k_: torch.from_numpy(v) for k_, v in g.items()}
+    d = {k_: v.to(dev) for k_, v in t.items()}
+    _, _, logp, _ = run_encdec(L, dev, packed, d, B, N, K)
+    assert torch.isfinite(logp).all()
+    assert maxdiff(torch.logsumexp(logp, -1), torch.zeros(B, N)) < 1e-5
+    for b in (0, 31, 63):
+        sl = slice(b, b + 1)
+        rV, rE = cpu_ref.encode_from_graph(wt, t["V"][sl], t["E"][sl], t["E_idx"][sl].long(), t["mask"][sl])
+        ref = cpu_ref.score_from_encoded(wt, rV, rE, t["E_idx"][sl].long(), t["S"][sl], t["mask"][sl],
+                                         t["chain_mask"][sl], t["randn"][sl])
+        assert maxdiff(logp[sl], ref["log_probs"]) < TOL_LOGP
+        assert torch.equal(logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1))
+    d1 = {k_: v[31:32].contiguous() for k_, v in d.items()}
+    _, _, logp1, _ = run_encdec(L, dev, packed, d1, 1, N, K)          # fused small-batch path on the same complex
+    assert maxdiff(logp1, logp[31:32]) < 5e-5
