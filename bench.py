@@ -36,6 +36,7 @@ from na_mpnn_amd.pack import PackedWeights        # noqa: E402
 
 WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48)}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
 # algorithmic FLOP / residue of the dense reference formulation, K=48, H=128
 ALGO_FLOP = {"enc_message": 7_864_320, "enc_edge_update": 7_864_320, "dec_message": 9_437_184}
@@ -47,12 +48,13 @@ EXEC_FLOP_EDGE = 48 * 3 * 2 * 128 * 128
 class Runner:
     """Owns the device tensors of one rank's batch and enqueues one step."""
 
-    def __init__(self, dev, B, N, K, seed):
+    def __init__(self, dev, B, N, K, seed, precision="fp32"):
         self.L = hip.lib()
         self.dev, self.B, self.N, self.K = dev, B, N, K
         w = synth.make_weights(0)
         self.w_np = w
         self.packed = PackedWeights({k: torch.from_numpy(v).to(dev) for k, v in w.items()}, 3, 3, spec.VOCAB, dev)
+        self.packed.set_precision(precision)
         # graphs are generated one at a time to bound host memory at B=64
         parts = [synth.make_graph(seed=seed + b, batch=1, n=N, k=K) for b in range(B)]
         self.g_np = {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
@@ -152,6 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
+                    help="per-edge GEMM precision; default fp32 for cfg2 (parity mode), bf16 for cfg3 (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -181,7 +185,8 @@ def main():
     cfg = WORKLOADS[args.workload]
     B, N, K = cfg["B"], cfg["N"], cfg["K"]
     cfg_idx = 1 if args.workload == "cfg2" else 2
-    runner = Runner(dev, B, N, K, seed=1 + cfg_idx + 1000 * rank)
+    precision = args.precision or ("bf16" if args.workload == "cfg3" else "fp32")
+    runner = Runner(dev, B, N, K, seed=1 + cfg_idx + 1000 * rank, precision=precision)
 
     def barrier():
         if dist is not None:
@@ -229,17 +234,19 @@ def main():
             traffic = json.load(f).get(args.workload, {}).get(dom)
     except OSError:
         pass
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     roofline = {"kernel": f"edge_mlp_kernel<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / peak, 4),
                 "traffic": traffic, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": EXEC_FLOP_EDGE * B * N,
-                "executed_frac": round(EXEC_FLOP_EDGE * B * N / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "executed_frac": round(EXEC_FLOP_EDGE * B * N / avg_s / 1e12 / peak, 4),
                 "avg_launch_ms": per_kernel[dom]["avg_ms"]}
 
     out = {"metric": "residues/sec (enc+dec fwd), N~1000 K=48 h=128", "value": round(value, 1), "unit": "residues/s",
            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if precision == "fp32" else "bf16 (per-edge GEMMs; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: B={B} x N={N} residues, K={K}, H=128, 3 enc + 3 dec layers, "
-                                  "fp32 MFMA, seeded random-init weights, per-rank independent complexes",
+                                  f"{precision} MFMA, seeded random-init weights, per-rank independent complexes",
                       "global_batch": B * n_gpus, "seq_len": N, "parallelism": f"replicas x{n_gpus}"},
            "roofline": roofline, "per_kernel": per_kernel,
            "whole_path": {"algorithmic_tflops": round(ALGO_FLOP_TOTAL * B * N / (ms_per_step * 1e-3) / 1e12, 3),

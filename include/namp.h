@@ -46,6 +46,12 @@ const char* namp_last_error(void);
  * into fragment-image order.  out_f, in_f multiples of 16.  img: out_f*in_f floats. */
 int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float* img, void* stream);
 
+/* Precision of the per-edge message / edge-update GEMMs.  Default (flags = 0): fp32 MFMA, the parity mode.
+ * NAMP_FLAG_BF16: inputs and weights rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) — BASELINE
+ * configs[2]'s throughput mode; ~1e-2 on log-probs, not parity-grade.  Residue-level math stays fp32. */
+#define NAMP_FLAG_BF16 1
+int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stream);   /* [128x128] block -> 32 KiB */
+
 /* EncLayer parameters (inference/model_utils.py:659-679).  W1/W11 are split by input block:
  * a = h_V_i columns [0,128), b = h_E_ik [128,256), c = h_V_j [256,384). */
 typedef struct NampEncLayerW {
@@ -55,6 +61,9 @@ typedef struct NampEncLayerW {
   const float *W12_img, *b12, *W13_img, *b13;
   const float *Win_img, *b_in, *Wout_img, *b_out;   /* dense.W_in [512x128], dense.W_out [128x512] */
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+  /* bf16 throughput mode: 32 KiB bf16 images of the six per-edge blocks (namp_pack_image_bf16) */
+  const float *W1b_bimg, *W2_bimg, *W3_bimg, *W11b_bimg, *W12_bimg, *W13_bimg;
+  int64_t flags;                                     /* NAMP_FLAG_BF16: run the per-edge GEMMs in bf16 */
 } NampEncLayerW;
 
 /* DecLayer parameters (inference/model_utils.py:619-634).  W1 [128x512] split by input block:
@@ -65,6 +74,8 @@ typedef struct NampDecLayerW {
   const float *W2_img, *b2, *W3_img, *b3;
   const float *Win_img, *b_in, *Wout_img, *b_out;
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float *W1e_bimg, *W2_bimg, *W3_bimg;        /* bf16 images (throughput mode) */
+  int64_t flags;
 } NampDecLayerW;
 
 /* ProteinFeaturesNA parameters (inference/model_utils.py:470-486): edge_embedding.weight [128 x 5200] as a

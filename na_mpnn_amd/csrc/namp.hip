@@ -87,6 +87,15 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_ENC_MSG, 16>, EDGE_TAIL_LDS);
   set((const void*)edge_mlp_kernel<MODE_DEC_MSG, 16>, EDGE_TAIL_LDS);
   set((const void*)edge_mlp_kernel<MODE_ENC_EDGE, 0>, 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 0, true>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 0, true>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_EDGE, 0, true>), 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel, SAMPLE_LDS);
@@ -116,26 +125,34 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE, int TAIL = 0>
+template <int MODE, int TAIL = 0, bool BF16 = false>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
-  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
+}
+
+// precision dispatch: flags bit 0 of the layer struct selects the bf16 message GEMMs (throughput mode)
+template <int MODE, int TAIL>
+int launch_edge_prec(const EdgeArgs& a, bool bf16, hipStream_t s) {
+  return bf16 ? launch_edge<MODE, TAIL, true>(a, s) : launch_edge<MODE, TAIL, false>(a, s);
 }
 
 // fused-tail flavour by residues per workgroup: <= 4 and <= 6 take the VALU tails (the latter needs 128
 // LayerNorm threads per residue: 2*npw <= waves), more take the 16-row MFMA tail
 template <int MODE>
-int launch_edge_tail(EdgeArgs a, hipStream_t s) {
+int launch_edge_tail(const EdgeArgs& a, bool bf16, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
-  if (e.npw <= 4) return launch_edge<MODE, 4>(a, s);
-  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8>(a, s);
-  return launch_edge<MODE, 16>(a, s);
+  if (e.npw <= 4) return launch_edge_prec<MODE, 4>(a, bf16, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge_prec<MODE, 8>(a, bf16, s);
+  return launch_edge_prec<MODE, 16>(a, bf16, s);
 }
+
+#define NAMP_FLAG_BF16 1
 
 void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b, const float* hV,
@@ -242,6 +259,14 @@ int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float
   return NAMP_OK;
 }
 
+int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stream) {
+  if (!W || !img) return fail(NAMP_EINVAL, "namp_pack_image_bf16: null pointer");
+  REQUIRE(col0 >= 0 && ld >= col0 + 128, "namp_pack_image_bf16: block [0:128, %d:%d) outside ld=%d", col0, col0 + 128, ld);
+  hipLaunchKernelGGL(pack_image_bf16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_gather_nodes_f32(const float* nodes, const int32_t* idx, float* out, int B, int N, int K, int C,
                           void* stream) {
   if (!nodes || !idx || !out) return fail(NAMP_EINVAL, "namp_gather_nodes_f32: null pointer");
@@ -309,10 +334,13 @@ int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_
   if (rc) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
-  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
+  if (bf) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  a.W1_img = bf ? w->W1b_bimg : w->W1b_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  a.b2 = w->b2; a.b3 = w->b3;
   a.partial = partial; a.G = a.G_enc = B * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge<MODE_ENC_MSG>(a, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_ENC_MSG, 0>(a, bf, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -329,10 +357,13 @@ int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t
   if (rc) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.hE_out = h_E_out; a.E_idx = E_idx; a.Pa = Pa; a.Pj0 = Pc;
-  a.W1_img = w->W11b_img; a.W2_img = w->W12_img; a.W3_img = w->W13_img; a.b2 = w->b12; a.b3 = w->b13;
+  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
+  if (bf) { REQUIRE_PTR(w->W11b_bimg); REQUIRE_PTR(w->W12_bimg); REQUIRE_PTR(w->W13_bimg); }
+  a.W1_img = bf ? w->W11b_bimg : w->W11b_img; a.W2_img = bf ? w->W12_bimg : w->W12_img; a.W3_img = bf ? w->W13_bimg : w->W13_img;
+  a.b2 = w->b12; a.b3 = w->b13;
   a.ln_g = w->ln3_g; a.ln_b = w->ln3_b; a.G = a.G_enc = B * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_ENC_EDGE, (hipStream_t)stream);
-  rc = launch_edge<MODE_ENC_EDGE>(a, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_ENC_EDGE, 0>(a, bf, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -368,10 +399,13 @@ int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_
   REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_dec_message: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
-  a.W1_img = w->W1e_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
+  if (bf) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  a.W1_img = bf ? w->W1e_bimg : w->W1e_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  a.b2 = w->b2; a.b3 = w->b3;
   a.partial = partial; a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge<MODE_DEC_MSG>(a, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_DEC_MSG, 0>(a, bf, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -391,12 +425,15 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
   if ((rc = check_proj(__func__, proj, nproj, nullptr))) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
-  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
+  if (bf) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  a.W1_img = bf ? w->W1b_bimg : w->W1b_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  a.b2 = w->b2; a.b3 = w->b3;
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_tail<MODE_ENC_MSG>(a, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_ENC_MSG>(a, bf, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -423,13 +460,16 @@ int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int3
   if ((rc = check_proj(__func__, proj, nproj, S))) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
-  a.W1_img = w->W1e_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
+  if (bf) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  a.W1_img = bf ? w->W1e_bimg : w->W1e_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  a.b2 = w->b2; a.b3 = w->b3;
   a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, S);
   a.tail.head_w = head_w; a.tail.head_b = head_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = vocab;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_tail<MODE_DEC_MSG>(a, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_DEC_MSG>(a, bf, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -95,6 +95,40 @@ __device__ __forceinline__ void chain_gemm(f4 (&acc)[NTN], const f4 (&x)[TK], co
   }
 }
 
+// ---- bf16 throughput mode (BASELINE configs[2]: "bf16 MFMA message GEMM") -------------------------------
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][n=l&15], j=0..7, and gets
+// D[4(l>>4)+r][l&15] like the fp32 form.  The register chain carries over with the reduction index of step s
+// enumerated as  k(s,g,j) = 32s + 16(j>>2) + 4g + (j&3): the eight values a lane feeds into step s are exactly
+// its fp32 accumulators of channel tiles 2s and 2s+1, converted (round-to-nearest-even) on the fly.  Inputs and
+// weights are rounded to bf16, accumulation is fp32 — about 1e-2 on log-probs, NOT the parity mode.
+// Weight image: img[s][tn][lane][j] = bf16(W[16tn + (lane&15)][k(s, lane>>4, j)]), 32 KiB per 128x128 block, so
+// all three layers sit in LDS at once and the edge kernel needs a single barrier.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+#define NAMP_BIMG_BYTES 32768
+
+template <bool ACT>
+__device__ __forceinline__ bf8 pack_bf16(const f4 lo, const f4 hi) {
+  const f4 a = ACT ? gelu4(lo) : lo, b = ACT ? gelu4(hi) : hi;
+  bf8 o;
+  o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+  o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+  return o;
+}
+
+template <bool FLIP, bool ACT>
+__device__ __forceinline__ void chain_gemm_bf16(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf8 xb = pack_bf16<ACT>(x[2 * s], x[2 * s + 1]);
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) {
+      const bf8 wf = w[(s * 8 + tn) * 64];
+      if (FLIP) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, wf, acc[tn], 0, 0, 0);
+      else      acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb, acc[tn], 0, 0, 0);
+    }
+  }
+}
+
 // Same contraction with the weight image streamed straight from global memory (L2 / L1 resident):
 // fragments of step tk+1 are requested before the MFMAs of step tk issue, so one L2 round trip is
 // always covered by 4*NTN MFMAs.  Used where each fragment is consumed once per wave or where the

@@ -20,6 +20,15 @@ __global__ void pack_image_kernel(const float* __restrict__ W, int ld, int col0,
   }
 }
 
+// bf16 fragment image of a [128 x 128] block (namp_device.h, bf16 throughput mode)
+__global__ void pack_image_bf16_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 128 * 128) return;
+  const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 7, s = e >> 12;
+  const int n = 16 * tn + (lane & 15), k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  img[e] = (__bf16)W[(size_t)n * ld + col0 + k];
+}
+
 // ------------------------------------------------------------------------------------------
 // gather_cat_kernel — a1 + a3: out[row] = [ nbrs[row][0:C1] | nodes[b*N + idx[row]][0:C2] ]
 // (reference gather_nodes / cat_neighbors_nodes, inference/model_utils.py:713-732).
@@ -469,7 +478,7 @@ struct EdgeArgs {
   const float* Pa;             // [G][128] per-residue first-layer term (bias folded in)
   const float* Pj0;            // ENC: Pc [G][128];   DEC: Pbw [G][128]
   const float* Pj1;            // DEC: Pfw [G_enc][128]
-  const float* W1_img;         // 64 KiB images
+  const float* W1_img;         // 64 KiB images (fp32) or 32 KiB bf16 images (BF16 = true)
   const float* W2_img;
   const float* W3_img;
   const float* b1;             // EMBED only (otherwise folded into Pa)
@@ -491,7 +500,9 @@ struct EdgeArgs {
 
 // TAIL: 0 = write partial sums; 4 / 8 = node_tail_rows<4/8> (the workgroup owns <= 4 / <= 6 residues);
 // 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
-template <int MODE, int TAIL>
+// BF16: message / edge GEMMs on v_mfma_f32_16x16x32_bf16 with all three 32 KiB images resident in LDS
+// (throughput mode, namp_device.h); everything else — tables, K-sum, LayerNorms, residue tail — stays fp32.
+template <int MODE, int TAIL, bool BF16 = false>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
@@ -563,6 +574,23 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
 
+  if (BF16) {
+    const bf8* bw = (const bf8*)smem + lane;               // image l at smem + l * 32 KiB
+    dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
+    if (MODE != MODE_EMBED) {
+      dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
+      dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+    }
+    wait_dma_and_sync();                                   // the only barrier of the MLP
+    chain_gemm_bf16<false, false>(acc, x, bw);
+    if (MODE != MODE_EMBED) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, true>(x, acc, bw + (NAMP_BIMG_BYTES / 16));
+    }
+  } else {
   // ---- weight staging: W1 -> buf0 and W2 -> buf1 by LDS-DMA.  Issued AFTER the per-row operand loads
   // above (the VM counter retires in order: loads queued behind a bulk DMA could not be consumed before it).
   dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
@@ -571,14 +599,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   // ---- layer 1 (T): acc = Pa + W1b . h_E (+ Pj afterwards)
   chain_gemm<8, 8, false>(acc, x, w0, 8);
 
-  if (MODE == MODE_EMBED) {
-    if (valid) {
-      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
-    }
-    return;
-  }
+  if (MODE != MODE_EMBED) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
   __syncthreads();                                        // every wave is done with buf0 (W1)
@@ -589,12 +610,23 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
   chain_gemm<8, 8, false, true>(x, acc, w1, 8);           // x = layer-2 pre-activations
   wait_dma_and_sync();                                    // W3 has landed in buf0
+  }
+  }
+  if (MODE == MODE_EMBED) {
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+    }
+    return;
+  }
 
   if (MODE == MODE_ENC_EDGE) {
     // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false, true>(acc, x, w0, 8);
+    if (BF16) chain_gemm_bf16<false, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
+    else      chain_gemm<8, 8, false, true>(acc, x, w0, 8);
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
@@ -611,7 +643,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const float b = a.b3[16 * t + m];
       acc[t] = (f4){b, b, b, b};
     }
-    chain_gemm<8, 8, true, true>(acc, x, w0, 8);
+    if (BF16) chain_gemm_bf16<true, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
+    else      chain_gemm<8, 8, true, true>(acc, x, w0, 8);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnam
 
 NAMP_ABI_VERSION = 1
 NAMP_MAX_LAYERS = 8
+NAMP_FLAG_BF16 = 1
 
 c_fp = C.c_void_p   # const float*  (device)
 c_ip = C.c_void_p   # const int32_t* (device)
@@ -28,13 +29,15 @@ class NampEncLayerW(C.Structure):
     _fields_ = _fields(["W1a_img", "W1b_img", "W1c_img", "b1", "W2_img", "b2", "W3_img", "b3",
                         "W11a_img", "W11b_img", "W11c_img", "b11", "W12_img", "b12", "W13_img", "b13",
                         "Win_img", "b_in", "Wout_img", "b_out",
-                        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b"])
+                        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
+                        "W1b_bimg", "W2_bimg", "W3_bimg", "W11b_bimg", "W12_bimg", "W13_bimg"]) + [("flags", C.c_int64)]
 
 
 class NampDecLayerW(C.Structure):
     _fields_ = _fields(["W1a_img", "W1e_img", "W1s_img", "W1v_img", "b1", "tok",
                         "W2_img", "b2", "W3_img", "b3", "Win_img", "b_in", "Wout_img", "b_out",
-                        "ln1_g", "ln1_b", "ln2_g", "ln2_b"])
+                        "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                        "W1e_bimg", "W2_bimg", "W3_bimg"]) + [("flags", C.c_int64)]
 
 
 class NampFeatW(C.Structure):
@@ -59,6 +62,7 @@ _PROTOTYPES = {
     "namp_abi_version": (i32, []),
     "namp_last_error": (C.c_char_p, []),
     "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
+    "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
     "namp_cat_neighbors_nodes_f32": (i32, [c_fp, c_fp, c_ip, c_fp, i32, i32, i32, i32, i32, vp]),
     "namp_node_linear": (i32, [c_fp, c_ip, i32, i32, i32, C.POINTER(NampProj), i32, C.POINTER(NampProj), vp]),

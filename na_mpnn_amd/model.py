@@ -130,6 +130,9 @@ class ProteinMPNN(nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws = None
+        # "fp32": exact fp32 MFMA everywhere (parity mode).  "bf16": the per-edge message / edge-update GEMMs run on
+        # bf16 MFMA with fp32 accumulation — BASELINE configs[2]'s throughput mode (~1e-2 on log-probs).
+        self.message_precision = "fp32"
 
     # ---------------------------------------------------------------------------------------
     # packed weights / workspace plumbing
@@ -145,6 +148,8 @@ class ProteinMPNN(nn.Module):
             else:
                 self._packed.repack(sd)
             self._packed_sig = sig
+        if getattr(self._packed, "precision", "fp32") != self.message_precision:
+            self._packed.set_precision(self.message_precision)
         return self._packed
 
     def _workspace(self, B_enc, B_dec, N, K, device):

@@ -43,6 +43,9 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     def vec(name, key, n):
         add(name, n, ("vec", key))
 
+    def bimg(name, key, col0):                      # 32 KiB bf16 image = 8192 float slots
+        add(name, H * H // 2, ("bimg", key, col0))
+
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
@@ -67,6 +70,8 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         img(p + "Wout_img", q + "dense.W_out.weight", 0, H, 4 * H); vec(p + "b_out", q + "dense.W_out.bias", H)
         for i in (1, 2, 3):
             vec(p + f"ln{i}_g", q + f"norm{i}.weight", H); vec(p + f"ln{i}_b", q + f"norm{i}.bias", H)
+        bimg(p + "W1b_bimg", q + "W1.weight", H); bimg(p + "W2_bimg", q + "W2.weight", 0); bimg(p + "W3_bimg", q + "W3.weight", 0)
+        bimg(p + "W11b_bimg", q + "W11.weight", H); bimg(p + "W12_bimg", q + "W12.weight", 0); bimg(p + "W13_bimg", q + "W13.weight", 0)
     for l in range(n_dec):
         p, q = f"dec{l}.", f"decoder_layers.{l}."
         for nm, c0 in (("W1a", 0), ("W1e", H), ("W1s", 2 * H), ("W1v", 3 * H)):
@@ -79,6 +84,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         img(p + "Wout_img", q + "dense.W_out.weight", 0, H, 4 * H); vec(p + "b_out", q + "dense.W_out.bias", H)
         for i in (1, 2):
             vec(p + f"ln{i}_g", q + f"norm{i}.weight", H); vec(p + f"ln{i}_b", q + f"norm{i}.bias", H)
+        bimg(p + "W1e_bimg", q + "W1.weight", H); bimg(p + "W2_bimg", q + "W2.weight", 0); bimg(p + "W3_bimg", q + "W3.weight", 0)
     return items, off
 
 
@@ -133,6 +139,10 @@ class PackedWeights:
                           f"pack_image({name})")
             elif recipe[0] == "vec":
                 self.flat[off:off + n].copy_(src(recipe[1]).reshape(-1))
+            elif recipe[0] == "bimg":
+                w = src(recipe[1])
+                hip.check(L.namp_pack_image_bf16(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
+                          f"pack_image_bf16({name})")
         # per-token tables need the packed W1s images: tok_l = W_s.weight @ W1s_l^T  [vocab,128]
         ws = src("W_s.weight")
         for l in range(self.n_dec):
@@ -148,15 +158,23 @@ class PackedWeights:
         m.n_enc, m.n_dec, m.vocab, m.reserved = self.n_enc, self.n_dec, self.vocab, 0
         for f in ("Wv_img", "Wv_b", "We_img", "We_b", "Wout_w", "Wout_b"):
             setattr(m, f, self.addr(f))
+        flags = hip.NAMP_FLAG_BF16 if getattr(self, "precision", "fp32") == "bf16" else 0
         for l in range(self.n_enc):
             for f, _ in hip.NampEncLayerW._fields_:
-                setattr(m.enc[l], f, self.addr(f"enc{l}.{f}"))
+                setattr(m.enc[l], f, flags if f == "flags" else self.addr(f"enc{l}.{f}"))
         for l in range(self.n_dec):
             for f, _ in hip.NampDecLayerW._fields_:
-                setattr(m.dec[l], f, self.addr(f"dec{l}.{f}"))
+                setattr(m.dec[l], f, flags if f == "flags" else self.addr(f"dec{l}.{f}"))
         for f, _ in hip.NampFeatW._fields_:
             setattr(m.feat, f, self.addr(f"feat.{f}"))
         self.struct = m
+
+    def set_precision(self, precision: str):
+        """"fp32" (parity mode, default) or "bf16" (per-edge GEMMs in bf16: throughput mode, BASELINE configs[2])."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        self._build_struct()
 
     def enc_layer(self, l):
         return C.byref(self.struct.enc[l])

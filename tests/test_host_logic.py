@@ -43,7 +43,7 @@ def test_struct_layout_matches_header():
     for cls in (hip.NampEncLayerW, hip.NampDecLayerW):
         body = re.search(r"typedef struct %s \{(.*?)\}" % cls.__name__, header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        names = re.findall(r"\*\s*([A-Za-z0-9_]+)", body)
+        names = re.findall(r"\*\s*([A-Za-z0-9_]+)", body) + re.findall(r"int64_t\s+([A-Za-z0-9_]+)", body)
         assert names == [f for f, _ in cls._fields_]
 
 
