@@ -200,7 +200,7 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
                      void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 
 /* ---- a9: autoregressive sampler ------------------------------------------------------------
- * ProteinMPNN.sample, non-symmetric branch (model_utils.py:126-218), after encode(): B_dec independent sample
+ * ProteinMPNN.sample (model_utils.py:101-327: plain branch :126-218, symmetry-tied branch :219-326), after encode(): B_dec independent sample
  * streams over B_enc encoded complexes (stream b uses complex b % B_enc), one persistent launch.
  *   mask_dec    [B_dec,N]  residue mask per stream (the caller may reproduce the reference's use of stream 0's
  *                          mask at every step, model_utils.py:186 — see na_mpnn_amd/model.py)
@@ -209,6 +209,11 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
  *   order, rank [B_dec,N]  decoding order and its inverse                       uniform [B_dec,N] in [0,1),
  *                          consumed one per step by an inverse-CDF draw (replaces torch.multinomial, :209)
  *   S_forced    [B_dec,N]  optional: use this token instead of the draw (teacher forcing)
+ *   group_first / group_last [B_dec,N] (both or neither): symmetry-tied sampling (model_utils.py:219-326) — consecutive
+ *                          visits of `order` form groups; the members' logits are summed with sym_weights [B_enc,N]
+ *                          (NULL = 1) and ONE token is drawn per group.  group_first[v] = first visit of v's group,
+ *                          group_last[v] = 1 on the visit that closes it.  NULL: every visit is its own group.
+ *   pair_bias   [B_enc,N,vocab,N,vocab] optional (model_utils.py:116,170-172): adds sum_j pair_bias[i,:,j,S_j]
  *   special_tokens  bit t set = token t is never drawn (UNK, DX, RX, MAS, PAD: model_utils.py:199-203)
  * Outputs: S_out int32 [B_dec,N]; probs_out / logp_out [B_dec,N,vocab] = chain_mask * (sampling
  * distribution / log_softmax(logits)) as model_utils.py:211-212. */
@@ -216,6 +221,8 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K);
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                         const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                        const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
+                        const float* pair_bias,
                         float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                         void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 

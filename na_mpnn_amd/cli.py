@@ -3,7 +3,7 @@
 Mirrors the contract of /root/reference/inference/run.py — the flags of :519-555, the mode defaults of
 :559-583, ``seqs/<name>.fa`` with the header lines of :445-455 / :501-511 and ``specificity/<name>.npz`` with the
 keys of :426-443 — on top of ``na_mpnn_amd.model.ProteinMPNN`` and ``na_mpnn_amd.pdbio`` (no prody).  Not provided:
-backbone PDB output (prody writer), ``--pair_bias_AA`` and ``--symmetry_residues`` (sampler branches not built).
+backbone PDB output (prody writer).
 
     python -m na_mpnn_amd.cli --mode design --pdb_path in.pdb --out_folder out/ [--checkpoint_na_mpnn ckpt.pt]
 
@@ -47,6 +47,9 @@ def build_parser():
     a("--redesigned_residues", type=str, default="")
     a("--parse_these_chains_only", type=str, default="")
     a("--bias_AA", type=str, default="")
+    a("--pair_bias_AA", type=str, default="", help="pair bias for sequence neighbours, e.g. 'KK:-10.0,KE:-10.0'")
+    a("--symmetry_residues", type=str, default="", help="tied residues, e.g. 'A12,A13,A14|C2,C3'")
+    a("--symmetry_weights", type=str, default="", help="weights matching --symmetry_residues, e.g. '1.0,1.0,1.0|-1.0,2.0'")
     a("--na_shared_tokens", type=int, default=1)
     a("--parse_na_only", type=int, default=0)
     a("--design_na_only", type=int, default=0)
@@ -89,6 +92,18 @@ def seq_string(tokens, rna_flag, int_to_str, dna_to_rna, chain_letters):
     return "/".join(out)
 
 
+def make_pair_bias(chain_labels, R_idx, pair_bias_AA):
+    """[1,L,33,L,33] bias between sequence neighbours on one chain (semantics of data_utils.py:7-16):
+    out[0,i,a,i+1,b] = pair_bias_AA[a,b] and out[0,i+1,a,i,b] = pair_bias_AA[b,a] where R_idx[i+1]-R_idx[i]==1."""
+    L = R_idx.shape[0]
+    adj = ((R_idx[1:] - R_idx[:-1]) == 1) & (chain_labels[1:] == chain_labels[:-1])
+    out = torch.zeros(1, L, pair_bias_AA.shape[0], L, pair_bias_AA.shape[1], dtype=torch.float32, device=pair_bias_AA.device)
+    i = torch.nonzero(adj)[:, 0]
+    out[0, i, :, i + 1, :] = pair_bias_AA
+    out[0, i + 1, :, i, :] = pair_bias_AA.t()
+    return out
+
+
 def main(argv=None):
     args = apply_mode_defaults(build_parser().parse_args(argv))
     if args.model_type != "na_mpnn":
@@ -124,6 +139,12 @@ def main(argv=None):
         for item in args.bias_AA.split(","):
             aa, val = item.split(":")
             bias_AA[str_to_int[aa]] = float(val)
+    pair_bias_AA = None
+    if args.pair_bias_AA:                                                           # run.py:215-223
+        pair_bias_AA = torch.zeros(33, 33, device=device)
+        for item in args.pair_bias_AA.split(","):
+            pair, val = item.split(":")
+            pair_bias_AA[str_to_int[pair[0]], str_to_int[pair[1]]] = float(val)
     omit_list = args.omit_AA + ("bdhuy" if shared else "")
     omit_AA = torch.tensor([float(c in omit_list) for c in alphabet], device=device)
 
@@ -144,7 +165,7 @@ def main(argv=None):
             name = name[:-4]
         try:
             run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bias_AA, omit_AA, int_to_str, dna_to_rna,
-                    rti, base)
+                    rti, base, pair_bias_AA)
         except Exception as e:                     # run.py:585-617
             if not args.catch_failed_inferences:
                 raise
@@ -153,7 +174,8 @@ def main(argv=None):
                 fh.write(repr(e))
 
 
-def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bias_AA, omit_AA, int_to_str, dna_to_rna, rti, base):
+def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bias_AA, omit_AA, int_to_str, dna_to_rna, rti, base,
+            pair_bias_AA=None):
     P = pdbio.parse_pdb(pdb, chains=list(args.parse_these_chains_only) or None, parse_na_only=bool(args.parse_na_only),
                         na_shared_tokens=bool(args.na_shared_tokens),
                         load_residues_with_missing_atoms=bool(args.load_residues_with_missing_atoms))
@@ -171,11 +193,20 @@ def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bia
         chains = [c for c in chains if c in P["na_chain_letters"]]
     chain_mask = np.array([c in chains for c in P["chain_letters"]], np.int32) * fixed_positions * (1 - redesigned)
 
+    if args.symmetry_residues:                                                      # run.py:313-332
+        sym_res = [[encoded_dict[t] for t in grp.split(",")] for grp in args.symmetry_residues.split("|")]
+        sym_w = ([[float(v) for v in grp.split(",")] for grp in args.symmetry_weights.split("|")] if args.symmetry_weights
+                 else [[1.0] * len(grp) for grp in sym_res])
+    else:
+        sym_res, sym_w = [[]], [[]]
+
     with torch.no_grad():
         fd = pdbio.to_feature_dict(P, chain_mask, device)
         fd.update({"batch_size": args.batch_size, "temperature": args.temperature,
                    "bias": (-1e8 * omit_AA[None, None, :] + bias_AA).repeat(1, L, 1),
-                   "symmetry_residues": [[]], "symmetry_weights": [[]]})
+                   "symmetry_residues": sym_res, "symmetry_weights": sym_w})
+        if pair_bias_AA is not None:
+            fd["pair_bias"] = make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0], pair_bias_AA)
         S_l, lp_l, sp_l, loss_l = [], [], [], []
         cmask = (fd["mask"] * fd["chain_mask"]).float()
         for _ in range(args.number_of_batches):

@@ -569,9 +569,12 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                         const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                        const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
+                        const float* pair_bias,
                         float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                         void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
   REQUIRE(w != nullptr, "namp_decoder_sample: null weights");
+  REQUIRE((group_first == nullptr) == (group_last == nullptr), "namp_decoder_sample: group_first and group_last go together");
   REQUIRE(w->n_dec >= 1 && w->n_dec <= 3, "namp_decoder_sample: supports 1..3 decoder layers (got %d)", w->n_dec);
   REQUIRE(w->vocab >= 1 && w->vocab <= 64, "namp_decoder_sample: vocab=%d must be in [1,64]", w->vocab);
   REQUIRE_PTR(h_V_enc); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
@@ -599,7 +602,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
 
   SampleArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
-  a.uniform = uniform; a.S_forced = S_forced; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
+  a.uniform = uniform; a.S_forced = S_forced; a.group_first = group_first; a.group_last = group_last;
+  a.sym_w = sym_weights; a.pair_bias = pair_bias; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
   a.probs_out = probs_out; a.logp_out = logp_out; a.special = special_tokens; a.inv_T = 1.0f / temperature;
   a.B_dec = B_dec; a.B_enc = B_enc; a.N = N; a.K = K; a.TPN = (K + 15) / 16; a.n_layers = w->n_dec; a.vocab = w->vocab;
   int slots = 12 / a.TPN; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;

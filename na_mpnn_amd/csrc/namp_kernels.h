@@ -726,6 +726,11 @@ struct SampleArgs {
   const int32_t* rank;         // [B_dec][N]
   const float* uniform;        // [B_dec][N] indexed by step
   const int32_t* S_forced;     // optional [B_dec][N] indexed by residue (teacher forcing)
+  // symmetry-tied sampling (model_utils.py:219-326): consecutive visits of `order` form groups that share one draw
+  const int32_t* group_first;  // optional [B_dec][N]: visit index of the first member of visit v's group (null: v itself)
+  const int32_t* group_last;   // optional [B_dec][N]: 1 if visit v closes its group                       (null: always)
+  const float* sym_w;          // optional [G_enc]: weight of a residue's logits in its group's sum        (null: 1)
+  const float* pair_bias;      // optional [G_enc][vocab][N][vocab] (model_utils.py:116,170-172)
   const float* head_w; const float* head_b;
   int32_t* S_out;              // [B_dec][N]   (also the running sequence read back for decoded neighbours)
   float* probs_out;            // [B_dec][N][vocab]
@@ -759,6 +764,14 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
   const SampleRows rows = {node_lds};
+  float tot = 0.f;                                  // running symmetry-group logit sum (head waves)
+  // every token starts "not drawn" (-1): the reference's h_S is all-zero until a residue is assigned (:264)
+  for (int s_ = 0; s_ < a.slots; ++s_) {
+    const int bs = blockIdx.x * a.slots + s_;
+    if (bs < a.B_dec)
+      for (int q = tid; q < a.N; q += blockDim.x) __hip_atomic_store(a.S_out + (long)bs * a.N + q, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
 
   for (int t = 0; t < a.N; ++t) {
     const int i_loc = a.order[(long)bb * a.N + t];
@@ -774,8 +787,9 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
     const int j_loc = a.E_idx[erow];
     const bool bw = a.rank[(long)bb * a.N + j_loc] < a.rank[(long)bb * a.N + i_loc];
     const int j_dec = bb * a.N + j_loc, j_enc = b_enc * a.N + j_loc;
-    int S_j = 0;
+    int S_j = -1;          // -1: neighbour visited but its token not drawn yet (only inside a symmetry group): h_S = 0
     if (bw) S_j = __hip_atomic_load(a.S_out + j_dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypass L1
+    const bool has_tok = bw && S_j >= 0;
     const float w_row = valid ? (1.0f / 30.0f) : 0.f;
 
 #pragma unroll
@@ -787,13 +801,13 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
         const float* src = a.hE + erow * NAMP_H + 4 * g;
         const float* pa = L.Pa + (long)(l == 0 ? node_enc : node) * NAMP_H + 4 * g;
         const float* pj = (bw ? L.Pv + (long)(l == 0 ? j_enc : j_dec) * NAMP_H : L.Pfw + (long)j_enc * NAMP_H) + 4 * g;
-        const float* tk = L.tok + (long)S_j * NAMP_H + 4 * g;
+        const float* tk = L.tok + (long)(has_tok ? S_j : 0) * NAMP_H + 4 * g;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           x[q] = *(const f4*)(src + 16 * q);
           acc[q] = *(const f4*)(pa + 16 * q);
           pjv[q] = *(const f4*)(pj + 16 * q);
-          if (bw) pjv[q] += *(const f4*)(tk + 16 * q);
+          if (has_tok) pjv[q] += *(const f4*)(tk + 16 * q);
         }
       }
       dma_to_lds(buf0, L.W1e_img, 64, wave, nwaves, lane);
@@ -845,7 +859,8 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
       __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
     }
 
-    // ---- output head + draw, one wave per stream slot.  h^(n_layers) row of slot n is yT[c * R + n].
+    // ---- output head + draw, one wave per stream slot (wave n owns slot n for the whole walk, so the running
+    // logit sum of a symmetry group lives in its registers).  h^(n_layers) row of slot n is yT[c * R + n].
     {
       const float* yT = (const float*)smem + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
       for (int n = wave; n < NAMP_SAMPLE_SLOTS; n += nwaves) {
@@ -865,7 +880,7 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
           }
           z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
         }
-        // log_softmax(logits)                                         (model_utils.py:190)
+        // log_softmax(logits) of this residue                          (model_utils.py:190 / :296-297)
         float mx = z;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -873,8 +888,29 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
         const float logp = (z - mx) - logf(e);
-        // softmax((logits + bias) / T), special tokens removed, renormalised   (model_utils.py:196-205)
-        float zt = (lane < a.vocab) ? (z + a.bias[(long)ne * a.vocab + lane]) * a.inv_T : -INFINITY;
+        if (lane < a.vocab) a.logp_out[(long)nd * a.vocab + lane] = a.chain_mask[ne] ? logp : 0.f;
+        // group logit sum: total += symmetry_weight[i] * logits          (model_utils.py:298)
+        const long vis = (long)bq * a.N + t;
+        const int v_first = a.group_first ? a.group_first[vis] : t;
+        const float wsym = a.sym_w ? a.sym_w[ne] : 1.0f;
+        const float zz = (lane < a.vocab) ? z : 0.f;
+        tot = (v_first == t) ? wsym * zz : fmaf(wsym, zz, tot);
+        const bool closes = a.group_last ? (a.group_last[vis] != 0) : true;
+        if (!closes) continue;
+        // softmax((total + bias_t [+ pair_bias_t]) / T) with bias of the group's last residue, special tokens removed,
+        // renormalised                                                   (model_utils.py:194-205 / :300-312)
+        float add = (lane < a.vocab) ? a.bias[(long)ne * a.vocab + lane] : 0.f;
+        if (a.pair_bias && lane < a.vocab) {
+          const float* pb = a.pair_bias + ((long)ne * a.vocab + lane) * a.N * a.vocab;
+          float acc_pb = 0.f;
+          for (int j2 = 0; j2 < a.N; ++j2) {
+            int Sj2 = __hip_atomic_load(a.S_out + (long)bq * a.N + j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (Sj2 < 0) Sj2 = a.vocab - 1;            // not decoded yet: the reference's initial S is PAD (:157)
+            acc_pb += pb[(long)j2 * a.vocab + Sj2];
+          }
+          add += acc_pb;
+        }
+        float zt = (lane < a.vocab) ? (tot + add) * a.inv_T : -INFINITY;
         float mt = zt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
@@ -895,18 +931,22 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
           const float up = __shfl_up(cdf, o);
           if (lane >= o) cdf += up;
         }
-        const float u = a.uniform[(long)bq * a.N + t];
+        const float u = a.uniform[vis];
         const unsigned long long hit = __ballot(p > 0.f && cdf > u);
         const unsigned long long any = __ballot(p > 0.f);
         int S_t = hit ? (int)__builtin_ctzll(hit) : (any ? 63 - (int)__builtin_clzll(any) : 0);
-        if (a.S_forced) S_t = a.S_forced[(long)bq * a.N + iq];
-        const int cm = a.chain_mask[ne];
-        if (!cm) S_t = a.S_true[ne];
-        if (lane < a.vocab) {
-          a.probs_out[(long)nd * a.vocab + lane] = cm ? p : 0.f;
-          a.logp_out[(long)nd * a.vocab + lane] = cm ? logp : 0.f;
+        // assign the draw to every member of the group, in visit order; a fixed member (chain_mask 0) replaces the
+        // running token by its own and passes THAT on — the reference's behaviour (model_utils.py:318-324)
+        for (int v = v_first; v <= t; ++v) {
+          const int im = a.order[(long)bq * a.N + v];
+          const int nem = (bq % a.B_enc) * a.N + im;
+          const long ndm = (long)bq * a.N + im;
+          if (a.S_forced) S_t = a.S_forced[ndm];
+          const int cm = a.chain_mask[nem];
+          if (!cm) S_t = a.S_true[nem];
+          if (lane < a.vocab) a.probs_out[ndm * a.vocab + lane] = cm ? p : 0.f;
+          if (lane == 0) __hip_atomic_store(a.S_out + ndm, S_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (lane == 0) __hip_atomic_store(a.S_out + nd, S_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();              // S of this step is published before the next step's neighbours read it

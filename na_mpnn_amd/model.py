@@ -374,17 +374,15 @@ class ProteinMPNN(nn.Module):
 
     @torch.no_grad()
     def sample(self, feature_dict):
-        """ProteinMPNN.sample, non-symmetric branch (model_utils.py:101-218), as one persistent HIP launch.
+        """ProteinMPNN.sample (model_utils.py:101-327; both the plain and the symmetry-tied branch, optional
+        ``pair_bias``) as one persistent HIP launch.
         The categorical draw uses torch.rand on the device (seed with torch.manual_seed) through an inverse
         CDF instead of torch.multinomial; ``feature_dict["S_forced"]`` (optional, [batch,L]) teacher-forces."""
         fd = feature_dict
         bs = fd["batch_size"]
         S_true, mask, bias = fd["S"], fd["mask"], fd["bias"]
         sym = fd.get("symmetry_residues", [[]])
-        if not (len(sym) == 1 and len(sym[0]) == 0):
-            raise NotImplementedError("symmetry-tied sampling (model_utils.py:219-326) is not built yet")
-        if "pair_bias" in fd:
-            raise NotImplementedError("pair_bias sampling is not built yet")
+        symmetric = not (len(sym) == 1 and len(sym[0]) == 0)
         B, L = S_true.shape
         dev = S_true.device
         h_V, h_E, E_idx = self.encode(fd)
@@ -392,13 +390,41 @@ class ProteinMPNN(nn.Module):
         chain_mask = mask * fd["chain_mask"]
         order = self.decoding_order(chain_mask, fd["randn"])                  # [max(B, bs), L]
         B_dec = B * bs
+        group_first = group_last = sym_w = None
+        if symmetric:
+            # model_utils.py:220-235: tied residues are visited together, in the order stream 0 reaches their first
+            # member; every stream then uses that one order
+            if B != 1:
+                raise ValueError("symmetry-tied sampling expects one input complex (B == 1)")
+            weights = torch.ones(L, dtype=torch.float32)
+            for i1, group in enumerate(sym):
+                for i2, item in enumerate(group):
+                    weights[item] = fd["symmetry_weights"][i1][i2]
+            visited, groups = set(), []
+            for t_dec in order[0].tolist():
+                if t_dec in visited:
+                    continue
+                hit = [g for g in sym if t_dec in g]
+                groups.append(list(hit[0]) if hit else [t_dec])
+                visited.update(groups[-1])
+            flat = [t for g in groups for t in g]
+            if sorted(flat) != list(range(L)):
+                raise ValueError("symmetry_residues groups must be disjoint")
+            gf, gl, v = [], [], 0
+            for g in groups:
+                gf += [v] * len(g); gl += [0] * (len(g) - 1) + [1]; v += len(g)
+            order = torch.tensor(flat, device=dev).unsqueeze(0).repeat(B_dec, 1)
+            group_first = torch.tensor(gf, dtype=torch.int32, device=dev).repeat(B_dec, 1).contiguous()
+            group_last = torch.tensor(gl, dtype=torch.int32, device=dev).repeat(B_dec, 1).contiguous()
+            sym_w = weights.to(dev).contiguous()
         if order.shape[0] != B_dec:
             raise ValueError(f"randn has {fd['randn'].shape[0]} rows; expected batch_size*B = {B_dec}")
         rank = self.ranks_of(order)
         mask_dec = mask.repeat(bs, 1)
-        if self.reference_sample_mask_quirk and B == 1 and bs > 1:
+        if self.reference_sample_mask_quirk and B == 1 and bs > 1 and not symmetric:   # :186 vs :292
             m0 = mask[0][order[0]]                                             # stream 0's mask along the steps
             mask_dec = torch.empty_like(mask_dec).scatter_(1, order, m0.expand(B_dec, L).contiguous())
+        pair_bias = fd["pair_bias"].float().contiguous() if "pair_bias" in fd else None
         uniform = torch.rand(B_dec, L, device=dev)
         special = 0
         for name in ("UNK", "DX", "RX", "MAS", "PAD"):                        # model_utils.py:199-203
@@ -416,7 +442,8 @@ class ProteinMPNN(nn.Module):
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
         hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
                                          cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(),
-                                         uniform.data_ptr(), hip.ptr(forced), float(fd["temperature"]), special,
+                                         uniform.data_ptr(), hip.ptr(forced), hip.ptr(group_first), hip.ptr(group_last),
+                                         hip.ptr(sym_w), hip.ptr(pair_bias), float(fd["temperature"]), special,
                                          S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
                                          B_dec, B, L, K, hip.current_stream()), "decoder_sample")
         torch.cuda.current_stream().synchronize()        # temporaries above must outlive the launch

@@ -297,6 +297,7 @@ def sample(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
     ``S_forced`` given, the draw is replaced by that sequence (teacher forcing)."""
     bs = fd["batch_size"]
     S_true, mask, bias, T = fd["S"], fd["mask"], fd["bias"], fd["temperature"]
+    pair_bias = fd.get("pair_bias")
     B, L = S_true.shape
     nl = w["W_out.weight"].shape[0]
     h_V, h_E, E_idx = encode(w, fd, top_k)
@@ -308,6 +309,8 @@ def sample(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
     mask_bw, mask_fw = m1 * m_att, m1 * (1. - m_att)
     S_true, h_V, h_E = S_true.repeat(bs, 1), h_V.repeat(bs, 1, 1), h_E.repeat(bs, 1, 1, 1)
     chain_mask, mask, bias = chain_mask.repeat(bs, 1), mask.repeat(bs, 1), bias.repeat(bs, 1, 1)
+    if pair_bias is not None:
+        pair_bias = pair_bias.repeat(bs, 1, 1, 1, 1)
     all_probs = torch.zeros((bs, L, nl))
     all_logp = torch.zeros((bs, L, nl))
     h_S = torch.zeros_like(h_V)
@@ -332,7 +335,12 @@ def sample(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
             stack[l + 1].scatter_(1, t[:, None, None].repeat(1, 1, H), out)
         logits = _lin(w, "W_out", g3(stack[-1])[:, 0])
         logp = F.log_softmax(logits, dim=-1)
-        probs = F.softmax((logits + bias_t) / T, dim=-1)
+        if pair_bias is not None:          # model_utils.py:169-172: sum_j pair_bias[t, :, j, S_j] with the running S
+            pb = torch.gather(pair_bias, 1, t[:, None, None, None, None].repeat(1, 1, nl, L, nl))[:, 0]
+            pb = torch.gather(pb, -1, S[:, None, :, None].repeat(1, nl, 1, 1))[:, :, :, 0].sum(-1)
+            probs = F.softmax((logits + bias_t + pb) / T, dim=-1)
+        else:
+            probs = F.softmax((logits + bias_t) / T, dim=-1)
         for tok in special:
             probs[:, tok] = 0
         probs = probs / torch.sum(probs, dim=-1, keepdim=True)
@@ -347,6 +355,71 @@ def sample(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
         h_S.scatter_(1, t[:, None, None].repeat(1, 1, H), F.embedding(S_t, w["W_s.weight"])[:, None, :])
         S.scatter_(1, t[:, None], S_t[:, None])
     return {"S": S, "sampling_probs": all_probs, "log_probs": all_logp, "decoding_order": order}
+
+
+def sample_symmetric(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
+    """Symmetry-tied branch of ProteinMPNN.sample (model_utils.py:219-326): tied residues are visited together,
+    their logits are summed with the given weights and ONE token is drawn per group (same RNG consumption as the
+    reference: one torch.multinomial per group)."""
+    bs = fd["batch_size"]
+    S_true, mask, bias, T = fd["S"], fd["mask"], fd["bias"], fd["temperature"]
+    groups_in, weights_in = fd["symmetry_residues"], fd["symmetry_weights"]
+    B, L = S_true.shape
+    nl = w["W_out.weight"].shape[0]
+    h_V, h_E, E_idx = encode(w, fd, top_k)
+    chain_mask = mask * fd["chain_mask"]
+    order = decoding_order_of(chain_mask, fd["randn"])
+    sym_w = torch.ones([L], dtype=torch.float32)
+    for i1, grp in enumerate(groups_in):
+        for i2, item in enumerate(grp):
+            sym_w[item] = weights_in[i1][i2]
+    new_order = []
+    for t_dec in list(order[0].numpy()):
+        if t_dec not in list(itertools.chain(*new_order)):
+            hit = [g for g in groups_in if t_dec in g]
+            new_order.append(hit[0] if hit else [t_dec])
+    order = torch.tensor(list(itertools.chain(*new_order)))[None].repeat(B, 1)
+    m_att = backward_mask(order, E_idx)
+    m1 = mask.view([B, L, 1, 1])
+    mask_bw, mask_fw = m1 * m_att, m1 * (1. - m_att)
+    rep = lambda a: a.repeat(bs, *([1] * (a.dim() - 1)))
+    S_true, h_V, h_E, E_idx = rep(S_true), rep(h_V), rep(h_E), rep(E_idx)
+    mask_fw, mask_bw, chain_mask, mask, bias = rep(mask_fw), rep(mask_bw), rep(chain_mask), rep(mask), rep(bias)
+    all_probs = torch.zeros((bs, L, nl))
+    all_logp = torch.zeros((bs, L, nl))
+    h_S = torch.zeros_like(h_V)
+    S = (nl - 1) * torch.ones((bs, L), dtype=torch.int64)
+    nd = n_layers(w, "decoder")
+    stack = [h_V] + [torch.zeros_like(h_V) for _ in range(nd)]
+    h_EX = cat_neighbors_nodes(torch.zeros_like(h_S), h_E, E_idx)
+    ctx_fw = mask_fw * cat_neighbors_nodes(h_V, h_EX, E_idx)
+    for t_list in new_order:
+        total = 0.0
+        for t in t_list:
+            cm_t, mask_t, bias_t = chain_mask[:, t], mask[:, t], bias[:, t]
+            E_idx_t, h_E_t = E_idx[:, t:t + 1], h_E[:, t:t + 1]
+            h_ES_t = cat_neighbors_nodes(h_S, h_E_t, E_idx_t)
+            for l in range(nd):
+                h_ESV_t = mask_bw[:, t:t + 1] * cat_neighbors_nodes(stack[l], h_ES_t, E_idx_t) + ctx_fw[:, t:t + 1]
+                stack[l + 1][:, t:t + 1, :] = dec_layer(w, f"decoder_layers.{l}.", stack[l][:, t:t + 1], h_ESV_t,
+                                                        mask_V=mask_t[:, None])
+            logits = _lin(w, "W_out", stack[-1][:, t])
+            all_logp[:, t] = (cm_t[:, None] * F.log_softmax(logits, dim=-1)).float()
+            total = total + sym_w[t] * logits
+        probs = F.softmax((total + bias_t) / T, dim=-1)
+        for tok in special:
+            probs[:, tok] = 0
+        probs = probs / torch.sum(probs, dim=-1, keepdim=True)
+        S_t = torch.multinomial(probs, 1)[:, 0] if S_forced is None else None
+        for t in t_list:
+            cm_t = chain_mask[:, t]
+            all_probs[:, t] = (cm_t[:, None] * probs).float()
+            if S_forced is not None:
+                S_t = S_forced[:, t]
+            S_t = (S_t * cm_t + S_true[:, t] * (1.0 - cm_t)).long()
+            h_S[:, t] = F.embedding(S_t, w["W_s.weight"])
+            S[:, t] = S_t
+    return {"S": S, "sampling_probs": all_probs, "log_probs": all_logp, "decoding_order": order.repeat(bs, 1)}
 
 
 # ----------------------------------------------------------------------------------------

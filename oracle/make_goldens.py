@@ -218,6 +218,51 @@ def g5_sample(weights, n=60, k=16, bs=3):
          sampling_probs=o["sampling_probs"].numpy(), decoding_order=o["decoding_order"].numpy().astype(np.int32))
 
 
+def reference_make_pair_bias():
+    """The reference's own make_pair_bias (inference/data_utils.py:7-16), loaded without importing the module
+    (its top-level `from prody import *` cannot run in this image)."""
+    import ast
+    src = open("/root/reference/inference/data_utils.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "make_pair_bias"][0]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module([fn], []), "data_utils.py", "exec"), ns)
+    return ns["make_pair_bias"]
+
+
+def g6_sample_variants(weights, n=40, k=16, bs=2):
+    """Symmetry-tied sampling (model_utils.py:219-326) and pair_bias sampling (:169-172, :194) of the reference."""
+    cx = synth.make_complex(seed=600, n=n, n_chains=2)
+    cx["chain_mask"][[3, 21]] = 0
+    fd = batchify(cx)
+    rng = np.random.default_rng(601)
+    fd.update({"batch_size": bs, "temperature": 0.7, "bias": torch.zeros(1, n, 33),
+               "randn": torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32))})
+    m = ref_model(weights, k)
+    w = tw(weights)
+    groups, gweights = [[0, 5, 9], [12, 13], [21, 30, 31, 32]], [[1.0, 0.5, 2.0], [1.0, -1.0], [0.7, 0.7, 0.7, 0.7]]
+    fds = dict(fd); fds.update({"symmetry_residues": groups, "symmetry_weights": gweights})
+    torch.manual_seed(11); o = m.sample(fds)
+    torch.manual_seed(11); o2 = cpu_ref.sample_symmetric(w, fds, k)
+    assert torch.equal(o["S"], o2["S"]) and torch.equal(o["decoding_order"], o2["decoding_order"])
+    same(o2["log_probs"], o["log_probs"], "symmetric sample log_probs"); same(o2["sampling_probs"], o["sampling_probs"], "symmetric probs")
+    o3 = cpu_ref.sample_symmetric(w, fds, k, S_forced=o["S"])
+    same(o3["log_probs"], o["log_probs"], "teacher-forced symmetric sample")
+    # pair bias
+    pb_AA = torch.from_numpy(rng.standard_normal((33, 33)).astype(np.float32))
+    fdp = dict(fd); fdp.update({"symmetry_residues": [[]], "symmetry_weights": [[]],
+                                "pair_bias": reference_make_pair_bias()(fd["chain_labels"][0], fd["R_idx"][0], pb_AA)})
+    from na_mpnn_amd.cli import make_pair_bias
+    assert torch.equal(fdp["pair_bias"], make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0], pb_AA)), "make_pair_bias"
+    torch.manual_seed(12); p = m.sample(fdp)
+    torch.manual_seed(12); p2 = cpu_ref.sample(w, fdp, k)
+    assert torch.equal(p["S"], p2["S"])
+    same(p2["log_probs"], p["log_probs"], "pair_bias log_probs"); same(p2["sampling_probs"], p["sampling_probs"], "pair_bias probs")
+    save("g6_sample_variants", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), randn=fd["randn"].numpy(), pair_bias_AA=pb_AA.numpy(),
+         sym_S=o["S"].numpy().astype(np.int8), sym_log_probs=o["log_probs"].numpy(), sym_probs=o["sampling_probs"].numpy(),
+         sym_order=o["decoding_order"].numpy().astype(np.int32),
+         pb_S=p["S"].numpy().astype(np.int8), pb_log_probs=p["log_probs"].numpy(), pb_probs=p["sampling_probs"].numpy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -234,6 +279,7 @@ def main():
     g4_from_X(weights, 150, 48, "n150_k48")
     g4_from_X(weights, 32, 48, "n32_k48_LltK")
     print("G5 sample"); g5_sample(weights)
+    print("G6 sample variants (symmetry-tied, pair_bias)"); g6_sample_variants(weights)
     print("all reference == oracle checks passed")
 
 

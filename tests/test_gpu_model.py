@@ -121,6 +121,70 @@ def test_sample_teacher_forced_golden(golden_dir, weights_np):
     assert maxdiff(out["sampling_probs"], g["sampling_probs"]) < 1e-3
 
 
+def test_sample_symmetric_and_pair_bias_golden(golden_dir, weights_np):
+    """Symmetry-tied groups (model_utils.py:219-326) and pair_bias (:169-172) with the reference's draws forced (G6)."""
+    from test_oracle_golden import g6_inputs
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "g6_sample_variants.npz"))
+    cx, k, fds, fdp = g6_inputs(g)
+    m = make_model(weights_np, k, dev)
+    to_dev = lambda fd: {k_: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    fds, fdp = to_dev(fds), to_dev(fdp)
+    fds["S_forced"] = torch.from_numpy(g["sym_S"].astype(np.int64)).to(dev)
+    out = m.sample(fds)
+    assert np.array_equal(out["decoding_order"].cpu().numpy(), g["sym_order"])
+    assert np.array_equal(out["S"].cpu().numpy(), g["sym_S"].astype(np.int64))
+    assert maxdiff(out["log_probs"], g["sym_log_probs"]) < 1e-3
+    assert maxdiff(out["sampling_probs"], g["sym_probs"]) < 1e-3
+    fdp["S_forced"] = torch.from_numpy(g["pb_S"].astype(np.int64)).to(dev)
+    out = m.sample(fdp)
+    assert np.array_equal(out["S"].cpu().numpy(), g["pb_S"].astype(np.int64))
+    assert maxdiff(out["log_probs"], g["pb_log_probs"]) < 1e-3
+    assert maxdiff(out["sampling_probs"], g["pb_probs"]) < 1e-3
+
+
+@pytest.mark.parametrize("variant", ["symmetric", "pair_bias"])
+def test_sample_variants_free_running(weights_np, variant):
+    """Free-running tied / pair-biased sampling: tied designable residues share one token, and the oracle teacher-forced
+    with the sampled sequence reproduces log_probs and sampling probabilities."""
+    from na_mpnn_amd.cli import make_pair_bias
+    dev = torch.device("cuda:0")
+    n, k, bs = 64, 24, 4
+    cx = synth.make_complex(seed=777, n=n, n_chains=2)
+    cx["chain_mask"][[2, 40]] = 0
+    rng = np.random.default_rng(9)
+    fd = _sample_fd(cx, dev, bs, 0.8, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
+    groups, gw = [[1, 2, 3], [10, 50], [40, 41], [20, 21, 22, 23, 24]], [[1., 1., 1.], [0.5, 1.5], [1., 2.], [1., -.5, 1., 1., 1.]]
+    if variant == "symmetric":
+        fd.update({"symmetry_residues": groups, "symmetry_weights": gw})
+    else:
+        fd["pair_bias"] = make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0],
+                                         torch.from_numpy(2.0 * rng.standard_normal((33, 33)).astype(np.float32)).to(dev))
+    m = make_model(weights_np, k, dev)
+    torch.manual_seed(3)
+    out = m.sample(fd)
+    S = out["S"].cpu()
+    cm = (cx["mask"] * cx["chain_mask"]).astype(bool)
+    assert torch.equal(S[:, ~cm], torch.from_numpy(cx["S"].astype(np.int64))[~cm].expand(bs, -1))
+    for tok in (20, 25, 30, 31, 32):
+        assert not (S[:, cm] == tok).any()
+    w = {k_: torch.from_numpy(v) for k_, v in weights_np.items()}
+    fdc = {k_: (v.cpu() if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    if variant == "symmetric":
+        for grp in groups:      # one draw per group; a fixed member overrides the running token for the members after it
+            for t_prev, t in zip(grp[:-1], grp[1:]):   # (the reference reuses S_t across the loop, model_utils.py:317-323)
+                if cm[t]:
+                    assert torch.equal(S[:, t], S[:, t_prev]), grp
+        ref = cpu_ref.sample_symmetric(w, fdc, k, S_forced=S)
+    else:
+        ref = cpu_ref.sample(w, fdc, k, S_forced=S)
+    assert torch.equal(ref["decoding_order"], out["decoding_order"].cpu())
+    assert torch.equal(ref["S"], S)
+    valid = torch.from_numpy(cx["mask"].astype(bool))
+    assert maxdiff(out["log_probs"][:, valid], ref["log_probs"][:, valid]) < 1e-3
+    assert maxdiff(out["sampling_probs"][:, valid], ref["sampling_probs"][:, valid]) < 1e-3
+
+
 @pytest.mark.parametrize("n,k,bs,T,mf", [(70, 48, 5, 0.3, 0.0), (90, 32, 2, 1.0, 0.05), (50, 20, 1, 0.1, 0.05)])
 def test_sample_free_running(weights_np, n, k, bs, T, mf):
     """Free-running sampler: (i) draws follow the returned distributions through the inverse CDF of the supplied

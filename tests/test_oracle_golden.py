@@ -137,3 +137,39 @@ def test_rank_compare_equals_reference_einsum():
     order = torch.from_numpy(np.stack([rng.permutation(L) for _ in range(2)]))
     E_idx = torch.from_numpy(rng.integers(0, L, (2, L, K)))
     assert torch.equal(cpu_ref.backward_mask(order, E_idx), cpu_ref.backward_mask_einsum(order, E_idx))
+
+
+G6_GROUPS = [[0, 5, 9], [12, 13], [21, 30, 31, 32]]
+G6_WEIGHTS = [[1.0, 0.5, 2.0], [1.0, -1.0], [0.7, 0.7, 0.7, 0.7]]
+
+
+def g6_inputs(g):
+    from na_mpnn_amd.cli import make_pair_bias
+    n, k, bs = 40, 16, 2
+    cx = synth.make_complex(seed=600, n=n, n_chains=2)
+    cx["chain_mask"][[3, 21]] = 0
+    assert np.array_equal(digest(*[cx[k_] for k_ in sorted(cx)]), g["in_digest"])
+    fd = {k_: torch.from_numpy(np.ascontiguousarray(v))[None] for k_, v in cx.items()}
+    fd.update({"batch_size": bs, "temperature": 0.7, "bias": torch.zeros(1, n, 33), "randn": torch.from_numpy(g["randn"])})
+    fds = dict(fd); fds.update({"symmetry_residues": G6_GROUPS, "symmetry_weights": G6_WEIGHTS})
+    fdp = dict(fd); fdp.update({"symmetry_residues": [[]], "symmetry_weights": [[]],
+                                "pair_bias": make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0], torch.from_numpy(g["pair_bias_AA"]))})
+    return cx, k, fds, fdp
+
+
+def test_g6_symmetric_and_pair_bias_sampling(golden_dir, weights_np):
+    """model_utils.py:219-326 (symmetry-tied groups) and :169-172 (pair_bias), teacher-forced with the reference's draws."""
+    g = load(golden_dir, "g6_sample_variants")
+    cx, k, fds, fdp = g6_inputs(g)
+    w = tw(weights_np)
+    o = cpu_ref.sample_symmetric(w, fds, k, S_forced=torch.from_numpy(g["sym_S"].astype(np.int64)))
+    assert np.array_equal(o["decoding_order"].numpy(), g["sym_order"])
+    exact(o["log_probs"], g["sym_log_probs"]); exact(o["sampling_probs"], g["sym_probs"])
+    assert np.array_equal(o["S"].numpy(), g["sym_S"])
+    for grp in G6_GROUPS:      # one draw per group; a fixed member overrides the running token for the members after it
+        for t_prev, t in zip(grp[:-1], grp[1:]):
+            if cx["chain_mask"][t] and cx["mask"][t]:
+                assert (g["sym_S"][:, t] == g["sym_S"][:, t_prev]).all()
+    p = cpu_ref.sample(w, fdp, k, S_forced=torch.from_numpy(g["pb_S"].astype(np.int64)))
+    exact(p["log_probs"], g["pb_log_probs"]); exact(p["sampling_probs"], g["pb_probs"])
+
