@@ -226,6 +226,43 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
                         float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                         void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 
+/* ---- a12: training (backward) -------------------------------------------------------------
+ * Gradient side of EncLayer / DecLayer / the edge featuriser (na_model_utils.py:196-283, 349-517, 589-646) for the
+ * reference's training step (na_run.py:218-238).  The residue-level ops (LayerNorms, FFN, the hoisted first-layer
+ * tables, logits, loss) are [B*N,128]-sized and stay with the caller's autograd; these entry points carry the
+ * per-edge work.  Activations are recomputed in the backward pass, the reference's torch.utils.checkpoint policy
+ * (na_model_utils.py:606,637).  mode: 0 = EncLayer message, 1 = DecLayer message, 2 = EncLayer edge update.
+ * All images are fp32 fragment images (namp_pack_image); "t" images are those of the transposed blocks.
+ *
+ * namp_train_edge_fwd: the forward of one per-edge MLP from raw images.  mode 0/1: out = partial sums
+ *   [B*N][ceil(K/16)][128] (as namp_enc_message / namp_dec_message; B_dec == B_enc); mode 2: out = the bare message
+ *   W13.gelu(W12.gelu(W11.[..])) + b13 per edge [B*N*K][128] (residual, dropout and LayerNorm3 are the caller's).
+ * namp_train_edge_bwd: given g_out = dL/d(sum_k message) [B*N][128] (modes 0/1; the 1/30 scale and mask_attend are
+ *   applied inside) or dL/d(message) per edge [B*N*K][128] (mode 2), recompute the chain and write per edge row
+ *   the pre-activations Z1, Z2, the gradients G1 = dL/dz1, G2 = dL/dz2, G3 = dL/dz3 (modes 0/1 only; mode 2: G3 == g_out)
+ *   and g_hE = dL/dh_E.  Then dW3 = G3^T gelu(Z2), dW2 = G2^T gelu(Z1), dW1b = G1^T h_E (namp_train_wgrad),
+ *   db3 = sum G3, db2 = sum G2, dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k].
+ * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
+ *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
+ * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated
+ *   on the fly: X18 [B*L][18][3] (16 atoms + Cb + N_na), M18 [B*L][18] 0/1 floats, E_pos [B*L*K][16] the positional
+ *   features, g_pre [B*L*K][128] = dL/d(pre-LayerNorm edge embedding); dW_part [namp_train_feat_wgrad_chunks][128][5200].
+ * namp_featurize with w->feat.ln_g == NULL writes the pre-LayerNorm rows to E (the training forward). */
+int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                        const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                        const float* W2_img, const float* W3_img, const float* b2, const float* b3, float* out,
+                        int B, int N, int K, void* stream);
+int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                        const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                        const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
+                        const float* b2, const float* g_out, float* Z1, float* Z2, float* G1, float* G2, float* G3,
+                        float* g_hE, int B, int N, int K, void* stream);
+int namp_train_wgrad_chunks(long rows);
+int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream);
+int namp_train_feat_wgrad_chunks(long edges);
+int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
+                          float* dW_part, int B, int L, int K, void* stream);
+
 /* ---- measurement hook (bench.py) ------------------------------------------------------------
  * When enabled (thread-local), every kernel launch made through this ABI is bracketed by HIP
  * events on the launch stream; namp_profile_collect() waits for them and returns the summed

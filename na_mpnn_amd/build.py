@@ -12,9 +12,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libnamp_hip.so")
-SOURCES = ["namp.hip"]
-DEPS = ["namp.hip", "namp_kernels.h", "namp_device.h", os.path.join("..", "..", "include", "namp.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc"]
+INC = os.path.join("..", "..", "include", "namp.h")
+# translation unit -> files it depends on (each unit is compiled to its own object, in parallel, then linked)
+UNITS = {"namp.hip": ["namp.hip", "namp_kernels.h", "namp_device.h", INC],
+         "namp_train.hip": ["namp_train.hip", "namp_train.h", "namp_device.h", INC]}
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+TIMEOUT_S = 1500
 
 
 def hipcc():
@@ -24,21 +28,46 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
+def _newer(target, deps):
+    if not os.path.exists(target):
         return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(os.path.join(CSRC, d)) <= t for d in DEPS)
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(os.path.join(CSRC, d)) <= t for d in deps)
+
+
+def _obj(unit):
+    return os.path.join(OBJ_DIR, unit.replace(".hip", ".o"))
+
+
+def up_to_date():
+    return _newer(OUT, sorted({d for deps in UNITS.values() for d in deps}))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    procs = []
+    for unit, deps in UNITS.items():
+        if not force and _newer(_obj(unit), deps):
+            continue
+        cmd = [cc] + CFLAGS + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit)]
+        if verbose:
+            print("[na_mpnn_amd.build]", " ".join(cmd), flush=True)
+        procs.append((unit, subprocess.Popen(cmd, cwd=CSRC)))
+    for unit, p in procs:
+        try:
+            rc = p.wait(timeout=TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise RuntimeError(f"hipcc timed out on {unit} after {TIMEOUT_S}s")
+        if rc != 0:
+            raise RuntimeError(f"hipcc failed on {unit} (exit {rc})")
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + [_obj(u) for u in UNITS] + ["-o", OUT]
     if verbose:
         print("[na_mpnn_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    subprocess.run(cmd, check=True, cwd=CSRC, timeout=TIMEOUT_S)
     return OUT
 
 

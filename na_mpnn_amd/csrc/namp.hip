@@ -21,6 +21,13 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+// error text setter for namp_train.hip (same thread-local buffer; not part of the ABI)
+__attribute__((visibility("hidden"))) int namp_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+
+namespace {
+
 // ---- optional per-kernel timing (bench.py): thread-local, off by default --------------------
 struct ProfRec { int kind; hipEvent_t a, b; };
 thread_local bool g_prof_on = false;
@@ -369,6 +376,30 @@ int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t
   return NAMP_OK;
 }
 
+int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                        const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                        const float* W2_img, const float* W3_img, const float* b2, const float* b3, float* out,
+                        int B, int N, int K, void* stream) {
+  REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_fwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
+  REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(out);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_fwd: null E_idx");
+  if (mode == MODE_DEC_MSG) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_fwd: decoder message needs rank"); }
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
+  a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.b2 = b2; a.b3 = b3;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == MODE_ENC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_ENC_MESSAGE, s); rc = launch_edge<MODE_ENC_MSG, 0>(a, s); }
+  else if (mode == MODE_DEC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_DEC_MESSAGE, s); rc = launch_edge<MODE_DEC_MSG, 0>(a, s); }
+  else { a.hE_out = out; ProfScope p_(NAMP_KIND_ENC_EDGE, s); rc = launch_edge<MODE_ENC_EDGE, 0>(a, s); }   // ln_g null: bare message
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                      const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
                      const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
@@ -521,7 +552,9 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
   REQUIRE(w != nullptr, "namp_featurize: null weights");
   REQUIRE_PTR(X); REQUIRE_PTR(ws); OPTIONAL_PTR(E); OPTIONAL_PTR(h_E);
   REQUIRE_PTR(w->feat.Wedge_img); REQUIRE_PTR(w->feat.pos_w); REQUIRE_PTR(w->feat.pos_b);
-  REQUIRE_PTR(w->feat.ln_g); REQUIRE_PTR(w->feat.ln_b);
+  OPTIONAL_PTR(w->feat.ln_g); OPTIONAL_PTR(w->feat.ln_b);
+  REQUIRE((w->feat.ln_g == nullptr) == (w->feat.ln_b == nullptr), "namp_featurize: norm_edges weight and bias go together");
+  REQUIRE(w->feat.ln_g || !h_E, "namp_featurize: h_E needs norm_edges (pre-LayerNorm output is E only)");
   if (!X_m || !mask || !R_idx || !chain_labels || !protein_mask || !dna_mask || !rna_mask || !E_idx)
     return fail(NAMP_EINVAL, "namp_featurize: null pointer argument");
   REQUIRE(E || h_E, "namp_featurize: at least one of E / h_E must be requested");

@@ -627,10 +627,12 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
     if (BF16) chain_gemm_bf16<false, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
     else      chain_gemm<8, 8, false, true>(acc, x, w0, 8);
-    const float* src = a.hE + erow * NAMP_H + 4 * g;
+    if (a.ln_g) {                                                  // null: write the bare message (training forward)
+      const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
-    layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+      for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
+      layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+    }
     if (valid) {
       float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
     }
   }
   // ---- LayerNorm (norm_edges) -> E; optional W_e embed -> h_E
-  layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+  if (a.ln_g) layernorm_row_T(acc, a.ln_g, a.ln_b, g);             // null: E_out receives the pre-LayerNorm rows
   if (a.E_out && valid) {
     float* dst = a.E_out + erow * NAMP_H + 4 * g;
 #pragma unroll

@@ -1,0 +1,358 @@
+// Backward (training) kernels of the NA-MPNN message path on gfx950 — the gradient side of
+// EncLayer / DecLayer (na_model_utils.py:196-283) and of the edge featuriser's 5200 -> 128 embedding
+// (na_model_utils.py:499-507).  The reference wraps every layer in torch.utils.checkpoint
+// (na_model_utils.py:606,637): activations are recomputed in the backward pass.  The same policy is
+// applied here at kernel granularity — edge_chain_bwd_kernel recomputes the per-edge MLP from its inputs
+// and walks it backwards in registers; nothing but the layer inputs is kept from the forward pass.
+//
+//   forward chain (per edge row e = (i, k), j = E_idx[i,k]):
+//       z1 = W1b . h_E[e] + Pa[i] + Pj[j]        a1 = gelu(z1)
+//       z2 = W2 . a1 + b2                        a2 = gelu(z2)
+//       z3 = W3 . a2 + b3
+//   backward, given g3 = dL/dz3 per row:
+//       g2 = (W3^T g3) * gelu'(z2)     g1 = (W2^T g2) * gelu'(z1)     dL/dh_E[e] = W1b^T g1
+//   and the row tensors Z1, Z2, G1, G2, G3 go to HBM, from which
+//       dW3 = G3^T gelu(Z2), dW2 = G2^T gelu(Z1), dW1b = G1^T h_E     (wgrad_kernel: contraction over edges)
+//       dL/dPa[i] = sum_k G1[i,k],  dL/dPj[j] += G1[e]               (residue-level, done by the caller)
+// The transposed products reuse the register chain of namp_device.h: "W^T . g" is the T-orientation
+// GEMM with the fragment image of W^T, so gradients flow lane-locally exactly like activations do.
+#pragma once
+#include "namp_device.h"
+
+// gelu(x) and d/dx gelu(x) = Phi(x) + x phi(x), sharing exp(-x^2/2) and the A-S 7.1.26 erf of gelu_erf().
+__device__ __forceinline__ void gelu_val_grad(float x, float& val, float& grad) {
+  const float v = x * 0.84932180028801904f;
+  const float e = __builtin_amdgcn_exp2f(-(v * v));                     // exp(-x^2 / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(v), 0.27273943f, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float y = fmaf(-(q * t), e, 1.0f);                              // |erf(x / sqrt 2)|
+  const float phi_big = fmaf(copysignf(0.5f, x), y, 0.5f);              // Phi(x)
+  val = x * phi_big;
+  grad = fmaf(x * e, 0.3989422804014327f, phi_big);
+}
+
+__device__ __forceinline__ f4 gelu_grad4(f4 z) {
+  float v, d0, d1, d2, d3;
+  gelu_val_grad(z.x, v, d0); gelu_val_grad(z.y, v, d1); gelu_val_grad(z.z, v, d2); gelu_val_grad(z.w, v, d3);
+  return (f4){d0, d1, d2, d3};
+}
+
+enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2 };
+
+struct EdgeBwdArgs {
+  const float* hE;             // [E][128] edge rows the forward pass consumed
+  const int32_t* E_idx;        // [G][K]
+  const int32_t* mask;         // ENC_MSG: [G] residue mask (null = ones)
+  const int32_t* mask_attend;  // ENC_MSG: optional explicit [G][K]
+  const int32_t* rank;         // DEC_MSG: [G]
+  const float* Pa;             // [G][128]
+  const float* Pj0;            // ENC: Pc;  DEC: Pbw
+  const float* Pj1;            // DEC: Pfw
+  const float* W1_img;         // forward images of W1b (or W1e), W2
+  const float* W2_img;
+  const float* W3t_img;        // images of W3^T, W2^T, W1b^T
+  const float* W2t_img;
+  const float* W1t_img;
+  const float* b2;
+  const float* g_rows;         // BWD_ROWS: dL/dz3 per edge row [E][128]
+  const float* g_node;         // MSG modes: dL/d(dh) per residue [G][128]; g3[e] = w_e * g_node[i]
+  float* Z1; float* Z2;        // [E][128] pre-activations (for wgrad)
+  float* G1; float* G2; float* G3;   // [E][128] (G3 only written in MSG modes)
+  float* g_hE;                 // [E][128]
+  long E;                      // G * K rows
+  int G, N, K;
+};
+
+// One wave = 16 consecutive edge rows of the flat [G*K] edge list (tiles may straddle residues: every
+// per-row operand is gathered per lane anyway).  8 waves per workgroup share the 2 x 64 KiB LDS weight ring;
+// the five images W1, W2, W3^T, W2^T, W1^T stream through it by LDS-DMA one GEMM ahead of their use.
+template <int MODE>
+__global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;
+  char* buf1 = smem + NAMP_IMG_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const long e_raw = ((long)blockIdx.x * nwaves + wave) * 16 + m;
+  const bool valid = e_raw < a.E;
+  const long e = valid ? e_raw : (a.E - 1);
+  const int node = (int)(e / a.K);
+  const int i_loc = node % a.N;
+  const int j = node - i_loc + a.E_idx[e];
+
+  f4 x[8], z1[8], z2[8], pjv[8];
+  float w_row = 0.f;
+  {
+    const float* src = a.hE + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+    const float* pj;
+    if (MODE == BWD_DEC_MSG) {
+      pj = (a.rank[j] < a.rank[node]) ? (a.Pj0 + (long)j * NAMP_H) : (a.Pj1 + (long)j * NAMP_H);
+      w_row = valid ? (1.0f / 30.0f) : 0.f;
+    } else {
+      pj = a.Pj0 + (long)j * NAMP_H;
+      if (MODE == BWD_ENC_MSG) {
+        int ma;
+        if (a.mask_attend) ma = a.mask_attend[e];
+        else ma = a.mask ? (a.mask[node] * a.mask[j]) : 1;
+        w_row = valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
+      }
+    }
+    const float* pa = a.Pa + (long)node * NAMP_H + 4 * g;
+    pj += 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { z1[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+  }
+  const f4* w0 = (const f4*)buf0 + lane;
+  const f4* w1 = (const f4*)buf1 + lane;
+
+  dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
+  dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
+  wait_dma_and_sync();
+  // ---- recompute: z1, z2
+  chain_gemm<8, 8, false>(z1, x, w0, 8);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
+  __syncthreads();                                            // everyone is done with W1
+  dma_to_lds(buf0, a.W3t_img, 64, wave, nwaves, lane);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+  chain_gemm<8, 8, false, true>(z2, z1, w1, 8);
+  if (valid) {
+    float* d1 = a.Z1 + e * NAMP_H + 4 * g;
+    float* d2 = a.Z2 + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { *(f4*)(d1 + 16 * t) = z1[t]; *(f4*)(d2 + 16 * t) = z2[t]; }
+  }
+  // ---- upstream gradient rows
+  f4 gr[8];
+  if (MODE == BWD_ROWS) {
+    const float* src = a.g_rows + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gr[t] = valid ? *(const f4*)(src + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+  } else {
+    const float* src = a.g_node + (long)node * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gr[t] = *(const f4*)(src + 16 * t) * w_row;
+    if (valid) {
+      float* d3 = a.G3 + e * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(d3 + 16 * t) = gr[t];
+    }
+  }
+  wait_dma_and_sync();                                        // W3^T landed in buf0; W2 (buf1) is free
+  dma_to_lds(buf1, a.W2t_img, 64, wave, nwaves, lane);
+  // ---- g2 = (W3^T g3) * gelu'(z2)
+  f4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<8, 8, false>(acc, gr, w0, 8);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * gelu_grad4(z2[t]);
+  if (valid) {
+    float* d = a.G2 + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
+  }
+  wait_dma_and_sync();                                        // W2^T landed in buf1; buf0 is free
+  dma_to_lds(buf0, a.W1t_img, 64, wave, nwaves, lane);
+  // ---- g1 = (W2^T g2) * gelu'(z1)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<8, 8, false>(acc, gr, w1, 8);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * gelu_grad4(z1[t]);
+  if (valid) {
+    float* d = a.G1 + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
+  }
+  wait_dma_and_sync();                                        // W1b^T landed in buf0
+  // ---- dL/dh_E = W1b^T g1
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<8, 8, false>(acc, gr, w0, 8);
+  if (valid) {
+    float* d = a.g_hE + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = acc[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad_kernel: dW[o][c] = sum_rows G[row][o] * act(A[row][c]),  db[o] = sum_rows G[row][o]   (128 x 128, rows ~ 10^6).
+// The contraction index is the row, 4 rows per v_mfma_f32_16x16x4_f32: with k-slot g of MFMA r standing for
+// row 4g + r of a 16-row step, lane (n = l&15, g) feeds G[row][16to + n] as the A operand and A[row][16tc + n]
+// as the B operand — both are plain strided reads of the row-major tensors, no transposes.  A workgroup
+// (4 waves, wave w owns output tiles to in {2w, 2w+1} x all tc: 64 accumulator VGPRs) reduces one chunk of rows
+// and writes its partial [128][128] (+ [128]); the caller sums the chunks (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------
+template <bool ACT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
+                                                    long rows_per_chunk, float* __restrict__ dW_part,
+                                                    float* __restrict__ db_part) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const long r_begin = (long)blockIdx.x * rows_per_chunk;
+  long r_end = r_begin + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  f4 acc[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  for (long r0 = r_begin; r0 < r_end; r0 += 16) {
+    float gv[2][4], av[8][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = r0 + 4 * g + r;
+      const bool ok = row < r_end;
+      const long rr = ok ? row : r_begin;
+      const float* gp = G + rr * NAMP_H + n;
+      const float* ap = A + rr * NAMP_H + n;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) gv[q][r] = ok ? gp[16 * (2 * wave + q)] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) av[t][r] = ap[16 * t];
+    }
+    if (ACT) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[t][r] = gelu_erf(av[t][r]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bsum[q] += (gv[q][0] + gv[q][1]) + (gv[q][2] + gv[q][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(gv[q][r], av[t][r], acc[q][t]);
+  }
+  // D[i = 4g + r][j = n]  ->  dW[16 to + 4g + r][16 tc + n]
+  float* out = dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * (2 * wave + q) + 4 * g + r) * NAMP_H + 16 * t + n] = acc[q][t][r];
+  if (db_part) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float s = xg_sum(bsum[q]);
+      if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * (2 * wave + q) + n] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// feat_wgrad_kernel: gradient of edge_embedding.weight [128 x 5200] (na_model_utils.py:499-507):
+//     dW[o][c] = sum_e g_pre[e][o] * feat[e][c],   feat = [E_pos (16) | RBF(a, b, r) (18*18*16)]
+// with the 5184 RBF features regenerated on the fly like the forward kernel does — they are never stored.
+// Column block q: q = 0 the positional features, q = 1 + 18a + b the 16 RBFs of atom pair (a, b): the B operand of
+// the row-contraction MFMA (see wgrad_kernel) for block q is exp(-((D_ab(e) - mu_n) / sigma)^2) on lane (n, g) —
+// produced directly in operand layout, one exp per MFMA group.  A workgroup = 4 waves x 2 column blocks over one
+// chunk of edges; the g_pre tile (64 edges x 128) is staged in LDS once per 8 blocks.  Partials per edge chunk.
+// ------------------------------------------------------------------------------------------
+#define FEATW_BLOCKS 325
+#define FEATW_COLS 5200
+#define FEATW_TILE 64
+#define FEATW_LD 132            // padded row length of the LDS g_pre tile (floats)
+
+__global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
+                                                         const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
+                                                         const float* __restrict__ g_pre, long E, long edges_per_chunk,
+                                                         int L, int K, float* __restrict__ dW_part) {
+  __shared__ float gt[FEATW_TILE * FEATW_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int blk0 = (blockIdx.x * 4 + wave) * 2;               // this wave's two column blocks
+  const long e_begin = (long)blockIdx.y * edges_per_chunk;
+  long e_end = e_begin + edges_per_chunk;
+  if (e_end > E) e_end = E;
+  const float mu = 2.0f + (float)n * (20.0f / 15.0f);
+  int pa[2], pb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = blk0 + q - 1;                                // atom pair index, -1 = positional block
+    pa[q] = p >= 0 ? p / 18 : 0;
+    pb[q] = p >= 0 ? p % 18 : 0;
+  }
+  f4 acc[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE) {
+    __syncthreads();                                           // previous tile fully consumed
+    // stage g_pre rows e0 .. e0+63 (zeros past the end)
+    for (int idx = tid; idx < FEATW_TILE * 32; idx += 256) {
+      const int row = idx >> 5, c4 = idx & 31;
+      const long er = e0 + row;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (er < e_end) v = *(const f4*)(g_pre + er * NAMP_H + 4 * c4);
+      *(f4*)(gt + row * FEATW_LD + 4 * c4) = v;
+    }
+    // per-lane edge of this tile: distance of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
+    const long el = e0 + lane;
+    const bool eok = el < e_end;
+    const long ec = eok ? el : e_begin;
+    const int node = (int)(ec / K);
+    const int j = node - node % L + E_idx[ec];
+    float dist[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
+      const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
+      const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+      const float mk = M18[(long)node * 18 + pa[q]] * M18[(long)j * 18 + pb[q]];
+      dist[q] = (eok && mk != 0.f) ? sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < FEATW_TILE / 4; ++s) {
+      const int row = 4 * s + g;                               // k-slot g of this MFMA group <-> edge e0 + 4s + g
+      float av[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) av[t] = gt[row * FEATW_LD + 16 * t + n];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float b;
+        if (blk0 + q == 0) {
+          const long er = e0 + row;
+          b = (er < e_end) ? E_pos[er * 16 + n] : 0.f;
+        } else {
+          const float d = __shfl(dist[q], row);
+          const float u = (d - mu) * 0.8f;
+          b = __expf(-(u * u));
+        }
+        if (blk0 + q < FEATW_BLOCKS) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(av[t], b, acc[q][t]);
+        }
+      }
+    }
+  }
+  // D[i = 4g + r][j = n] -> dW[16t + 4g + r][16 blk + n]
+  float* out = dW_part + (long)blockIdx.y * NAMP_H * FEATW_COLS;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (blk0 + q >= FEATW_BLOCKS) continue;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(long)(16 * t + 4 * g + r) * FEATW_COLS + 16 * (blk0 + q) + n] = acc[q][t][r];
+  }
+}

@@ -1,0 +1,133 @@
+// Training (backward) entry points of libnamp_hip.so — see include/namp.h "training" section and namp_train.h.
+#include "../../include/namp.h"
+#include "namp_train.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+
+int namp_internal_fail(int code, const char* msg);      // namp.hip
+
+namespace {
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return namp_internal_fail(code, buf);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define REQUIRE_PTR(p)                                                                         \
+  do {                                                                                         \
+    if ((p) == nullptr) return fail(NAMP_EINVAL, "%s: null pointer argument '%s'", __func__, #p); \
+    if (!aligned16(p)) return fail(NAMP_EINVAL, "%s: '%s' is not 16-byte aligned", __func__, #p); \
+  } while (0)
+#define REQUIRE(cond, ...)                                   \
+  do {                                                       \
+    if (!(cond)) return fail(NAMP_EINVAL, __VA_ARGS__);      \
+  } while (0)
+#define CHECK_LAUNCH()                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = hipGetLastError();                                                          \
+    if (e_ != hipSuccess) return fail(NAMP_ELAUNCH, "%s: %s", __func__, hipGetErrorString(e_)); \
+  } while (0)
+
+std::once_flag g_once;
+hipError_t g_attr_err = hipSuccess;
+
+int ensure_attributes() {
+  std::call_once(g_once, [] {
+    auto set = [](const void* f) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NAMP_IMG_BYTES);
+      if (e != hipSuccess) g_attr_err = e;
+    };
+    set((const void*)edge_chain_bwd_kernel<BWD_ENC_MSG>);
+    set((const void*)edge_chain_bwd_kernel<BWD_DEC_MSG>);
+    set((const void*)edge_chain_bwd_kernel<BWD_ROWS>);
+  });
+  if (g_attr_err != hipSuccess)
+    return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
+  return NAMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                        const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                        const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
+                        const float* b2, const float* g_out, float* Z1, float* Z2, float* G1, float* G2, float* G3,
+                        float* g_hE, int B, int N, int K, void* stream) {
+  REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
+  REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
+  REQUIRE_PTR(Z1); REQUIRE_PTR(Z2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_bwd: null E_idx");
+  if (mode != 2) REQUIRE_PTR(G3);
+  if (mode == 1) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_bwd: decoder message needs rank"); }
+  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_bwd: bad dims B=%d N=%d K=%d", B, N, K);
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  EdgeBwdArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
+  a.W1_img = W1_img; a.W2_img = W2_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img; a.b2 = b2;
+  if (mode == 2) a.g_rows = g_out; else a.g_node = g_out;
+  a.Z1 = Z1; a.Z2 = Z2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
+  a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
+  const int grid = (int)((a.E + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ENC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_DEC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
+  else hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ROWS>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_wgrad_chunks(long rows) {
+  if (rows <= 0) return 0;
+  long n = (rows + 1023) / 1024;           // >= 1024 rows (64 MFMA steps) per workgroup
+  if (n > 512) n = 512;
+  return (int)n;
+}
+
+int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream) {
+  REQUIRE_PTR(G); REQUIRE_PTR(A); REQUIRE_PTR(dW_part);
+  REQUIRE(rows >= 1, "namp_train_wgrad: rows=%ld", rows);
+  const int nchunk = namp_train_wgrad_chunks(rows);
+  long per = (rows + nchunk - 1) / nchunk;
+  per = (per + 15) / 16 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_feat_wgrad_chunks(long edges) {
+  if (edges <= 0) return 0;
+  long n = (edges + 4095) / 4096;
+  if (n > 48) n = 48;
+  return (int)n;
+}
+
+int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
+                          float* dW_part, int B, int L, int K, void* stream) {
+  REQUIRE_PTR(X18); REQUIRE_PTR(M18); REQUIRE_PTR(E_pos); REQUIRE_PTR(g_pre); REQUIRE_PTR(dW_part);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null E_idx");
+  REQUIRE(B >= 1 && L >= 1 && K >= 1 && K <= L, "namp_train_feat_wgrad: bad dims B=%d L=%d K=%d", B, L, K);
+  const long E = (long)B * L * K;
+  const int nchunk = namp_train_feat_wgrad_chunks(E);
+  long per = (E + nchunk - 1) / nchunk;
+  per = (per + FEATW_TILE - 1) / FEATW_TILE * FEATW_TILE;
+  hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
+                     E, per, L, K, dW_part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+}  // extern "C"

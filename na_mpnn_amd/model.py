@@ -354,7 +354,10 @@ class ProteinMPNN(nn.Module):
         """Training-copy surface (na_model_utils.py:589-646): feature_dict -> (log_probs, probs).
         ``decoding_randn`` replaces the internal torch.randn (:623) when reproducibility is needed."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("HIP backward kernels are not built yet: call under torch.no_grad()")
+            from . import train                      # differentiable path: HIP per-edge forward/backward + torch autograd
+            if not self._hip_featuriser_ok():
+                raise NotImplementedError("training needs the reference's atom order (run.py:15-19)")
+            return train.forward_train(self, feature_dict, decoding_randn)
         with torch.no_grad():
             mask = feature_dict["mask"]
             h_V, h_E, E_idx = self.encode(feature_dict)

@@ -1,0 +1,347 @@
+"""Training path: differentiable forward of ``ProteinMPNN`` on the HIP kernels, the
+label-smoothed loss, the Noam/Adam schedule and the checkpoint file format of the reference's ``na_run.py``.
+
+Split of work
+    per-edge ([B,N,K,128]-sized) forward and backward   -> libnamp_hip.so (``namp_train_*``; csrc/namp_train.h)
+    per-residue ([B,N,128]-sized) ops, logits, loss     -> torch autograd on the device (LayerNorm, FFN, the hoisted
+                                                           first-layer tables, W_out, log_softmax: < 2 % of the flops)
+The reference checkpoints every layer (``torch.utils.checkpoint``, na_model_utils.py:606,637): only layer inputs
+survive the forward pass and activations are recomputed in backward.  ``_EdgeMLP`` keeps the same policy — it
+saves its inputs and ``namp_train_edge_bwd`` recomputes the chain in registers.
+
+There is no CPU fallback: every tensor must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import hip, spec
+
+H = 128
+ENC_MSG, DEC_MSG, ENC_EDGE = 0, 1, 2
+
+
+def _image(block):
+    """Fragment image of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear weight."""
+    assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
+    img = torch.empty(H * H, dtype=torch.float32, device=block.device)
+    hip.check(hip.lib().namp_pack_image(block.data_ptr(), block.stride(0), 0, H, H, img.data_ptr(), hip.current_stream()),
+              "pack_image")
+    return img
+
+
+def _image_t(block):
+    return _image(block.detach().t().contiguous())
+
+
+def _wgrad(G, A, gelu_A, want_bias):
+    """sum over rows of G^T act(A) (and of G): [128,128] (, [128])."""
+    L = hip.lib()
+    rows = G.shape[0]
+    n = L.namp_train_wgrad_chunks(rows)
+    dW = torch.empty(n, H, H, device=G.device)
+    db = torch.empty(n, H, device=G.device) if want_bias else None
+    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), rows, dW.data_ptr(), hip.ptr(db),
+                                 hip.current_stream()), "train_wgrad")
+    return dW.sum(0), (db.sum(0) if want_bias else None)
+
+
+class _EdgeMLP(torch.autograd.Function):
+    """One per-edge 3-layer MLP of EncLayer / DecLayer with the hoisted first layer
+    ``z1 = W1b.h_E[i,k] + Pa[i] + Pj[j]``.  mode 0/1 -> sum_k w_ik * MLP / 30 per residue; mode 2 -> the message per edge."""
+
+    @staticmethod
+    def forward(ctx, mode, h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, b3, E_idx32, mask32, mask_attend32, rank32):
+        B, N, K = E_idx32.shape
+        L = hip.lib()
+        h_E, Pa, Pj0 = h_E.contiguous(), Pa.contiguous(), Pj0.contiguous()
+        Pj1 = Pj1.contiguous() if Pj1 is not None else None
+        imgs = [_image(W1b.detach()), _image(W2.detach()), _image(W3.detach())]
+        b2c, b3c = b2.detach().contiguous(), b3.detach().contiguous()
+        if mode == ENC_EDGE:
+            out = torch.empty(B, N, K, H, device=h_E.device)
+        else:
+            out = torch.empty(B * N, (K + 15) // 16, H, device=h_E.device)
+        hip.check(L.namp_train_edge_fwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
+                                        hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
+                                        imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
+                                        out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
+        ctx.mode = mode
+        ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
+        return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        mode = ctx.mode
+        h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32 = ctx.saved_tensors
+        B, N, K = E_idx32.shape
+        E = B * N * K
+        dev = h_E.device
+        L = hip.lib()
+        g = g.contiguous()
+        img1, img2 = _image(W1b.detach()), _image(W2.detach())
+        img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
+        Z1, Z2, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(5))
+        G3 = torch.empty(E, H, device=dev) if mode != ENC_EDGE else None
+        b2c = b2.detach().contiguous()
+        hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
+                                        hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
+                                        img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
+                                        g.data_ptr(), Z1.data_ptr(), Z2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
+                                        g_hE.data_ptr(), B, N, K, hip.current_stream()), "train_edge_bwd")
+        if mode == ENC_EDGE:
+            G3 = g.view(E, H)
+        dW3, db3 = _wgrad(G3, Z2, True, True)
+        dW2, db2 = _wgrad(G2, Z1, True, True)
+        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
+        g_Pa = G1.view(B * N, K, H).sum(1).view_as(Pa)
+        jflat = (E_idx32.long() + (torch.arange(B, device=dev) * N)[:, None, None]).view(-1)
+        if mode == DEC_MSG:
+            r = rank32.view(-1)
+            bw = (r[jflat] < r.repeat_interleave(K)).unsqueeze(1)
+            g_Pj0 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1 * bw).view_as(Pj0)
+            g_Pj1 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1 * (~bw)).view_as(Pj1)
+        else:
+            g_Pj0 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1).view_as(Pj0)
+            g_Pj1 = None
+        return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None)
+
+
+def _atom_frames(model, X, fd):
+    """X18 [B,L,18,3] and M18 [B,L,18] (na_model_utils.py:472-497): 16 atoms + virtual Cb + virtual N_na."""
+    ad = model.atom_dict
+    Ca = X[:, :, ad["CA"]]
+    Cb = model._virtual(X[:, :, ad["N"]], Ca, X[:, :, ad["C"]], -0.58273431, 0.56802827, -0.54067466)
+    C1p = X[:, :, ad["C1'"]]
+    Nna = model._virtual(X[:, :, ad["O4'"]], C1p, X[:, :, ad["C2'"]], -0.56967352, 0.51055973, -0.53122153)
+    X18 = torch.cat((X, Cb[:, :, None], Nna[:, :, None]), -2).contiguous()
+    M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (fd["rna_mask"] + fd["dna_mask"])[:, :, None]), -1)
+    return X18, M18.float().contiguous()
+
+
+def _edge_embedding_fwd(fp, X, ints, top_k, ref_atom):
+    """Fused HIP featuriser without its LayerNorm: y = edge_embedding([E_pos | RBF]) [B,L,K,128] and E_idx int32
+    (na_model_utils.py:489-507); no autograd here, see _EdgeEmbeddingGrad."""
+    L = hip.lib()
+    B, Lr = X.shape[:2]
+    K = int(min(top_k, Lr))
+    dev = X.device
+    Wd = fp.edge_embedding.weight.detach().contiguous()
+    img = torch.empty(Wd.numel(), device=dev)
+    hip.check(L.namp_pack_image(Wd.data_ptr(), Wd.shape[1], 0, H, Wd.shape[1], img.data_ptr(), hip.current_stream()),
+              "pack_image(edge_embedding)")
+    m = hip.NampModelW()
+    pw, pb = fp.embeddings.linear.weight.detach().contiguous(), fp.embeddings.linear.bias.detach().contiguous()
+    m.feat.Wedge_img, m.feat.pos_w, m.feat.pos_b = img.data_ptr(), pw.data_ptr(), pb.data_ptr()
+    m.feat.ln_g = m.feat.ln_b = None                          # pre-LayerNorm rows
+    E_idx = torch.empty(B, Lr, K, dtype=torch.int32, device=dev)
+    y = torch.empty(B, Lr, K, H, device=dev)
+    ws = torch.empty(L.namp_featurize_workspace_bytes(B, Lr), dtype=torch.uint8, device=dev)
+    hip.check(L.namp_featurize(C.byref(m), X.data_ptr(), *[t.data_ptr() for t in ints], int(top_k), int(ref_atom),
+                               E_idx.data_ptr(), y.data_ptr(), None, ws.data_ptr(), ws.numel(), B, Lr,
+                               hip.current_stream()), "featurize")
+    return y, E_idx
+
+
+class _EdgeEmbeddingGrad(torch.autograd.Function):
+    """Identity on y that routes dL/dy into edge_embedding.weight and the positional features E_pos."""
+
+    @staticmethod
+    def forward(ctx, y, Wedge, E_pos, X18, M18, E_idx):
+        ctx.save_for_backward(Wedge, E_pos, X18, M18, E_idx)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        Wedge, E_pos, X18, M18, E_idx = ctx.saved_tensors
+        L = hip.lib()
+        B, Lr, K = E_idx.shape
+        g = g_y.contiguous()
+        n = L.namp_train_feat_wgrad_chunks(B * Lr * K)
+        part = torch.empty(n, H, Wedge.shape[1], device=g.device)
+        Ep = E_pos.detach().contiguous()
+        hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
+                                          part.data_ptr(), B, Lr, K, hip.current_stream()), "train_feat_wgrad")
+        g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
+        return None, part.sum(0), g_Epos, None, None, None
+
+
+def edge_embedding(model, fd):
+    """-> y_pre [B,L,K,128] (differentiable w.r.t. features.edge_embedding / features.embeddings), E_idx int32."""
+    fp = model.features
+    X = model._noised_X(fd).float().contiguous()
+    X18, M18 = _atom_frames(model, X, fd)
+    ints = [fd[k].to(torch.int32).contiguous() for k in
+            ("X_m", "mask", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask")]
+    with torch.no_grad():
+        y, E_idx = _edge_embedding_fwd(fp, X, ints, model.k_neighbors, model.atom_dict[model.na_ref_atom])
+    # positional features as a torch expression (PositionalEncodings, na_model_utils.py:537-541) so that autograd
+    # carries dL/dE_pos into embeddings.linear
+    B, Lr, K = E_idx.shape
+    R, ch = fd["R_idx"].long(), fd["chain_labels"].long()
+    j = E_idx.long()
+    bidx = torch.arange(B, device=X.device)[:, None, None]
+    off = R[:, :, None] - R[bidx, j]
+    same = (ch[:, :, None] == ch[bidx, j]).long()
+    d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
+    E_pos = fp.embeddings.linear.weight.t()[d] + fp.embeddings.linear.bias          # [B,L,K,16]
+    y = _EdgeEmbeddingGrad.apply(y, fp.edge_embedding.weight, E_pos, X18, M18, E_idx)
+    return y, E_idx
+
+
+def _ln(x, norm):
+    return F.layer_norm(x, (H,), norm.weight, norm.bias, 1e-5)
+
+
+def _ffn(x, dense):
+    return dense.W_out(F.gelu(dense.W_in(x)))
+
+
+def forward_train(model, fd, decoding_randn=None):
+    """Differentiable ProteinMPNN.forward of the training copy (na_model_utils.py:589-646) -> (log_probs, probs)."""
+    mask = fd["mask"]
+    if not mask.is_cuda:
+        raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
+    drop = (lambda t: F.dropout(t, model.dropout.p, True)) if (model.training and model.dropout.p > 0) else (lambda t: t)
+    fp = model.features
+    y, E_idx = edge_embedding(model, fd)
+    B, N, K = E_idx.shape
+    E = _ln(y, fp.norm_edges)
+    V = model._node_features(fd)
+    h_V, h_E = model.W_v(V), model.W_e(E)
+    mask32 = mask.to(torch.int32).contiguous()
+    maskf = mask.float().unsqueeze(-1)
+    for p in model.encoder_layers:                                                   # EncLayer, na_model_utils.py:218-241
+        W1, W11 = p.W1.weight, p.W11.weight
+        Pa, Pc = F.linear(h_V, W1[:, :H], p.W1.bias), F.linear(h_V, W1[:, 2 * H:])
+        dh = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
+                            E_idx, mask32, None, None)
+        h_V = _ln(h_V + drop(dh), p.norm1)
+        h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
+        Pa, Pc = F.linear(h_V, W11[:, :H], p.W11.bias), F.linear(h_V, W11[:, 2 * H:])
+        msg = _EdgeMLP.apply(ENC_EDGE, h_E, Pa, Pc, None, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight,
+                             p.W13.bias, E_idx, None, None, None)
+        h_E = _ln(h_E + drop(msg), p.norm3)
+    chain_M = mask
+    if model.decode_protein_first:
+        chain_M = chain_M.masked_fill(fd["protein_mask"].to(torch.bool), 0.0)
+    if decoding_randn is None:
+        decoding_randn = torch.randn(chain_M.shape, device=mask.device)
+    rank32 = model.ranks_of(model.decoding_order(chain_M, decoding_randn)).to(torch.int32).contiguous()
+    h_S = model.W_s(fd["S"].long())
+    h_V_enc = h_V
+    for p in model.decoder_layers:                                                   # DecLayer on the implicit h_ESV, :610-640
+        W1 = p.W1.weight
+        Pa = F.linear(h_V, W1[:, :H], p.W1.bias)
+        Pbw = F.linear(h_S, W1[:, 2 * H:3 * H]) + F.linear(h_V, W1[:, 3 * H:])
+        Pfw = F.linear(h_V_enc, W1[:, 3 * H:])
+        dh = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
+                            E_idx, None, None, rank32)
+        h_V = _ln(h_V + drop(dh), p.norm1)
+        h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
+    logits = model.W_out(h_V)
+    return F.log_softmax(logits, dim=-1), F.softmax(logits, dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loss / optimiser / checkpoints  (na_model_utils.py:100-146, 648-686; na_run.py:100-130, 330-353)
+# ------------------------------------------------------------------------------------------------------------
+def loss_nll(S, log_probs, mask):
+    """na_model_utils.py:100-109."""
+    loss = F.nll_loss(log_probs.contiguous().view(-1, log_probs.size(-1)), S.contiguous().view(-1), reduction="none").view(S.size())
+    true_false = (S == torch.argmax(log_probs, -1)).float()
+    return loss, torch.sum(loss * mask) / torch.sum(mask), true_false
+
+
+def loss_smoothed(S, log_probs, mask, polymer_masks, polymer_restype_masks, polymer_restype_nums, weight=0.1, tokens=2000.0,
+                  num_letters=33, ppm_mask=None, aligned_ppm=None):
+    """Label-smoothed negative log-likelihood in fp64 with per-polymer smoothing mass (na_model_utils.py:111-146)."""
+    pr, dr, rr = (polymer_restype_masks[k] for k in ("protein", "dna", "rna"))
+    onehot = F.one_hot(S, num_letters).to(torch.float64)
+    if ppm_mask is not None:
+        onehot[ppm_mask.bool()] = aligned_ppm[ppm_mask.bool()]
+    eps = sum(polymer_masks[k][:, :, None] * polymer_restype_masks[k][None, None, :] * (weight / polymer_restype_nums[k])
+              for k in ("protein", "dna", "rna"))
+    onehot[:, :, (pr + dr + rr).bool()] *= (1 - weight)
+    onehot = onehot + eps
+    loss = -(onehot * log_probs).sum(-1)
+    return loss, torch.sum(loss * mask) / tokens
+
+
+class NoamOpt:
+    """Learning-rate schedule wrapper (na_model_utils.py:648-680): lr = factor * d^-0.5 * min(step^-0.5, step * warmup^-1.5)."""
+
+    def __init__(self, model_size, factor, warmup, optimizer, step):
+        self.optimizer, self._step, self.warmup, self.factor, self.model_size, self._rate = \
+            optimizer, step, warmup, factor, model_size, 0
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    def rate(self, step=None):
+        step = self._step if step is None else step
+        return self.factor * (self.model_size ** (-0.5) * min(step ** (-0.5), step * self.warmup ** (-1.5)))
+
+    def step(self):
+        self._step += 1
+        self._rate = self.rate()
+        for p in self.optimizer.param_groups:
+            p["lr"] = self._rate
+        self.optimizer.step()
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+
+def get_std_opt(parameters, d_model, step):
+    """na_model_utils.py:682-686."""
+    return NoamOpt(d_model, 2, 4000, torch.optim.Adam(parameters, lr=0, betas=(0.9, 0.98), eps=1e-9), step)
+
+
+def save_checkpoint(path, model, optimizer, epoch, step, save_step=None):
+    """The reference's checkpoint dict (na_run.py:330-353), loadable by inference/run.py:198-200."""
+    torch.save({"epoch": epoch, "step": step, "save_step": step if save_step is None else save_step,
+                "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.optimizer.state_dict()}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, map_location=None):
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ck["model_state_dict"])
+    if optimizer is not None and "optimizer_state_dict" in ck:
+        optimizer.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        optimizer._step = ck.get("step", optimizer._step)
+    return ck
+
+
+def polymer_restype_tables(restype_to_int, num_letters, device):
+    """0/1 vectors over the vocabulary marking each polymer's residue types and the list lengths the reference
+    divides the smoothing mass by (na_data_utils.py:185-223,281-283; na_run.py:138-154): 21 / 5 / 5."""
+    names = {"protein": spec.RESTYPES[:20] + ["UNK"], "dna": ["DA", "DC", "DG", "DT", "DX"], "rna": ["A", "C", "G", "U", "RX"]}
+    masks, nums = {}, {}
+    for key, lst in names.items():
+        v = torch.zeros(num_letters, device=device)
+        v[[restype_to_int[n] for n in lst]] = 1
+        masks[key], nums[key] = v, len(lst)
+    return masks, nums
+
+
+def train_step(model, optimizer, fd, polymer_restype_masks, polymer_restype_nums, tokens_with_no_loss, label_smoothing=0.1,
+               loss_tokens=2000.0, gradient_norm=0.0, decoding_randn=None):
+    """One optimisation step of na_run.py:198-238 (fp32): forward, label-smoothed loss, backward, clip, Noam/Adam."""
+    optimizer.zero_grad()
+    S, mask = fd["S"].long(), fd["mask"]
+    S_mask = 1 - torch.any(S[:, :, None] == tokens_with_no_loss[None, None, :], dim=-1).long()
+    mask_for_loss = mask * S_mask
+    polymer_masks = {"protein": fd["protein_mask"], "dna": fd["dna_mask"], "rna": fd["rna_mask"]}
+    log_probs, _ = forward_train(model, fd, decoding_randn)
+    _, loss = loss_smoothed(S, log_probs, mask_for_loss, polymer_masks, polymer_restype_masks, polymer_restype_nums,
+                            weight=label_smoothing, tokens=loss_tokens, num_letters=log_probs.shape[-1])
+    loss.backward()
+    if gradient_norm > 0.0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_norm)
+    optimizer.step()
+    return loss.detach(), log_probs.detach()

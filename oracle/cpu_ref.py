@@ -285,6 +285,60 @@ def forward_train(w, fd, top_k, randn, decode_protein_first=False):
 
 
 # ----------------------------------------------------------------------------------------
+# a12: training tail — label-smoothed loss, gradients by torch autograd through the restatement above,
+# Noam learning rate (na_model_utils.py:100-146, 648-686; na_run.py:131-154, 198-238)
+# ----------------------------------------------------------------------------------------
+NO_LOSS_TOKENS = ("UNK", "DX", "RX", "MAS", "PAD")            # na_run.py:131-136
+POLYMER_RESTYPES = {"protein": 21, "dna": 5, "rna": 5}        # list lengths of na_data_utils.py:185-223
+
+
+def restype_masks(restype_to_int, num_letters=33):
+    """na_run.py:138-154: 0/1 vocabulary vectors per polymer (+ the reference's divisors 21 / 5 / 5)."""
+    prot = [k for k, v in restype_to_int.items() if v <= 20][:21]
+    names = {"protein": prot, "dna": ["DA", "DC", "DG", "DT", "DX"], "rna": ["A", "C", "G", "U", "RX"]}
+    out = {}
+    for key, lst in names.items():
+        v = torch.zeros(num_letters)
+        v[[restype_to_int[n] for n in lst]] = 1
+        out[key] = v
+    return out, dict(POLYMER_RESTYPES)
+
+
+def loss_smoothed(S, log_probs, mask, polymer_masks, restype_mask, restype_num, weight=0.1, tokens=2000.0, num_letters=33):
+    """na_model_utils.py:111-146 with an empty ppm_mask: fp64 one-hot, (1-weight) on the polymer letters, plus
+    weight/num on the letters of the residue's own polymer; sum(loss*mask)/tokens."""
+    onehot = F.one_hot(S, num_letters).to(torch.float64)
+    eps = sum(polymer_masks[k][:, :, None] * restype_mask[k][None, None, :] * (weight / restype_num[k])
+              for k in ("protein", "dna", "rna"))
+    allm = restype_mask["protein"] + restype_mask["dna"] + restype_mask["rna"]
+    onehot[:, :, allm.bool()] *= (1 - weight)
+    onehot = onehot + eps
+    loss = -(onehot * log_probs).sum(-1)
+    return loss, torch.sum(loss * mask) / tokens
+
+
+def noam_rate(step, model_size=128, factor=2, warmup=4000):
+    """NoamOpt.rate (na_model_utils.py:672-678)."""
+    return factor * (model_size ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5)))
+
+
+def train_loss_and_grads(w, fd, top_k, randn, restype_to_int, weight=0.1, tokens=2000.0):
+    """One training forward/backward of na_run.py:198-238 (dropout 0, no coordinate noise) on the restatement:
+    returns loss (fp64 scalar), log_probs and {key: grad}."""
+    wg = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
+    with torch.enable_grad():
+        log_probs, _ = forward_train(wg, fd, top_k, randn)
+        S = fd["S"].long()
+        no_loss = torch.tensor([restype_to_int[t] for t in NO_LOSS_TOKENS])
+        S_mask = 1 - torch.any(S[:, :, None] == no_loss[None, None, :], dim=-1).long()
+        rm, rn = restype_masks(restype_to_int, log_probs.shape[-1])
+        pm = {"protein": fd["protein_mask"], "dna": fd["dna_mask"], "rna": fd["rna_mask"]}
+        _, loss = loss_smoothed(S, log_probs, fd["mask"] * S_mask, pm, rm, rn, weight, tokens, log_probs.shape[-1])
+        loss.backward()
+    return loss.detach(), log_probs.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in wg.items()}
+
+
+# ----------------------------------------------------------------------------------------
 # a9: autoregressive sampler, non-symmetric branch (model_utils.py:126-218)
 # ----------------------------------------------------------------------------------------
 SPECIAL_TOKENS = (20, 25, 30, 31, 32)   # UNK, DX, RX, MAS, PAD (run.py:32-66)

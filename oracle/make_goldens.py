@@ -263,10 +263,73 @@ def g6_sample_variants(weights, n=40, k=16, bs=2):
          pb_S=p["S"].numpy().astype(np.int8), pb_log_probs=p["log_probs"].numpy(), pb_probs=p["sampling_probs"].numpy())
 
 
+def g7_inputs(n=72, n2=55, k=24):
+    """Padded batch of two complexes (the second shorter: mask = 0 tail) with mixed polymers and missing atoms."""
+    a = synth.make_complex(seed=700, n=n, n_chains=3, masked_frac=0.04)
+    b = synth.make_complex(seed=701, n=n2, n_chains=2)
+    fd = {}
+    for key in a:
+        pad = np.zeros((n - n2,) + b[key].shape[1:], b[key].dtype)
+        fd[key] = torch.from_numpy(np.stack([a[key], np.concatenate([b[key], pad])]))
+    fd["S"] = fd["S"].long()
+    fd["S"][1, n2:] = 32                        # PAD token on the padding
+    return fd, k
+
+
+def g7_training(weights):
+    """Training step of the reference (na_run.py:198-238): train-mode forward through torch.utils.checkpoint
+    (dropout 0, no coordinate noise), loss_smoothed, backward, one NoamOpt/Adam step."""
+    fd, k = g7_inputs()
+    rti = spec.restype_to_int()
+    m = ref_train_model(weights, k).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    rm, rn = cpu_ref.restype_masks(rti)
+    S, mask = fd["S"], fd["mask"]
+    no_loss = torch.tensor([rti[t] for t in cpu_ref.NO_LOSS_TOKENS])
+    mask_for_loss = mask * (1 - torch.any(S[:, :, None] == no_loss[None, None, :], dim=-1).long())
+    pm = {"protein": fd["protein_mask"], "dna": fd["dna_mask"], "rna": fd["rna_mask"]}
+    torch.manual_seed(77)
+    randn = torch.randn(mask.shape)
+    opt = ref_train.get_std_opt(m.parameters(), 128, 0)
+    with torch.enable_grad():
+        torch.manual_seed(77)
+        lp, _ = m(fd)
+        _, loss = ref_train.loss_smoothed(S, lp, mask_for_loss, polymer_masks=pm, polymer_restype_masks=rm,
+                                          polymer_restype_nums=rn, weight=0.1, tokens=2000.0, num_letters=33,
+                                          ppm_mask=torch.zeros_like(mask), aligned_ppm=torch.zeros(lp.shape, dtype=torch.float64))
+        opt.zero_grad()
+        loss.backward()
+    grads = {n_: p.grad.detach().clone() for n_, p in m.named_parameters()}
+    o_loss, o_lp, o_g = cpu_ref.train_loss_and_grads(tw(weights), fd, k, randn, rti)
+    same(o_lp, lp.detach(), "train-mode log_probs")
+    assert float(o_loss) == float(loss), (float(o_loss), float(loss))
+    worst = max(float((o_g[n_] - g).abs().max() / (g.abs().max() + 1e-30)) for n_, g in grads.items())
+    print(f"  oracle autograd vs reference (checkpointed) autograd: worst relative grad difference {worst:.2e}")
+    assert worst < 1e-5
+    before = {n_: p.detach().clone() for n_, p in m.named_parameters()}
+    opt.step()
+    assert abs(opt._rate - cpu_ref.noam_rate(1)) < 1e-18
+    names = sorted(grads)
+    rng = np.random.default_rng(7)
+    pick = {n_: rng.integers(0, grads[n_].numel(), 16) for n_ in names}
+    save("g7_training", names=np.array(names), randn=randn.numpy(), loss=np.float64(loss.item()), log_probs=lp.detach().numpy(),
+         grad_norm=np.array([float(grads[n_].double().norm()) for n_ in names]),
+         grad_absmax=np.array([float(grads[n_].abs().max()) for n_ in names]),
+         pick=np.stack([pick[n_] for n_ in names]),
+         grad_pick=np.stack([grads[n_].reshape(-1)[pick[n_]].numpy() for n_ in names]),
+         lr_step1=np.float64(opt._rate),
+         delta_pick=np.stack([(dict(m.named_parameters())[n_].detach() - before[n_]).reshape(-1)[pick[n_]].numpy() for n_ in names]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     weights = synth.make_weights(0)
+    if len(sys.argv) > 1:                       # e.g. `python oracle/make_goldens.py g7_training`: regenerate one fixture
+        for name in sys.argv[1:]:
+            print(name); globals()[name](weights)
+        return
     print("G1 gather"); g1_gather()
     print("G2 layers"); g2_layers(weights)
     print("G3 enc+dec from graph")
@@ -280,6 +343,7 @@ def main():
     g4_from_X(weights, 32, 48, "n32_k48_LltK")
     print("G5 sample"); g5_sample(weights)
     print("G6 sample variants (symmetry-tied, pair_bias)"); g6_sample_variants(weights)
+    print("G7 training step"); g7_training(weights)
     print("all reference == oracle checks passed")
 
 

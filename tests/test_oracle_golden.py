@@ -173,3 +173,34 @@ def test_g6_symmetric_and_pair_bias_sampling(golden_dir, weights_np):
     p = cpu_ref.sample(w, fdp, k, S_forced=torch.from_numpy(g["pb_S"].astype(np.int64)))
     exact(p["log_probs"], g["pb_log_probs"]); exact(p["sampling_probs"], g["pb_probs"])
 
+
+def g7_inputs():
+    n, n2, k = 72, 55, 24
+    a = synth.make_complex(seed=700, n=n, n_chains=3, masked_frac=0.04)
+    b = synth.make_complex(seed=701, n=n2, n_chains=2)
+    fd = {}
+    for key in a:
+        pad = np.zeros((n - n2,) + b[key].shape[1:], b[key].dtype)
+        fd[key] = torch.from_numpy(np.stack([a[key], np.concatenate([b[key], pad])]))
+    fd["S"] = fd["S"].long()
+    fd["S"][1, n2:] = 32
+    return fd, k
+
+
+def test_g7_training_step(golden_dir, weights_np):
+    """a12: loss and gradients of one training step (na_run.py:198-238) — the reference ran in train mode through
+    torch.utils.checkpoint; the oracle's plain autograd must give the same numbers."""
+    from na_mpnn_amd import spec
+    g = load(golden_dir, "g7_training")
+    fd, k = g7_inputs()
+    loss, lp, grads = cpu_ref.train_loss_and_grads(tw(weights_np), fd, k, torch.from_numpy(g["randn"]), spec.restype_to_int())
+    exact(lp, g["log_probs"])
+    assert float(loss) == float(g["loss"])
+    names = [str(n) for n in g["names"]]
+    assert sorted(grads) == names
+    for i, n in enumerate(names):
+        got = grads[n].reshape(-1)[torch.from_numpy(g["pick"][i])].numpy()
+        assert np.array_equal(got, g["grad_pick"][i]), n
+        assert abs(float(grads[n].double().norm()) - g["grad_norm"][i]) <= 1e-12 * max(1.0, g["grad_norm"][i])
+    assert abs(cpu_ref.noam_rate(1) - float(g["lr_step1"])) < 1e-18
+
