@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
   float bsum[2] = {0.f, 0.f};
-  for (long r0 = r_begin; r0 < r_end; r0 += 16) {
-    float gv[2][4], av[8][4];
+  float gv[2][4], av[8][4], gn[2][4], an[8][4];
+  // operands of the 16-row step starting at r0 (rows past the chunk end contribute zeros through G)
+  auto load = [&](long r0, float (&go)[2][4], float (&ao)[8][4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = r0 + 4 * g + r;
@@ -219,10 +220,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
       const float* gp = G + rr * NAMP_H + n;
       const float* ap = A + rr * NAMP_H + n;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) gv[q][r] = ok ? gp[16 * (2 * wave + q)] : 0.f;
+      for (int q = 0; q < 2; ++q) { const float v = gp[16 * (2 * wave + q)]; go[q][r] = ok ? v : 0.f; }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) av[t][r] = ap[16 * t];
+      for (int t = 0; t < 8; ++t) ao[t][r] = ap[16 * t];
     }
+  };
+  if (r_begin < r_end) load(r_begin, gv, av);
+  for (long r0 = r_begin; r0 < r_end; r0 += 16) {
+    const bool more = r0 + 16 < r_end;
+    if (more) load(r0 + 16, gn, an);                          // next step's loads fly under this step's 64 MFMAs
     if (ACT) {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -237,6 +243,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(gv[q][r], av[t][r], acc[q][t]);
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gv[q][r] = gn[q][r];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t][r] = an[t][r];
+      }
+    }
   }
   // D[i = 4g + r][j = n]  ->  dW[16 to + 4g + r][16 tc + n]
   float* out = dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;

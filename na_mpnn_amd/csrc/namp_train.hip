@@ -90,8 +90,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
 
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
-  long n = (rows + 1023) / 1024;           // >= 1024 rows (64 MFMA steps) per workgroup
-  if (n > 512) n = 512;
+  long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 4 workgroups per CU
+  if (n > 1024) n = 1024;
   return (int)n;
 }
 

@@ -110,6 +110,32 @@ class _EdgeMLP(torch.autograd.Function):
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None)
 
 
+class _TableRows(torch.autograd.Function):
+    """table[idx] for a table with FEW rows (the 66 relative-position classes, the 6 polymer types).  The stock
+    index backward scatters ~10^6 rows into those few with atomics (measured: 1/3 of the training step); here the
+    gradient is the per-class sum, computed as chunked one-hot GEMMs."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.nrows = table.shape[0]
+        return table[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        C_ = g.shape[-1]
+        g2, i2 = g.reshape(-1, C_), idx.reshape(-1)
+        E = g2.shape[0]
+        chunk = 4096
+        S = (E + chunk - 1) // chunk
+        if S * chunk != E:
+            g2 = F.pad(g2, (0, 0, 0, S * chunk - E))
+            i2 = F.pad(i2, (0, S * chunk - E), value=0)          # padded rows carry zero gradient
+        oh = F.one_hot(i2.view(S, chunk), ctx.nrows).to(g2.dtype)
+        return torch.bmm(oh.transpose(1, 2), g2.view(S, chunk, C_)).sum(0), None
+
+
 def _atom_frames(model, X, fd):
     """X18 [B,L,18,3] and M18 [B,L,18] (na_model_utils.py:472-497): 16 atoms + virtual Cb + virtual N_na."""
     ad = model.atom_dict
@@ -187,7 +213,7 @@ def edge_embedding(model, fd):
     off = R[:, :, None] - R[bidx, j]
     same = (ch[:, :, None] == ch[bidx, j]).long()
     d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
-    E_pos = fp.embeddings.linear.weight.t()[d] + fp.embeddings.linear.bias          # [B,L,K,16]
+    E_pos = _TableRows.apply(fp.embeddings.linear.weight.t(), d) + fp.embeddings.linear.bias     # [B,L,K,16]
     y = _EdgeEmbeddingGrad.apply(y, fp.edge_embedding.weight, E_pos, X18, M18, E_idx)
     return y, E_idx
 
@@ -210,7 +236,7 @@ def forward_train(model, fd, decoding_randn=None):
     y, E_idx = edge_embedding(model, fd)
     B, N, K = E_idx.shape
     E = _ln(y, fp.norm_edges)
-    V = model._node_features(fd)
+    V = _ln(_TableRows.apply(fp.node_embedding.weight.t(), fd["R_polymer_type"].long()), fp.norm_nodes)   # one-hot @ W^T
     h_V, h_E = model.W_v(V), model.W_e(E)
     mask32 = mask.to(torch.int32).contiguous()
     maskf = mask.float().unsqueeze(-1)

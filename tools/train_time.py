@@ -1,0 +1,60 @@
+"""Time the training step (fwd + bwd + Adam) at a cfg5-like shape and list the top device kernels.
+
+    python tools/train_time.py [--B 16] [--N 1500] [--K 48] [--steps 5] [--profile]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from na_mpnn_amd import spec, synth, train          # noqa: E402
+from na_mpnn_amd.model import ProteinMPNN           # noqa: E402
+
+
+def make_batch(B, N, dev, seed=5):
+    cxs = [synth.make_complex(seed=seed + b, n=N, n_chains=4) for b in range(B)]
+    fd = {k: torch.from_numpy(np.stack([c[k] for c in cxs])).to(dev) for k in cxs[0]}
+    fd["S"] = fd["S"].long()
+    return fd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=16); ap.add_argument("--N", type=int, default=1500)
+    ap.add_argument("--K", type=int, default=48); ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--profile", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rti = spec.restype_to_int()
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=a.K, dropout=a.dropout, atom_dict=spec.atom_dict(),
+                    restype_to_int=rti, polytype_to_int=spec.polytype_to_int(), augment_eps=0.1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()})
+    m.to(dev).train()
+    fd = make_batch(a.B, a.N, dev)
+    opt = train.get_std_opt(m.parameters(), 128, 0)
+    rm, rn = train.polymer_restype_tables(rti, 33, dev)
+    no_loss = torch.tensor([rti[t] for t in ("UNK", "DX", "RX", "MAS", "PAD")], device=dev)
+    step = lambda: train.train_step(m, opt, fd, rm, rn, no_loss, loss_tokens=6000.0, gradient_norm=1.0)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"B={a.B} N={a.N} K={a.K}: {dt * 1e3:.1f} ms/step, {a.B * a.N / dt:.0f} residues/s trained, loss {float(loss):.4f}, "
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if a.profile:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step(); torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=70))
+
+
+if __name__ == "__main__":
+    main()
