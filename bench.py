@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — residues/s of the NA-MPNN encoder+decoder forward on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 from na_mpnn_amd import hip, shard, spec, synth   # noqa: E402
 from na_mpnn_amd.pack import PackedWeights        # noqa: E402
 
-WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48), "cfg5": dict(B=16, N=1500, K=48)}
+WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48), "cfg4": dict(B=1373, N=0, K=48),
+             "cfg5": dict(B=16, N=1500, K=48)}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
@@ -248,6 +249,77 @@ def train_bench(args, dev, rank, world, dist):
         print(json.dumps(out), flush=True)
 
 
+def split_bench(args, dev, rank, world, dist):
+    """BASELINE configs[3] ("cfg4"): the design_test split (1,373 complexes; synthetic coordinates of the split's size
+    distribution) sharded over the ranks by LPT as independent complexes; each complex runs the whole
+    path FROM COORDINATES (featurise + encode + decode, `ProteinMPNN.score`), and one RCCL all-gather collates the
+    arg-max sequences.  A "step" is one pass over the rank's shard (strong scaling: total work fixed)."""
+    from na_mpnn_amd.model import ProteinMPNN
+    lengths = shard.synthetic_lengths()
+    if args.split_limit:
+        lengths = lengths[:args.split_limit]
+    mine = shard.lpt_assign(lengths, world)[rank]
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=48, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                    polytype_to_int=spec.polytype_to_int())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()})
+    m.to(dev).eval()
+    # token-bucket batches inside the shard (the reference's StructureLoader rule, na_data_utils.py:1405-1426)
+    batches = shard.token_batches(lengths, indices=mine, max_tokens=args.batch_tokens)
+    fds = []
+    for b in batches:
+        cxs = [synth.make_complex(seed=40000 + i, n=int(lengths[i]), n_chains=1 + i % 4) for i in b]
+        fd = shard.pad_batch(cxs, device=dev)
+        fd["batch_size"] = 1
+        fd["randn"] = torch.from_numpy(np.random.default_rng(b[0]).standard_normal(tuple(fd["mask"].shape)).astype(np.float32)).to(dev)
+        fds.append(fd)
+    result = {}
+
+    def step():
+        for b, fd in zip(batches, fds):
+            seq = m.score(fd)["log_probs"].argmax(-1)
+            for row, i in enumerate(b):
+                result[i] = seq[row, :int(lengths[i])]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_res = int(lengths.sum())
+    t1 = time.perf_counter()
+    collated = shard.all_gather_ragged(result, len(lengths), device=dev)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    n_coll = sum(int(x.numel()) for x in collated if x is not None)
+    my_res = int(sum(lengths[i] for i in mine))
+    out = {"metric": "residues/sec (featurise + enc + dec forward from coordinates), design_test-sized split", "unit": "residues/s",
+           "value": round(total_res * args.steps / elapsed, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"cfg4: {len(lengths)} complexes, {total_res} residues (N_i log-uniform 50..3000), K=48, fp32, one "
+                                  "score() from coordinates per token-bucket batch, LPT shards, no data-path collective",
+                      "global_batch": len(lengths), "seq_len": int(np.median(lengths)), "parallelism": f"independent complexes x{world}"},
+           "shard": {"rank0_complexes": len(mine), "rank0_batches": len(batches), "batch_tokens": args.batch_tokens, "rank0_residues": my_res, "ideal_residues_per_rank": total_res // world},
+           "collation": {"collective": "all_reduce(lengths) + all_gather(padded int32 sequences)", "ms": round(gather_ms, 3),
+                         "residues_collated": n_coll}}
+    assert n_coll == total_res, (n_coll, total_res)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def cpu_train_baseline(cx, K, rti, n=300):
     """The oracle's training step (autograd through oracle/cpu_ref.py + Adam) on the host: B=1, first n residues."""
     from oracle import cpu_ref
@@ -280,6 +352,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
                     help="per-edge GEMM precision; default fp32 for cfg2 (parity mode), bf16 for cfg3 (BASELINE configs[2])")
+    ap.add_argument("--split-limit", type=int, default=0, help="cfg4: use only the first n complexes of the split")
+    ap.add_argument("--batch-tokens", type=int, default=8000, help="cfg4: padded-token budget per batch inside a shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -306,6 +380,15 @@ def main():
     n_gpus = world
     torch.set_grad_enabled(False)
 
+    if args.workload == "cfg4":
+        if args.steps == 50:
+            args.steps = 2
+        args.warmup = min(args.warmup, 1)
+        split_bench(args, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "cfg5":
         if args.steps == 50:
             args.steps = 10                      # a training step is ~100x a cfg2 forward

@@ -203,7 +203,8 @@ class ProteinMPNN(nn.Module):
         hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
                                     int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
                                     ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
-        torch.cuda.current_stream().synchronize()      # int32 temporaries / workspace must outlive the launches
+        # no host sync: the int32 temporaries and the workspace come from torch's stream-ordered caching allocator, so
+        # their blocks are only reused by work enqueued AFTER these launches on the same stream
         return self._node_features(fd), E, hE, E_idx
 
     @torch.no_grad()
@@ -449,7 +450,7 @@ class ProteinMPNN(nn.Module):
                                          hip.ptr(sym_w), hip.ptr(pair_bias), float(fd["temperature"]), special,
                                          S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
                                          B_dec, B, L, K, hip.current_stream()), "decoder_sample")
-        torch.cuda.current_stream().synchronize()        # temporaries above must outlive the launch
+        # (no host sync needed: temporaries are stream-ordered allocations, see _featurize_hip)
         return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                 "uniform": uniform}
 

@@ -35,6 +35,51 @@ def synthetic_lengths(n_complexes: int = 1373, seed: int = 4, lo: int = 50, hi: 
     return np.minimum(n, cap)
 
 
+def token_batches(lengths, indices=None, max_tokens: int = 6000, keep_oversize: bool = True):
+    """Length-sorted token-bucket batches, the rule of the reference's StructureLoader (na_data_utils.py:1405-1426):
+    walk the complexes by ascending length and close a batch when ``length * (batch size + 1)`` would exceed
+    ``max_tokens``.  The reference drops complexes longer than the budget (training); inference keeps them as
+    singleton batches (``keep_oversize``).  Returns a list of index lists."""
+    idx = np.arange(len(lengths)) if indices is None else np.asarray(indices, dtype=np.int64)
+    order = idx[np.argsort(np.asarray(lengths)[idx], kind="stable")]
+    out, batch = [], []
+    for ix in order:
+        size = int(lengths[ix])
+        if size > max_tokens:
+            if keep_oversize:
+                out.append([int(ix)])
+            continue
+        if size * (len(batch) + 1) <= max_tokens:
+            batch.append(int(ix))
+        else:
+            if batch:
+                out.append(batch)
+            batch = [int(ix)]
+    if batch:
+        out.append(batch)
+    return out
+
+
+# padding values of the reference's batch featurize (na_model_utils.py:14-35)
+PAD_VALUES = {"S": 32, "R_polymer_type": 5, "R_idx": -100, "chain_labels": -1}
+
+
+def pad_batch(complexes, device=None):
+    """Stack per-complex numpy dicts (no batch dimension) into one padded feature_dict: zeros everywhere (mask = 0 on
+    the padding) except S = PAD, R_polymer_type = PAD, R_idx = -100, chain_labels = -1."""
+    L = max(c["X"].shape[0] for c in complexes)
+    fd = {}
+    for key in complexes[0]:
+        rows = []
+        for c in complexes:
+            a = np.asarray(c[key])
+            p = np.full((L - a.shape[0],) + a.shape[1:], PAD_VALUES.get(key, 0), dtype=a.dtype)
+            rows.append(np.concatenate([a, p], 0))
+        t = torch.from_numpy(np.stack(rows))
+        fd[key] = t.to(device) if device is not None else t
+    return fd
+
+
 def all_gather_ragged(local: dict, n_total: int, device=None, group=None):
     """Collate {complex index: 1-D int tensor} from every rank.
 

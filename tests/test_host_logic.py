@@ -92,3 +92,40 @@ def test_synthetic_generators_are_deterministic():
     assert g["E_idx"].shape == (1, 10, 10)                          # L < K -> K' = L
     w1, w2 = synth.make_weights(0), synth.make_weights(0)
     assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+
+
+def test_token_batches_follow_the_reference_rule():
+    """StructureLoader (na_data_utils.py:1405-1426): ascending lengths, close when size*(n+1) > budget."""
+    from na_mpnn_amd import shard
+    lengths = np.array([50, 700, 60, 3000, 55, 7000, 650, 2999, 10])
+    b = shard.token_batches(lengths, max_tokens=6000)
+    assert sorted(i for x in b for i in x) == list(range(9))                 # inference keeps the oversize complex
+    assert [5] in b and all(len(x) == 1 or max(lengths[x]) * len(x) <= 6000 for x in b)
+    flat = [i for x in b if x != [5] for i in x]
+    assert list(lengths[flat]) == sorted(lengths[flat])                       # ascending walk
+    assert shard.token_batches(lengths, max_tokens=6000, keep_oversize=False) == [x for x in b if x != [5]]
+    # restating the loop literally
+    exp, cur = [], []
+    for ix in np.argsort(lengths, kind="stable"):
+        if lengths[ix] > 6000:
+            continue
+        if lengths[ix] * (len(cur) + 1) <= 6000:
+            cur.append(int(ix))
+        else:
+            exp.append(cur); cur = [int(ix)]
+    exp.append(cur)
+    assert shard.token_batches(lengths, max_tokens=6000, keep_oversize=False) == exp
+    sub = shard.token_batches(lengths, indices=[1, 6, 0], max_tokens=1400)
+    assert sub == [[0, 6], [1]]                  # 50 | 650*2 <= 1400 | 700*3 > 1400
+
+
+def test_pad_batch_uses_the_reference_padding_values():
+    from na_mpnn_amd import shard, synth
+    cxs = [synth.make_complex(seed=i, n=n) for i, n in enumerate((12, 20, 7))]
+    fd = shard.pad_batch(cxs)
+    assert fd["X"].shape == (3, 20, 16, 3) and fd["mask"].shape == (3, 20)
+    assert int(fd["mask"][2, 7:].sum()) == 0 and float(fd["X"][0, 12:].abs().sum()) == 0.0
+    assert (fd["S"][0, 12:] == 32).all() and (fd["R_polymer_type"][2, 7:] == 5).all()
+    assert (fd["R_idx"][0, 12:] == -100).all() and (fd["chain_labels"][2, 7:] == -1).all()
+    assert np.array_equal(fd["X"][1].numpy(), cxs[1]["X"])
+
