@@ -9,6 +9,7 @@ import sys
 
 
 def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*", "", name)
     return name if len(name) < 90 else name[:87] + "..."
 
