@@ -148,6 +148,14 @@ int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_
 int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
                             const int32_t* mask_attend, const float* Pa, const float* Pc, const float* h_V,
                             float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream);
+/* EncLayer l-1's edge update (tables ePa / ePc = W11a.h_V + b11, W11c.h_V; h_E updated IN PLACE) fused in front of
+ * EncLayer l's message phase + residue tail: the updated edge rows go from LayerNorm3 straight into the message MLP
+ * in registers, so h_E is read once and one launch carries model_utils.py:699-703 of layer l-1 and :684-697 of layer l.
+ * fp32 only.  Same results as namp_enc_edge_update(w_prev) followed by namp_enc_message_update(w). */
+int namp_enc_edge_message_update(const NampEncLayerW* w_prev, const float* ePa, const float* ePc, float* h_E,
+                                 const NampEncLayerW* w, const int32_t* E_idx, const int32_t* mask,
+                                 const int32_t* mask_attend, const float* Pa, const float* Pc, const float* h_V,
+                                 float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream);
 int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
                             const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
                             float* h_V_out, const NampProj* proj, int nproj, const int32_t* S,
@@ -198,6 +206,15 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
                      const int32_t* S, const int32_t* mask, const int32_t* rank,
                      float* log_probs, float* logits, float* h_V_dec,
                      void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
+
+/* ProteinMPNN.score's device path (model_utils.py:88-94 + 406-421) in one call: (V, E, E_idx, mask, S, rank) -> h_V, h_E
+ * (encoder outputs, as namp_encoder_fwd) and log_probs [B,N,vocab] (as namp_decoder_fwd with B_dec == B_enc).  While the
+ * batch takes the fused residue tail (fp32, B*N <= namp_fused_tail_max_residues()) the encoder/decoder boundary is
+ * fused as well (decoder tables projected by the last EncLayer's launch, last edge update in front of DecLayer 0's
+ * message phase); otherwise it is namp_encoder_fwd + namp_decoder_fwd.  ws_bytes >= 2 * namp_workspace_bytes(B,B,N,K). */
+int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx, const int32_t* mask,
+                    const int32_t* S, const int32_t* rank, float* h_V, float* h_E, float* log_probs, float* logits,
+                    void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
 
 /* ---- a9: autoregressive sampler ------------------------------------------------------------
  * ProteinMPNN.sample (model_utils.py:101-327: plain branch :126-218, symmetry-tied branch :219-326), after encode(): B_dec independent sample
@@ -276,7 +293,9 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
 #define NAMP_KIND_DEC_MESSAGE 6
 #define NAMP_KIND_LOGITS 7
 #define NAMP_KIND_FEATURES 8
-#define NAMP_NUM_KINDS 9
+#define NAMP_KIND_ENC_EDGE_MESSAGE 9   /* namp_enc_edge_message_update: edge update of layer l-1 + message of layer l */
+#define NAMP_KIND_ENC_EDGE_DEC_MESSAGE 10   /* namp_encdec_fwd: last edge update + DecLayer 0 message */
+#define NAMP_NUM_KINDS 11
 int namp_profile_enable(int on);
 int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nkinds);
 

@@ -103,6 +103,12 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, true>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, true>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_EDGE, 0, true>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, false, true>), EDGE_TAIL_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel, SAMPLE_LDS);
@@ -132,14 +138,14 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE, int TAIL = 0, bool BF16 = false>
+template <int MODE, int TAIL = 0, bool BF16 = false, bool FUSE = false>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
-  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16, FUSE>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
 }
 
@@ -157,6 +163,15 @@ int launch_edge_tail(const EdgeArgs& a, bool bf16, hipStream_t s) {
   if (e.npw <= 4) return launch_edge_prec<MODE, 4>(a, bf16, s);
   if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge_prec<MODE, 8>(a, bf16, s);
   return launch_edge_prec<MODE, 16>(a, bf16, s);
+}
+
+// edge update of the previous layer fused in front of the message phase (fp32 only)
+template <int MODE>
+int launch_edge_tail_fused(const EdgeArgs& a, hipStream_t s) {
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  if (e.npw <= 4) return launch_edge<MODE, 4, false, true>(a, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, false, true>(a, s);
+  return launch_edge<MODE, 16, false, true>(a, s);
 }
 
 #define NAMP_FLAG_BF16 1
@@ -470,6 +485,41 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
   return NAMP_OK;
 }
 
+int namp_enc_edge_message_update(const NampEncLayerW* w_prev, const float* ePa, const float* ePc, float* h_E,
+                                 const NampEncLayerW* w, const int32_t* E_idx, const int32_t* mask,
+                                 const int32_t* mask_attend, const float* Pa, const float* Pc, const float* h_V,
+                                 float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream) {
+  REQUIRE(w_prev != nullptr && w != nullptr, "namp_enc_edge_message_update: null weights");
+  REQUIRE((w->flags & NAMP_FLAG_BF16) == 0 && (w_prev->flags & NAMP_FLAG_BF16) == 0,
+          "namp_enc_edge_message_update: fp32 only (use the separate launches in bf16 mode)");
+  REQUIRE_PTR(h_E); REQUIRE_PTR(ePa); REQUIRE_PTR(ePc); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
+  REQUIRE_PTR(w_prev->W11b_img); REQUIRE_PTR(w_prev->W12_img); REQUIRE_PTR(w_prev->W13_img); REQUIRE_PTR(w_prev->b12);
+  REQUIRE_PTR(w_prev->b13); REQUIRE_PTR(w_prev->ln3_g); REQUIRE_PTR(w_prev->ln3_b);
+  REQUIRE_PTR(w->W1b_img); REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  REQUIRE_PTR(w->Win_img); REQUIRE_PTR(w->Wout_img); REQUIRE_PTR(w->b_in); REQUIRE_PTR(w->b_out);
+  REQUIRE_PTR(w->ln1_g); REQUIRE_PTR(w->ln1_b); REQUIRE_PTR(w->ln2_g); REQUIRE_PTR(w->ln2_b);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_enc_edge_message_update: null E_idx");
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  if ((rc = check_proj(__func__, proj, nproj, nullptr))) return rc;
+  for (int i = 0; i < nproj; ++i)
+    REQUIRE(proj[i].out != ePa && proj[i].out != ePc && proj[i].out != Pa && proj[i].out != Pc,
+            "namp_enc_edge_message_update: projection %d writes a table this launch still gathers", i);
+  EdgeArgs a = {};
+  a.hE = h_E; a.hE_out = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
+  a.ePa = ePa; a.ePj = ePc; a.eW1_img = w_prev->W11b_img; a.eW2_img = w_prev->W12_img; a.eW3_img = w_prev->W13_img;
+  a.eb2 = w_prev->b12; a.eb3 = w_prev->b13; a.ln_g = w_prev->ln3_g; a.ln_b = w_prev->ln3_b;
+  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
+            h_V_out, proj, nproj, nullptr);
+  ProfScope prof_(NAMP_KIND_ENC_EDGE_MESSAGE, (hipStream_t)stream);
+  rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* rank,
                             const float* Pa, const float* Pbw, const float* Pfw, const float* h_V, const int32_t* mask,
                             float* h_V_out, const NampProj* proj, int nproj, const int32_t* S,
@@ -671,7 +721,7 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N, tpn = (K + 15) / 16;
-  const size_t enc = (2 + 6 + tpn) * tbl(Ge);
+  const size_t enc = (2 + 8 + tpn) * tbl(Ge);
   const size_t dec = (2 + 4 + tpn) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
   return (enc > dec ? enc : dec) + 4096;
 }
@@ -720,11 +770,12 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   const int G = B * N, tpn = (K + 15) / 16;
   Carver c(ws, ws_bytes);
   float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
-  float* P[6];
-  for (int i = 0; i < 6; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
+  float* P[8];
+  for (int i = 0; i < 8; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
   float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_encoder_fwd: workspace too small (%zu bytes)", ws_bytes);
   const bool fused = G <= NAMP_FUSED_TAIL_MAX_RESIDUES;
+  const bool chain_edges = fused && (w->enc[0].flags & NAMP_FLAG_BF16) == 0;
 
   // h_V = W_v.V + b (model_utils.py:88) chained with enc[0]'s Pa / Pc tables in one launch
   const NampEncLayerW* L0 = &w->enc[0];
@@ -740,8 +791,11 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
     // message tables of layer l live in P[tm], P[tm+1] (ping-pong {0,1} / {4,5}: with the fused tail the
     // next layer's tables are written while other workgroups still gather this layer's); the
     // edge-update tables in P[2], P[3].
+    // With the fused tail and fp32 weights, layer l-1's edge update rides in front of layer l's message phase (one
+    // launch, h_E read once): the edge tables then ping-pong too ({2,3} / {6,7}).
     const int tm = (l & 1) ? 4 : 0, tn = (l & 1) ? 0 : 4;
-    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[2]}, {L->W11c_img, nullptr, nullptr, P[3]}, {}, {}};
+    const int te = chain_edges ? ((l & 1) ? 6 : 2) : 2, tp = (l & 1) ? 2 : 6;
+    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[te]}, {L->W11c_img, nullptr, nullptr, P[te + 1]}, {}, {}};
     int np = 2;
     if (!last) {
       const NampEncLayerW* Ln = &w->enc[l + 1];
@@ -749,7 +803,11 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
       pe[3] = {Ln->W1c_img, nullptr, nullptr, P[tn + 1]};
       np = 4;
     }
-    if (fused) {
+    if (chain_edges && l > 0) {
+      if ((rc = namp_enc_edge_message_update(&w->enc[l - 1], P[tp], P[tp + 1], h_E, L, E_idx, mask, nullptr, P[tm], P[tm + 1],
+                                             hv[cur], out, pe, np, B, N, K, stream)))
+        return rc;
+    } else if (fused) {
       if ((rc = namp_enc_message_update(L, h_E, E_idx, mask, nullptr, P[tm], P[tm + 1], hv[cur], out, pe, np, B, N, K,
                                         stream)))
         return rc;
@@ -759,8 +817,132 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
                                  hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
         return rc;
     }
-    if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[2], P[3], h_E, B, N, K, stream))) return rc;
+    if (!chain_edges || last) {
+      if ((rc = namp_enc_edge_update(L, h_E, E_idx, P[te], P[te + 1], h_E, B, N, K, stream))) return rc;
+    }
     cur ^= 1;
+  }
+  return NAMP_OK;
+}
+
+// ProteinMPNN.score's device path in one call: encoder + parallel decoder.  While the batch takes the fused residue
+// tail (fp32, B*N <= NAMP_FUSED_TAIL_MAX_RESIDUES) the encoder/decoder boundary is fused too: the last EncLayer's
+// message launch also projects the decoder's layer-0 and encoder-context tables, and the last edge update rides in
+// front of DecLayer 0's message phase — 2 + n_enc + n_dec launches instead of 3 + 2 n_enc + n_dec.
+int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx, const int32_t* mask,
+                    const int32_t* S, const int32_t* rank, float* h_V, float* h_E, float* log_probs, float* logits,
+                    void* ws, size_t ws_bytes, int B, int N, int K, void* stream) {
+  REQUIRE(w != nullptr, "namp_encdec_fwd: null weights");
+  REQUIRE(w->n_enc >= 1 && w->n_enc <= NAMP_MAX_LAYERS && w->n_dec >= 1 && w->n_dec <= NAMP_MAX_LAYERS,
+          "namp_encdec_fwd: n_enc=%d / n_dec=%d out of range", w->n_enc, w->n_dec);
+  REQUIRE_PTR(V); OPTIONAL_PTR(E); REQUIRE_PTR(h_V); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
+  if (!E_idx || !S || !rank || !log_probs) return fail(NAMP_EINVAL, "namp_encdec_fwd: null E_idx / S / rank / log_probs");
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  const int G = B * N;
+  const size_t half = namp_workspace_bytes(B, B, N, K);
+  REQUIRE(ws_bytes >= 2 * half, "namp_encdec_fwd: workspace too small (%zu bytes, need 2 x namp_workspace_bytes = %zu)", ws_bytes, 2 * half);
+  const bool bf = (w->enc[0].flags & NAMP_FLAG_BF16) != 0 || (w->dec[0].flags & NAMP_FLAG_BF16) != 0;
+  if (G > NAMP_FUSED_TAIL_MAX_RESIDUES || bf || w->n_dec + 4 > 8) {
+    if ((rc = namp_encoder_fwd(w, V, E, E_idx, mask, h_V, h_E, ws, half, B, N, K, stream))) return rc;
+    return namp_decoder_fwd(w, h_V, h_E, E_idx, S, mask, rank, log_probs, logits, nullptr, (char*)ws + half, half, B, B, N, K, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(ws, ws_bytes);
+  float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* P[8];
+  for (int i = 0; i < 8; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
+  float* dhv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* PA[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* PB[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* Pfw[NAMP_MAX_LAYERS];
+  for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)G * NAMP_HIDDEN);
+  if (!Pfw[w->n_dec - 1]) return fail(NAMP_EWORKSPACE, "namp_encdec_fwd: workspace too small (%zu bytes)", ws_bytes);
+
+  const NampEncLayerW* L0 = &w->enc[0];
+  NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
+  NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
+  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  if (E && (rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
+  int cur = 0;
+  for (int l = 0; l < w->n_enc; ++l) {
+    const NampEncLayerW* L = &w->enc[l];
+    const bool last = (l + 1 == w->n_enc);
+    float* out = last ? h_V : hv[cur ^ 1];
+    const int tm = (l & 1) ? 4 : 0, tn = (l & 1) ? 0 : 4, te = (l & 1) ? 6 : 2, tp = (l & 1) ? 2 : 6;
+    NampProj pe[8];
+    int np = 0;
+    pe[np++] = {L->W11a_img, L->b11, nullptr, P[te]};
+    pe[np++] = {L->W11c_img, nullptr, nullptr, P[te + 1]};
+    if (!last) {
+      const NampEncLayerW* Ln = &w->enc[l + 1];
+      pe[np++] = {Ln->W1a_img, Ln->b1, nullptr, P[tn]};
+      pe[np++] = {Ln->W1c_img, nullptr, nullptr, P[tn + 1]};
+    } else {          // decoder tables from h_V_enc (model_utils.py:406-413): Pfw_l, and layer 0's Pa / Pbw
+      const NampDecLayerW* D0 = &w->dec[0];
+      for (int d = 0; d < w->n_dec; ++d) pe[np++] = {w->dec[d].W1v_img, nullptr, nullptr, Pfw[d]};
+      pe[np++] = {D0->W1a_img, D0->b1, nullptr, PA[0]};
+      pe[np++] = {D0->W1v_img, nullptr, D0->tok, PB[0]};
+    }
+    if ((rc = check_proj(__func__, pe, np, S))) return rc;
+    EdgeArgs a = {};
+    a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.Pa = P[tm]; a.Pj0 = P[tm + 1];
+    a.W1_img = L->W1b_img; a.W2_img = L->W2_img; a.W3_img = L->W3_img; a.b2 = L->b2; a.b3 = L->b3;
+    a.G = a.G_enc = G; a.N = N; a.K = K;
+    fill_tail(a.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur], mask, out,
+              pe, np, S);
+    if (l == 0) {
+      ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
+      rc = launch_edge_tail<MODE_ENC_MSG>(a, false, s);
+    } else {
+      const NampEncLayerW* Lp = &w->enc[l - 1];
+      a.hE_out = h_E; a.ePa = P[tp]; a.ePj = P[tp + 1];
+      a.eW1_img = Lp->W11b_img; a.eW2_img = Lp->W12_img; a.eW3_img = Lp->W13_img; a.eb2 = Lp->b12; a.eb3 = Lp->b13;
+      a.ln_g = Lp->ln3_g; a.ln_b = Lp->ln3_b;
+      ProfScope prof_(NAMP_KIND_ENC_EDGE_MESSAGE, s);
+      rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, s);
+    }
+    if (rc) return rc;
+    CHECK_LAUNCH();
+    cur ^= 1;
+  }
+  const int te_last = ((w->n_enc - 1) & 1) ? 6 : 2;
+  const float* hin = h_V;
+  for (int l = 0; l < w->n_dec; ++l) {
+    const NampDecLayerW* D = &w->dec[l];
+    const bool last = (l + 1 == w->n_dec);
+    float* out = dhv[l & 1];
+    NampProj pn[2] = {{}, {}};
+    int np = 0;
+    if (!last) {
+      const NampDecLayerW* Dn = &w->dec[l + 1];
+      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, PA[(l + 1) & 1]};
+      pn[1] = {Dn->W1v_img, nullptr, Dn->tok, PB[(l + 1) & 1]};
+      np = 2;
+    }
+    if (l > 0) {
+      if ((rc = namp_dec_message_update(D, h_E, E_idx, rank, PA[l & 1], PB[l & 1], Pfw[l], hin, mask, out, pn, np, S,
+                                        last ? w->Wout_w : nullptr, w->Wout_b, log_probs, logits, w->vocab, B, B, N, K, stream)))
+        return rc;
+    } else {          // last EncLayer's edge update + DecLayer 0 message + tail
+      const NampEncLayerW* Lp = &w->enc[w->n_enc - 1];
+      EdgeArgs a = {};
+      a.hE = h_E; a.hE_out = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = PA[0]; a.Pj0 = PB[0]; a.Pj1 = Pfw[0];
+      a.ePa = P[te_last]; a.ePj = P[te_last + 1];
+      a.eW1_img = Lp->W11b_img; a.eW2_img = Lp->W12_img; a.eW3_img = Lp->W13_img; a.eb2 = Lp->b12; a.eb3 = Lp->b13;
+      a.ln_g = Lp->ln3_g; a.ln_b = Lp->ln3_b;
+      a.W1_img = D->W1e_img; a.W2_img = D->W2_img; a.W3_img = D->W3_img; a.b2 = D->b2; a.b3 = D->b3;
+      a.G = a.G_enc = G; a.N = N; a.K = K;
+      if ((rc = check_proj(__func__, pn, np, S))) return rc;
+      fill_tail(a.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin, mask, out,
+                pn, np, S);
+      if (last) { a.tail.head_w = w->Wout_w; a.tail.head_b = w->Wout_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = w->vocab; }
+      ProfScope prof_(NAMP_KIND_ENC_EDGE_DEC_MESSAGE, s);
+      rc = launch_edge_tail_fused<MODE_DEC_MSG>(a, s);
+      if (rc) return rc;
+      CHECK_LAUNCH();
+    }
+    hin = out;
   }
   return NAMP_OK;
 }

@@ -486,6 +486,12 @@ struct EdgeArgs {
   const float* b3;
   const float* ln_g;           // ENC_EDGE
   const float* ln_b;
+  // FUSE (message modes with the fused tail): the PREVIOUS layer's edge update runs first on the same rows —
+  // h_E <- LN3(h_E + MLP'(..)) with these tables / images, stored to hE_out — and the message phase consumes it
+  // from registers (one launch, one read of h_E, for EncLayer l's edge update + layer l+1's message)
+  const float* ePa; const float* ePj;
+  const float* eW1_img; const float* eW2_img; const float* eW3_img;
+  const float* eb2; const float* eb3;
   float* partial;              // MSG modes without the fused tail: [G][TPN][128]
   NodeTail tail;               // MSG modes with the fused tail (TAIL = true)
   int G;                       // residues processed by this launch (decoder: B_dec*N)
@@ -502,8 +508,9 @@ struct EdgeArgs {
 // 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
 // BF16: message / edge GEMMs on v_mfma_f32_16x16x32_bf16 with all three 32 KiB images resident in LDS
 // (throughput mode, namp_device.h); everything else — tables, K-sum, LayerNorms, residue tail — stays fp32.
-template <int MODE, int TAIL, bool BF16 = false>
+template <int MODE, int TAIL, bool BF16 = false, bool FUSE = false>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
+  static_assert(!FUSE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "FUSE: fp32 message + tail only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
@@ -547,6 +554,14 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g); pjv[t] = (f4){0.f, 0.f, 0.f, 0.f}; }
+  } else if (FUSE) {
+    // edge-update tables first (EncLayer addressing: j in the same complex); the message tables follow after LayerNorm3
+    const int j_loc = a.E_idx[erow];
+    const int j = node_enc - i_loc + j_loc;
+    const float* pa = a.ePa + (long)node_enc * NAMP_H + 4 * g;
+    const float* pj = a.ePj + (long)j * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
   } else {
     const int j_loc = a.E_idx[erow];
     const float* pj;
@@ -591,18 +606,72 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       chain_gemm_bf16<false, true>(x, acc, bw + (NAMP_BIMG_BYTES / 16));
     }
   } else {
+  if (FUSE) {
+    // ---- fused edge update of the previous layer: images eW1 -> buf1, eW2 -> buf0, eW3 -> buf1, so that the
+    // message images land in their usual slots (W1 buf0, W2 buf1, W3 buf0) one GEMM ahead of their use
+    dma_to_lds(buf1, a.eW1_img, 64, wave, nwaves, lane);
+    dma_to_lds(buf0, a.eW2_img, 64, wave, nwaves, lane);
+    wait_dma_and_sync();
+    chain_gemm<8, 8, false>(acc, x, w1, 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
+    __syncthreads();                                      // every wave is done with buf1 (eW1)
+    dma_to_lds(buf1, a.eW3_img, 64, wave, nwaves, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pjv[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
+    chain_gemm<8, 8, false, true>(pjv, acc, w0, 8);       // pjv = edge-MLP layer-2 pre-activations
+    wait_dma_and_sync();                                  // eW3 landed; buf0 (eW2) is free
+    dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.eb3 + 16 * t + 4 * g);
+    chain_gemm<8, 8, false, true>(acc, pjv, w1, 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] += acc[t];           // residual
+    layernorm_row_T(x, a.ln_g, a.ln_b, g);                // x = updated h_E row: stored, and the message input
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
+    }
+    // message tables of this layer
+    {
+      const int j_loc = a.E_idx[erow];
+      const float* pj;
+      if (MODE == MODE_DEC_MSG) {
+        const int j_dec = b_dec * a.N + j_loc;
+        const bool bw = a.rank[j_dec] < a.rank[node];
+        pj = bw ? (a.Pj0 + (long)j_dec * NAMP_H) : (a.Pj1 + (long)(node_enc - i_loc + j_loc) * NAMP_H);
+        w_row = valid ? (1.0f / 30.0f) : 0.f;
+      } else {
+        const int j = node - i_loc + j_loc;
+        pj = a.Pj0 + (long)j * NAMP_H;
+        int ma;
+        if (a.mask_attend) ma = a.mask_attend[erow];
+        else ma = a.mask ? (a.mask[node] * a.mask[j]) : 1;
+        w_row = valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
+      }
+      const float* pa = a.Pa + (long)node * NAMP_H + 4 * g;
+      pj += 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+    }
+    wait_dma_and_sync();                                  // W1 landed in buf0; buf1 (eW3) is free
+    dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
+  } else {
   // ---- weight staging: W1 -> buf0 and W2 -> buf1 by LDS-DMA.  Issued AFTER the per-row operand loads
   // above (the VM counter retires in order: loads queued behind a bulk DMA could not be consumed before it).
   dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
   if (MODE != MODE_EMBED) dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
   wait_dma_and_sync();
+  }
   // ---- layer 1 (T): acc = Pa + W1b . h_E (+ Pj afterwards)
   chain_gemm<8, 8, false>(acc, x, w0, 8);
 
   if (MODE != MODE_EMBED) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
-  __syncthreads();                                        // every wave is done with buf0 (W1)
+  if (FUSE) wait_dma_and_sync();                          // W2 (issued one GEMM ago) landed; buf0 (W1) is free
+  else __syncthreads();                                   // every wave is done with buf0 (W1)
   dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);     // lands while layer 2 runs out of buf1
 
   // ---- layer 2 (T); GELU of layer 1 is applied k-tile by k-tile inside the MFMA loop

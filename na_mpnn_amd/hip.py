@@ -74,6 +74,8 @@ _PROTOTYPES = {
                                i32, i32, i32, i32, vp]),
     "namp_enc_message_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
                                       C.POINTER(NampProj), i32, i32, i32, i32, vp]),
+    "namp_enc_edge_message_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_fp, C.POINTER(NampEncLayerW), c_ip, c_ip, c_ip,
+                                           c_fp, c_fp, c_fp, c_fp, C.POINTER(NampProj), i32, i32, i32, i32, vp]),
     "namp_dec_message_update": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp,
                                       C.POINTER(NampProj), i32, c_ip, c_fp, c_fp, c_fp, c_fp, i32,
                                       i32, i32, i32, i32, vp]),
@@ -99,12 +101,14 @@ _PROTOTYPES = {
                                  vp, sz, i32, i32, i32, vp]),
     "namp_encoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_fp, c_fp,
                                vp, sz, i32, i32, i32, vp]),
+    "namp_encdec_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
+                              vp, sz, i32, i32, i32, vp]),
     "namp_decoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp,
                                vp, sz, i32, i32, i32, i32, vp]),
 }
 
 KERNEL_KINDS = ["gather", "node_linear", "edge_embed", "enc_message", "enc_edge_update", "node_update",
-                "dec_message", "logits", "features"]
+                "dec_message", "logits", "features", "enc_edge_message", "enc_edge_dec_message"]
 
 _lib = None
 

@@ -327,15 +327,44 @@ class ProteinMPNN(nn.Module):
         return (log_probs, logits) if want_logits else log_probs
 
     @torch.no_grad()
+    def encode_decode(self, feature_dict, S, rank, want_logits=False):
+        """encode() + decode_graph() for one decoder batch per complex, as ONE library call (namp_encdec_fwd): lets the
+        kernels fuse across the encoder/decoder boundary.  Returns h_V, h_E, E_idx, log_probs(, logits)."""
+        mask = feature_dict["mask"]
+        if self._hip_featuriser_ok():
+            V, E, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
+        else:
+            V, E, E_idx = self.featurize_torch(feature_dict)
+            h_E = torch.empty(*E_idx.shape, H, device=V.device)
+        W = self._weights()
+        B, N, K = E_idx.shape
+        V = V.float().contiguous()
+        E32, S32, m32, r32 = _i32(E_idx), _i32(S), _i32(mask), _i32(rank)
+        h_V = torch.empty(B, N, H, device=V.device)
+        log_probs = torch.empty(B, N, self.num_letters, device=V.device)
+        logits = torch.empty_like(log_probs) if want_logits else None
+        need = 2 * hip.lib().namp_workspace_bytes(B, B, N, K)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != V.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=V.device)
+        hip.check(hip.lib().namp_encdec_fwd(W.model(), V.data_ptr(), hip.ptr(E.float().contiguous() if E is not None else None),
+                                            E32.data_ptr(), m32.data_ptr(), S32.data_ptr(), r32.data_ptr(), h_V.data_ptr(),
+                                            h_E.data_ptr(), log_probs.data_ptr(), hip.ptr(logits), self._ws.data_ptr(),
+                                            self._ws.numel(), B, N, K, hip.current_stream()), "encdec_fwd")
+        return h_V, h_E, E_idx.long(), log_probs, logits
+
+    @torch.no_grad()
     def score(self, feature_dict):
         """ProteinMPNN.score (model_utils.py:366-424)."""
         bs = feature_dict["batch_size"]
         S_true, mask = feature_dict["S"], feature_dict["mask"]
         B, L = S_true.shape
-        h_V, h_E, E_idx = self.encode(feature_dict)
         chain_mask = mask * feature_dict["chain_mask"]
         order = self.decoding_order(chain_mask, feature_dict["randn"])
         rank = self.ranks_of(order)[:B]          # the reference's gather keeps only E_idx's batch rows (:393)
+        if bs == 1:
+            log_probs = self.encode_decode(feature_dict, S_true, rank)[3]
+            return {"S": S_true, "log_probs": log_probs, "decoding_order": order[0]}
+        h_V, h_E, E_idx = self.encode(feature_dict)
         rep = lambda t: t.repeat(bs, *([1] * (t.dim() - 1)))
         log_probs = self.decode_graph(h_V, h_E, E_idx, rep(S_true), rep(mask), rep(rank))
         return {"S": rep(S_true), "log_probs": log_probs, "decoding_order": order[0]}
@@ -361,14 +390,13 @@ class ProteinMPNN(nn.Module):
             return train.forward_train(self, feature_dict, decoding_randn)
         with torch.no_grad():
             mask = feature_dict["mask"]
-            h_V, h_E, E_idx = self.encode(feature_dict)
             chain_M = mask
             if self.decode_protein_first:
                 chain_M = chain_M.masked_fill(feature_dict["protein_mask"].to(torch.bool), 0.0)
             if decoding_randn is None:
                 decoding_randn = torch.randn(chain_M.shape, device=mask.device)
             rank = self.ranks_of(self.decoding_order(chain_M, decoding_randn))
-            log_probs, logits = self.decode_graph(h_V, h_E, E_idx, feature_dict["S"], mask, rank, want_logits=True)
+            _, _, _, log_probs, logits = self.encode_decode(feature_dict, feature_dict["S"], rank, want_logits=True)
             return log_probs, torch.softmax(logits, dim=-1)
 
     # reference quirk (model_utils.py:186): DecLayer receives mask_t of shape [B], which broadcasts so that

@@ -158,10 +158,21 @@ def test_enc_layer_golden(L, dev, wt, packed, golden_dir):
     assert maxdiff(hV, rV) < TOL_ACT and maxdiff(hE, rE) < TOL_ACT
 
 
-def run_encdec(L, dev, packed, d, B, N, K):
+def run_encdec(L, dev, packed, d, B, N, K, joint=False):
     hV = torch.empty(B, N, 128, device=dev)
     hE = torch.empty(B, N, K, 128, device=dev)
-    ws = torch.empty(L.namp_workspace_bytes(B, B, N, K), dtype=torch.uint8, device=dev)
+    ws = torch.empty(2 * L.namp_workspace_bytes(B, B, N, K), dtype=torch.uint8, device=dev)
+    if joint:        # the same path as ONE call, fused across the encoder/decoder boundary (namp_encdec_fwd)
+        order = torch.argsort((d["mask"] * d["chain_mask"] + 0.0001) * torch.abs(d["randn"]))
+        rank = torch.empty_like(order)
+        rank.scatter_(1, order, torch.arange(N, device=dev).expand(B, -1))
+        rank = rank.to(torch.int32)
+        logp = torch.empty(B, N, 33, device=dev)
+        hip.check(L.namp_encdec_fwd(packed.model(), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
+                                    d["mask"].data_ptr(), d["S"].data_ptr(), rank.data_ptr(), hV.data_ptr(), hE.data_ptr(),
+                                    logp.data_ptr(), None, ws.data_ptr(), ws.numel(), B, N, K, stream()))
+        torch.cuda.synchronize()
+        return hV, hE, logp, order
     hip.check(L.namp_encoder_fwd(packed.model(), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(),
                                  d["mask"].data_ptr(), hV.data_ptr(), hE.data_ptr(), ws.data_ptr(), ws.numel(),
                                  B, N, K, stream()))
@@ -177,14 +188,16 @@ def run_encdec(L, dev, packed, d, B, N, K):
     return hV, hE, logp, order
 
 
+@pytest.mark.parametrize("joint", [False, True])
 @pytest.mark.parametrize("n,tag,mf,batch", [(256, "n256", 0.05, 1), (40, "n40_LltK", 0.0, 1),
                                              (200, "b3_n200", 0.1, 3), (1000, "n1000", 0.0, 1)])
-def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch):
-    """a7+a8, the BASELINE metric scope: (V,E,E_idx) -> log_probs vs reference goldens (G3)."""
+def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch, joint):
+    """a7+a8, the BASELINE metric scope: (V,E,E_idx) -> log_probs vs reference goldens (G3); as namp_encoder_fwd +
+    namp_decoder_fwd and as the single fused call namp_encdec_fwd (what bench.py times)."""
     g = np.load(os.path.join(golden_dir, f"g3_encdec_{tag}.npz"))
     t, d = graph(dev, seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=mf)
     K = t["E_idx"].shape[-1]
-    hV, hE, logp, order = run_encdec(L, dev, packed, d, batch, n, K)
+    hV, hE, logp, order = run_encdec(L, dev, packed, d, batch, n, K, joint)
     stride = int(g["row_stride"])
     d_hv = maxdiff(hV[:, ::stride], torch.from_numpy(g["enc_hV_layers"][-1]))
     d_he = maxdiff(hE[:, ::max(1, n // 16)][:, :16], torch.from_numpy(g["enc_hE_rows"]))
@@ -312,6 +325,43 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_logits_log_softmax(packed.addr("Wout_w"), packed.addr("Wout_b"), hv[0].data_ptr(), lp[1].data_ptr(),
                                         None, Gd, 33, s))
     assert maxdiff(lp[0], lp[1]) <= 2e-6
+
+
+@pytest.mark.parametrize("n,k,b", [(300, 48, 1), (130, 30, 2), (75, 16, 1), (23, 48, 1)])
+def test_fused_edge_message_matches_separate_launches(L, dev, packed, n, k, b):
+    """namp_enc_edge_message_update (layer l-1's edge update + layer l's message + tail, one launch) ==
+    namp_enc_edge_update followed by namp_enc_message_update: the same GEMMs on the same rows in the same order."""
+    t, d = graph(dev, seed=77 + n, batch=b, n=n, k=k, masked_frac=0.1)
+    K = t["E_idx"].shape[-1]
+    G = b * n
+    a = lambda nm: packed.addr("enc2." + nm)
+    ePa, ePc, Pa, Pc = (torch.randn(G, 128, device=dev) for _ in range(4))
+    hE = [d["E"].clone(), d["E"].clone()]
+    outs = [[torch.empty(G, 128, device=dev) for _ in range(2)] for _ in range(2)]
+    hv = [torch.empty(G, 128, device=dev) for _ in range(2)]
+    def projs(o):
+        return (hip.NampProj * 2)(hip.NampProj(a("W11a_img"), a("b11"), None, o[0].data_ptr()),
+                                  hip.NampProj(a("W11c_img"), None, None, o[1].data_ptr()))
+    s = stream()
+    hip.check(L.namp_enc_edge_message_update(packed.enc_layer(1), ePa.data_ptr(), ePc.data_ptr(), hE[0].data_ptr(),
+                                             packed.enc_layer(2), d["E_idx"].data_ptr(), d["mask"].data_ptr(), None,
+                                             Pa.data_ptr(), Pc.data_ptr(), d["V"].data_ptr(), hv[0].data_ptr(),
+                                             projs(outs[0]), 2, b, n, K, s))
+    hip.check(L.namp_enc_edge_update(packed.enc_layer(1), hE[1].data_ptr(), d["E_idx"].data_ptr(), ePa.data_ptr(), ePc.data_ptr(),
+                                     hE[1].data_ptr(), b, n, K, s))
+    hip.check(L.namp_enc_message_update(packed.enc_layer(2), hE[1].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(),
+                                        None, Pa.data_ptr(), Pc.data_ptr(), d["V"].data_ptr(), hv[1].data_ptr(),
+                                        projs(outs[1]), 2, b, n, K, s))
+    assert torch.equal(hE[0], hE[1])
+    assert torch.equal(hv[0], hv[1])
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    # a projection must not overwrite a table the launch is still gathering
+    bad = (hip.NampProj * 1)(hip.NampProj(a("W11a_img"), a("b11"), None, ePa.data_ptr()))
+    rc = L.namp_enc_edge_message_update(packed.enc_layer(1), ePa.data_ptr(), ePc.data_ptr(), hE[0].data_ptr(),
+                                        packed.enc_layer(2), d["E_idx"].data_ptr(), d["mask"].data_ptr(), None,
+                                        Pa.data_ptr(), Pc.data_ptr(), d["V"].data_ptr(), hv[0].data_ptr(), bad, 1, b, n, K, s)
+    assert rc == -1 and b"still gathers" in L.namp_last_error()
 
 
 def test_unfused_path_large_batch(L, dev, wt, packed):
