@@ -103,12 +103,15 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, true>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, true>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_EDGE, 0, true>), 2 * NAMP_IMG_BYTES);
-  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, true>), EDGE_TAIL_LDS);
-  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, true>), EDGE_TAIL_LDS);
-  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, true>), EDGE_TAIL_LDS);
-  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, false, true>), EDGE_TAIL_LDS);
-  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, false, true>), EDGE_TAIL_LDS);
-  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, false, true>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, false, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel, SAMPLE_LDS);
@@ -138,14 +141,14 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE, int TAIL = 0, bool BF16 = false, bool FUSE = false>
+template <int MODE, int TAIL = 0, bool BF16 = false, int PRE = PRE_NONE>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
-  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16, FUSE>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16, PRE>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
 }
 
@@ -166,12 +169,12 @@ int launch_edge_tail(const EdgeArgs& a, bool bf16, hipStream_t s) {
 }
 
 // edge update of the previous layer fused in front of the message phase (fp32 only)
-template <int MODE>
+template <int MODE, int PRE = PRE_EDGE>
 int launch_edge_tail_fused(const EdgeArgs& a, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
-  if (e.npw <= 4) return launch_edge<MODE, 4, false, true>(a, s);
-  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, false, true>(a, s);
-  return launch_edge<MODE, 16, false, true>(a, s);
+  if (e.npw <= 4) return launch_edge<MODE, 4, false, PRE>(a, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, false, PRE>(a, s);
+  return launch_edge<MODE, 16, false, PRE>(a, s);
 }
 
 #define NAMP_FLAG_BF16 1
@@ -863,7 +866,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
   if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
-  if (E && (rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;
+  if (E) { REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }    // embedded inside the first message launch
   int cur = 0;
   for (int l = 0; l < w->n_enc; ++l) {
     const NampEncLayerW* L = &w->enc[l];
@@ -891,7 +894,11 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
     a.G = a.G_enc = G; a.N = N; a.K = K;
     fill_tail(a.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur], mask, out,
               pe, np, S);
-    if (l == 0) {
+    if (l == 0 && E) {      // h_E = W_e.E + b_e (model_utils.py:89) in front of the first message phase
+      a.hE = E; a.hE_out = h_E; a.eW1_img = w->We_img; a.eb2 = w->We_b;
+      ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
+      rc = launch_edge_tail_fused<MODE_ENC_MSG, PRE_EMBED>(a, s);
+    } else if (l == 0) {
       ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
       rc = launch_edge_tail<MODE_ENC_MSG>(a, false, s);
     } else {

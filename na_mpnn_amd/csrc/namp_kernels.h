@@ -508,9 +508,14 @@ struct EdgeArgs {
 // 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
 // BF16: message / edge GEMMs on v_mfma_f32_16x16x32_bf16 with all three 32 KiB images resident in LDS
 // (throughput mode, namp_device.h); everything else — tables, K-sum, LayerNorms, residue tail — stays fp32.
-template <int MODE, int TAIL, bool BF16 = false, bool FUSE = false>
+// PRE: a stage run on the same rows in front of the message phase (fp32 message modes with the fused tail):
+//   PRE_EDGE  — the previous layer's edge update (h_E <- LN3(h_E + MLP'), see EdgeArgs);
+//   PRE_EMBED — h_E = W_e . E + b_e (eW1_img / eb2), model_utils.py:89, for the first EncLayer.
+enum { PRE_NONE = 0, PRE_EMBED = 1, PRE_EDGE = 3 };
+template <int MODE, int TAIL, bool BF16 = false, int PRE = PRE_NONE>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
-  static_assert(!FUSE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "FUSE: fp32 message + tail only");
+  static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32 message + tail only");
+  constexpr bool FUSE = (PRE == PRE_EDGE);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
@@ -554,6 +559,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g); pjv[t] = (f4){0.f, 0.f, 0.f, 0.f}; }
+  } else if (PRE == PRE_EMBED) {
+    // tables are loaded after the embedding GEMM
   } else if (FUSE) {
     // edge-update tables first (EncLayer addressing: j in the same complex); the message tables follow after LayerNorm3
     const int j_loc = a.E_idx[erow];
@@ -633,6 +640,24 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
     }
+  }
+  if (PRE != PRE_NONE) {
+    if (PRE == PRE_EMBED) {
+      // ---- fused edge embedding: W_e -> buf1 and W1 -> buf0 up front; x <- W_e . x + b_e, stored as h_E
+      dma_to_lds(buf1, a.eW1_img, 64, wave, nwaves, lane);
+      dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
+      wait_dma_and_sync();
+      chain_gemm<8, 8, false>(acc, x, w1, 8);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[t] = acc[t];
+      if (valid) {
+        float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
+      }
+    }
     // message tables of this layer
     {
       const int j_loc = a.E_idx[erow];
@@ -655,7 +680,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
     }
-    wait_dma_and_sync();                                  // W1 landed in buf0; buf1 (eW3) is free
+    if (PRE == PRE_EMBED) __syncthreads();                // W1 landed with W_e; every wave is done with buf1 (W_e)
+    else wait_dma_and_sync();                             // W1 landed in buf0; buf1 (eW3) is free
     dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
   } else {
   // ---- weight staging: W1 -> buf0 and W2 -> buf1 by LDS-DMA.  Issued AFTER the per-row operand loads
@@ -670,7 +696,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   if (MODE != MODE_EMBED) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
-  if (FUSE) wait_dma_and_sync();                          // W2 (issued one GEMM ago) landed; buf0 (W1) is free
+  if (PRE != PRE_NONE) wait_dma_and_sync();               // W2 (issued one GEMM ago) landed; buf0 (W1) is free
   else __syncthreads();                                   // every wave is done with buf0 (W1)
   dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);     // lands while layer 2 runs out of buf1
 
