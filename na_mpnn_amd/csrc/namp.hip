@@ -112,6 +112,9 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel, SAMPLE_LDS);
@@ -153,8 +156,32 @@ int launch_edge(EdgeArgs a, hipStream_t s) {
 }
 
 // precision dispatch: flags bit 0 of the layer struct selects the bf16 message GEMMs (throughput mode)
+int device_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// bf16 throughput mode on a grid larger than two waves of workgroups: persistent workgroups (weights resident in LDS,
+// no barriers in the tile loop) instead of one workgroup per <= 12 tiles
+template <int MODE>
+int launch_edge_bf16_persistent(EdgeArgs a, hipStream_t s) {
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  a.TPN = e.tpn;
+  hipLaunchKernelGGL((edge_mlp_bf16_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
+  return NAMP_OK;
+}
+
 template <int MODE, int TAIL>
 int launch_edge_prec(const EdgeArgs& a, bool bf16, hipStream_t s) {
+  if (bf16 && TAIL == 0 && MODE != MODE_EMBED && edge_geom(a.G, a.K).grid > 2 * device_cus())
+    return launch_edge_bf16_persistent<MODE == MODE_EMBED ? MODE_ENC_MSG : MODE>(a, s);
   return bf16 ? launch_edge<MODE, TAIL, true>(a, s) : launch_edge<MODE, TAIL, false>(a, s);
 }
 
