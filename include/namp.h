@@ -99,6 +99,11 @@ typedef struct NampModelW {
 /* gather_nodes (model_utils.py:713-721): out[b,i,k,:] = nodes[b, idx[b,i,k], :]   (C floats) */
 int namp_gather_nodes_f32(const float* nodes, const int32_t* idx, float* out,
                           int B, int N, int K, int C, void* stream);
+/* The general form: T tables of R rows, M lookups per table: out[t,m,:] = tables[t, idx[t,m], :].  gather_nodes is
+ * (T=B, R=N, M=N*K), gather_edges (T=B*N, R=N, M=K), gather_nodes_t (model_utils.py:723-727) (T=B, R=N, M=K). */
+int namp_gather_rows_f32(const float* tables, const int32_t* idx, float* out, long T, int R, int M, int C, void* stream);
+/* gather_edges (model_utils.py:707-711): out[b,i,k,:] = edges[b,i,idx[b,i,k],:]   (edges [B,N,N,C]) */
+int namp_gather_edges_f32(const float* edges, const int32_t* idx, float* out, int B, int N, int K, int C, void* stream);
 /* cat_neighbors_nodes (model_utils.py:729-732): out = [h_neighbors (C1) | h_nodes[idx] (C2)] */
 int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors, const int32_t* idx,
                                  float* out, int B, int N, int K, int C1, int C2, void* stream);

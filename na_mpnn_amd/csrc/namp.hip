@@ -258,22 +258,24 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   return NAMP_OK;
 }
 
+// rows_per_table = output rows that share one lookup table of N rows (gather_nodes: N*K; gather_edges: K)
 int launch_gather(const float* nodes, const float* nbrs, const int32_t* idx, float* out,
-                  long B, int N, int K, int C1, int C2, hipStream_t s) {
-  const long rows = B * N * K;
+                  long B, int N, int K, int C1, int C2, hipStream_t s, int rows_per_table = 0) {
+  const long rows = rows_per_table ? B * rows_per_table : B * N * K;      // rows_per_table: B tables of N rows, that many lookups each
+  const int NK = rows_per_table ? rows_per_table : N * K;
   if (((C1 | C2) & 3) == 0) {
     const long total = rows * ((C1 + C2) >> 2);
     long blocks = (total + 256L * 4 - 1) / (256L * 4);
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gather_cat_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
-                       N * K, N, C1, C2);
+                       NK, N, C1, C2);
   } else {
     const long total = rows * (C1 + C2);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(gather_cat_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
-                       N * K, N, C1, C2);
+                       NK, N, C1, C2);
   }
   return NAMP_OK;
 }
@@ -329,6 +331,23 @@ int namp_gather_nodes_f32(const float* nodes, const int32_t* idx, float* out, in
   launch_gather(nodes, nullptr, idx, out, B, N, K, 0, C, (hipStream_t)stream);
   CHECK_LAUNCH();
   return NAMP_OK;
+}
+
+int namp_gather_rows_f32(const float* tables, const int32_t* idx, float* out, long T, int R, int M, int C, void* stream) {
+  if (!tables || !idx || !out) return fail(NAMP_EINVAL, "namp_gather_rows_f32: null pointer");
+  REQUIRE(T >= 0 && R >= 0 && M >= 0 && C >= 1, "namp_gather_rows_f32: bad dims T=%ld R=%d M=%d C=%d", T, R, M, C);
+  if (T * M == 0) return NAMP_OK;
+  if ((C & 3) == 0) { REQUIRE_PTR(tables); REQUIRE_PTR(out); }
+  ProfScope prof_(NAMP_KIND_GATHER, (hipStream_t)stream);
+  // launch_gather(B, N, K, ..., rows_per_table): rows = B*N*K output rows, tables of N rows, one table per rows_per_table rows
+  launch_gather(tables, nullptr, idx, out, T, R, 1, 0, C, (hipStream_t)stream, M);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_gather_edges_f32(const float* edges, const int32_t* idx, float* out, int B, int N, int K, int C, void* stream) {
+  REQUIRE(B >= 0 && N >= 0 && K >= 0, "namp_gather_edges_f32: bad dims B=%d N=%d K=%d", B, N, K);
+  return namp_gather_rows_f32(edges, idx, out, (long)B * N, N, K, C, stream);      // every (b, i) owns the table edges[b, i]
 }
 
 int namp_cat_neighbors_nodes_f32(const float* h_nodes, const float* h_neighbors, const int32_t* idx, float* out,

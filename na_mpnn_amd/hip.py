@@ -64,6 +64,8 @@ _PROTOTYPES = {
     "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
     "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
+    "namp_gather_rows_f32": (i32, [c_fp, c_ip, c_fp, C.c_long, i32, i32, i32, vp]),
+    "namp_gather_edges_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
     "namp_cat_neighbors_nodes_f32": (i32, [c_fp, c_fp, c_ip, c_fp, i32, i32, i32, i32, i32, vp]),
     "namp_node_linear": (i32, [c_fp, c_ip, i32, i32, i32, C.POINTER(NampProj), i32, C.POINTER(NampProj), vp]),
     "namp_edge_embed": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, vp]),

@@ -94,6 +94,32 @@ def test_gather_and_cat_bit_exact(L, dev, golden_dir):
     hip.check(L.namp_gather_nodes_f32(nodes.data_ptr(), idx.data_ptr(), out.data_ptr(), 0, N, K, 16, stream()))
 
 
+def test_reference_named_gather_helpers(dev):
+    """na_mpnn_amd.ops: gather_edges / gather_nodes / gather_nodes_t / cat_neighbors_nodes with the reference's names and
+    shapes (model_utils.py:707-732), float and integer payloads, bit-exact against the oracle's torch.gather forms."""
+    from na_mpnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, N, K = 2, 37, 9
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    for C in (1, 3, 54, 128):
+        nodes = torch.randn(B, N, C, generator=g)
+        edges = torch.randn(B, N, N, C, generator=g)
+        nbrs = torch.randn(B, N, K, 5 if C % 4 else 8, generator=g)
+        assert torch.equal(ops.gather_nodes(nodes.to(dev), idx.to(dev)).cpu(), cpu_ref.gather_nodes(nodes, idx))
+        assert torch.equal(ops.gather_edges(edges.to(dev), idx.to(dev)).cpu(), cpu_ref.gather_edges(edges, idx))
+        assert torch.equal(ops.cat_neighbors_nodes(nodes.to(dev), nbrs.to(dev), idx.to(dev)).cpu(),
+                           cpu_ref.cat_neighbors_nodes(nodes, nbrs, idx))
+        it = torch.randint(0, N, (B, 11), generator=g)
+        ref_t = torch.gather(nodes, 1, it.unsqueeze(-1).expand(-1, -1, C))
+        assert torch.equal(ops.gather_nodes_t(nodes.to(dev), it.to(dev)).cpu(), ref_t)
+    # integer payloads (the reference gathers the int32 mask and int64 offset matrices this way)
+    mask = torch.randint(0, 2, (B, N, 1), generator=g, dtype=torch.int32)
+    out = ops.gather_nodes(mask.to(dev), idx.to(dev))
+    assert out.dtype == torch.int32 and torch.equal(out.cpu(), cpu_ref.gather_nodes(mask, idx))
+    off = torch.randint(-50, 50, (B, N, N, 1), generator=g, dtype=torch.int32)
+    assert torch.equal(ops.gather_edges(off.to(dev), idx.to(dev)).cpu(), cpu_ref.gather_edges(off, idx))
+
+
 def test_gather_cat_full_size(L, dev):
     """cfg2-sized [1,1000,48,128|128] concat, bit-exact vs torch on the same device data."""
     t, d = graph(dev, seed=11, batch=2, n=1000, k=48)
