@@ -1477,26 +1477,60 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
       for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(w[tn * 64][r], xk[r], acc[tn]);
   }
 
-  // ---- RBF chunks: c = 3a + bg, 6 k-tiles each, through the LDS ring
+  // ---- RBF chunks: c = 3a + bg, 6 k-tiles each, through the LDS ring.  An RBF feature is exactly zero when either atom is
+  // absent (M18), and absence is structured: a protein residue has 5 of the 18 atoms (N, CA, C, O, Cb), a nucleotide the
+  // other 13.  Zero k-tiles are skipped — for the whole workgroup (no DMA, no barrier) when no row of the workgroup needs
+  // the chunk, per wave (no distance / exp / MFMA work) when none of the wave's 16 neighbours has atom b or its own residue
+  // lacks atom a.  Adding exact zeros changes nothing, so the result is bit-identical to the dense evaluation; on
+  // protein-protein neighbourhoods 25 of the 324 atom pairs remain.
+  const uint32_t mi_s = __builtin_amdgcn_readfirstlane(wave_active ? mi : 0u);
+  uint32_t mj_w = valid ? mj : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mj_w |= __shfl_xor(mj_w, o);
+  const uint32_t mj_s = __builtin_amdgcn_readfirstlane(mj_w);
+  uint32_t* vote = (uint32_t*)(smem + FEAT_CHUNK_BYTES);            // free tail of ring slot 0: [2][nwaves]
+  if (lane == 0) { vote[wave] = mi_s; vote[16 + wave] = mj_s; }
+  __syncthreads();
+  uint32_t wg_mi = 0, wg_mj = 0;
+  for (int q = 0; q < nwaves; ++q) { wg_mi |= vote[q]; wg_mj |= vote[16 + q]; }
+  unsigned long long need = 0;
+  for (int aa = 0; aa < 18; ++aa)
+    if ((wg_mi >> aa) & 1u)
+      for (int bg = 0; bg < 3; ++bg)
+        if ((wg_mj >> (6 * bg)) & 63u) need |= 1ull << (3 * aa + bg);
+  need = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(need >> 32)) << 32) |
+         __builtin_amdgcn_readfirstlane((uint32_t)need);
   const float* img1 = a.Wedge_img + 8 * 64 * 4;                    // k-tile 1 onwards
   const int chunk_kb = FEAT_CHUNK_BYTES / 1024;
-  dma_to_lds(smem, img1, chunk_kb, wave, nwaves, lane);
+  __syncthreads();                                                  // votes consumed before the ring overwrites... (slot tail is not DMA'd, but keep order simple)
+  int slot = 0;
+  if (need) dma_to_lds(smem, img1 + (long)__builtin_ctzll(need) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
   // RBF centres of this lane: mu = 2 + (4g + r) * 20/15, sigma = 1.25  (model_utils.py:499-507)
   const float mu0 = 2.0f + (4 * g + 0) * (20.0f / 15.0f), mu1 = 2.0f + (4 * g + 1) * (20.0f / 15.0f);
   const float mu2 = 2.0f + (4 * g + 2) * (20.0f / 15.0f), mu3 = 2.0f + (4 * g + 3) * (20.0f / 15.0f);
 #pragma unroll 1
   for (int aa = 0; aa < 18; ++aa) {
+    if (!((need >> (3 * aa)) & 7ull)) continue;                      // workgroup-uniform: no chunk of atom a is needed
     const float xi0 = xi_base[3 * aa], xi1 = xi_base[3 * aa + 1], xi2 = xi_base[3 * aa + 2];
     const float mia = (float)((mi >> aa) & 1u);
+    const bool wave_a = (mi_s >> aa) & 1u;
 #pragma unroll
     for (int bg = 0; bg < 3; ++bg) {
       const int c = 3 * aa + bg;
-      wait_dma_and_sync();                                           // chunk c has landed; everyone is done with c-1
-      if (c + 1 < 54) dma_to_lds(smem + ((c + 1) & 1) * NAMP_IMG_BYTES, img1 + (long)(c + 1) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
-      const f4* w = (const f4*)(smem + (c & 1) * NAMP_IMG_BYTES) + lane;
+      if (!((need >> c) & 1ull)) continue;                           // workgroup-uniform
+      wait_dma_and_sync();                                           // chunk c has landed; everyone is done with the previous one
+      {
+        const unsigned long long rest = (c + 1 < 64) ? (need >> (c + 1)) : 0ull;
+        if (rest) dma_to_lds(smem + (slot ^ 1) * NAMP_IMG_BYTES, img1 + (long)(c + 1 + __builtin_ctzll(rest)) * (FEAT_CHUNK_BYTES / 4),
+                             chunk_kb, wave, nwaves, lane);
+      }
+      const f4* w = (const f4*)(smem + slot * NAMP_IMG_BYTES) + lane;
+      slot ^= 1;
+      if (!wave_a) continue;                                         // wave-uniform: this residue lacks atom a
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const int bb = 6 * bg + q;
+        if (!((mj_s >> bb) & 1u)) continue;                          // wave-uniform: no neighbour of this tile has atom b
         const float dx = xi0 - xj[3 * bb], dy = xi1 - xj[3 * bb + 1], dz = xi2 - xj[3 * bb + 2];
         const float D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);
         const float mk = mia * (float)((mj >> bb) & 1u);

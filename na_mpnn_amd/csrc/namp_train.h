@@ -310,16 +310,11 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE) {
-    __syncthreads();                                           // previous tile fully consumed
-    // stage g_pre rows e0 .. e0+63 (zeros past the end)
-    for (int idx = tid; idx < FEATW_TILE * 32; idx += 256) {
-      const int row = idx >> 5, c4 = idx & 31;
-      const long er = e0 + row;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (er < e_end) v = *(const f4*)(g_pre + er * NAMP_H + 4 * c4);
-      *(f4*)(gt + row * FEATW_LD + 4 * c4) = v;
-    }
+  __shared__ int wg_live[2];
+  if (tid < 2) wg_live[tid] = 0;
+  __syncthreads();
+  int par = 0;
+  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE, par ^= 1) {
     // per-lane edge of this tile: distance of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
     const long el = e0 + lane;
     const bool eok = el < e_end;
@@ -335,30 +330,53 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
       const float mk = M18[(long)node * 18 + pa[q]] * M18[(long)j * 18 + pb[q]];
       dist[q] = (eok && mk != 0.f) ? sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
     }
+    // Absent atoms make whole (a, b) blocks exactly zero for runs of edges (a protein residue has 5 of the 18 atoms): a
+    // block none of whose 64 edges has both atoms contributes nothing.  Its MFMAs are skipped (per wave), and the g_pre
+    // staging + step loop altogether when no wave of the workgroup has a live block for this tile (exact: only zeros
+    // are left out).
+    bool live[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) live[q] = (blk0 + q < FEATW_BLOCKS) && ((blk0 + q == 0) || (__ballot(dist[q] < 1e29f) != 0ull));
+    if ((live[0] || live[1]) && lane == 0) wg_live[par] = 1;
+    __syncthreads();                                           // votes are in; the previous tile is fully consumed
+    const bool any_live = wg_live[par] != 0;
+    if (tid == 0) wg_live[par ^ 1] = 0;                        // (read again only after the next tile's barrier)
+    if (!any_live) continue;
+    // stage g_pre rows e0 .. e0+63 (zeros past the end)
+    for (int idx = tid; idx < FEATW_TILE * 32; idx += 256) {
+      const int row = idx >> 5, c4 = idx & 31;
+      const long er = e0 + row;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (er < e_end) v = *(const f4*)(g_pre + er * NAMP_H + 4 * c4);
+      *(f4*)(gt + row * FEATW_LD + 4 * c4) = v;
+    }
     __syncthreads();
+    if (live[0] || live[1]) {
 #pragma unroll 4
-    for (int s = 0; s < FEATW_TILE / 4; ++s) {
-      const int row = 4 * s + g;                               // k-slot g of this MFMA group <-> edge e0 + 4s + g
-      float av[8];
+      for (int s = 0; s < FEATW_TILE / 4; ++s) {
+        const int row = 4 * s + g;                             // k-slot g of this MFMA group <-> edge e0 + 4s + g
+        float av[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) av[t] = gt[row * FEATW_LD + 16 * t + n];
+        for (int t = 0; t < 8; ++t) av[t] = gt[row * FEATW_LD + 16 * t + n];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float b;
-        if (blk0 + q == 0) {
-          const long er = e0 + row;
-          b = (er < e_end) ? E_pos[er * 16 + n] : 0.f;
-        } else {
-          const float d = __shfl(dist[q], row);
-          const float u = (d - mu) * 0.8f;
-          b = __expf(-(u * u));
-        }
-        if (blk0 + q < FEATW_BLOCKS) {
+        for (int q = 0; q < 2; ++q) {
+          float b;
+          if (blk0 + q == 0) {
+            const long er = e0 + row;
+            b = (er < e_end) ? E_pos[er * 16 + n] : 0.f;
+          } else {
+            const float d = __shfl(dist[q], row);
+            const float u = (d - mu) * 0.8f;
+            b = __expf(-(u * u));
+          }
+          if (live[q]) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(av[t], b, acc[q][t]);
+            for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(av[t], b, acc[q][t]);
+          }
         }
       }
     }
+    __syncthreads();                                           // tile consumed: the next staging may overwrite it
   }
   // D[i = 4g + r][j = n] -> dW[16t + 4g + r][16 blk + n]
   float* out = dW_part + (long)blockIdx.y * NAMP_H * FEATW_COLS;

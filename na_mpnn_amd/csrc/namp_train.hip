@@ -110,8 +110,8 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, floa
 
 int namp_train_feat_wgrad_chunks(long edges) {
   if (edges <= 0) return 0;
-  long n = (edges + 4095) / 4096;
-  if (n > 48) n = 48;
+  long n = (edges + 4095) / 4096;          // finer chunks than the dense cost needs: the block sparsity makes workgroups uneven
+  if (n > 128) n = 128;
   return (int)n;
 }
 
