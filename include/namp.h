@@ -261,8 +261,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   W13.gelu(W12.gelu(W11.[..])) + b13 per edge [B*N*K][128] (residual, dropout and LayerNorm3 are the caller's).
  * namp_train_edge_bwd: given g_out = dL/d(sum_k message) [B*N][128] (modes 0/1; the 1/30 scale and mask_attend are
  *   applied inside) or dL/d(message) per edge [B*N*K][128] (mode 2), recompute the chain and write per edge row
- *   the pre-activations Z1, Z2, the gradients G1 = dL/dz1, G2 = dL/dz2, G3 = dL/dz3 (modes 0/1 only; mode 2: G3 == g_out)
- *   and g_hE = dL/dh_E.  Then dW3 = G3^T gelu(Z2), dW2 = G2^T gelu(Z1), dW1b = G1^T h_E (namp_train_wgrad),
+ *   the activations A1 = gelu(z1), A2 = gelu(z2), the gradients G1 = dL/dz1, G2 = dL/dz2, G3 = dL/dz3 (modes 0/1 only;
+ *   mode 2: G3 == g_out) and g_hE = dL/dh_E.  Then dW3 = G3^T A2, dW2 = G2^T A1, dW1b = G1^T h_E (namp_train_wgrad),
  *   db3 = sum G3, db2 = sum G2, dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k].
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
@@ -277,7 +277,7 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
 int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
-                        const float* b2, const float* g_out, float* Z1, float* Z2, float* G1, float* G2, float* G3,
+                        const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                         float* g_hE, int B, int N, int K, void* stream);
 int namp_train_wgrad_chunks(long rows);
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream);

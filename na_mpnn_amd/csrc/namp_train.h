@@ -11,8 +11,8 @@
 //       z3 = W3 . a2 + b3
 //   backward, given g3 = dL/dz3 per row:
 //       g2 = (W3^T g3) * gelu'(z2)     g1 = (W2^T g2) * gelu'(z1)     dL/dh_E[e] = W1b^T g1
-//   and the row tensors Z1, Z2, G1, G2, G3 go to HBM, from which
-//       dW3 = G3^T gelu(Z2), dW2 = G2^T gelu(Z1), dW1b = G1^T h_E     (wgrad_kernel: contraction over edges)
+//   and the row tensors A1 = a1, A2 = a2, G1, G2, G3 go to HBM, from which
+//       dW3 = G3^T A2, dW2 = G2^T A1, dW1b = G1^T h_E                 (wgrad_kernel: contraction over edges)
 //       dL/dPa[i] = sum_k G1[i,k],  dL/dPj[j] += G1[e]               (residue-level, done by the caller)
 // The transposed products reuse the register chain of namp_device.h: "W^T . g" is the T-orientation
 // GEMM with the fragment image of W^T, so gradients flow lane-locally exactly like activations do.
@@ -34,10 +34,12 @@ __device__ __forceinline__ void gelu_val_grad(float x, float& val, float& grad) 
   grad = fmaf(x * e, 0.3989422804014327f, phi_big);
 }
 
-__device__ __forceinline__ f4 gelu_grad4(f4 z) {
-  float v, d0, d1, d2, d3;
-  gelu_val_grad(z.x, v, d0); gelu_val_grad(z.y, v, d1); gelu_val_grad(z.z, v, d2); gelu_val_grad(z.w, v, d3);
-  return (f4){d0, d1, d2, d3};
+// in: pre-activations z; out: z <- gelu'(z), returns gelu(z) — one exp / rcp pair serves both
+__device__ __forceinline__ f4 gelu_split4(f4& z) {
+  float v0, v1, v2, v3, d0, d1, d2, d3;
+  gelu_val_grad(z.x, v0, d0); gelu_val_grad(z.y, v1, d1); gelu_val_grad(z.z, v2, d2); gelu_val_grad(z.w, v3, d3);
+  z = (f4){d0, d1, d2, d3};
+  return (f4){v0, v1, v2, v3};
 }
 
 enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2 };
@@ -59,7 +61,7 @@ struct EdgeBwdArgs {
   const float* b2;
   const float* g_rows;         // BWD_ROWS: dL/dz3 per edge row [E][128]
   const float* g_node;         // MSG modes: dL/d(dh) per residue [G][128]; g3[e] = w_e * g_node[i]
-  float* Z1; float* Z2;        // [E][128] pre-activations (for wgrad)
+  float* A1; float* A2;        // [E][128] activations gelu(z1), gelu(z2) (for wgrad)
   float* G1; float* G2; float* G3;   // [E][128] (G3 only written in MSG modes)
   float* g_hE;                 // [E][128]
   long E;                      // G * K rows
@@ -121,14 +123,23 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
   __syncthreads();                                            // everyone is done with W1
   dma_to_lds(buf0, a.W3t_img, 64, wave, nwaves, lane);
+  // activations and their derivatives from ONE evaluation each: x <- a1 = gelu(z1), z1 <- gelu'(z1)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z1[t]);
+  if (valid) {
+    float* d1 = a.A1 + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(d1 + 16 * t) = x[t];
+  }
 #pragma unroll
   for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false, true>(z2, z1, w1, 8);
-  if (valid) {
-    float* d1 = a.Z1 + e * NAMP_H + 4 * g;
-    float* d2 = a.Z2 + e * NAMP_H + 4 * g;
+  chain_gemm<8, 8, false>(z2, x, w1, 8);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { *(f4*)(d1 + 16 * t) = z1[t]; *(f4*)(d2 + 16 * t) = z2[t]; }
+  for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z2[t]);      // x <- a2 (only stored, for dW3), z2 <- gelu'(z2)
+  if (valid) {
+    float* d2 = a.A2 + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(d2 + 16 * t) = x[t];
   }
   // ---- upstream gradient rows
   f4 gr[8];
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   chain_gemm<8, 8, false>(acc, gr, w0, 8);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * gelu_grad4(z2[t]);
+  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
   if (valid) {
     float* d = a.G2 + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   chain_gemm<8, 8, false>(acc, gr, w1, 8);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * gelu_grad4(z1[t]);
+  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
   if (valid) {
     float* d = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll

@@ -61,12 +61,12 @@ extern "C" {
 int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
-                        const float* b2, const float* g_out, float* Z1, float* Z2, float* G1, float* G2, float* G3,
+                        const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                         float* g_hE, int B, int N, int K, void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
-  REQUIRE_PTR(Z1); REQUIRE_PTR(Z2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
+  REQUIRE_PTR(A1); REQUIRE_PTR(A2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_bwd: null E_idx");
   if (mode != 2) REQUIRE_PTR(G3);
   if (mode == 1) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_bwd: decoder message needs rank"); }
@@ -77,7 +77,7 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img; a.b2 = b2;
   if (mode == 2) a.g_rows = g_out; else a.g_node = g_out;
-  a.Z1 = Z1; a.Z2 = Z2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
+  a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;

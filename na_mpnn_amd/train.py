@@ -84,18 +84,18 @@ class _EdgeMLP(torch.autograd.Function):
         g = g.contiguous()
         img1, img2 = _image(W1b.detach()), _image(W2.detach())
         img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
-        Z1, Z2, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(5))
+        A1, A2, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(5))
         G3 = torch.empty(E, H, device=dev) if mode != ENC_EDGE else None
         b2c = b2.detach().contiguous()
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
-                                        g.data_ptr(), Z1.data_ptr(), Z2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
+                                        g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
                                         g_hE.data_ptr(), B, N, K, hip.current_stream()), "train_edge_bwd")
         if mode == ENC_EDGE:
             G3 = g.view(E, H)
-        dW3, db3 = _wgrad(G3, Z2, True, True)
-        dW2, db2 = _wgrad(G2, Z1, True, True)
+        dW3, db3 = _wgrad(G3, A2, False, True)
+        dW2, db2 = _wgrad(G2, A1, False, True)
         dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
         g_Pa = G1.view(B * N, K, H).sum(1).view_as(Pa)
         jflat = (E_idx32.long() + (torch.arange(B, device=dev) * N)[:, None, None]).view(-1)
