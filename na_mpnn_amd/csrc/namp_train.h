@@ -64,6 +64,8 @@ struct EdgeBwdArgs {
   float* A1; float* A2;        // [E][128] activations gelu(z1), gelu(z2) (for wgrad)
   float* G1; float* G2; float* G3;   // [E][128] (G3 only written in MSG modes)
   float* g_hE;                 // [E][128]
+  float* g_Pa;                 // optional [G][128], ZEROED by the caller: += sum_k G1[i,k]   (fp32 atomics)
+  float* g_Pj0; float* g_Pj1;  // optional [G][128], zeroed: += G1[e] at the row's gathered table (Pj0 / Pj1 like the forward)
   long E;                      // G * K rows
   int G, N, K;
 };
@@ -89,13 +91,16 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 
   f4 x[8], z1[8], z2[8], pjv[8];
   float w_row = 0.f;
+  float* gpj = a.g_Pj0;        // table-gradient buffer this row scatters into
   {
     const float* src = a.hE + e * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
     const float* pj;
     if (MODE == BWD_DEC_MSG) {
-      pj = (a.rank[j] < a.rank[node]) ? (a.Pj0 + (long)j * NAMP_H) : (a.Pj1 + (long)j * NAMP_H);
+      const bool bwd = a.rank[j] < a.rank[node];
+      pj = bwd ? (a.Pj0 + (long)j * NAMP_H) : (a.Pj1 + (long)j * NAMP_H);
+      gpj = bwd ? a.g_Pj0 : a.g_Pj1;
       w_row = valid ? (1.0f / 30.0f) : 0.f;
     } else {
       pj = a.Pj0 + (long)j * NAMP_H;
@@ -183,6 +188,50 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     float* d = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
+  }
+  // gradients of the hoisted first-layer tables, accumulated here instead of re-reading G1 (sum over k / scatter over j)
+  if (a.g_Pj0) {
+    if (valid) {
+      float* d = gpj + (long)j * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        unsafeAtomicAdd(d + 16 * t + 0, gr[t].x); unsafeAtomicAdd(d + 16 * t + 1, gr[t].y);
+        unsafeAtomicAdd(d + 16 * t + 2, gr[t].z); unsafeAtomicAdd(d + 16 * t + 3, gr[t].w);
+      }
+    }
+  }
+  if (a.g_Pa) {
+    // rows of a tile are consecutive edges: residues are non-decreasing, usually one or two per tile -> reduce over the
+    // rows of the first / the last residue with two masked butterflies and add once per residue; other shapes (K < 8) go row by row
+    const int n_first = __shfl(node, g << 4), n_last = __shfl(node, (g << 4) | 15);
+    const bool two = (node == n_first) || (node == n_last);
+    const bool simple = __ballot(valid && !two) == 0ull;
+    if (simple) {
+      const float sel_a = (valid && node == n_first) ? 1.f : 0.f;
+      const float sel_b = (valid && node == n_last && n_last != n_first) ? 1.f : 0.f;
+      float* da = a.g_Pa + (long)n_first * NAMP_H + 4 * g;
+      float* db = a.g_Pa + (long)n_last * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sa = gr[t][r] * sel_a, sb = gr[t][r] * sel_b;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+          if (m == 0) {
+            unsafeAtomicAdd(da + 16 * t + r, sa);
+            if (n_last != n_first) unsafeAtomicAdd(db + 16 * t + r, sb);
+          }
+        }
+      }
+    } else if (valid) {
+      float* d = a.g_Pa + (long)node * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        unsafeAtomicAdd(d + 16 * t + 0, gr[t].x); unsafeAtomicAdd(d + 16 * t + 1, gr[t].y);
+        unsafeAtomicAdd(d + 16 * t + 2, gr[t].z); unsafeAtomicAdd(d + 16 * t + 3, gr[t].w);
+      }
+    }
   }
   wait_dma_and_sync();                                        // W1b^T landed in buf0
   // ---- dL/dh_E = W1b^T g1

@@ -62,7 +62,7 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, int B, int N, int K, void* stream) {
+                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int B, int N, int K, void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
@@ -77,6 +77,9 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img; a.b2 = b2;
   if (mode == 2) a.g_rows = g_out; else a.g_node = g_out;
+  REQUIRE((g_Pa == nullptr) == (g_Pj0 == nullptr), "namp_train_edge_bwd: g_Pa and g_Pj0 go together");
+  REQUIRE(mode != 1 || (g_Pj0 == nullptr) == (g_Pj1 == nullptr), "namp_train_edge_bwd: decoder message needs g_Pj1 with g_Pj0");
+  a.g_Pa = g_Pa; a.g_Pj0 = g_Pj0; a.g_Pj1 = g_Pj1;
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   const int grid = (int)((a.E + 127) / 128);

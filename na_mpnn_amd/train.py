@@ -87,26 +87,22 @@ class _EdgeMLP(torch.autograd.Function):
         A1, A2, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(5))
         G3 = torch.empty(E, H, device=dev) if mode != ENC_EDGE else None
         b2c = b2.detach().contiguous()
+        g_Pa = torch.zeros(B * N, H, device=dev)
+        g_Pj0 = torch.zeros(B * N, H, device=dev)
+        g_Pj1 = torch.zeros(B * N, H, device=dev) if mode == DEC_MSG else None
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), B, N, K, hip.current_stream()), "train_edge_bwd")
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), g_Pj0.data_ptr(), hip.ptr(g_Pj1), B, N, K,
+                                        hip.current_stream()), "train_edge_bwd")
         if mode == ENC_EDGE:
             G3 = g.view(E, H)
         dW3, db3 = _wgrad(G3, A2, False, True)
         dW2, db2 = _wgrad(G2, A1, False, True)
         dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
-        g_Pa = G1.view(B * N, K, H).sum(1).view_as(Pa)
-        jflat = (E_idx32.long() + (torch.arange(B, device=dev) * N)[:, None, None]).view(-1)
-        if mode == DEC_MSG:
-            r = rank32.view(-1)
-            bw = (r[jflat] < r.repeat_interleave(K)).unsqueeze(1)
-            g_Pj0 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1 * bw).view_as(Pj0)
-            g_Pj1 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1 * (~bw)).view_as(Pj1)
-        else:
-            g_Pj0 = torch.zeros(B * N, H, device=dev).index_add_(0, jflat, G1).view_as(Pj0)
-            g_Pj1 = None
+        g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
+        g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None)
 
 
@@ -134,6 +130,34 @@ class _TableRows(torch.autograd.Function):
             i2 = F.pad(i2, (0, S * chunk - E), value=0)          # padded rows carry zero gradient
         oh = F.one_hot(i2.view(S, chunk), ctx.nrows).to(g2.dtype)
         return torch.bmm(oh.transpose(1, 2), g2.view(S, chunk, C_)).sum(0), None
+
+
+class _EdgeLinear(torch.autograd.Function):
+    """y = x W^T + b over [B,N,K,128] edge rows (W_e, na_model_utils.py:598) on the single-GEMM mode of the edge kernel;
+    backward: dL/dx with the image of W^T, dW / db with the row-contraction kernel (the library GEMM spends 2 ms on this
+    128 x 128 x 10^6 shape)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        B, N, K, _ = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        hip.check(hip.lib().namp_edge_embed(_image(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
+                                            y.data_ptr(), B, N, K, hip.current_stream()), "edge_embed")
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        B, N, K, _ = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        zero = torch.zeros(H, device=x.device)
+        hip.check(hip.lib().namp_edge_embed(_image_t(W).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, K,
+                                            hip.current_stream()), "edge_embed (dgrad)")
+        dW, db = _wgrad(g.view(-1, H), x.view(-1, H), False, True)
+        return gx, dW, db
 
 
 def _atom_frames(model, X, fd):
@@ -237,7 +261,7 @@ def forward_train(model, fd, decoding_randn=None):
     B, N, K = E_idx.shape
     E = _ln(y, fp.norm_edges)
     V = _ln(_TableRows.apply(fp.node_embedding.weight.t(), fd["R_polymer_type"].long()), fp.norm_nodes)   # one-hot @ W^T
-    h_V, h_E = model.W_v(V), model.W_e(E)
+    h_V, h_E = model.W_v(V), _EdgeLinear.apply(E, model.W_e.weight, model.W_e.bias)
     mask32 = mask.to(torch.int32).contiguous()
     maskf = mask.float().unsqueeze(-1)
     for p in model.encoder_layers:                                                   # EncLayer, na_model_utils.py:218-241
