@@ -257,8 +257,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  * All images are fp32 fragment images (namp_pack_image); "t" images are those of the transposed blocks.
  *
  * namp_train_edge_fwd: the forward of one per-edge MLP from raw images.  mode 0/1: out = partial sums
- *   [B*N][ceil(K/16)][128] (as namp_enc_message / namp_dec_message; B_dec == B_enc); mode 2: out = the bare message
- *   W13.gelu(W12.gelu(W11.[..])) + b13 per edge [B*N*K][128] (residual, dropout and LayerNorm3 are the caller's).
+ *   [B*N][ceil(K/16)][128] (as namp_enc_message / namp_dec_message; B_dec == B_enc); mode 2: out = per edge [B*N*K][128]
+ *   either the bare message W13.gelu(W12.gelu(W11.[..])) + b13 (ln_g NULL, drop_p 0) or the finished edge update (below).
  * namp_train_edge_bwd: given g_out = dL/d(sum_k message) [B*N][128] (modes 0/1; the 1/30 scale and mask_attend are
  *   applied inside) or dL/d(message) per edge [B*N*K][128] (mode 2), recompute the chain and write per edge row
  *   the activations A1 = gelu(z1), A2 = gelu(z2), the gradients G1 = dL/dz1, G2 = dL/dz2, G3 = dL/dz3 (modes 0/1 only;
@@ -274,8 +274,22 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  * namp_featurize with w->feat.ln_g == NULL writes the pre-LayerNorm rows to E (the training forward). */
 int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
-                        const float* W2_img, const float* W3_img, const float* b2, const float* b3, float* out,
+                        const float* W2_img, const float* W3_img, const float* b2, const float* b3,
+                        const float* ln_g, const float* ln_b, float drop_p, uint32_t drop_seed, float* out,
                         int B, int N, int K, void* stream);
+/* The whole EncLayer edge update with its tail (na_model_utils.py:236-240), forward = namp_train_edge_fwd(mode 2, ln_g, ln_b,
+ * drop_p, drop_seed): out = LayerNorm3(h_E + dropout(message)); the dropout mask is a counter-based hash of (drop_seed, edge
+ * row, channel), regenerated — not stored — by the backward launch.  Backward: g_out = dL/d(out) per edge row; recomputes
+ * the message (6 GEMMs per row: 3 recompute + 3 data gradients), differentiates LayerNorm3 and the mask in registers and
+ * writes A1, A2, G1, G2, G3 (for namp_train_wgrad), g_hE (chain + residual path), the table gradients (atomics, as
+ * namp_train_edge_bwd) and per-workgroup partial sums dgb_part [namp_train_edge_update_bwd_groups][2][128] of
+ * d(ln weight) = sum g*xhat and d(ln bias) = sum g. */
+int namp_train_edge_update_bwd_groups(int B, int N, int K);
+int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
+                               const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
+                               const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
+                               uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
+                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int B, int N, int K, void* stream);
 int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,

@@ -442,8 +442,13 @@ int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t
 
 int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
-                        const float* W2_img, const float* W3_img, const float* b2, const float* b3, float* out,
+                        const float* W2_img, const float* W3_img, const float* b2, const float* b3,
+                        const float* ln_g, const float* ln_b, float drop_p, uint32_t drop_seed, float* out,
                         int B, int N, int K, void* stream) {
+  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_fwd: drop_p=%g must be in [0,1)", (double)drop_p);
+  REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "namp_train_edge_fwd: ln_g and ln_b go together");
+  REQUIRE(mode == 2 || (ln_g == nullptr && drop_p == 0.f), "namp_train_edge_fwd: LayerNorm3 / dropout belong to mode 2");
+  OPTIONAL_PTR(ln_g); OPTIONAL_PTR(ln_b);
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_fwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
   REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(out);
@@ -458,7 +463,12 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
   hipStream_t s = (hipStream_t)stream;
   if (mode == MODE_ENC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_ENC_MESSAGE, s); rc = launch_edge<MODE_ENC_MSG, 0>(a, s); }
   else if (mode == MODE_DEC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_DEC_MESSAGE, s); rc = launch_edge<MODE_DEC_MSG, 0>(a, s); }
-  else { a.hE_out = out; ProfScope p_(NAMP_KIND_ENC_EDGE, s); rc = launch_edge<MODE_ENC_EDGE, 0>(a, s); }   // ln_g null: bare message
+  else {
+    a.hE_out = out; a.ln_g = ln_g; a.ln_b = ln_b;                                 // ln_g null: bare message
+    if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
+    ProfScope p_(NAMP_KIND_ENC_EDGE, s);
+    rc = launch_edge<MODE_ENC_EDGE, 0>(a, s);
+  }
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;

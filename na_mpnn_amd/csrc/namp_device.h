@@ -179,6 +179,20 @@ __device__ __forceinline__ void wait_dma_and_sync() {
   __syncthreads();
 }
 
+// Dropout mask of the training path (EncLayer.dropout3 on the per-edge message, na_model_utils.py:239): a counter-based
+// hash of (seed, edge row, channel), so the forward and the backward launch regenerate the same mask without storing it.
+// keep iff hash >= thresh (thresh = p * 2^32); kept values are scaled by 1 / (1 - p).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_row_key(uint32_t seed, long erow) {
+  return mix32(seed ^ (uint32_t)erow ^ mix32((uint32_t)((unsigned long)erow >> 32) + 0x9E3779B9U));
+}
+__device__ __forceinline__ float drop_factor(uint32_t row_key, int channel, uint32_t thresh, float scale) {
+  return mix32(row_key + (uint32_t)channel * 0x9E3779B9U) >= thresh ? scale : 0.f;
+}
+
 // sum over the 4 lane groups g (lanes l, l^16, l^32, l^48 hold the same column)
 __device__ __forceinline__ float xg_sum(float v) {
   v += __shfl_xor(v, 16);

@@ -492,6 +492,7 @@ struct EdgeArgs {
   const float* ePa; const float* ePj;
   const float* eW1_img; const float* eW2_img; const float* eW3_img;
   const float* eb2; const float* eb3;
+  uint32_t drop_thresh, drop_seed; float drop_scale;   // ENC_EDGE, training only: dropout on the message (thresh 0 = off)
   float* partial;              // MSG modes without the fused tail: [G][TPN][128]
   NodeTail tail;               // MSG modes with the fused tail (TAIL = true)
   int G;                       // residues processed by this launch (decoder: B_dec*N)
@@ -722,7 +723,14 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
     if (BF16) chain_gemm_bf16<false, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
     else      chain_gemm<8, 8, false, true>(acc, x, w0, 8);
-    if (a.ln_g) {                                                  // null: write the bare message (training forward)
+    if (a.drop_thresh) {                                           // training forward: dropout3 on the message
+      const uint32_t key = drop_row_key(a.drop_seed, erow);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
+    }
+    if (a.ln_g) {                                                  // null: write the bare message
       const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);

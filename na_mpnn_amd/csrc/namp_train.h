@@ -42,7 +42,7 @@ __device__ __forceinline__ f4 gelu_split4(f4& z) {
   return (f4){v0, v1, v2, v3};
 }
 
-enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2 };
+enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2, BWD_EDGE_LN = 3 };
 
 struct EdgeBwdArgs {
   const float* hE;             // [E][128] edge rows the forward pass consumed
@@ -66,6 +66,11 @@ struct EdgeBwdArgs {
   float* g_hE;                 // [E][128]
   float* g_Pa;                 // optional [G][128], ZEROED by the caller: += sum_k G1[i,k]   (fp32 atomics)
   float* g_Pj0; float* g_Pj1;  // optional [G][128], zeroed: += G1[e] at the row's gathered table (Pj0 / Pj1 like the forward)
+  // BWD_EDGE_LN: the whole edge update h_E' = LN3(h_E + dropout(z3)) is differentiated here; g_rows = dL/dh_E'
+  const float* W3_img; const float* b3;      // forward image of W3 (z3 is recomputed)
+  const float* ln_g;                          // LayerNorm3 weight
+  uint32_t drop_thresh, drop_seed; float drop_scale;
+  float* dgb_part;             // [gridDim.x][2][128]: per-workgroup sums of g*xhat (-> d ln weight) and g (-> d ln bias)
   long E;                      // G * K rows
   int G, N, K;
 };
@@ -76,6 +81,8 @@ struct EdgeBwdArgs {
 template <int MODE>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
+  if (MODE == BWD_EDGE_LN) { if (threadIdx.x < 2 * NAMP_H) colsum[threadIdx.x] = 0.f; }
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
   __syncthreads();                                            // everyone is done with W1
-  dma_to_lds(buf0, a.W3t_img, 64, wave, nwaves, lane);
+  dma_to_lds(buf0, MODE == BWD_EDGE_LN ? a.W3_img : a.W3t_img, 64, wave, nwaves, lane);
   // activations and their derivatives from ONE evaluation each: x <- a1 = gelu(z1), z1 <- gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z1[t]);
@@ -148,7 +155,69 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   }
   // ---- upstream gradient rows
   f4 gr[8];
-  if (MODE == BWD_ROWS) {
+  if (MODE == BWD_EDGE_LN) {
+    // z3 = W3 a2 + b3 (a2 is still in x), then backwards through LayerNorm3 and the dropout mask
+    wait_dma_and_sync();                                      // W3 landed in buf0; W2 (buf1) is free
+    dma_to_lds(buf1, a.W3t_img, 64, wave, nwaves, lane);
+    f4 z3[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+    chain_gemm<8, 8, false>(z3, x, w0, 8);
+    asm volatile("" ::: "memory");       // the row loads below have kernel-constant addresses: do not hoist them (96 VGPRs) over the GEMMs
+    const uint32_t key = drop_row_key(a.drop_seed, e);
+    const float* hsrc = a.hE + e * NAMP_H + 4 * g;
+    const float* gsrc = a.g_rows + e * NAMP_H + 4 * g;
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (a.drop_thresh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z3[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
+      }
+      z3[t] += *(const f4*)(hsrc + 16 * t);                    // x = h_E + dropout(z3)
+      s1 += (z3[t].x + z3[t].y) + (z3[t].z + z3[t].w);
+    }
+    const float mean = xg_sum(s1) * (1.0f / 128.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { z3[t] -= mean; s2 += (z3[t].x * z3[t].x + z3[t].y * z3[t].y) + (z3[t].z * z3[t].z + z3[t].w * z3[t].w); }
+    const float rstd = rsqrtf(xg_sum(s2) * (1.0f / 128.0f) + 1e-5f);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      z3[t] *= rstd;                                           // xhat
+      const f4 gy = valid ? *(const f4*)(gsrc + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+      const f4 gg = gy * *(const f4*)(a.ln_g + 16 * t + 4 * g);
+      gr[t] = gg;
+      m1 += (gg.x + gg.y) + (gg.z + gg.w);
+      m2 += (gg.x * z3[t].x + gg.y * z3[t].y) + (gg.z * z3[t].z + gg.w * z3[t].w);
+      // column sums over the tile's rows for d(ln weight) = sum g*xhat and d(ln bias) = sum g  ->  LDS
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float cw = gy[r] * z3[t][r], cb = gy[r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { cw += __shfl_xor(cw, o); cb += __shfl_xor(cb, o); }
+        if (m == 0) { atomicAdd(&colsum[16 * t + 4 * g + r], cw); atomicAdd(&colsum[NAMP_H + 16 * t + 4 * g + r], cb); }
+      }
+    }
+    m1 = xg_sum(m1) * (1.0f / 128.0f);
+    m2 = xg_sum(m2) * (1.0f / 128.0f);
+    float* gres = a.g_hE + e * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      gr[t] = (gr[t] - m1 - z3[t] * m2) * rstd;               // dL/dx of LayerNorm = the residual part of dL/dh_E:
+      if (valid) *(f4*)(gres + 16 * t) = gr[t];                // parked in the output row (L2), picked up by the last GEMM
+      if (a.drop_thresh) {                                     // through the (regenerated) dropout mask: g3 = dL/dz3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gr[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
+      }
+    }
+    if (valid) {
+      float* d3 = a.G3 + e * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(d3 + 16 * t) = gr[t];
+    }
+  } else if (MODE == BWD_ROWS) {
     const float* src = a.g_rows + e * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) gr[t] = valid ? *(const f4*)(src + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
@@ -162,13 +231,19 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
       for (int t = 0; t < 8; ++t) *(f4*)(d3 + 16 * t) = gr[t];
     }
   }
-  wait_dma_and_sync();                                        // W3^T landed in buf0; W2 (buf1) is free
-  dma_to_lds(buf1, a.W2t_img, 64, wave, nwaves, lane);
+  // images from here on: W3^T, W2^T, W1b^T in slots (A, B, A) with A = buf0 — or buf1 in BWD_EDGE_LN, whose extra z3 GEMM
+  // shifted the ring by one
+  const f4* wA = (MODE == BWD_EDGE_LN) ? w1 : w0;
+  const f4* wB = (MODE == BWD_EDGE_LN) ? w0 : w1;
+  char* bufA = (MODE == BWD_EDGE_LN) ? buf1 : buf0;
+  char* bufB = (MODE == BWD_EDGE_LN) ? buf0 : buf1;
+  wait_dma_and_sync();                                        // W3^T landed in slot A; slot B is free
+  dma_to_lds(bufB, a.W2t_img, 64, wave, nwaves, lane);
   // ---- g2 = (W3^T g3) * gelu'(z2)
   f4 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, w0, 8);
+  chain_gemm<8, 8, false>(acc, gr, wA, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
   if (valid) {
@@ -176,12 +251,12 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
   }
-  wait_dma_and_sync();                                        // W2^T landed in buf1; buf0 is free
-  dma_to_lds(buf0, a.W1t_img, 64, wave, nwaves, lane);
+  wait_dma_and_sync();                                        // W2^T landed in slot B; slot A is free
+  dma_to_lds(bufA, a.W1t_img, 64, wave, nwaves, lane);
   // ---- g1 = (W2^T g2) * gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, w1, 8);
+  chain_gemm<8, 8, false>(acc, gr, wB, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
   if (valid) {
@@ -233,15 +308,20 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
       }
     }
   }
-  wait_dma_and_sync();                                        // W1b^T landed in buf0
-  // ---- dL/dh_E = W1b^T g1
+  wait_dma_and_sync();                                        // W1b^T landed in slot A
+  // ---- dL/dh_E = W1b^T g1 (+ the residual path of the edge update)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, w0, 8);
+  for (int t = 0; t < 8; ++t)
+    acc[t] = (MODE == BWD_EDGE_LN && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+  chain_gemm<8, 8, false>(acc, gr, wA, 8);
   if (valid) {
     float* d = a.g_hE + e * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = acc[t];
+  }
+  if (MODE == BWD_EDGE_LN) {
+    __syncthreads();
+    if (threadIdx.x < 2 * NAMP_H) a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + threadIdx.x] = colsum[threadIdx.x];
   }
 }
 

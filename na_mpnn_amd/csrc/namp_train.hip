@@ -48,6 +48,7 @@ int ensure_attributes() {
     set((const void*)edge_chain_bwd_kernel<BWD_ENC_MSG>);
     set((const void*)edge_chain_bwd_kernel<BWD_DEC_MSG>);
     set((const void*)edge_chain_bwd_kernel<BWD_ROWS>);
+    set((const void*)edge_chain_bwd_kernel<BWD_EDGE_LN>);
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -87,6 +88,39 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   if (mode == 0) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ENC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
   else if (mode == 1) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_DEC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
   else hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ROWS>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_edge_update_bwd_groups(int B, int N, int K) {
+  if (B < 1 || N < 1 || K < 1) return 0;
+  return (int)(((long)B * N * K + 127) / 128);
+}
+
+int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
+                               const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
+                               const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
+                               uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
+                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int B, int N, int K, void* stream) {
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
+  REQUIRE_PTR(W3t_img); REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(ln_g);
+  REQUIRE_PTR(g_out); REQUIRE_PTR(A1); REQUIRE_PTR(A2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(G3); REQUIRE_PTR(g_hE);
+  REQUIRE_PTR(dgb_part);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_update_bwd: null E_idx");
+  REQUIRE((g_Pa == nullptr) == (g_Pc == nullptr), "namp_train_edge_update_bwd: g_Pa and g_Pc go together");
+  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_update_bwd: drop_p=%g must be in [0,1)", (double)drop_p);
+  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_update_bwd: bad dims B=%d N=%d K=%d", B, N, K);
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  EdgeBwdArgs a = {};
+  a.hE = h_E; a.E_idx = E_idx; a.Pa = Pa; a.Pj0 = Pc;
+  a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img;
+  a.b2 = b2; a.b3 = b3; a.ln_g = ln_g; a.g_rows = g_out;
+  if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
+  a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.g_Pa = g_Pa; a.g_Pj0 = g_Pc; a.dgb_part = dgb_part;
+  a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
+  hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_EDGE_LN>, dim3(namp_train_edge_update_bwd_groups(B, N, K)), dim3(512),
+                     2 * NAMP_IMG_BYTES, (hipStream_t)stream, a);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

@@ -68,7 +68,7 @@ class _EdgeMLP(torch.autograd.Function):
         hip.check(L.namp_train_edge_fwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
-                                        out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
+                                        None, None, 0.0, 0, out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
         ctx.mode = mode
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
@@ -104,6 +104,55 @@ class _EdgeMLP(torch.autograd.Function):
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None)
+
+
+class _EdgeUpdate(torch.autograd.Function):
+    """The whole EncLayer edge update h_E' = LayerNorm3(h_E + dropout3(MLP'([h_V_i | h_E | h_V_j])))
+    (na_model_utils.py:236-240) as one forward and one backward launch: the message never goes to memory, the dropout mask
+    is a counter-based hash regenerated in backward, LayerNorm3 is differentiated in registers."""
+
+    @staticmethod
+    def forward(ctx, h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, ln_b, E_idx32, p, seed):
+        B, N, K = E_idx32.shape
+        h_E, Pa, Pc = h_E.contiguous(), Pa.contiguous(), Pc.contiguous()
+        imgs = [_image(W1b.detach()), _image(W2.detach()), _image(W3.detach())]
+        b2c, b3c = b2.detach().contiguous(), b3.detach().contiguous()
+        g_, b_ = ln_w.detach().contiguous(), ln_b.detach().contiguous()
+        out = torch.empty_like(h_E)
+        hip.check(hip.lib().namp_train_edge_fwd(ENC_EDGE, h_E.data_ptr(), E_idx32.data_ptr(), None, None, None, Pa.data_ptr(),
+                                                Pc.data_ptr(), None, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(),
+                                                b2c.data_ptr(), b3c.data_ptr(), g_.data_ptr(), b_.data_ptr(), float(p), int(seed),
+                                                out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
+        ctx.p, ctx.seed = float(p), int(seed)
+        ctx.save_for_backward(h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32 = ctx.saved_tensors
+        B, N, K = E_idx32.shape
+        E = B * N * K
+        dev = h_E.device
+        L = hip.lib()
+        g = g.contiguous()
+        img1, img2, img3 = _image(W1b.detach()), _image(W2.detach()), _image(W3.detach())
+        img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
+        A1, A2, G1, G2, G3, g_hE = (torch.empty(E, H, device=dev) for _ in range(6))
+        g_Pa, g_Pc = torch.zeros(B * N, H, device=dev), torch.zeros(B * N, H, device=dev)
+        part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
+        b2c, b3c, lw = b2.detach().contiguous(), b3.detach().contiguous(), ln_w.detach().contiguous()
+        hip.check(L.namp_train_edge_update_bwd(h_E.data_ptr(), E_idx32.data_ptr(), Pa.data_ptr(), Pc.data_ptr(), img1.data_ptr(),
+                                               img2.data_ptr(), img3.data_ptr(), img3t.data_ptr(), img2t.data_ptr(),
+                                               img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
+                                               g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
+                                               G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), g_Pc.data_ptr(), part.data_ptr(),
+                                               B, N, K, hip.current_stream()), "train_edge_update_bwd")
+        dW3, db3 = _wgrad(G3, A2, False, True)
+        dW2, db2 = _wgrad(G2, A1, False, True)
+        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
+        dgb = part.sum(0)
+        return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
+                None, None, None)
 
 
 class _TableRows(torch.autograd.Function):
@@ -255,7 +304,8 @@ def forward_train(model, fd, decoding_randn=None):
     mask = fd["mask"]
     if not mask.is_cuda:
         raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
-    drop = (lambda t: F.dropout(t, model.dropout.p, True)) if (model.training and model.dropout.p > 0) else (lambda t: t)
+    drop_p = float(model.dropout.p) if model.training else 0.0
+    drop = (lambda t: F.dropout(t, drop_p, True)) if drop_p > 0 else (lambda t: t)
     fp = model.features
     y, E_idx = edge_embedding(model, fd)
     B, N, K = E_idx.shape
@@ -272,9 +322,9 @@ def forward_train(model, fd, decoding_randn=None):
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
         Pa, Pc = F.linear(h_V, W11[:, :H], p.W11.bias), F.linear(h_V, W11[:, 2 * H:])
-        msg = _EdgeMLP.apply(ENC_EDGE, h_E, Pa, Pc, None, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight,
-                             p.W13.bias, E_idx, None, None, None)
-        h_E = _ln(h_E + drop(msg), p.norm3)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # host RNG: follows torch.manual_seed
+        h_E = _EdgeUpdate.apply(h_E, Pa, Pc, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight, p.W13.bias,
+                                p.norm3.weight, p.norm3.bias, E_idx, drop_p, seed)
     chain_M = mask
     if model.decode_protein_first:
         chain_M = chain_M.masked_fill(fd["protein_mask"].to(torch.bool), 0.0)
