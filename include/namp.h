@@ -265,7 +265,7 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   mode 2: G3 == g_out) and g_hE = dL/dh_E.  Then dW3 = G3^T A2, dW2 = G2^T A1, dW1b = G1^T h_E (namp_train_wgrad),
  *   db3 = sum G3, db2 = sum G2, dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k] — the last two are accumulated by the
  *   launch itself with fp32 atomics into g_Pa / g_Pj0 (/ g_Pj1: rows that gathered Pfw) when those ZEROED [B*N][128]
- *   buffers are given (NULL: the caller reduces G1).
+ *   buffers are given (each optional; NULL: the caller reduces G1 — namp_train_scatter_rows does dL/dPj without atomics).
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
  * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated
@@ -295,6 +295,11 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                         float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int B, int N, int K, void* stream);
+/* dL/dPj = transpose of the neighbour gather, as a gather over the reverse adjacency: rev_edge [B*N*K] = edge ids sorted by
+ * the table row they gathered (global row b*N + E_idx), rev_off [B*N+1] their offsets per row; out0[j] = sum of G1[e] over the
+ * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */
+int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                            float* out0, float* out1, int G, void* stream);
 int namp_train_wgrad_chunks(long rows);
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream);
 int namp_train_feat_wgrad_chunks(long edges);

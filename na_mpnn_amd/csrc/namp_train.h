@@ -529,3 +529,33 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
       for (int r = 0; r < 4; ++r) out[(long)(16 * t + 4 * g + r) * FEATW_COLS + 16 * (blk0 + q) + n] = acc[q][t][r];
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// scatter_rows_kernel: dL/dPj[j] = sum over the edges e that gathered table row j of G1[e] — the transpose of the
+// neighbour gather, evaluated as a GATHER over the reverse adjacency (edges sorted by target once per step, shared by
+// all nine per-edge stages): one wave per target row streams its ~K incoming 512-B rows and sums them in registers.
+// Deterministic, no atomics (the atomic scatter inside edge_chain_bwd_kernel cost 0.85 ms per launch at cfg5, this
+// 0.2 ms).  sel (DecLayer): per edge 1 = the row gathered Pbw -> out0, 0 = Pfw -> out1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ G1, const int32_t* __restrict__ rev_edge,
+                                                           const int32_t* __restrict__ rev_off, const uint8_t* __restrict__ sel,
+                                                           float* __restrict__ out0, float* __restrict__ out1, int G) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= G) return;
+  const int beg = rev_off[j], end = rev_off[j + 1];
+  const int half = lane >> 5, c4 = lane & 31;                 // two edges per step, 32 lanes x float4 each
+  f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int p = beg + half; p < end; p += 2) {
+    const int e = rev_edge[p];
+    const f4 v = *(const f4*)(G1 + (long)e * NAMP_H + 4 * c4);
+    if (!sel || sel[e]) s0 += v; else s1 += v;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { s0[r] += __shfl_xor(s0[r], 32); s1[r] += __shfl_xor(s1[r], 32); }
+  if (half == 0) {
+    *(f4*)(out0 + (long)j * NAMP_H + 4 * c4) = s0;
+    if (out1) *(f4*)(out1 + (long)j * NAMP_H + 4 * c4) = s1;
+  }
+}
+

@@ -78,7 +78,6 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img; a.b2 = b2;
   if (mode == 2) a.g_rows = g_out; else a.g_node = g_out;
-  REQUIRE((g_Pa == nullptr) == (g_Pj0 == nullptr), "namp_train_edge_bwd: g_Pa and g_Pj0 go together");
   REQUIRE(mode != 1 || (g_Pj0 == nullptr) == (g_Pj1 == nullptr), "namp_train_edge_bwd: decoder message needs g_Pj1 with g_Pj0");
   a.g_Pa = g_Pa; a.g_Pj0 = g_Pj0; a.g_Pj1 = g_Pj1;
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
@@ -107,7 +106,6 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   REQUIRE_PTR(g_out); REQUIRE_PTR(A1); REQUIRE_PTR(A2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(G3); REQUIRE_PTR(g_hE);
   REQUIRE_PTR(dgb_part);
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_update_bwd: null E_idx");
-  REQUIRE((g_Pa == nullptr) == (g_Pc == nullptr), "namp_train_edge_update_bwd: g_Pa and g_Pc go together");
   REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_update_bwd: drop_p=%g must be in [0,1)", (double)drop_p);
   REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_update_bwd: bad dims B=%d N=%d K=%d", B, N, K);
   int rc = ensure_attributes();
@@ -121,6 +119,18 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_EDGE_LN>, dim3(namp_train_edge_update_bwd_groups(B, N, K)), dim3(512),
                      2 * NAMP_IMG_BYTES, (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                            float* out0, float* out1, int G, void* stream) {
+  REQUIRE_PTR(G1); REQUIRE_PTR(out0);
+  if (!rev_edge || !rev_off) return fail(NAMP_EINVAL, "namp_train_scatter_rows: null reverse adjacency");
+  REQUIRE((sel == nullptr) == (out1 == nullptr), "namp_train_scatter_rows: sel and out1 go together");
+  REQUIRE(G >= 1, "namp_train_scatter_rows: G=%d", G);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, G1, rev_edge, rev_off, sel, out0,
+                     out1, G);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

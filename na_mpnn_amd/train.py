@@ -49,12 +49,36 @@ def _wgrad(G, A, gelu_A, want_bias):
     return dW.sum(0), (db.sum(0) if want_bias else None)
 
 
+class ReverseAdjacency:
+    """Edges grouped by the table row they gather (global row b*N + E_idx[b,i,k]) — the transpose of the neighbour
+    gather, built once per step and shared by all per-edge stages' backward passes."""
+
+    def __init__(self, E_idx32):
+        B, N, K = E_idx32.shape
+        dev = E_idx32.device
+        jflat = (E_idx32.long() + (torch.arange(B, device=dev) * N)[:, None, None]).view(-1)
+        order = torch.argsort(jflat, stable=True)
+        self.edges = order.to(torch.int32).contiguous()
+        counts = torch.bincount(jflat, minlength=B * N)
+        self.offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).to(torch.int32).contiguous()
+        self.jflat = jflat
+        self.G = B * N
+
+    def scatter(self, G1, sel=None):
+        """-> sum of G1 rows per gathered table row [G,128] (two outputs when sel, uint8 per edge, is given)."""
+        out0 = torch.empty(self.G, H, device=G1.device)
+        out1 = torch.empty(self.G, H, device=G1.device) if sel is not None else None
+        hip.check(hip.lib().namp_train_scatter_rows(G1.data_ptr(), self.edges.data_ptr(), self.offsets.data_ptr(), hip.ptr(sel),
+                                                    out0.data_ptr(), hip.ptr(out1), self.G, hip.current_stream()), "scatter_rows")
+        return out0, out1
+
+
 class _EdgeMLP(torch.autograd.Function):
     """One per-edge 3-layer MLP of EncLayer / DecLayer with the hoisted first layer
     ``z1 = W1b.h_E[i,k] + Pa[i] + Pj[j]``.  mode 0/1 -> sum_k w_ik * MLP / 30 per residue; mode 2 -> the message per edge."""
 
     @staticmethod
-    def forward(ctx, mode, h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, b3, E_idx32, mask32, mask_attend32, rank32):
+    def forward(ctx, mode, h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, b3, E_idx32, mask32, mask_attend32, rank32, rev=None):
         B, N, K = E_idx32.shape
         L = hip.lib()
         h_E, Pa, Pj0 = h_E.contiguous(), Pa.contiguous(), Pj0.contiguous()
@@ -69,7 +93,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
                                         None, None, 0.0, 0, out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.mode = mode
+        ctx.mode, ctx.rev = mode, rev
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
 
@@ -88,14 +112,19 @@ class _EdgeMLP(torch.autograd.Function):
         G3 = torch.empty(E, H, device=dev) if mode != ENC_EDGE else None
         b2c = b2.detach().contiguous()
         g_Pa = torch.zeros(B * N, H, device=dev)
-        g_Pj0 = torch.zeros(B * N, H, device=dev)
-        g_Pj1 = torch.zeros(B * N, H, device=dev) if mode == DEC_MSG else None
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), g_Pj0.data_ptr(), hip.ptr(g_Pj1), B, N, K,
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, B, N, K,
                                         hip.current_stream()), "train_edge_bwd")
+        rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
+        if mode == DEC_MSG:
+            r = rank32.view(-1)
+            sel = (r[rev.jflat] < r.repeat_interleave(K)).to(torch.uint8).contiguous()
+            g_Pj0, g_Pj1 = rev.scatter(G1, sel)
+        else:
+            g_Pj0, g_Pj1 = rev.scatter(G1)
         if mode == ENC_EDGE:
             G3 = g.view(E, H)
         dW3, db3 = _wgrad(G3, A2, False, True)
@@ -103,7 +132,7 @@ class _EdgeMLP(torch.autograd.Function):
         dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
-        return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None)
+        return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
 
 
 class _EdgeUpdate(torch.autograd.Function):
@@ -112,7 +141,7 @@ class _EdgeUpdate(torch.autograd.Function):
     is a counter-based hash regenerated in backward, LayerNorm3 is differentiated in registers."""
 
     @staticmethod
-    def forward(ctx, h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, ln_b, E_idx32, p, seed):
+    def forward(ctx, h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, ln_b, E_idx32, p, seed, rev=None):
         B, N, K = E_idx32.shape
         h_E, Pa, Pc = h_E.contiguous(), Pa.contiguous(), Pc.contiguous()
         imgs = [_image(W1b.detach()), _image(W2.detach()), _image(W3.detach())]
@@ -123,7 +152,7 @@ class _EdgeUpdate(torch.autograd.Function):
                                                 Pc.data_ptr(), None, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(),
                                                 b2c.data_ptr(), b3c.data_ptr(), g_.data_ptr(), b_.data_ptr(), float(p), int(seed),
                                                 out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.p, ctx.seed = float(p), int(seed)
+        ctx.p, ctx.seed, ctx.rev = float(p), int(seed), rev
         ctx.save_for_backward(h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32)
         return out
 
@@ -138,21 +167,23 @@ class _EdgeUpdate(torch.autograd.Function):
         img1, img2, img3 = _image(W1b.detach()), _image(W2.detach()), _image(W3.detach())
         img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
         A1, A2, G1, G2, G3, g_hE = (torch.empty(E, H, device=dev) for _ in range(6))
-        g_Pa, g_Pc = torch.zeros(B * N, H, device=dev), torch.zeros(B * N, H, device=dev)
+        g_Pa = torch.zeros(B * N, H, device=dev)
         part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
         b2c, b3c, lw = b2.detach().contiguous(), b3.detach().contiguous(), ln_w.detach().contiguous()
         hip.check(L.namp_train_edge_update_bwd(h_E.data_ptr(), E_idx32.data_ptr(), Pa.data_ptr(), Pc.data_ptr(), img1.data_ptr(),
                                                img2.data_ptr(), img3.data_ptr(), img3t.data_ptr(), img2t.data_ptr(),
                                                img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
                                                g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
-                                               G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), g_Pc.data_ptr(), part.data_ptr(),
+                                               G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
                                                B, N, K, hip.current_stream()), "train_edge_update_bwd")
+        rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
+        g_Pc, _ = rev.scatter(G1)
         dW3, db3 = _wgrad(G3, A2, False, True)
         dW2, db2 = _wgrad(G2, A1, False, True)
         dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
         dgb = part.sum(0)
         return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
-                None, None, None)
+                None, None, None, None)
 
 
 class _TableRows(torch.autograd.Function):
@@ -314,17 +345,18 @@ def forward_train(model, fd, decoding_randn=None):
     h_V, h_E = model.W_v(V), _EdgeLinear.apply(E, model.W_e.weight, model.W_e.bias)
     mask32 = mask.to(torch.int32).contiguous()
     maskf = mask.float().unsqueeze(-1)
+    rev = ReverseAdjacency(E_idx) if torch.is_grad_enabled() else None
     for p in model.encoder_layers:                                                   # EncLayer, na_model_utils.py:218-241
         W1, W11 = p.W1.weight, p.W11.weight
         Pa, Pc = F.linear(h_V, W1[:, :H], p.W1.bias), F.linear(h_V, W1[:, 2 * H:])
         dh = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
-                            E_idx, mask32, None, None)
+                            E_idx, mask32, None, None, rev)
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
         Pa, Pc = F.linear(h_V, W11[:, :H], p.W11.bias), F.linear(h_V, W11[:, 2 * H:])
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # host RNG: follows torch.manual_seed
         h_E = _EdgeUpdate.apply(h_E, Pa, Pc, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight, p.W13.bias,
-                                p.norm3.weight, p.norm3.bias, E_idx, drop_p, seed)
+                                p.norm3.weight, p.norm3.bias, E_idx, drop_p, seed, rev)
     chain_M = mask
     if model.decode_protein_first:
         chain_M = chain_M.masked_fill(fd["protein_mask"].to(torch.bool), 0.0)
@@ -339,7 +371,7 @@ def forward_train(model, fd, decoding_randn=None):
         Pbw = F.linear(h_S, W1[:, 2 * H:3 * H]) + F.linear(h_V, W1[:, 3 * H:])
         Pfw = F.linear(h_V_enc, W1[:, 3 * H:])
         dh = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
-                            E_idx, None, None, rank32)
+                            E_idx, None, None, rank32, rev)
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
     logits = model.W_out(h_V)
