@@ -306,6 +306,22 @@ int namp_train_feat_wgrad_chunks(long edges);
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
                           float* dW_part, int B, int L, int K, void* stream);
 
+/* Level-parallel form of the plain sampling branch (no symmetry groups, no pair_bias).  The step for residue i depends
+ * only on the neighbours visited before it, so visits can be grouped into dependency levels and every level decoded in
+ * one launch over all streams: ~64 launches instead of 1000 sequential steps at N = 1000, K = 48.  Same arithmetic per
+ * residue and the same uniform per visit as namp_decoder_sample, hence identical draws.
+ *   namp_sample_levels: level[b][t] (int32, indexed by VISIT t of stream b) = 1 + max level of the earlier neighbours.
+ *   namp_decoder_sample_levels: work = int32 pairs (stream, visit) sorted by level [B_dec*N][2] (device);
+ *     level_counts = HOST array of n_levels counts (the caller reads the histogram back; this library never synchronises). */
+int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
+                       int N, int K, void* stream);
+int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                               const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* work, const int32_t* level_counts, int n_levels,
+                               float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                               void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
+
 /* ---- measurement hook (bench.py) ------------------------------------------------------------
  * When enabled (thread-local), every kernel launch made through this ABI is bracketed by HIP
  * events on the launch stream; namp_profile_collect() waits for them and returns the summed

@@ -117,7 +117,8 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
-  set((const void*)dec_sample_kernel, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true>, SAMPLE_LDS);
   set((const void*)edge_features_kernel, FEAT_LDS);
   set((const void*)knn_kernel, 8192 * 8 + 64);
 }
@@ -708,13 +709,14 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   return (3 + 1) * tbl(Ge) + (2 + 2 + 3) * tbl(Gd) + 4096;
 }
 
-int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                        const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
-                        const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
-                        const float* pair_bias,
-                        float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
-                        void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                          const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                          const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                          const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
+                          const float* pair_bias,
+                          float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                          void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream,
+                          SampleArgs* a_out, int* nwaves_out) {
   REQUIRE(w != nullptr, "namp_decoder_sample: null weights");
   REQUIRE((group_first == nullptr) == (group_last == nullptr), "namp_decoder_sample: group_first and group_last go together");
   REQUIRE(w->n_dec >= 1 && w->n_dec <= 3, "namp_decoder_sample: supports 1..3 decoder layers (got %d)", w->n_dec);
@@ -770,12 +772,73 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
     fill_tail(L.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b,
               (l == 0) ? h_V_enc : hs[l - 1], mask_dec, hs[l], pn, np, nullptr);
   }
+  *a_out = a;
+  *nwaves_out = nwaves;
+  return NAMP_OK;
+}
+
+int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                        const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                        const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
+                        const float* pair_bias,
+                        float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                        void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+  SampleArgs a; int nwaves = 0;
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, group_first,
+                          group_last, sym_weights, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws,
+                          ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
+  if (rc) return rc;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  hipLaunchKernelGGL(dec_sample_kernel, dim3((B_dec + slots - 1) / slots), dim3(nwaves * 64), SAMPLE_LDS,
-                     (hipStream_t)stream, a);
+  hipLaunchKernelGGL(dec_sample_kernel<false>, dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
+                     (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
+
+int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
+                       int N, int K, void* stream) {
+  if (!E_idx || !order || !rank || !level) return fail(NAMP_EINVAL, "namp_sample_levels: null pointer argument");
+  REQUIRE(B_dec >= 1 && B_enc >= 1 && B_dec % B_enc == 0 && N >= 1 && K >= 1 && N <= 16384,
+          "namp_sample_levels: bad dims B_dec=%d B_enc=%d N=%d K=%d", B_dec, B_enc, N, K);
+  hipLaunchKernelGGL(sample_levels_kernel, dim3(B_dec), dim3(64), (size_t)N * 4, (hipStream_t)stream, E_idx, order, rank, level,
+                     B_enc, N, K);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                               const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* work, const int32_t* level_counts, int n_levels,
+                               float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                               void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+  REQUIRE(work != nullptr && level_counts != nullptr && n_levels >= 1, "namp_decoder_sample_levels: work list / level counts missing");
+  long total = 0;
+  for (int l = 0; l < n_levels; ++l) { REQUIRE(level_counts[l] >= 0, "namp_decoder_sample_levels: negative level count"); total += level_counts[l]; }
+  REQUIRE(total == (long)B_dec * N, "namp_decoder_sample_levels: level counts sum to %ld, expected B_dec*N = %ld", total, (long)B_dec * N);
+  SampleArgs a; int nwaves = 0;
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
+                          nullptr, nullptr, nullptr, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+                          B_dec, B_enc, N, K, stream, &a, &nwaves);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(S_out, 0xFF, (size_t)B_dec * N * sizeof(int32_t), s);          // every token "not drawn" (-1)
+  if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_levels: hipMemsetAsync: %s", hipGetErrorString(e));
+  ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
+  long off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const int cnt = level_counts[l];
+    if (cnt == 0) continue;
+    hipLaunchKernelGGL(dec_sample_kernel<true>, dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
+                       work + 2 * off, cnt);
+    off += cnt;
+  }
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+
 
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;

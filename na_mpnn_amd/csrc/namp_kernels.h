@@ -939,7 +939,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 // that share cache lines with not-yet-written neighbours (S) are read with L1-bypassing loads.
 // ------------------------------------------------------------------------------------------
 #define NAMP_SAMPLE_SLOTS 4
-#define SAMPLE_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)
+#define SAMPLE_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)     // ring + per-wave partial sums + node / visit ids
 
 struct SampleLayer {
   const float* W1e_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
@@ -979,40 +979,86 @@ struct SampleRows {             // tile row n -> residue of stream (b0 + n) at t
   __device__ __forceinline__ int operator()(int n) const { return node_lds[n]; }
 };
 
-__global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
+// sample_levels_kernel: dependency level of every visit of the plain sampling branch.  One wave per stream walks its
+// decoding order once: level(i) = 1 + max level of the neighbours visited before i (0 if none) — lanes cover the K
+// neighbours, levels live in LDS.  level_out[b][t] is indexed by VISIT t.
+__global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __restrict__ E_idx, const int32_t* __restrict__ order,
+                                                          const int32_t* __restrict__ rank, int32_t* __restrict__ level_out,
+                                                          int B_enc, int N, int K) {
+  extern __shared__ int lv[];                                    // [N]
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b_enc = b % B_enc;
+  const int32_t* rk = rank + (long)b * N;
+  for (int t = 0; t < N; ++t) {
+    const int i = order[(long)b * N + t];
+    int d = -1;
+    for (int k = lane; k < K; k += 64) {
+      const int j = E_idx[((long)b_enc * N + i) * K + k];
+      if (rk[j] < t) d = max(d, lv[j]);                          // rank[i] == t; earlier neighbours already have their level
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) d = max(d, __shfl_xor(d, o));
+    if (lane == 0) { lv[i] = d + 1; level_out[(long)b * N + t] = d + 1; }
+    __builtin_amdgcn_s_waitcnt(0);                               // LDS write visible to the wave's next iteration
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LEVEL = false: the sequential walk, one workgroup per <= 4 streams (needed for symmetry groups and pair_bias, whose steps
+// depend on every earlier one).  LEVEL = true: ONE step for an arbitrary list of (stream, visit) pairs — the plain branch's
+// step for residue i depends only on the neighbours decoded before it, so the host groups the visits of all streams into
+// dependency levels (sample_levels_kernel: level = 1 + max level of the earlier neighbours) and launches one grid per level:
+// ~64 launches instead of 1000 sequential steps at N = 1000, K = 48, with every workgroup of the chip busy.  Same arithmetic
+// per residue, same uniform per visit, hence the same draws.
+template <bool LEVEL>
+__global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
   float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);            // [12 waves][128]
   int* node_lds = (int*)(dpart + 12 * NAMP_H);                   // [4] residue (dec-global) per slot, -1 idle
+  int* t_lds = node_lds + NAMP_SAMPLE_SLOTS;                     // [4] visit index per slot (LEVEL)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int slot = wave / a.TPN, kt = wave - slot * a.TPN;
-  const int b = blockIdx.x * a.slots + slot;
-  const bool wave_active = (slot < a.slots) && (b < a.B_dec);
-  const int bb = wave_active ? b : 0;
+  const int item = blockIdx.x * a.slots + slot;                  // LEVEL: index into the work list; else: the stream
+  const bool wave_active = (slot < a.slots) && (LEVEL ? item < nwork : item < a.B_dec);
+  const int bb = wave_active ? (LEVEL ? work[2 * item] : item) : (LEVEL ? work[0] : 0);
+  const int t_level = LEVEL ? work[2 * (wave_active ? item : 0) + 1] : 0;
   const int b_enc = bb % a.B_enc;
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
   const SampleRows rows = {node_lds};
   float tot = 0.f;                                  // running symmetry-group logit sum (head waves)
   // every token starts "not drawn" (-1): the reference's h_S is all-zero until a residue is assigned (:264)
-  for (int s_ = 0; s_ < a.slots; ++s_) {
-    const int bs = blockIdx.x * a.slots + s_;
-    if (bs < a.B_dec)
-      for (int q = tid; q < a.N; q += blockDim.x) __hip_atomic_store(a.S_out + (long)bs * a.N + q, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (LEVEL: the host fills S_out with -1 before the first level)
+  if (!LEVEL) {
+    for (int s_ = 0; s_ < a.slots; ++s_) {
+      const int bs = blockIdx.x * a.slots + s_;
+      if (bs < a.B_dec)
+        for (int q = tid; q < a.N; q += blockDim.x) __hip_atomic_store(a.S_out + (long)bs * a.N + q, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  for (int t = 0; t < a.N; ++t) {
+  for (int t_seq = 0; t_seq < (LEVEL ? 1 : a.N); ++t_seq) {
+    const int t = LEVEL ? t_level : t_seq;
     const int i_loc = a.order[(long)bb * a.N + t];
     const int node = bb * a.N + i_loc;                   // stream-global residue
     const int node_enc = b_enc * a.N + i_loc;
     if (tid < NAMP_SAMPLE_SLOTS) {
-      const int bs = blockIdx.x * a.slots + tid;
-      node_lds[tid] = (tid < a.slots && bs < a.B_dec) ? bs * a.N + a.order[(long)bs * a.N + t] : -1;
+      const int it = blockIdx.x * a.slots + tid;
+      if (LEVEL) {
+        const bool ok = tid < a.slots && it < nwork;
+        const int bs = ok ? work[2 * it] : 0, ts = ok ? work[2 * it + 1] : 0;
+        node_lds[tid] = ok ? bs * a.N + a.order[(long)bs * a.N + ts] : -1;
+        t_lds[tid] = ts;
+      } else {
+        node_lds[tid] = (tid < a.slots && it < a.B_dec) ? it * a.N + a.order[(long)it * a.N + t] : -1;
+        t_lds[tid] = t;
+      }
     }
     const int k = 16 * kt + m;
     const bool valid = wave_active && (k < a.K);
@@ -1123,6 +1169,7 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a) {
         const float logp = (z - mx) - logf(e);
         if (lane < a.vocab) a.logp_out[(long)nd * a.vocab + lane] = a.chain_mask[ne] ? logp : 0.f;
         // group logit sum: total += symmetry_weight[i] * logits          (model_utils.py:298)
+        const int t = t_lds[n];                          // this slot's visit (== the walk's step unless LEVEL)
         const long vis = (long)bq * a.N + t;
         const int v_first = a.group_first ? a.group_first[vis] : t;
         const float wsym = a.sym_w ? a.sym_w[ne] : 1.0f;

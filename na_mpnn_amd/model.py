@@ -403,6 +403,8 @@ class ProteinMPNN(nn.Module):
     # every stream is masked with STREAM 0's mask at that step.  True reproduces it; it only matters when
     # batch_size > 1 and masked residues coexist with fixed (chain_mask = 0) ones.
     reference_sample_mask_quirk = True
+    # decode the plain sampling branch by dependency level (False: the one-launch sequential walk; same results)
+    sample_level_parallel = True
 
     @torch.no_grad()
     def sample(self, feature_dict):
@@ -472,6 +474,25 @@ class ProteinMPNN(nn.Module):
         bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
         forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
+        if self.sample_level_parallel and not symmetric and pair_bias is None:
+            # plain branch: residue i depends only on the neighbours decoded before it -> decode by dependency level
+            # (one launch per level over all streams, ~64 levels at L = 1000 instead of 1000 sequential steps)
+            level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
+            hip.check(Lb.namp_sample_levels(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), level.data_ptr(), B_dec, B, L, K,
+                                            hip.current_stream()), "sample_levels")
+            flat = level.view(-1).long()
+            perm = torch.argsort(flat, stable=True)
+            counts = torch.bincount(flat).cpu().tolist()                       # the one host sync of the sampler
+            work = torch.stack((perm // L, perm % L), 1).to(torch.int32).contiguous()
+            counts_c = (C.c_int32 * len(counts))(*counts)
+            hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
+                                                    cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(),
+                                                    r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), work.data_ptr(), counts_c,
+                                                    len(counts), float(fd["temperature"]), special, S_out.data_ptr(),
+                                                    probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(), B_dec, B, L, K,
+                                                    hip.current_stream()), "decoder_sample_levels")
+            return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
+                    "uniform": uniform, "levels": len(counts)}
         hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
                                          cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(),
                                          uniform.data_ptr(), hip.ptr(forced), hip.ptr(group_first), hip.ptr(group_last),

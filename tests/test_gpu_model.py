@@ -235,6 +235,29 @@ def test_sample_free_running(weights_np, n, k, bs, T, mf):
     assert maxdiff(out["sampling_probs"][:, valid], ref["sampling_probs"][:, valid]) < 1e-3
 
 
+@pytest.mark.parametrize("n,k,bs,mf", [(120, 24, 3, 0.05), (300, 48, 1, 0.0), (40, 48, 2, 0.0)])
+def test_level_parallel_sampling_equals_the_sequential_walk(weights_np, n, k, bs, mf):
+    """sample() decoded by dependency level (one launch per level over all streams) gives bit-identical tokens,
+    probabilities and log-probabilities to the one-launch sequential walk under the same uniforms."""
+    dev = torch.device("cuda:0")
+    cx = synth.make_complex(seed=900 + n, n=n, masked_frac=mf)
+    cx["chain_mask"][::7] = 0
+    rng = np.random.default_rng(n)
+    fd = _sample_fd(cx, dev, bs, 0.4, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
+    m = make_model(weights_np, k, dev)
+    outs = []
+    for lvl in (True, False):
+        m.sample_level_parallel = lvl
+        torch.manual_seed(21)
+        outs.append(m.sample(fd))
+    a, b = outs
+    assert "levels" in a and a["levels"] <= n and (a["levels"] < n or k >= n) and "levels" not in b   # complete graph: no parallelism
+    assert torch.equal(a["uniform"], b["uniform"]) and torch.equal(a["decoding_order"], b["decoding_order"])
+    assert torch.equal(a["S"], b["S"])
+    assert torch.equal(a["sampling_probs"], b["sampling_probs"])
+    assert torch.equal(a["log_probs"], b["log_probs"])
+
+
 def test_cpu_tensors_are_rejected(weights_np):
     m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=8, atom_dict=spec.atom_dict(),
                     restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
