@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — residues/s of the NA-MPNN encoder+decoder forward on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 from na_mpnn_amd import hip, shard, spec, synth   # noqa: E402
 from na_mpnn_amd.pack import PackedWeights        # noqa: E402
 
-WORKLOADS = {"cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48), "cfg4": dict(B=1373, N=0, K=48),
+WORKLOADS = {"cfg1": dict(B=1, N=97, K=32), "cfg2": dict(B=1, N=1000, K=48), "cfg3": dict(B=64, N=1000, K=48), "cfg4": dict(B=1373, N=0, K=48),
              "cfg5": dict(B=16, N=1500, K=48)}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
@@ -322,6 +322,66 @@ def split_bench(args, dev, rank, world, dist):
         print(json.dumps(out), flush=True)
 
 
+def design_bench(args, dev, rank, world, dist):
+    """BASELINE configs[0] on the GPU: the design call of inference/run.py (`model.sample(feature_dict)`, run.py:367) on a
+    4oqu-sized complex (97 RNA residues, K=32, batch_size 1, T=0.1), from coordinates: featurise + encode + sample."""
+    from na_mpnn_amd.model import ProteinMPNN
+    n, K, bs = 97, 32, args.design_batch
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=K, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                    polytype_to_int=spec.polytype_to_int())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()})
+    m.to(dev).eval()
+    cx = synth.make_complex(seed=4 + rank, n=n, n_chains=1, frac_protein=0.0, frac_dna=0.0)          # one RNA chain, like 4oqu
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(dev) for k, v in cx.items()}
+    fd.update({"batch_size": bs, "temperature": 0.1, "bias": torch.zeros(1, n, 33, device=dev),
+               "symmetry_residues": [[]], "symmetry_weights": [[]]})
+
+    def step():
+        fd["randn"] = torch.randn(bs, n, device=dev)
+        return m.sample(fd)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = {"metric": "sampled residues/sec (design: featurise + encode + autoregressive sample), 4oqu-sized complex",
+           "value": round(world * bs * n * args.steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"cfg1: model.sample() on one {n}-residue RNA chain, K={K}, batch_size={bs}, T=0.1, fp32, from "
+                                  "coordinates; level-parallel decoding", "global_batch": bs * world, "seq_len": n,
+                      "parallelism": f"replicas x{world}"},
+           "levels": out.get("levels")}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import cpu_ref
+            torch.set_num_threads(min(8, os.cpu_count() or 1))
+            w = {k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()}
+            fdc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in fd.items()}
+            fdc["batch_size"] = 1; fdc["randn"] = fdc["randn"][:1]
+            with torch.no_grad():
+                cpu_ref.sample(w, fdc, K)
+                t1 = time.perf_counter(); cpu_ref.sample(w, fdc, K); dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {"value": round(n / dt, 1), "unit": "residues/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"oracle/cpu_ref.py features + encode + sample(), one {n}-residue complex, batch_size 1, "
+                                             f"eager PyTorch CPU ({dt:.2f} s)"}
+        print(json.dumps(res), flush=True)
+
+
 def cpu_train_baseline(cx, K, rti, n=300):
     """The oracle's training step (autograd through oracle/cpu_ref.py + Adam) on the host: B=1, first n residues."""
     from oracle import cpu_ref
@@ -354,6 +414,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
                     help="per-edge GEMM precision; default fp32 for cfg2 (parity mode), bf16 for cfg3 (BASELINE configs[2])")
+    ap.add_argument("--design-batch", type=int, default=1, help="cfg1: batch_size of the design call")
     ap.add_argument("--split-limit", type=int, default=0, help="cfg4: use only the first n complexes of the split")
     ap.add_argument("--batch-tokens", type=int, default=8000, help="cfg4: padded-token budget per batch inside a shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -382,6 +443,14 @@ def main():
     n_gpus = world
     torch.set_grad_enabled(False)
 
+    if args.workload == "cfg1":
+        if args.steps == 50:
+            args.steps = 20
+        design_bench(args, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "cfg4":
         if args.steps == 50:
             args.steps = 2
