@@ -148,17 +148,22 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   chain_gemm<8, 8, false>(z2, x, w1, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z2[t]);      // x <- a2 (only stored, for dW3), z2 <- gelu'(z2)
-  if (valid) {
-    float* d2 = a.A2 + e * NAMP_H + 4 * g;
+  // Row stores are issued right AFTER a ring barrier, never right before one: s_waitcnt vmcnt(0) also waits for store
+  // acknowledgements (gfx9 has one counter), and a store issued after the barrier has a whole GEMM to retire.
+  auto store_rows = [&](float* base, const f4 (&v)[8]) {
+    if (valid) {
+      float* d = base + e * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(d2 + 16 * t) = x[t];
-  }
+      for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = v[t];
+    }
+  };
   // ---- upstream gradient rows
   f4 gr[8];
   if (MODE == BWD_EDGE_LN) {
     // z3 = W3 a2 + b3 (a2 is still in x), then backwards through LayerNorm3 and the dropout mask
     wait_dma_and_sync();                                      // W3 landed in buf0; W2 (buf1) is free
     dma_to_lds(buf1, a.W3t_img, 64, wave, nwaves, lane);
+    store_rows(a.A2, x);
     f4 z3[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
@@ -212,11 +217,6 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
         for (int r = 0; r < 4; ++r) gr[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
       }
     }
-    if (valid) {
-      float* d3 = a.G3 + e * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(d3 + 16 * t) = gr[t];
-    }
   } else if (MODE == BWD_ROWS) {
     const float* src = a.g_rows + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -225,11 +225,6 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     const float* src = a.g_node + (long)node * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) gr[t] = *(const f4*)(src + 16 * t) * w_row;
-    if (valid) {
-      float* d3 = a.G3 + e * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(d3 + 16 * t) = gr[t];
-    }
   }
   // images from here on: W3^T, W2^T, W1b^T in slots (A, B, A) with A = buf0 — or buf1 in BWD_EDGE_LN, whose extra z3 GEMM
   // shifted the ring by one
@@ -239,6 +234,8 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   char* bufB = (MODE == BWD_EDGE_LN) ? buf0 : buf1;
   wait_dma_and_sync();                                        // W3^T landed in slot A; slot B is free
   dma_to_lds(bufB, a.W2t_img, 64, wave, nwaves, lane);
+  if (MODE != BWD_EDGE_LN) store_rows(a.A2, x);
+  if (MODE != BWD_ROWS) store_rows(a.G3, gr);
   // ---- g2 = (W3^T g3) * gelu'(z2)
   f4 acc[8];
 #pragma unroll
@@ -246,24 +243,17 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   chain_gemm<8, 8, false>(acc, gr, wA, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
-  if (valid) {
-    float* d = a.G2 + e * NAMP_H + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
-  }
   wait_dma_and_sync();                                        // W2^T landed in slot B; slot A is free
   dma_to_lds(bufA, a.W1t_img, 64, wave, nwaves, lane);
+  store_rows(a.G2, gr);
   // ---- g1 = (W2^T g2) * gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   chain_gemm<8, 8, false>(acc, gr, wB, 8);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
-  if (valid) {
-    float* d = a.G1 + e * NAMP_H + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = gr[t];
-  }
+  wait_dma_and_sync();                                        // W1b^T landed in slot A
+  store_rows(a.G1, gr);
   // gradients of the hoisted first-layer tables, accumulated here instead of re-reading G1 (sum over k / scatter over j)
   if (a.g_Pj0) {
     if (valid) {
@@ -308,7 +298,6 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
       }
     }
   }
-  wait_dma_and_sync();                                        // W1b^T landed in slot A
   // ---- dL/dh_E = W1b^T g1 (+ the residual path of the edge update)
 #pragma unroll
   for (int t = 0; t < 8; ++t)
