@@ -142,6 +142,11 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     float* d1 = a.A1 + e * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(d1 + 16 * t) = x[t];
+    if (MODE == BWD_EDGE_LN) {       // 6-GEMM variant: gelu'(z1) waits in its own G1 row (L2) instead of 32 VGPRs
+      float* p1 = a.G1 + e * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(p1 + 16 * t) = z1[t];
+    }
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
@@ -250,8 +255,14 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   chain_gemm<8, 8, false>(acc, gr, wB, 8);
+  if (MODE == BWD_EDGE_LN) {
+    const float* p1 = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
+    for (int t = 0; t < 8; ++t) gr[t] = valid ? acc[t] * *(const f4*)(p1 + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
+  }
   wait_dma_and_sync();                                        // W1b^T landed in slot A
   store_rows(a.G1, gr);
   // gradients of the hoisted first-layer tables, accumulated here instead of re-reading G1 (sum over k / scatter over j)
