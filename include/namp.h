@@ -303,8 +303,9 @@ int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int3
 int namp_train_wgrad_chunks(long rows);
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream);
 int namp_train_feat_wgrad_chunks(long edges);
+long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_ws (atom-presence words per 64-edge tile) */
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
-                          float* dW_part, int B, int L, int K, void* stream);
+                          float* dW_part, int32_t* tile_ws, int B, int L, int K, void* stream);
 
 /* Level-parallel form of the plain sampling branch (no symmetry groups, no pair_bias).  The step for residue i depends
  * only on the neighbours visited before it, so visits can be grouped into dependency levels and every level decoded in

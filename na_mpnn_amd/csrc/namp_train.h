@@ -424,15 +424,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 #define FEATW_TILE 64
 #define FEATW_LD 132            // padded row length of the LDS g_pre tile (floats)
 
+// tile_presence_kernel: for every 64-edge tile, which of the 18 atoms occur on the residue side (word 0) and on the
+// neighbour side (word 1) of any of its edges.  An (a, b) block can only be non-zero on a tile that has a on one side and
+// b on the other; feat_wgrad_kernel reads these two words instead of voting across the workgroup for every tile.
+__global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restrict__ M18, const int32_t* __restrict__ E_idx, long E,
+                                                           int L, int K, int32_t* __restrict__ pres) {
+  const int lane = threadIdx.x & 63;
+  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile * FEATW_TILE >= E) return;
+  const long el = tile * FEATW_TILE + lane;
+  uint32_t bi = 0, bj = 0;
+  if (el < E) {
+    const int node = (int)(el / K);
+    const int j = node - node % L + E_idx[el];
+    for (int q = 0; q < 18; ++q) {
+      if (M18[(long)node * 18 + q] != 0.f) bi |= 1u << q;
+      if (M18[(long)j * 18 + q] != 0.f) bj |= 1u << q;
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { bi |= __shfl_xor(bi, o); bj |= __shfl_xor(bj, o); }
+  if (lane == 0) { pres[2 * tile] = (int32_t)bi; pres[2 * tile + 1] = (int32_t)bj; }
+}
+
 __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                          const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
-                                                         const float* __restrict__ g_pre, long E, long edges_per_chunk,
-                                                         int L, int K, float* __restrict__ dW_part) {
+                                                         const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
+                                                         long E, long edges_per_chunk, int L, int K,
+                                                         float* __restrict__ dW_part) {
   __shared__ float gt[FEATW_TILE * FEATW_LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int blk0 = (blockIdx.x * 4 + wave) * 2;               // this wave's two column blocks
+  const int wg_blk0 = blockIdx.x * 8;                         // the workgroup's eight
   const long e_begin = (long)blockIdx.y * edges_per_chunk;
   long e_end = e_begin + edges_per_chunk;
   if (e_end > E) e_end = E;
@@ -450,38 +475,27 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  __shared__ int wg_live[2];
-  if (tid < 2) wg_live[tid] = 0;
-  __syncthreads();
-  int par = 0;
-  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE, par ^= 1) {
-    // per-lane edge of this tile: distance of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
-    const long el = e0 + lane;
-    const bool eok = el < e_end;
-    const long ec = eok ? el : e_begin;
-    const int node = (int)(ec / K);
-    const int j = node - node % L + E_idx[ec];
-    float dist[2];
+  // block `blk` can be non-zero on a tile with presence words (pi, pj)?  (block 0 = positional: always)
+  auto block_live = [](int blk, uint32_t pi, uint32_t pj) {
+    if (blk >= FEATW_BLOCKS) return false;
+    if (blk == 0) return true;
+    const int p = blk - 1;
+    return (((pi >> (p / 18)) & (pj >> (p % 18))) & 1u) != 0u;
+  };
+  bool staged = false;                                         // has this workgroup's LDS tile been read since its last staging?
+  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE) {
+    // Absent atoms make whole (a, b) blocks exactly zero for runs of edges (a protein residue has 5 of the 18 atoms).
+    // Liveness comes from the per-tile presence words — workgroup-uniform, no vote: tiles on which none of the
+    // workgroup's eight blocks is live cost two scalar loads; otherwise only the live blocks' MFMAs run.
+    const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE)]);
+    const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE) + 1]);
+    bool any_live = false;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
-      const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
-      const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-      const float mk = M18[(long)node * 18 + pa[q]] * M18[(long)j * 18 + pb[q]];
-      dist[q] = (eok && mk != 0.f) ? sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
-    }
-    // Absent atoms make whole (a, b) blocks exactly zero for runs of edges (a protein residue has 5 of the 18 atoms): a
-    // block none of whose 64 edges has both atoms contributes nothing.  Its MFMAs are skipped (per wave), and the g_pre
-    // staging + step loop altogether when no wave of the workgroup has a live block for this tile (exact: only zeros
-    // are left out).
-    bool live[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) live[q] = (blk0 + q < FEATW_BLOCKS) && ((blk0 + q == 0) || (__ballot(dist[q] < 1e29f) != 0ull));
-    if ((live[0] || live[1]) && lane == 0) wg_live[par] = 1;
-    __syncthreads();                                           // votes are in; the previous tile is fully consumed
-    const bool any_live = wg_live[par] != 0;
-    if (tid == 0) wg_live[par ^ 1] = 0;                        // (read again only after the next tile's barrier)
+    for (int q = 0; q < 8; ++q) any_live = any_live || block_live(wg_blk0 + q, pi, pj);
     if (!any_live) continue;
+    const bool live0 = block_live(blk0, pi, pj), live1 = block_live(blk0 + 1, pi, pj);
+    if (staged) __syncthreads();                               // the previous staged tile is fully consumed
+    staged = true;
     // stage g_pre rows e0 .. e0+63 (zeros past the end)
     for (int idx = tid; idx < FEATW_TILE * 32; idx += 256) {
       const int row = idx >> 5, c4 = idx & 31;
@@ -490,8 +504,25 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
       if (er < e_end) v = *(const f4*)(g_pre + er * NAMP_H + 4 * c4);
       *(f4*)(gt + row * FEATW_LD + 4 * c4) = v;
     }
+    // per-lane edge of this tile: distance of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
+    float dist[2] = {1e30f, 1e30f};
+    if (live0 || live1) {
+      const long el = e0 + lane;
+      const bool eok = el < e_end;
+      const long ec = eok ? el : e_begin;
+      const int node = (int)(ec / K);
+      const int j = node - node % L + E_idx[ec];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
+        const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float mk = M18[(long)node * 18 + pa[q]] * M18[(long)j * 18 + pb[q]];
+        dist[q] = (eok && mk != 0.f) ? sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
+      }
+    }
     __syncthreads();
-    if (live[0] || live[1]) {
+    if (live0 || live1) {
 #pragma unroll 4
       for (int s = 0; s < FEATW_TILE / 4; ++s) {
         const int row = 4 * s + g;                             // k-slot g of this MFMA group <-> edge e0 + 4s + g
@@ -509,14 +540,13 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
             const float u = (d - mu) * 0.8f;
             b = __expf(-(u * u));
           }
-          if (live[q]) {
+          if (q == 0 ? live0 : live1) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc[q][t] = mfma4(av[t], b, acc[q][t]);
           }
         }
       }
     }
-    __syncthreads();                                           // tile consumed: the next staging may overwrite it
   }
   // D[i = 4g + r][j = n] -> dW[16t + 4g + r][16 blk + n]
   float* out = dW_part + (long)blockIdx.y * NAMP_H * FEATW_COLS;

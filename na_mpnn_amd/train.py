@@ -293,8 +293,9 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         n = L.namp_train_feat_wgrad_chunks(B * Lr * K)
         part = torch.empty(n, H, Wedge.shape[1], device=g.device)
         Ep = E_pos.detach().contiguous()
+        tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
         hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
-                                          part.data_ptr(), B, Lr, K, hip.current_stream()), "train_feat_wgrad")
+                                          part.data_ptr(), tws.data_ptr(), B, Lr, K, hip.current_stream()), "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
         return None, part.sum(0), g_Epos, None, None, None
 
