@@ -224,7 +224,8 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
 /* ---- a9: autoregressive sampler ------------------------------------------------------------
  * ProteinMPNN.sample (model_utils.py:101-327: plain branch :126-218, symmetry-tied branch :219-326), after encode(): B_dec independent sample
  * streams over B_enc encoded complexes (stream b uses complex b % B_enc), one persistent launch.
- *   mask_dec    [B_dec,N]  residue mask per stream (the caller may reproduce the reference's use of stream 0's
+ *   mask        [B_enc,N]  the residue mask: a masked residue decodes from an all-zero context (mask_bw / mask_fw, :135-137)
+ *   mask_dec    [B_dec,N]  OUTPUT mask of the residue update per stream (the caller may reproduce the reference's use of stream 0's
  *                          mask at every step, model_utils.py:186 — see na_mpnn_amd/model.py)
  *   chain_mask  [B_enc,N]  mask*chain_mask: 1 = design, 0 = keep S_true       S_true [B_enc,N]
  *   bias        [B_enc,N,vocab] added to the logits before the temperature softmax (model_utils.py:196)
@@ -241,7 +242,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
  * distribution / log_softmax(logits)) as model_utils.py:211-212. */
 size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K);
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                        const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                         const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
                         const float* pair_bias,
@@ -317,7 +318,7 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream);
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                               const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                               const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                                const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                                const int32_t* work, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,

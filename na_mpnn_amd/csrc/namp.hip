@@ -710,7 +710,7 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
 }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                          const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                          const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                           const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                           const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
                           const float* pair_bias,
@@ -722,7 +722,7 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   REQUIRE(w->n_dec >= 1 && w->n_dec <= 3, "namp_decoder_sample: supports 1..3 decoder layers (got %d)", w->n_dec);
   REQUIRE(w->vocab >= 1 && w->vocab <= 64, "namp_decoder_sample: vocab=%d must be in [1,64]", w->vocab);
   REQUIRE_PTR(h_V_enc); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
-  if (!E_idx || !chain_mask || !S_true || !bias || !order || !rank || !uniform || !S_out || !probs_out || !logp_out)
+  if (!E_idx || !mask || !chain_mask || !S_true || !bias || !order || !rank || !uniform || !S_out || !probs_out || !logp_out)
     return fail(NAMP_EINVAL, "namp_decoder_sample: null pointer argument");
   REQUIRE(temperature > 0.f, "namp_decoder_sample: temperature must be > 0");
   int rc = check_dims(__func__, B_dec, N, K);
@@ -745,7 +745,7 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, nf, nullptr, stream))) return rc;
 
   SampleArgs a = {};
-  a.hE = h_E; a.E_idx = E_idx; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
+  a.hE = h_E; a.E_idx = E_idx; a.mask_true = mask; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
   a.uniform = uniform; a.S_forced = S_forced; a.group_first = group_first; a.group_last = group_last;
   a.sym_w = sym_weights; a.pair_bias = pair_bias; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
   a.probs_out = probs_out; a.logp_out = logp_out; a.special = special_tokens; a.inv_T = 1.0f / temperature;
@@ -778,14 +778,14 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
 }
 
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                        const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                        const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                         const int32_t* group_first, const int32_t* group_last, const float* sym_weights,
                         const float* pair_bias,
                         float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                         void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
   SampleArgs a; int nwaves = 0;
-  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, group_first,
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, group_first,
                           group_last, sym_weights, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws,
                           ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
@@ -808,7 +808,7 @@ int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t
 }
 
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
-                               const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                               const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                                const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                                const int32_t* work, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
@@ -818,7 +818,7 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   for (int l = 0; l < n_levels; ++l) { REQUIRE(level_counts[l] >= 0, "namp_decoder_sample_levels: negative level count"); total += level_counts[l]; }
   REQUIRE(total == (long)B_dec * N, "namp_decoder_sample_levels: level counts sum to %ld, expected B_dec*N = %ld", total, (long)B_dec * N);
   SampleArgs a; int nwaves = 0;
-  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
                           nullptr, nullptr, nullptr, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
                           B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;

@@ -952,6 +952,8 @@ struct SampleLayer {
 
 struct SampleArgs {
   const float* hE; const int32_t* E_idx;
+  const int32_t* mask_true;    // [G_enc]  the residue mask itself: gates the whole context of a residue (mask_bw / mask_fw,
+                               //          model_utils.py:135-137) — NOT the same as tail.mask when the stream-0 quirk is on
   const int32_t* chain_mask;   // [G_enc]  mask * chain_mask
   const int32_t* S_true;       // [G_enc]
   const float* bias;           // [G_enc][vocab]
@@ -1070,6 +1072,9 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
     if (bw) S_j = __hip_atomic_load(a.S_out + j_dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypass L1
     const bool has_tok = bw && S_j >= 0;
     const float w_row = valid ? (1.0f / 30.0f) : 0.f;
+    // mask_bw and mask_fw both carry mask_i: a masked residue sees an all-zero context [0 | 0 | 0] next to its own h_V.  (The
+    // parallel decoder never notices — its output mask is the same mask_i — but here the output mask may be stream 0's.)
+    const float ctx = a.mask_true[node_enc] ? 1.0f : 0.0f;
 
 #pragma unroll
     for (int l = 0; l < 3; ++l) {          // unrolled: a.l[l] must be a static index into the kernarg struct
@@ -1083,10 +1088,11 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
         const float* tk = L.tok + (long)(has_tok ? S_j : 0) * NAMP_H + 4 * g;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          x[q] = *(const f4*)(src + 16 * q);
+          x[q] = *(const f4*)(src + 16 * q) * ctx;
           acc[q] = *(const f4*)(pa + 16 * q);
           pjv[q] = *(const f4*)(pj + 16 * q);
           if (has_tok) pjv[q] += *(const f4*)(tk + 16 * q);
+          pjv[q] *= ctx;
         }
       }
       dma_to_lds(buf0, L.W1e_img, 64, wave, nwaves, lane);

@@ -88,7 +88,7 @@ _PROTOTYPES = {
     "namp_featurize_workspace_bytes": (sz, [i32, i32]),
     "namp_featurize": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
                              vp, sz, i32, i32, vp]),
-    "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+    "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                   c_ip, c_ip, c_fp, c_fp,
                                   C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, vp]),
@@ -102,7 +102,7 @@ _PROTOTYPES = {
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
     "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, vp]),
     "namp_sample_levels": (i32, [c_ip, c_ip, c_ip, c_ip, i32, i32, i32, i32, vp]),
-    "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+    "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                          c_ip, C.POINTER(C.c_int32), i32,
                                          C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),

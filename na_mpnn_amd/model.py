@@ -470,7 +470,7 @@ class ProteinMPNN(nn.Module):
         logp = torch.empty_like(probs)
         ws = torch.empty(Lb.namp_sample_workspace_bytes(B, B_dec, L, K), dtype=torch.uint8, device=dev)
         E32, cm32, St32 = _i32(E_idx), _i32(chain_mask), _i32(S_true)
-        md32, o32, r32 = _i32(mask_dec), _i32(order), _i32(rank)
+        md32, o32, r32, m32 = _i32(mask_dec), _i32(order), _i32(rank), _i32(mask)
         bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
         forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
@@ -485,7 +485,7 @@ class ProteinMPNN(nn.Module):
             counts = torch.bincount(flat).cpu().tolist()                       # the one host sync of the sampler
             work = torch.stack((perm // L, perm % L), 1).to(torch.int32).contiguous()
             counts_c = (C.c_int32 * len(counts))(*counts)
-            hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
+            hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),
                                                     cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(),
                                                     r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), work.data_ptr(), counts_c,
                                                     len(counts), float(fd["temperature"]), special, S_out.data_ptr(),
@@ -493,7 +493,7 @@ class ProteinMPNN(nn.Module):
                                                     hip.current_stream()), "decoder_sample_levels")
             return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                     "uniform": uniform, "levels": len(counts)}
-        hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), md32.data_ptr(),
+        hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),
                                          cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(),
                                          uniform.data_ptr(), hip.ptr(forced), hip.ptr(group_first), hip.ptr(group_last),
                                          hip.ptr(sym_w), hip.ptr(pair_bias), float(fd["temperature"]), special,
