@@ -1412,7 +1412,7 @@ __global__ void prep_atoms_kernel(const float* __restrict__ X, const int32_t* __
 
 // knn_kernel: _dist (model_utils.py:489-497).  One workgroup per residue row: masked distances to all L
 // residues, row maximum, then a bitonic sort of 64-bit keys (distance bits << 32 | index) in LDS and the K
-// smallest are written in ascending order (ties resolved by index; torch.topk leaves them unspecified).
+// smallest are written in ascending order (ties: unmasked before masked, then by index; torch.topk leaves them unspecified).
 // The distance uses the reference's operation order with contraction off so that near-ties round identically.
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
                                                   int32_t* __restrict__ E_idx, int L, int Lp2, int K) {
@@ -1444,7 +1444,10 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, c
     if (j < L) {
       const float m2 = mi * (float)mb[j];
       const float d = __uint_as_float((unsigned)(keys[j] >> 32)) + (1.0f - m2) * dmax;
-      keys[j] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+      // ties: lower index first, but a real distance beats the "masked -> row maximum" substitute it equals (the farthest
+      // unmasked residue always ties with every masked / padded one; torch.topk leaves the choice open — keeping the real
+      // residue is the deterministic, padding-independent answer)
+      keys[j] = ((unsigned long long)__float_as_uint(d) << 32) | (m2 == 0.f ? 0x80000000ull : 0ull) | (unsigned)j;
     } else {
       keys[j] = ~0ull;
     }
@@ -1463,7 +1466,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, c
       __syncthreads();
     }
   }
-  for (int k = tid; k < K; k += 256) E_idx[(long)row * K + k] = (int32_t)(keys[k] & 0xffffffffu);
+  for (int k = tid; k < K; k += 256) E_idx[(long)row * K + k] = (int32_t)(keys[k] & 0x7fffffffu);
 }
 
 // edge_features_kernel: RBF + positional features -> edge_embedding (5200 -> 128, no bias) -> LayerNorm

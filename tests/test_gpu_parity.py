@@ -236,6 +236,23 @@ def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch, 
         "argmax sequence differs from the reference"
 
 
+@pytest.mark.parametrize("joint", [False, True])
+@pytest.mark.parametrize("n,k,b,mf", [(1, 1, 1, 0.0), (2, 2, 3, 0.0), (5, 3, 2, 0.3), (16, 16, 1, 0.0), (17, 9, 4, 0.2), (31, 31, 2, 0.5),
+                                      (63, 17, 3, 0.1), (100, 64, 2, 0.0), (130, 80, 1, 0.1), (257, 33, 2, 0.05), (300, 120, 1, 0.0)])
+def test_random_shapes_against_the_oracle(L, dev, wt, packed, n, k, b, mf, joint):
+    """(V, E, E_idx) -> log_probs against the CPU oracle over odd shapes: K from 1 to 120 (1..8 tiles per residue), K = N,
+    batches, heavy masking; separate calls and the fused single call."""
+    t, d = graph(dev, seed=9000 + 13 * n + k, batch=b, n=n, k=k, masked_frac=mf)
+    K = t["E_idx"].shape[-1]
+    hV, hE, logp, order = run_encdec(L, dev, packed, d, b, n, K, joint)
+    ref = cpu_ref.encdec_from_graph(wt, t["V"], t["E"], t["E_idx"].long(), t["S"], t["mask"], t["chain_mask"], t["randn"])
+    valid = t["mask"].bool()
+    assert torch.isfinite(logp).all()
+    if valid.any():
+        assert maxdiff(logp.cpu()[valid], ref["log_probs"][valid]) < TOL_LOGP
+        assert torch.equal(logp.cpu().argmax(-1)[valid], ref["log_probs"].argmax(-1)[valid])
+
+
 def test_decoder_batch_replication_and_unconditional(L, dev, wt, packed):
     """B_dec = 3 x B_enc with different sequences / orders per decoder batch; rank = 0 -> unconditional."""
     t, d = graph(dev, seed=21, batch=1, n=90, k=32)
