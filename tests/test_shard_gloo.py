@@ -60,3 +60,35 @@ def test_two_rank_gloo_all_gather():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert sum(n for _, _, n in res) == len(lengths)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7), torch.nn.Linear(7, 3))
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1)) if i != 2 else None     # one parameter without a gradient
+    n = shard.allreduce_gradients(net.parameters())
+    expect = [(sum(r + 1 for r in range(world)) / world) * (i + 1) if i != 2 else 0.0 for i in range(len(list(net.parameters())))]
+    ok = all(torch.allclose(p.grad, torch.full_like(p, e)) for p, e in zip(net.parameters(), expect))
+    q.put((rank, ok, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce():
+    """The data-parallel training exchange: one bucketed all-reduce averages every parameter's gradient over the ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and all(n == 5 * 7 + 7 + 7 + 7 + 7 * 3 + 3 for _, _, n in res)
+    assert shard.allreduce_gradients(torch.nn.Linear(2, 2).parameters()) == 0          # no process group: nothing to do
+
