@@ -216,7 +216,10 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
  * (encoder outputs, as namp_encoder_fwd) and log_probs [B,N,vocab] (as namp_decoder_fwd with B_dec == B_enc).  While the
  * batch takes the fused residue tail (fp32, B*N <= namp_fused_tail_max_residues()) the encoder/decoder boundary is
  * fused as well (decoder tables projected by the last EncLayer's launch, last edge update in front of DecLayer 0's
- * message phase); otherwise it is namp_encoder_fwd + namp_decoder_fwd.  ws_bytes >= 2 * namp_workspace_bytes(B,B,N,K). */
+ * message phase); otherwise it is namp_encoder_fwd + namp_decoder_fwd.  ws_bytes >= 2 * namp_workspace_bytes(B,B,N,K).
+ * In the bf16 throughput mode on a batch beyond the fused-tail regime (with E given) h_E and the gathered tables are also
+ * STORED in bf16 (fragment order) between launches — those launches are bound by HBM bytes, not MFMA — and the h_E buffer
+ * serves as that store: it does not hold fp32 h_E afterwards (use namp_encoder_fwd when h_E itself is wanted). */
 int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx, const int32_t* mask,
                     const int32_t* S, const int32_t* rank, float* h_V, float* h_E, float* log_probs, float* logits,
                     void* ws, size_t ws_bytes, int B, int N, int K, void* stream);

@@ -5,6 +5,7 @@
 #include "namp_kernels.h"
 
 #include <cstdarg>
+#include <initializer_list>
 #include <cstdio>
 #include <mutex>
 #include <vector>
@@ -115,6 +116,9 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
@@ -177,6 +181,25 @@ int launch_edge_bf16_persistent(EdgeArgs a, hipStream_t s) {
   a.TPN = e.tpn;
   hipLaunchKernelGGL((edge_mlp_bf16_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
   return NAMP_OK;
+}
+
+// bf16 STORAGE variant (h_E and the gathered tables in bf16 fragment order): large batches of the bf16 throughput mode
+template <int MODE>
+int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  a.TPN = e.tpn;
+  hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
+  return NAMP_OK;
+}
+
+void launch_cvt_tables(const float* const* src, __bf16* const* dst, int n, long rows, hipStream_t s) {
+  CvtTables c = {};
+  c.n = n; c.rows = rows;
+  for (int i = 0; i < n; ++i) { c.src[i] = src[i]; c.dst[i] = dst[i]; }
+  const long total = rows * 16;
+  hipLaunchKernelGGL(cvt_tables_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c);
 }
 
 template <int MODE, int TAIL>
@@ -947,6 +970,130 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   return NAMP_OK;
 }
 
+// bf16 throughput mode on a large batch (unfused residue tail), whole path with bf16 STORAGE of h_E and of the gathered
+// tables (fragment order, see edge_mlp_bf16s_kernel).  The caller's h_E buffer is used as the bf16 store (its first half);
+// it does not hold fp32 h_E afterwards.
+static int encdec_bf16_storage(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx, const int32_t* mask,
+                               const int32_t* S, const int32_t* rank, float* h_V, float* h_E, float* log_probs, float* logits,
+                               void* ws, size_t ws_bytes, int B, int N, int K, void* stream) {
+  const int G = B * N, tpn = (K + 15) / 16;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  Carver c(ws, ws_bytes);
+  float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
+  float* P[6];
+  for (int i = 0; i < 6; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
+  float* Pfw[NAMP_MAX_LAYERS];
+  for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)G * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  __bf16* T16[4 + NAMP_MAX_LAYERS];                       // bf16 tables: 0,1 message / Pa,Pbw; 2,3 edge update; 4.. Pfw_l
+  for (int i = 0; i < 4 + w->n_dec; ++i) T16[i] = (__bf16*)c.take((size_t)G * NAMP_HIDDEN / 2);
+  if (!T16[3 + w->n_dec]) return fail(NAMP_EWORKSPACE, "namp_encdec_fwd: workspace too small (%zu bytes)", ws_bytes);
+  __bf16* h16 = (__bf16*)h_E;
+  auto cvt = [&](std::initializer_list<const float*> src, std::initializer_list<__bf16*> dst) {
+    const float* sp[4]; __bf16* dp[4]; int n = 0;
+    for (auto p : src) sp[n++] = p;
+    n = 0;
+    for (auto p : dst) dp[n++] = p;
+    launch_cvt_tables(sp, dp, n, G, s);
+  };
+  // encoder
+  const NampEncLayerW* L0 = &w->enc[0];
+  NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
+  NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
+  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  cvt({P[0], P[1]}, {T16[0], T16[1]});
+  {
+    EdgeArgs a = {};
+    a.hE = E; a.hE16_out = h16; a.W1_img = w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
+    ProfScope prof_(NAMP_KIND_EDGE_EMBED, s);
+    if ((rc = launch_edge<MODE_EMBED>(a, s))) return rc;
+  }
+  int cur = 0;
+  for (int l = 0; l < w->n_enc; ++l) {
+    const NampEncLayerW* L = &w->enc[l];
+    const bool last = (l + 1 == w->n_enc);
+    float* out = last ? h_V : hv[cur ^ 1];
+    REQUIRE_PTR(L->W1b_bimg); REQUIRE_PTR(L->W2_bimg); REQUIRE_PTR(L->W3_bimg);
+    REQUIRE_PTR(L->W11b_bimg); REQUIRE_PTR(L->W12_bimg); REQUIRE_PTR(L->W13_bimg);
+    {
+      EdgeArgs a = {};
+      a.hE16 = h16; a.E_idx = E_idx; a.mask = mask; a.Pa16 = T16[0]; a.Pj016 = T16[1];
+      a.W1_img = L->W1b_bimg; a.W2_img = L->W2_bimg; a.W3_img = L->W3_bimg; a.b2 = L->b2; a.b3 = L->b3;
+      a.partial = partial; a.G = a.G_enc = G; a.N = N; a.K = K;
+      ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
+      if ((rc = launch_edge_bf16s<MODE_ENC_MSG>(a, s))) return rc;
+    }
+    NampProj pe[4] = {{L->W11a_img, L->b11, nullptr, P[2]}, {L->W11c_img, nullptr, nullptr, P[3]}, {}, {}};
+    int np = 2;
+    if (!last) {
+      const NampEncLayerW* Ln = &w->enc[l + 1];
+      pe[2] = {Ln->W1a_img, Ln->b1, nullptr, P[0]};
+      pe[3] = {Ln->W1c_img, nullptr, nullptr, P[1]};
+      np = 4;
+    }
+    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur],
+                               partial, mask, out, pe, np, nullptr, G, K, stream)))
+      return rc;
+    if (last) cvt({P[2], P[3]}, {T16[2], T16[3]});
+    else cvt({P[2], P[3], P[0], P[1]}, {T16[2], T16[3], T16[0], T16[1]});
+    {
+      EdgeArgs a = {};
+      a.hE16 = h16; a.hE16_out = h16; a.E_idx = E_idx; a.Pa16 = T16[2]; a.Pj016 = T16[3];
+      a.W1_img = L->W11b_bimg; a.W2_img = L->W12_bimg; a.W3_img = L->W13_bimg; a.b2 = L->b12; a.b3 = L->b13;
+      a.ln_g = L->ln3_g; a.ln_b = L->ln3_b; a.G = a.G_enc = G; a.N = N; a.K = K;
+      ProfScope prof_(NAMP_KIND_ENC_EDGE, s);
+      if ((rc = launch_edge_bf16s<MODE_ENC_EDGE>(a, s))) return rc;
+    }
+    cur ^= 1;
+  }
+  // decoder tables from h_V_enc: Pfw_l, layer 0's Pa / Pbw
+  const NampDecLayerW* D0 = &w->dec[0];
+  NampProj pf[NAMP_MAX_LAYERS + 2];
+  int nf = 0;
+  for (int l = 0; l < w->n_dec; ++l) pf[nf++] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
+  pf[nf++] = {D0->W1a_img, D0->b1, nullptr, P[0]};
+  pf[nf++] = {D0->W1v_img, nullptr, D0->tok, P[1]};
+  if ((rc = namp_node_linear(h_V, S, B, B, N, pf, nf, nullptr, stream))) return rc;
+  cvt({P[0], P[1]}, {T16[0], T16[1]});
+  for (int l = 0; l < w->n_dec; l += 4) {
+    const float* sp[4]; __bf16* dp[4]; int n = 0;
+    for (int q = l; q < w->n_dec && q < l + 4; ++q) { sp[n] = Pfw[q]; dp[n] = T16[4 + q]; ++n; }
+    launch_cvt_tables(sp, dp, n, G, s);
+  }
+  const float* hin = h_V;
+  for (int l = 0; l < w->n_dec; ++l) {
+    const NampDecLayerW* D = &w->dec[l];
+    const bool last = (l + 1 == w->n_dec);
+    float* out = hv[l & 1];
+    REQUIRE_PTR(D->W1e_bimg); REQUIRE_PTR(D->W2_bimg); REQUIRE_PTR(D->W3_bimg);
+    {
+      EdgeArgs a = {};
+      a.hE16 = h16; a.E_idx = E_idx; a.rank = rank; a.Pa16 = T16[0]; a.Pj016 = T16[1]; a.Pj116 = T16[4 + l];
+      a.W1_img = D->W1e_bimg; a.W2_img = D->W2_bimg; a.W3_img = D->W3_bimg; a.b2 = D->b2; a.b3 = D->b3;
+      a.partial = partial; a.G = a.G_enc = G; a.N = N; a.K = K;
+      ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
+      if ((rc = launch_edge_bf16s<MODE_DEC_MSG>(a, s))) return rc;
+    }
+    NampProj pn[2] = {{}, {}};
+    int np = 0;
+    if (!last) {
+      const NampDecLayerW* Dn = &w->dec[l + 1];
+      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, P[0]};
+      pn[1] = {Dn->W1v_img, nullptr, Dn->tok, P[1]};
+      np = 2;
+    }
+    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin, partial,
+                               mask, out, pn, np, S, G, K, stream)))
+      return rc;
+    if (!last) cvt({P[0], P[1]}, {T16[0], T16[1]});
+    hin = out;
+  }
+  CHECK_LAUNCH();
+  return namp_logits_log_softmax(w->Wout_w, w->Wout_b, hin, log_probs, logits, G, w->vocab, stream);
+}
+
 // ProteinMPNN.score's device path in one call: encoder + parallel decoder.  While the batch takes the fused residue
 // tail (fp32, B*N <= NAMP_FUSED_TAIL_MAX_RESIDUES) the encoder/decoder boundary is fused too: the last EncLayer's
 // message launch also projects the decoder's layer-0 and encoder-context tables, and the last edge update rides in
@@ -965,6 +1112,8 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   const size_t half = namp_workspace_bytes(B, B, N, K);
   REQUIRE(ws_bytes >= 2 * half, "namp_encdec_fwd: workspace too small (%zu bytes, need 2 x namp_workspace_bytes = %zu)", ws_bytes, 2 * half);
   const bool bf = (w->enc[0].flags & NAMP_FLAG_BF16) != 0 || (w->dec[0].flags & NAMP_FLAG_BF16) != 0;
+  if (bf && E && G > NAMP_FUSED_TAIL_MAX_RESIDUES && edge_geom(G, K).grid > 2 * device_cus())
+    return encdec_bf16_storage(w, V, E, E_idx, mask, S, rank, h_V, h_E, log_probs, logits, ws, ws_bytes, B, N, K, stream);
   if (G > NAMP_FUSED_TAIL_MAX_RESIDUES || bf || w->n_dec + 4 > 8) {
     if ((rc = namp_encoder_fwd(w, V, E, E_idx, mask, h_V, h_E, ws, half, B, N, K, stream))) return rc;
     return namp_decoder_fwd(w, h_V, h_E, E_idx, S, mask, rank, log_probs, logits, nullptr, (char*)ws + half, half, B, B, N, K, stream);

@@ -493,6 +493,10 @@ struct EdgeArgs {
   const float* eW1_img; const float* eW2_img; const float* eW3_img;
   const float* eb2; const float* eb3;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // ENC_EDGE, training only: dropout on the message (thresh 0 = off)
+  // bf16 STORAGE (throughput mode on large batches, edge_mlp_bf16s_kernel): rows of 128 bf16 in fragment order
+  // [g][s][j] <-> channel 32s + 16(j>>2) + 4g + (j&3), i.e. lane (m, g) owns one contiguous 64-byte segment of its row
+  const __bf16* hE16; __bf16* hE16_out;
+  const __bf16* Pa16; const __bf16* Pj016; const __bf16* Pj116;
   float* partial;              // MSG modes without the fused tail: [G][TPN][128]
   NodeTail tail;               // MSG modes with the fused tail (TAIL = true)
   int G;                       // residues processed by this launch (decoder: B_dec*N)
@@ -710,9 +714,15 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   }
   if (MODE == MODE_EMBED) {
     if (valid) {
-      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+      if (a.hE16_out) {                 // bf16 storage in fragment order: this lane's 32 channels are one 64-byte segment
+        bf8* dst = (bf8*)(a.hE16_out + erow * NAMP_H + 32 * g);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+        for (int sq = 0; sq < 4; ++sq) dst[sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+      } else {
+        float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+      }
     }
     return;
   }
@@ -807,7 +817,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 // per-row operands of one tile that do not depend on its h_E row: resolved one tile ahead so that the dependent
 // E_idx -> mask / rank -> table-address chain of tile n+1 completes under tile n's GEMMs
 struct TileMeta {
-  const float* pa; const float* pj; long erow; float w_row; int node, kt; bool valid;
+  long pa_row, pj_row; bool pj_from1;      // table rows: Pa[pa_row]; Pj0[pj_row] or (pj_from1) Pj1[pj_row]
+  long erow; float w_row; int node, kt; bool valid;
 };
 
 template <int MODE>
@@ -826,11 +837,13 @@ __device__ __forceinline__ TileMeta tile_meta(const EdgeArgs& a, long tile, int 
   if (MODE == MODE_DEC_MSG) {
     const int j_dec = b_dec * a.N + j_loc;
     const bool bwd = a.rank[j_dec] < a.rank[t.node];
-    t.pj = bwd ? (a.Pj0 + (long)j_dec * NAMP_H) : (a.Pj1 + (long)(node_enc - i_loc + j_loc) * NAMP_H);
+    t.pj_from1 = !bwd;
+    t.pj_row = bwd ? (long)j_dec : (long)(node_enc - i_loc + j_loc);
     t.w_row = t.valid ? (1.0f / 30.0f) : 0.f;
   } else {
     const int j = t.node - i_loc + j_loc;
-    t.pj = a.Pj0 + (long)j * NAMP_H;
+    t.pj_from1 = false;
+    t.pj_row = j;
     if (MODE == MODE_ENC_MSG) {
       int ma;
       if (a.mask_attend) ma = a.mask_attend[t.erow];
@@ -838,8 +851,7 @@ __device__ __forceinline__ TileMeta tile_meta(const EdgeArgs& a, long tile, int 
       t.w_row = t.valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
     }
   }
-  t.pa = a.Pa + (long)t.node * NAMP_H + 4 * g;
-  t.pj += 4 * g;
+  t.pa_row = t.node;
   return t;
 }
 
@@ -872,8 +884,12 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xn[t];
     const TileMeta me = cur;
+    {
+      const float* pa = a.Pa + me.pa_row * NAMP_H + 4 * g;
+      const float* pj = (me.pj_from1 ? a.Pj1 : a.Pj0) + me.pj_row * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(me.pa + 16 * t); pjv[t] = *(const f4*)(me.pj + 16 * t); }
+      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+    }
     // next tile: metadata chain + h_E row, in flight under this tile's GEMMs
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
@@ -980,6 +996,122 @@ struct SampleRows {             // tile row n -> residue of stream (b0 + n) at t
   const int* node_lds;
   __device__ __forceinline__ int operator()(int n) const { return node_lds[n]; }
 };
+
+// ------------------------------------------------------------------------------------------
+// bf16 STORAGE variant of the persistent throughput kernel.  With bf16 MFMA the large-batch launches are bound by the
+// bytes of h_E and of the gathered table rows, so those are kept in bf16 too — in FRAGMENT ORDER: position [g][s][j] of a
+// row holds channel 32s + 16(j>>2) + 4g + (j&3), which is at once (i) the 8 values lane (m, g) feeds into MFMA step s and
+// (ii) its fp32 accumulators (tile 2s + (j>>2), element j&3).  Every per-row access is therefore one contiguous 64-byte
+// segment per lane (256 B per row, four 16-byte loads), GEMM-1 operands need no conversion at all, and the edge update
+// writes rows in the order the next launch reads them.  fp32 accumulation, fp32 LayerNorm / K-sum / residue tail.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf16_row_to_f32(f4 (&out)[8], const __bf16* __restrict__ seg) {
+#pragma unroll
+  for (int sq = 0; sq < 4; ++sq) {
+    const bf8 v = *(const bf8*)(seg + 8 * sq);
+    out[2 * sq] = (f4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    out[2 * sq + 1] = (f4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+}
+
+// fp32 [rows][128] (plain channel order) -> bf16 fragment order, for up to 4 tables per launch
+struct CvtTables { const float* src[4]; __bf16* dst[4]; int n; long rows; };
+__global__ void cvt_tables_bf16_kernel(const CvtTables c) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte output piece: (row, g, s)
+  if (e >= c.rows * 16) return;
+  const long row = e >> 4;
+  const int g = (int)(e >> 2) & 3, sq = (int)e & 3;
+  for (int q = 0; q < c.n; ++q) {
+    const float* s0 = c.src[q] + row * NAMP_H + 32 * sq + 4 * g;
+    const f4 lo = *(const f4*)s0, hi = *(const f4*)(s0 + 16);
+    *(bf8*)(c.dst[q] + row * NAMP_H + 32 * g + 8 * sq) = pack_bf16<false>(lo, hi);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const long ntiles = (long)a.G * a.TPN;
+  const long stride = (long)gridDim.x * nwaves;
+  long tile = (long)blockIdx.x * nwaves + wave;
+  TileMeta cur = tile_meta<MODE>(a, tile < ntiles ? tile : 0, m, g);
+  bf8 xn[4];
+  {
+    const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H + 32 * g);
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) xn[sq] = src[sq];
+  }
+  dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
+  dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
+  dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+  wait_dma_and_sync();
+  const bf8* bw = (const bf8*)smem + lane;
+  for (; tile < ntiles; tile += stride) {
+    asm volatile("" ::: "memory");        // keep the (loop-invariant) LDS weight fragments out of registers
+    bf8 xb[4];
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) xb[sq] = xn[sq];
+    const TileMeta me = cur;
+    f4 acc[8], pjv[8];
+    bf16_row_to_f32(acc, a.Pa16 + me.pa_row * NAMP_H + 32 * g);
+    bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H + 32 * g);
+    const long nt = tile + stride;
+    cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
+    {
+      const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H + 32 * g);
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) xn[sq] = src[sq];
+    }
+    // layer 1: the stored row IS the MFMA operand
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[(sq * 8 + tn) * 64], xb[sq], acc[tn], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
+    f4 (&y)[8] = pjv;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+    chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
+    if (MODE == MODE_ENC_EDGE) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) {                                  // residual: the row is still in registers
+        acc[2 * sq] += (f4){(float)xb[sq][0], (float)xb[sq][1], (float)xb[sq][2], (float)xb[sq][3]};
+        acc[2 * sq + 1] += (f4){(float)xb[sq][4], (float)xb[sq][5], (float)xb[sq][6], (float)xb[sq][7]};
+      }
+      layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+      if (me.valid) {
+        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H + 32 * g);
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) dst[sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float b = a.b3[16 * t + m];
+        acc[t] = (f4){b, b, b, b};
+      }
+      chain_gemm_bf16<true, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
+      float wr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
+      float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        s_ = xg_sum(s_);
+        if (g == 0) dst[16 * t] = s_;
+      }
+    }
+  }
+}
 
 // sample_levels_kernel: dependency level of every visit of the plain sampling branch.  One wave per stream walks its
 // decoding order once: level(i) = 1 + max level of the neighbours visited before i (0 if none) — lanes cover the K
