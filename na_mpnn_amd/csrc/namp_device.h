@@ -106,9 +106,31 @@ __device__ __forceinline__ void chain_gemm(f4 (&acc)[NTN], const f4 (&x)[TK], co
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 #define NAMP_BIMG_BYTES 32768
 
+// GELU of the bf16 throughput mode: its output is rounded to bf16 (ulp 2^-8 relative) right away, so the exact-erf form
+// with its two quarter-rate transcendentals per value is wasted there.  x * Phi(x) with Phi(x) - 1/2 = x * Q(x^2), Q a
+// degree-7 least-squares fit on |x| <= 4 (clamped beyond: Phi(4) = 0.99997): max |error| 4.9e-4 over the real line, 12
+// full-rate VALU ops, written on 4-vectors so that the packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32) can be selected.
+__device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
+#ifdef NAMP_ABL_NOGELU
+  return x;
+#endif
+  const f4 lim = (f4){4.f, 4.f, 4.f, 4.f};
+  const f4 xc = __builtin_elementwise_min(__builtin_elementwise_max(x, -lim), lim);
+  const f4 t = xc * xc;
+  f4 q = (f4){-1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f};
+  q = q * t + 1.0826653014e-07f;
+  q = q * t + -3.7514161992e-06f;
+  q = q * t + 7.5968897781e-05f;
+  q = q * t + -1.0135644180e-03f;
+  q = q * t + 9.5286519412e-03f;
+  q = q * t + -6.5922144089e-02f;
+  q = q * t + 3.9868862006e-01f;
+  return x * (xc * q + 0.5f);
+}
+
 template <bool ACT>
 __device__ __forceinline__ bf8 pack_bf16(const f4 lo, const f4 hi) {
-  const f4 a = ACT ? gelu4(lo) : lo, b = ACT ? gelu4(hi) : hi;
+  const f4 a = ACT ? gelu4_bf16mode(lo) : lo, b = ACT ? gelu4_bf16mode(hi) : hi;
   bf8 o;
   o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
   o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
