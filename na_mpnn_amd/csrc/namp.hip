@@ -121,6 +121,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
+  set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<true>, SAMPLE_LDS);
   set((const void*)edge_features_kernel, FEAT_LDS);
@@ -278,7 +279,12 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   NodeUpdateArgs a;
   fill_tail(a.t, ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, hV, mask, hV_out, proj, nproj, S);
   a.partial = partial; a.G = G; a.TPN = TPN;
-  hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_TAIL_LDS, s, a);
+  // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
+  // 4 tiles would halve the stream again but spill: 64 accumulator VGPRs of hidden state next to 128 of weights)
+  if (G >= 32 * 2 * device_cus())
+    hipLaunchKernelGGL(node_update_multi_kernel<2>, dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
+  else
+    hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_TAIL_LDS, s, a);
   return NAMP_OK;
 }
 

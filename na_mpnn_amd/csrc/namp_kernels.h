@@ -1470,6 +1470,151 @@ __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a
   node_tail<true>(a.t, x, row0, 16, a.G, (float*)smem, tid, wave, 8, lane);
 }
 
+// node_update_multi_kernel<T> — the same residue update for T 16-row tiles per workgroup (large batches).  With one tile
+// per workgroup every 16 residues re-stream the 768 KiB of FFN + projection weights from L2 (3 GB per launch at
+// B*N = 64,000: the launch is L2-bandwidth-bound).  Here each wave's weight fragments are requested once per phase and
+// applied to all T tiles: W_in (its 64 hidden units) against the T LayerNorm-1 tiles kept in LDS, then W_out, then each
+// projection fragment against the T output tiles.  Arithmetic per row is that of node_tail<true>.
+#define NODE_MULTI_LDS(T) (((2 * (T) * 16) + 8 * 16) * FFN_LD * 4)
+
+template <int T>
+__global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                       // [T][16][FFN_LD]  LN1 outputs
+  float* ys = xs + T * 16 * FFN_LD;               // [T][16][FFN_LD]  h_V' tiles
+  float* ps = ys + T * 16 * FFN_LD;               // [8][16][FFN_LD]  per-wave partial FFN outputs of the tile in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 16 * T;
+  const NodeTail& t = a.t;
+  // ---- phase 0: pre-activation + LayerNorm1, one wave per tile
+  for (int q = wave; q < T; q += 8) {
+    const int row = row0 + 16 * q + m;
+    const int rr = row < a.G ? row : (a.G - 1);
+    f4 x[8];
+    const float* src = t.hV + (long)rr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = *(const f4*)(src + 16 * c);
+    if (a.partial) {
+      for (int p = 0; p < a.TPN; ++p) {
+        const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] += *(const f4*)(ps_ + 16 * c);
+      }
+    }
+    layernorm_row_T(x, t.ln1_g, t.ln1_b, g);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+  }
+  __syncthreads();
+  // ---- phase A: hidden = gelu(W_in x + b_in); wave w owns hidden units 64w .. 64w+63
+  f4 hacc[T][4];
+  {
+    f4 win[8][4];
+    const f4* w = (const f4*)t.Win_img + (4 * wave) * 64 + lane;
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) win[tk][tn] = w[(tk * 32 + tn) * 64];
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hacc[q][c] = *(const f4*)(t.b_in + 64 * wave + 16 * c + 4 * g);
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) {
+        const f4 xv = *(const f4*)(xs + (q * 16 + m) * FFN_LD + 16 * tk + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma4(win[tk][tn][r], xv[r], hacc[q][tn]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hacc[q][c] = gelu4(hacc[q][c]);
+    }
+  }
+  // ---- phase B: W_out, then LayerNorm2 per tile
+  {
+    f4 wo[4][8];
+    const f4* w = (const f4*)t.Wout_img + (4 * wave) * 8 * 64 + lane;
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) wo[tk][tn] = w[(tk * 8 + tn) * 64];
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      f4 oacc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) oacc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[tk][tn][r], hacc[q][tk][r], oacc[tn]);
+      float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = oacc[c];
+      __syncthreads();
+      {   // LN2: thread -> (row = tid/32, 4 channels)
+        const int r = tid >> 5, c = (tid & 31) * 4;
+        f4 v = *(const f4*)(xs + (q * 16 + r) * FFN_LD + c) + *(const f4*)(t.b_out + c);
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) v += *(const f4*)(ps + (w2 * 16 + r) * FFN_LD + c);
+        float s_ = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s_ += __shfl_xor(s_, o);
+        const float mean = s_ * (1.0f / 128.0f);
+        v -= mean;
+        float qq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) qq += __shfl_xor(qq, o);
+        const float rstd = rsqrtf(qq * (1.0f / 128.0f) + 1e-5f);
+        const int orow = row0 + 16 * q + r;
+        const bool ok = orow < a.G;
+        const float mk = (t.mask && ok) ? (float)t.mask[orow] : 1.0f;
+        const f4 y = (v * rstd * *(const f4*)(t.ln2_g + c) + *(const f4*)(t.ln2_b + c)) * mk;
+        *(f4*)(ys + (q * 16 + r) * FFN_LD + c) = y;
+        if (ok) *(f4*)(t.hV_out + (long)orow * NAMP_H + c) = y;
+      }
+      __syncthreads();                                        // ps is free for the next tile; ys[q] is complete
+    }
+  }
+  if (t.nproj == 0 && !t.head_w) return;
+  if (t.head_w) {
+    for (int n = wave; n < 16 * T; n += 8)
+      if (row0 + n < a.G) tail_head_row(t, ys + n * FFN_LD, 1, row0 + n, lane);
+  }
+  // ---- projections of h_V': unit (block pi, channel tile tn) -> one wave; its fragment serves all T tiles
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) {
+    if (pi >= t.nproj) break;
+    const ProjDesc d = t.p[pi];
+    {
+      const int tn = wave;                                    // 8 waves <-> 8 channel tiles
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)d.img)[(tk * 8 + tn) * 64 + lane];
+      const f4 bias = d.bias ? *(const f4*)(d.bias + 16 * tn + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const int row = row0 + 16 * q + m;
+        const bool valid = row < a.G;
+        const int rr = valid ? row : (a.G - 1);
+        f4 acc = bias;
+        if (d.tok) acc += *(const f4*)(d.tok + (long)t.S[rr] * NAMP_H + 16 * tn + 4 * g);
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) {
+          const f4 xv = *(const f4*)(ys + (q * 16 + m) * FFN_LD + 16 * tk + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma4(wf[tk][r], xv[r], acc);
+        }
+        if (valid) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // logits_kernel — log_softmax(W_out . h_V + b) over the 33-letter vocabulary
 // (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.
