@@ -379,3 +379,27 @@ def test_extreme_shapes_score_and_sample(weights_np, n, k, kw):
         assert maxdiff(outs[0]["log_probs"][:, valid], refs["log_probs"][:, valid]) < 1e-3
         assert maxdiff(outs[0]["sampling_probs"][:, valid], refs["sampling_probs"][:, valid]) < 1e-3
 
+
+def test_maximum_size_complex_padding_invariance(weights_np):
+    """N = 6000 (the cap of the design_test-sized split) from coordinates: rows are normalised and finite, and
+    every residue's log-probs are unchanged when the complex sits in a padded batch next to a shorter one (size-independent
+    property; the oracle would need ~2 GB of RBF temporaries here)."""
+    from na_mpnn_amd import shard
+    dev = torch.device("cuda:0")
+    big = synth.make_complex(seed=6000, n=6000, n_chains=6)
+    small = synth.make_complex(seed=6001, n=777, n_chains=2)
+    m = make_model(weights_np, 48, dev)
+    randn = torch.randn(2, 6000, generator=torch.Generator().manual_seed(1)).to(dev)
+    fd1 = fd_of(big, dev); fd1["randn"] = randn[:1]
+    lp1 = m.score(fd1)["log_probs"]
+    assert torch.isfinite(lp1).all()
+    assert float((torch.logsumexp(lp1, -1)).abs().max()) < 1e-4
+    fd2 = shard.pad_batch([big, small], device=dev)
+    fd2["batch_size"] = 1; fd2["randn"] = randn
+    lp2 = m.score(fd2)["log_probs"]
+    assert float((lp2[0] - lp1[0]).abs().max()) < 1e-4          # different launch shapes (fused vs unfused tails), same rows
+    assert torch.equal(lp2[0].argmax(-1), lp1[0].argmax(-1))
+    fd3 = fd_of(small, dev); fd3["randn"] = randn[1:, :777]
+    lp3 = m.score(fd3)["log_probs"]
+    assert float((lp2[1, :777] - lp3[0]).abs().max()) < 1e-4
+
