@@ -51,6 +51,12 @@ int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float
  * configs[2]'s throughput mode; ~1e-2 on log-probs, not parity-grade.  Residue-level math stays fp32. */
 #define NAMP_FLAG_BF16 1
 int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stream);   /* [128x128] block -> 32 KiB */
+/* NAMP_FLAG_X3: the per-edge GEMMs as THREE bf16 products of split operands (x = x_hi + x_mid, W = W_hi + W_mid;
+ * W.x ~= W_hi.x_hi + W_hi.x_mid + W_mid.x_hi, fp32 accumulate): fp32-equivalent to ~2^-16 per product at 3/16 of the fp32
+ * MFMA cost — the default PARITY mode of the Python surface (log-probs move by 3e-5 against exact fp32 on the N=1000
+ * golden, bar 1e-3, arg-max unchanged).  The x3 image = bf16 fragment image of W_hi followed by that of W_mid (64 KiB). */
+#define NAMP_FLAG_X3 2
+int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream);     /* [128x128] block -> 64 KiB */
 
 /* EncLayer parameters (inference/model_utils.py:659-679).  W1/W11 are split by input block:
  * a = h_V_i columns [0,128), b = h_E_ik [128,256), c = h_V_j [256,384). */
@@ -63,7 +69,8 @@ typedef struct NampEncLayerW {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
   /* bf16 throughput mode: 32 KiB bf16 images of the six per-edge blocks (namp_pack_image_bf16) */
   const float *W1b_bimg, *W2_bimg, *W3_bimg, *W11b_bimg, *W12_bimg, *W13_bimg;
-  int64_t flags;                                     /* NAMP_FLAG_BF16: run the per-edge GEMMs in bf16 */
+  const float *W1b_ximg, *W2_ximg, *W3_ximg, *W11b_ximg, *W12_ximg, *W13_ximg;   /* x3 images (namp_pack_image_x3) */
+  int64_t flags;                                     /* NAMP_FLAG_BF16 / NAMP_FLAG_X3: precision of the per-edge GEMMs */
 } NampEncLayerW;
 
 /* DecLayer parameters (inference/model_utils.py:619-634).  W1 [128x512] split by input block:
@@ -75,6 +82,7 @@ typedef struct NampDecLayerW {
   const float *Win_img, *b_in, *Wout_img, *b_out;
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *W1e_bimg, *W2_bimg, *W3_bimg;        /* bf16 images (throughput mode) */
+  const float *W1e_ximg, *W2_ximg, *W3_ximg;        /* x3 images */
   int64_t flags;
 } NampDecLayerW;
 
@@ -92,6 +100,7 @@ typedef struct NampModelW {
   NampEncLayerW enc[NAMP_MAX_LAYERS];
   NampDecLayerW dec[NAMP_MAX_LAYERS];
   NampFeatW feat;
+  const float* We_ximg;            /* x3 image of W_e (the embedding fused in front of EncLayer 0, namp_encdec_fwd) */
 } NampModelW;
 
 /* ---- a1/a3: neighbour gather ----------------------------------------------------------- */

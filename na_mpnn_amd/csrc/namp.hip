@@ -113,6 +113,24 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, false, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, false, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, false, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 0, PREC_X3>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 0, PREC_X3>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_EDGE, 0, PREC_X3>), 2 * NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, PREC_X3>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 4, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 8, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_DEC_MSG, 16, PREC_X3, PRE_EDGE>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
@@ -150,14 +168,14 @@ EdgeGeom edge_geom(int G, int K) {
   return e;
 }
 
-template <int MODE, int TAIL = 0, bool BF16 = false, int PRE = PRE_NONE>
+template <int MODE, int TAIL = 0, int PREC = PREC_F32, int PRE = PRE_NONE>
 int launch_edge(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   const int lds = TAIL ? EDGE_TAIL_LDS : (MODE == MODE_EMBED) ? NAMP_IMG_BYTES : 2 * NAMP_IMG_BYTES;
-  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, BF16, PRE>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
+  hipLaunchKernelGGL((edge_mlp_kernel<MODE, TAIL, PREC, PRE>), dim3(e.grid), dim3(e.nwaves * 64), lds, s, a);
   return NAMP_OK;
 }
 
@@ -203,33 +221,46 @@ void launch_cvt_tables(const float* const* src, __bf16* const* dst, int n, long 
   hipLaunchKernelGGL(cvt_tables_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c);
 }
 
+// precision of the per-edge GEMMs from a layer's flags: bf16 throughput mode, split-bf16 (fp32-equivalent) or exact fp32
+#define NAMP_FLAG_BF16 1
+#define NAMP_FLAG_X3 2
+inline int prec_of(int64_t flags) { return (flags & NAMP_FLAG_BF16) ? PREC_BF16 : (flags & NAMP_FLAG_X3) ? PREC_X3 : PREC_F32; }
+inline const float* pick_img(int prec, const float* img, const float* bimg, const float* ximg) {
+  return prec == PREC_BF16 ? bimg : prec == PREC_X3 ? ximg : img;
+}
+
 template <int MODE, int TAIL>
-int launch_edge_prec(const EdgeArgs& a, bool bf16, hipStream_t s) {
-  if (bf16 && TAIL == 0 && MODE != MODE_EMBED && edge_geom(a.G, a.K).grid > 2 * device_cus())
+int launch_edge_prec(const EdgeArgs& a, int prec, hipStream_t s) {
+  if (prec == PREC_BF16 && TAIL == 0 && MODE != MODE_EMBED && edge_geom(a.G, a.K).grid > 2 * device_cus())
     return launch_edge_bf16_persistent<MODE == MODE_EMBED ? MODE_ENC_MSG : MODE>(a, s);
-  return bf16 ? launch_edge<MODE, TAIL, true>(a, s) : launch_edge<MODE, TAIL, false>(a, s);
+  if (prec == PREC_BF16) return launch_edge<MODE, TAIL, PREC_BF16>(a, s);
+  if (prec == PREC_X3) return launch_edge<MODE, TAIL, PREC_X3>(a, s);
+  return launch_edge<MODE, TAIL, PREC_F32>(a, s);
 }
 
 // fused-tail flavour by residues per workgroup: <= 4 and <= 6 take the VALU tails (the latter needs 128
 // LayerNorm threads per residue: 2*npw <= waves), more take the 16-row MFMA tail
 template <int MODE>
-int launch_edge_tail(const EdgeArgs& a, bool bf16, hipStream_t s) {
+int launch_edge_tail(const EdgeArgs& a, int prec, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
-  if (e.npw <= 4) return launch_edge_prec<MODE, 4>(a, bf16, s);
-  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge_prec<MODE, 8>(a, bf16, s);
-  return launch_edge_prec<MODE, 16>(a, bf16, s);
+  if (e.npw <= 4) return launch_edge_prec<MODE, 4>(a, prec, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge_prec<MODE, 8>(a, prec, s);
+  return launch_edge_prec<MODE, 16>(a, prec, s);
 }
 
-// edge update of the previous layer fused in front of the message phase (fp32 only)
+// a PRE stage (edge update of the previous layer / edge embedding) fused in front of the message phase (fp32-class only)
 template <int MODE, int PRE = PRE_EDGE>
-int launch_edge_tail_fused(const EdgeArgs& a, hipStream_t s) {
+int launch_edge_tail_fused(const EdgeArgs& a, int prec, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
-  if (e.npw <= 4) return launch_edge<MODE, 4, false, PRE>(a, s);
-  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, false, PRE>(a, s);
-  return launch_edge<MODE, 16, false, PRE>(a, s);
+  if (prec == PREC_X3) {
+    if (e.npw <= 4) return launch_edge<MODE, 4, PREC_X3, PRE>(a, s);
+    if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, PREC_X3, PRE>(a, s);
+    return launch_edge<MODE, 16, PREC_X3, PRE>(a, s);
+  }
+  if (e.npw <= 4) return launch_edge<MODE, 4, PREC_F32, PRE>(a, s);
+  if (e.npw <= 8 && 2 * e.npw <= e.nwaves) return launch_edge<MODE, 8, PREC_F32, PRE>(a, s);
+  return launch_edge<MODE, 16, PREC_F32, PRE>(a, s);
 }
-
-#define NAMP_FLAG_BF16 1
 
 void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b, const float* hV,
@@ -343,6 +374,14 @@ int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float
   return NAMP_OK;
 }
 
+int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream) {
+  REQUIRE_PTR(W); REQUIRE_PTR(img);
+  REQUIRE(ld >= 128 && col0 >= 0 && col0 + 128 <= ld, "namp_pack_image_x3: block [128 x 128] at column %d does not fit ld=%d", col0, ld);
+  hipLaunchKernelGGL(pack_image_x3_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stream) {
   if (!W || !img) return fail(NAMP_EINVAL, "namp_pack_image_bf16: null pointer");
   REQUIRE(col0 >= 0 && ld >= col0 + 128, "namp_pack_image_bf16: block [0:128, %d:%d) outside ld=%d", col0, col0 + 128, ld);
@@ -435,13 +474,15 @@ int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_
   if (rc) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
-  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
-  if (bf) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
-  a.W1_img = bf ? w->W1b_bimg : w->W1b_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  const int prec = prec_of(w->flags);
+  if (prec == PREC_BF16) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  if (prec == PREC_X3) { REQUIRE_PTR(w->W1b_ximg); REQUIRE_PTR(w->W2_ximg); REQUIRE_PTR(w->W3_ximg); }
+  a.W1_img = pick_img(prec, w->W1b_img, w->W1b_bimg, w->W1b_ximg); a.W2_img = pick_img(prec, w->W2_img, w->W2_bimg, w->W2_ximg);
+  a.W3_img = pick_img(prec, w->W3_img, w->W3_bimg, w->W3_ximg);
   a.b2 = w->b2; a.b3 = w->b3;
   a.partial = partial; a.G = a.G_enc = B * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_prec<MODE_ENC_MSG, 0>(a, bf, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_ENC_MSG, 0>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -458,13 +499,15 @@ int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t
   if (rc) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.hE_out = h_E_out; a.E_idx = E_idx; a.Pa = Pa; a.Pj0 = Pc;
-  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
-  if (bf) { REQUIRE_PTR(w->W11b_bimg); REQUIRE_PTR(w->W12_bimg); REQUIRE_PTR(w->W13_bimg); }
-  a.W1_img = bf ? w->W11b_bimg : w->W11b_img; a.W2_img = bf ? w->W12_bimg : w->W12_img; a.W3_img = bf ? w->W13_bimg : w->W13_img;
+  const int prec = prec_of(w->flags);
+  if (prec == PREC_BF16) { REQUIRE_PTR(w->W11b_bimg); REQUIRE_PTR(w->W12_bimg); REQUIRE_PTR(w->W13_bimg); }
+  if (prec == PREC_X3) { REQUIRE_PTR(w->W11b_ximg); REQUIRE_PTR(w->W12_ximg); REQUIRE_PTR(w->W13_ximg); }
+  a.W1_img = pick_img(prec, w->W11b_img, w->W11b_bimg, w->W11b_ximg); a.W2_img = pick_img(prec, w->W12_img, w->W12_bimg, w->W12_ximg);
+  a.W3_img = pick_img(prec, w->W13_img, w->W13_bimg, w->W13_ximg);
   a.b2 = w->b12; a.b3 = w->b13;
   a.ln_g = w->ln3_g; a.ln_b = w->ln3_b; a.G = a.G_enc = B * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_ENC_EDGE, (hipStream_t)stream);
-  rc = launch_edge_prec<MODE_ENC_EDGE, 0>(a, bf, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_ENC_EDGE, 0>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -534,13 +577,15 @@ int namp_dec_message(const NampDecLayerW* w, const float* h_E, const int32_t* E_
   REQUIRE(B_enc >= 1 && B_dec % B_enc == 0, "namp_dec_message: B_dec=%d must be a multiple of B_enc=%d", B_dec, B_enc);
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
-  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
-  if (bf) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
-  a.W1_img = bf ? w->W1e_bimg : w->W1e_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  const int prec = prec_of(w->flags);
+  if (prec == PREC_BF16) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  if (prec == PREC_X3) { REQUIRE_PTR(w->W1e_ximg); REQUIRE_PTR(w->W2_ximg); REQUIRE_PTR(w->W3_ximg); }
+  a.W1_img = pick_img(prec, w->W1e_img, w->W1e_bimg, w->W1e_ximg); a.W2_img = pick_img(prec, w->W2_img, w->W2_bimg, w->W2_ximg);
+  a.W3_img = pick_img(prec, w->W3_img, w->W3_bimg, w->W3_ximg);
   a.b2 = w->b2; a.b3 = w->b3;
   a.partial = partial; a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_prec<MODE_DEC_MSG, 0>(a, bf, (hipStream_t)stream);
+  rc = launch_edge_prec<MODE_DEC_MSG, 0>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -560,15 +605,17 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
   if ((rc = check_proj(__func__, proj, nproj, nullptr))) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
-  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
-  if (bf) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
-  a.W1_img = bf ? w->W1b_bimg : w->W1b_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  const int prec = prec_of(w->flags);
+  if (prec == PREC_BF16) { REQUIRE_PTR(w->W1b_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  if (prec == PREC_X3) { REQUIRE_PTR(w->W1b_ximg); REQUIRE_PTR(w->W2_ximg); REQUIRE_PTR(w->W3_ximg); }
+  a.W1_img = pick_img(prec, w->W1b_img, w->W1b_bimg, w->W1b_ximg); a.W2_img = pick_img(prec, w->W2_img, w->W2_bimg, w->W2_ximg);
+  a.W3_img = pick_img(prec, w->W3_img, w->W3_bimg, w->W3_ximg);
   a.b2 = w->b2; a.b3 = w->b3;
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_tail<MODE_ENC_MSG>(a, bf, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_ENC_MSG>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -580,7 +627,13 @@ int namp_enc_edge_message_update(const NampEncLayerW* w_prev, const float* ePa, 
                                  float* h_V_out, const NampProj* proj, int nproj, int B, int N, int K, void* stream) {
   REQUIRE(w_prev != nullptr && w != nullptr, "namp_enc_edge_message_update: null weights");
   REQUIRE((w->flags & NAMP_FLAG_BF16) == 0 && (w_prev->flags & NAMP_FLAG_BF16) == 0,
-          "namp_enc_edge_message_update: fp32 only (use the separate launches in bf16 mode)");
+          "namp_enc_edge_message_update: fp32-class precisions only (use the separate launches in bf16 mode)");
+  const int prec = prec_of(w->flags);
+  REQUIRE(prec == prec_of(w_prev->flags), "namp_enc_edge_message_update: both layers must use the same precision");
+  if (prec == PREC_X3) {
+    REQUIRE_PTR(w_prev->W11b_ximg); REQUIRE_PTR(w_prev->W12_ximg); REQUIRE_PTR(w_prev->W13_ximg);
+    REQUIRE_PTR(w->W1b_ximg); REQUIRE_PTR(w->W2_ximg); REQUIRE_PTR(w->W3_ximg);
+  }
   REQUIRE_PTR(h_E); REQUIRE_PTR(ePa); REQUIRE_PTR(ePc); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
   REQUIRE_PTR(w_prev->W11b_img); REQUIRE_PTR(w_prev->W12_img); REQUIRE_PTR(w_prev->W13_img); REQUIRE_PTR(w_prev->b12);
   REQUIRE_PTR(w_prev->b13); REQUIRE_PTR(w_prev->ln3_g); REQUIRE_PTR(w_prev->ln3_b);
@@ -596,14 +649,17 @@ int namp_enc_edge_message_update(const NampEncLayerW* w_prev, const float* ePa, 
             "namp_enc_edge_message_update: projection %d writes a table this launch still gathers", i);
   EdgeArgs a = {};
   a.hE = h_E; a.hE_out = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.Pa = Pa; a.Pj0 = Pc;
-  a.ePa = ePa; a.ePj = ePc; a.eW1_img = w_prev->W11b_img; a.eW2_img = w_prev->W12_img; a.eW3_img = w_prev->W13_img;
+  a.ePa = ePa; a.ePj = ePc;
+  a.eW1_img = pick_img(prec, w_prev->W11b_img, nullptr, w_prev->W11b_ximg); a.eW2_img = pick_img(prec, w_prev->W12_img, nullptr, w_prev->W12_ximg);
+  a.eW3_img = pick_img(prec, w_prev->W13_img, nullptr, w_prev->W13_ximg);
   a.eb2 = w_prev->b12; a.eb3 = w_prev->b13; a.ln_g = w_prev->ln3_g; a.ln_b = w_prev->ln3_b;
-  a.W1_img = w->W1b_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img; a.b2 = w->b2; a.b3 = w->b3;
+  a.W1_img = pick_img(prec, w->W1b_img, nullptr, w->W1b_ximg); a.W2_img = pick_img(prec, w->W2_img, nullptr, w->W2_ximg);
+  a.W3_img = pick_img(prec, w->W3_img, nullptr, w->W3_ximg); a.b2 = w->b2; a.b3 = w->b3;
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
   ProfScope prof_(NAMP_KIND_ENC_EDGE_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, (hipStream_t)stream);
+  rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -630,16 +686,18 @@ int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int3
   if ((rc = check_proj(__func__, proj, nproj, S))) return rc;
   EdgeArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = Pa; a.Pj0 = Pbw; a.Pj1 = Pfw;
-  const bool bf = (w->flags & NAMP_FLAG_BF16) != 0;
-  if (bf) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
-  a.W1_img = bf ? w->W1e_bimg : w->W1e_img; a.W2_img = bf ? w->W2_bimg : w->W2_img; a.W3_img = bf ? w->W3_bimg : w->W3_img;
+  const int prec = prec_of(w->flags);
+  if (prec == PREC_BF16) { REQUIRE_PTR(w->W1e_bimg); REQUIRE_PTR(w->W2_bimg); REQUIRE_PTR(w->W3_bimg); }
+  if (prec == PREC_X3) { REQUIRE_PTR(w->W1e_ximg); REQUIRE_PTR(w->W2_ximg); REQUIRE_PTR(w->W3_ximg); }
+  a.W1_img = pick_img(prec, w->W1e_img, w->W1e_bimg, w->W1e_ximg); a.W2_img = pick_img(prec, w->W2_img, w->W2_bimg, w->W2_ximg);
+  a.W3_img = pick_img(prec, w->W3_img, w->W3_bimg, w->W3_ximg);
   a.b2 = w->b2; a.b3 = w->b3;
   a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, S);
   a.tail.head_w = head_w; a.tail.head_b = head_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = vocab;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  rc = launch_edge_tail<MODE_DEC_MSG>(a, bf, (hipStream_t)stream);
+  rc = launch_edge_tail<MODE_DEC_MSG>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -1118,6 +1176,8 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   const size_t half = namp_workspace_bytes(B, B, N, K);
   REQUIRE(ws_bytes >= 2 * half, "namp_encdec_fwd: workspace too small (%zu bytes, need 2 x namp_workspace_bytes = %zu)", ws_bytes, 2 * half);
   const bool bf = (w->enc[0].flags & NAMP_FLAG_BF16) != 0 || (w->dec[0].flags & NAMP_FLAG_BF16) != 0;
+  const int prec = prec_of(w->enc[0].flags);
+  REQUIRE(prec == prec_of(w->dec[0].flags), "namp_encdec_fwd: encoder and decoder layers must use the same precision");
   if (bf && E && G > NAMP_FUSED_TAIL_MAX_RESIDUES && edge_geom(G, K).grid > 2 * device_cus())
     return encdec_bf16_storage(w, V, E, E_idx, mask, S, rank, h_V, h_E, log_probs, logits, ws, ws_bytes, B, N, K, stream);
   if (G > NAMP_FUSED_TAIL_MAX_RESIDUES || bf || w->n_dec + 4 > 8) {
@@ -1164,24 +1224,29 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
     if ((rc = check_proj(__func__, pe, np, S))) return rc;
     EdgeArgs a = {};
     a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.Pa = P[tm]; a.Pj0 = P[tm + 1];
-    a.W1_img = L->W1b_img; a.W2_img = L->W2_img; a.W3_img = L->W3_img; a.b2 = L->b2; a.b3 = L->b3;
+    a.W1_img = pick_img(prec, L->W1b_img, nullptr, L->W1b_ximg); a.W2_img = pick_img(prec, L->W2_img, nullptr, L->W2_ximg);
+    a.W3_img = pick_img(prec, L->W3_img, nullptr, L->W3_ximg); a.b2 = L->b2; a.b3 = L->b3;
+    REQUIRE_PTR(a.W1_img); REQUIRE_PTR(a.W2_img); REQUIRE_PTR(a.W3_img);
     a.G = a.G_enc = G; a.N = N; a.K = K;
     fill_tail(a.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur], mask, out,
               pe, np, S);
     if (l == 0 && E) {      // h_E = W_e.E + b_e (model_utils.py:89) in front of the first message phase
-      a.hE = E; a.hE_out = h_E; a.eW1_img = w->We_img; a.eb2 = w->We_b;
+      a.hE = E; a.hE_out = h_E; a.eW1_img = pick_img(prec, w->We_img, nullptr, w->We_ximg); a.eb2 = w->We_b;
+      REQUIRE_PTR(a.eW1_img);
       ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
-      rc = launch_edge_tail_fused<MODE_ENC_MSG, PRE_EMBED>(a, s);
+      rc = launch_edge_tail_fused<MODE_ENC_MSG, PRE_EMBED>(a, prec, s);
     } else if (l == 0) {
       ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
-      rc = launch_edge_tail<MODE_ENC_MSG>(a, false, s);
+      rc = launch_edge_tail<MODE_ENC_MSG>(a, prec, s);
     } else {
       const NampEncLayerW* Lp = &w->enc[l - 1];
       a.hE_out = h_E; a.ePa = P[tp]; a.ePj = P[tp + 1];
-      a.eW1_img = Lp->W11b_img; a.eW2_img = Lp->W12_img; a.eW3_img = Lp->W13_img; a.eb2 = Lp->b12; a.eb3 = Lp->b13;
+      a.eW1_img = pick_img(prec, Lp->W11b_img, nullptr, Lp->W11b_ximg); a.eW2_img = pick_img(prec, Lp->W12_img, nullptr, Lp->W12_ximg);
+      a.eW3_img = pick_img(prec, Lp->W13_img, nullptr, Lp->W13_ximg); a.eb2 = Lp->b12; a.eb3 = Lp->b13;
+      REQUIRE_PTR(a.eW1_img); REQUIRE_PTR(a.eW2_img); REQUIRE_PTR(a.eW3_img);
       a.ln_g = Lp->ln3_g; a.ln_b = Lp->ln3_b;
       ProfScope prof_(NAMP_KIND_ENC_EDGE_MESSAGE, s);
-      rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, s);
+      rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, prec, s);
     }
     if (rc) return rc;
     CHECK_LAUNCH();
@@ -1210,16 +1275,19 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
       EdgeArgs a = {};
       a.hE = h_E; a.hE_out = h_E; a.E_idx = E_idx; a.rank = rank; a.Pa = PA[0]; a.Pj0 = PB[0]; a.Pj1 = Pfw[0];
       a.ePa = P[te_last]; a.ePj = P[te_last + 1];
-      a.eW1_img = Lp->W11b_img; a.eW2_img = Lp->W12_img; a.eW3_img = Lp->W13_img; a.eb2 = Lp->b12; a.eb3 = Lp->b13;
+      a.eW1_img = pick_img(prec, Lp->W11b_img, nullptr, Lp->W11b_ximg); a.eW2_img = pick_img(prec, Lp->W12_img, nullptr, Lp->W12_ximg);
+      a.eW3_img = pick_img(prec, Lp->W13_img, nullptr, Lp->W13_ximg); a.eb2 = Lp->b12; a.eb3 = Lp->b13;
       a.ln_g = Lp->ln3_g; a.ln_b = Lp->ln3_b;
-      a.W1_img = D->W1e_img; a.W2_img = D->W2_img; a.W3_img = D->W3_img; a.b2 = D->b2; a.b3 = D->b3;
+      a.W1_img = pick_img(prec, D->W1e_img, nullptr, D->W1e_ximg); a.W2_img = pick_img(prec, D->W2_img, nullptr, D->W2_ximg);
+      a.W3_img = pick_img(prec, D->W3_img, nullptr, D->W3_ximg); a.b2 = D->b2; a.b3 = D->b3;
+      REQUIRE_PTR(a.eW1_img); REQUIRE_PTR(a.eW2_img); REQUIRE_PTR(a.eW3_img); REQUIRE_PTR(a.W1_img); REQUIRE_PTR(a.W2_img); REQUIRE_PTR(a.W3_img);
       a.G = a.G_enc = G; a.N = N; a.K = K;
       if ((rc = check_proj(__func__, pn, np, S))) return rc;
       fill_tail(a.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin, mask, out,
                 pn, np, S);
       if (last) { a.tail.head_w = w->Wout_w; a.tail.head_b = w->Wout_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = w->vocab; }
       ProfScope prof_(NAMP_KIND_ENC_EDGE_DEC_MESSAGE, s);
-      rc = launch_edge_tail_fused<MODE_DEC_MSG>(a, s);
+      rc = launch_edge_tail_fused<MODE_DEC_MSG>(a, prec, s);
       if (rc) return rc;
       CHECK_LAUNCH();
     }

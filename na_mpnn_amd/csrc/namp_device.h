@@ -151,6 +151,50 @@ __device__ __forceinline__ void chain_gemm_bf16(f4 (&acc)[8], const f4 (&x)[8], 
   }
 }
 
+// ---- split-bf16 ("bf16x3") evaluation of an fp32 GEMM -------------------------------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950, so an fp32-accurate product is cheaper as THREE bf16 products of
+// split operands:  x = x_hi + x_mid + O(2^-16 x)  with x_hi = bf16(x), x_mid = bf16(x - x_hi)  (likewise W), and
+//      W . x  ~=  W_hi.x_hi + W_hi.x_mid + W_mid.x_hi          (dropped terms are O(2^-16) relative, fp32 accumulation).
+// 96 bf16 MFMAs (1,536 pipe cycles) replace 256 fp32 MFMAs (8,192) per 16x128x128 tile GEMM.  End to end on the N=1000
+// golden the log-probs move by 3.1e-5 (bar: 1e-3) and every arg-max is unchanged — same order as the 1e-5 the exact-fp32
+// build differs from the CPU reference by.  The "x3 image" of a block is its bf16 fragment image of W_hi followed by the
+// one of W_mid: 2 x 32 KiB = the size of the fp32 image, so the LDS ring and its DMA schedule are unchanged.
+// The register chain carries over as in the bf16 mode (k(s,g,j) = 32s + 16(j>>2) + 4g + (j&3)).
+template <bool FLIP, bool ACT>
+__device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const f4 a = ACT ? gelu4(x[2 * s]) : x[2 * s], b = ACT ? gelu4(x[2 * s + 1]) : x[2 * s + 1];
+    bf8 hi, mid;
+    hi[0] = (__bf16)a.x; hi[1] = (__bf16)a.y; hi[2] = (__bf16)a.z; hi[3] = (__bf16)a.w;
+    hi[4] = (__bf16)b.x; hi[5] = (__bf16)b.y; hi[6] = (__bf16)b.z; hi[7] = (__bf16)b.w;
+    mid[0] = (__bf16)(a.x - (float)hi[0]); mid[1] = (__bf16)(a.y - (float)hi[1]);
+    mid[2] = (__bf16)(a.z - (float)hi[2]); mid[3] = (__bf16)(a.w - (float)hi[3]);
+    mid[4] = (__bf16)(b.x - (float)hi[4]); mid[5] = (__bf16)(b.y - (float)hi[5]);
+    mid[6] = (__bf16)(b.z - (float)hi[6]); mid[7] = (__bf16)(b.w - (float)hi[7]);
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) {
+      const bf8 wh = w[(s * 8 + tn) * 64], wm = w[(NAMP_BIMG_BYTES / 16) + (s * 8 + tn) * 64];
+      if (FLIP) {
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid, wh, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wm, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh, acc[tn], 0, 0, 0);
+      } else {
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mid, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[tn], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// one 128 x 128 tile GEMM of the edge kernels out of a 64 KiB LDS slot: exact fp32 MFMA or the split-bf16 form
+template <bool X3, bool FLIP, bool ACT>
+__device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {
+  if constexpr (X3) chain_gemm_x3<FLIP, ACT>(acc, x, (const bf8*)w);
+  else chain_gemm<8, 8, FLIP, ACT>(acc, x, w, 8);
+}
+
 // Same contraction with the weight image streamed straight from global memory (L2 / L1 resident):
 // fragments of step tk+1 are requested before the MFMAs of step tk issue, so one L2 round trip is
 // always covered by 4*NTN MFMAs.  Used where each fragment is consumed once per wave or where the

@@ -29,6 +29,18 @@ __global__ void pack_image_bf16_kernel(const float* __restrict__ W, int ld, int 
   img[e] = (__bf16)W[(size_t)n * ld + col0 + k];
 }
 
+// x3 image (namp_device.h, chain_gemm_x3): bf16 fragment image of W_hi = bf16(W), then the one of W_mid = bf16(W - W_hi)
+__global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 128 * 128) return;
+  const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 7, s = e >> 12;
+  const int n = 16 * tn + (lane & 15), k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  const float v = W[(size_t)n * ld + col0 + k];
+  const __bf16 hi = (__bf16)v;
+  img[e] = hi;
+  img[128 * 128 + e] = (__bf16)(v - (float)hi);
+}
+
 // ------------------------------------------------------------------------------------------
 // gather_cat_kernel — a1 + a3: out[row] = [ nbrs[row][0:C1] | nodes[b*N + idx[row]][0:C2] ]
 // (reference gather_nodes / cat_neighbors_nodes, inference/model_utils.py:713-732).
@@ -517,9 +529,14 @@ struct EdgeArgs {
 //   PRE_EDGE  — the previous layer's edge update (h_E <- LN3(h_E + MLP'), see EdgeArgs);
 //   PRE_EMBED — h_E = W_e . E + b_e (eW1_img / eb2), model_utils.py:89, for the first EncLayer.
 enum { PRE_NONE = 0, PRE_EMBED = 1, PRE_EDGE = 3 };
-template <int MODE, int TAIL, bool BF16 = false, int PRE = PRE_NONE>
+// PREC: how the per-edge 128 x 128 GEMMs are evaluated — PREC_F32 exact fp32 MFMA; PREC_X3 split-bf16 (fp32-equivalent
+// to ~2^-16, the default parity mode: namp_device.h chain_gemm_x3); PREC_BF16 plain bf16 (throughput mode).
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_X3 = 2 };
+template <int MODE, int TAIL, int PREC = PREC_F32, int PRE = PRE_NONE>
 __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
-  static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32 message + tail only");
+  constexpr bool BF16 = (PREC == PREC_BF16);
+  constexpr bool X3 = (PREC == PREC_X3);
+  static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32-class message + tail only");
   constexpr bool FUSE = (PRE == PRE_EDGE);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
@@ -624,19 +641,19 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     dma_to_lds(buf1, a.eW1_img, 64, wave, nwaves, lane);
     dma_to_lds(buf0, a.eW2_img, 64, wave, nwaves, lane);
     wait_dma_and_sync();
-    chain_gemm<8, 8, false>(acc, x, w1, 8);
+    gemm128<X3, false, false>(acc, x, w1);
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
     __syncthreads();                                      // every wave is done with buf1 (eW1)
     dma_to_lds(buf1, a.eW3_img, 64, wave, nwaves, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) pjv[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false, true>(pjv, acc, w0, 8);       // pjv = edge-MLP layer-2 pre-activations
+    gemm128<X3, false, true>(pjv, acc, w0);       // pjv = edge-MLP layer-2 pre-activations
     wait_dma_and_sync();                                  // eW3 landed; buf0 (eW2) is free
     dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.eb3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false, true>(acc, pjv, w1, 8);
+    gemm128<X3, false, true>(acc, pjv, w1);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] += acc[t];           // residual
     layernorm_row_T(x, a.ln_g, a.ln_b, g);                // x = updated h_E row: stored, and the message input
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
       wait_dma_and_sync();
-      chain_gemm<8, 8, false>(acc, x, w1, 8);
+      gemm128<X3, false, false>(acc, x, w1);
 #pragma unroll
       for (int t = 0; t < 8; ++t) x[t] = acc[t];
       if (valid) {
@@ -696,7 +713,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   wait_dma_and_sync();
   }
   // ---- layer 1 (T): acc = Pa + W1b . h_E (+ Pj afterwards)
-  chain_gemm<8, 8, false>(acc, x, w0, 8);
+  gemm128<X3, false, false>(acc, x, w0);
 
   if (MODE != MODE_EMBED) {
 #pragma unroll
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   // ---- layer 2 (T); GELU of layer 1 is applied k-tile by k-tile inside the MFMA loop
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false, true>(x, acc, w1, 8);           // x = layer-2 pre-activations
+  gemm128<X3, false, true>(x, acc, w1);           // x = layer-2 pre-activations
   wait_dma_and_sync();                                    // W3 has landed in buf0
   }
   }
@@ -732,7 +749,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
     if (BF16) chain_gemm_bf16<false, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
-    else      chain_gemm<8, 8, false, true>(acc, x, w0, 8);
+    else      gemm128<X3, false, true>(acc, x, w0);
     if (a.drop_thresh) {                                           // training forward: dropout3 on the message
       const uint32_t key = drop_row_key(a.drop_seed, erow);
 #pragma unroll
@@ -759,7 +776,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       acc[t] = (f4){b, b, b, b};
     }
     if (BF16) chain_gemm_bf16<true, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
-    else      chain_gemm<8, 8, true, true>(acc, x, w0, 8);
+    else      gemm128<X3, true, true>(acc, x, w0);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnam
 NAMP_ABI_VERSION = 1
 NAMP_MAX_LAYERS = 8
 NAMP_FLAG_BF16 = 1
+NAMP_FLAG_X3 = 2
 
 c_fp = C.c_void_p   # const float*  (device)
 c_ip = C.c_void_p   # const int32_t* (device)
@@ -30,14 +31,15 @@ class NampEncLayerW(C.Structure):
                         "W11a_img", "W11b_img", "W11c_img", "b11", "W12_img", "b12", "W13_img", "b13",
                         "Win_img", "b_in", "Wout_img", "b_out",
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
-                        "W1b_bimg", "W2_bimg", "W3_bimg", "W11b_bimg", "W12_bimg", "W13_bimg"]) + [("flags", C.c_int64)]
+                        "W1b_bimg", "W2_bimg", "W3_bimg", "W11b_bimg", "W12_bimg", "W13_bimg",
+                        "W1b_ximg", "W2_ximg", "W3_ximg", "W11b_ximg", "W12_ximg", "W13_ximg"]) + [("flags", C.c_int64)]
 
 
 class NampDecLayerW(C.Structure):
     _fields_ = _fields(["W1a_img", "W1e_img", "W1s_img", "W1v_img", "b1", "tok",
                         "W2_img", "b2", "W3_img", "b3", "Win_img", "b_in", "Wout_img", "b_out",
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b",
-                        "W1e_bimg", "W2_bimg", "W3_bimg"]) + [("flags", C.c_int64)]
+                        "W1e_bimg", "W2_bimg", "W3_bimg", "W1e_ximg", "W2_ximg", "W3_ximg"]) + [("flags", C.c_int64)]
 
 
 class NampFeatW(C.Structure):
@@ -49,7 +51,7 @@ class NampModelW(C.Structure):
                 ("Wv_img", c_fp), ("Wv_b", c_fp), ("We_img", c_fp), ("We_b", c_fp),
                 ("Wout_w", c_fp), ("Wout_b", c_fp),
                 ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS),
-                ("feat", NampFeatW)]
+                ("feat", NampFeatW), ("We_ximg", c_fp)]
 
 
 class NampProj(C.Structure):
@@ -63,6 +65,7 @@ _PROTOTYPES = {
     "namp_last_error": (C.c_char_p, []),
     "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
     "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
+    "namp_pack_image_x3": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
     "namp_gather_rows_f32": (i32, [c_fp, c_ip, c_fp, C.c_long, i32, i32, i32, vp]),
     "namp_gather_edges_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),

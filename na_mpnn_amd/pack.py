@@ -46,7 +46,11 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     def bimg(name, key, col0):                      # 32 KiB bf16 image = 8192 float slots
         add(name, H * H // 2, ("bimg", key, col0))
 
+    def ximg(name, key, col0):                      # 64 KiB x3 image (bf16 hi | bf16 mid) = 16384 float slots
+        add(name, H * H, ("ximg", key, col0))
+
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
+    ximg("We_ximg", "W_e.weight", 0)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
     # featuriser (ProteinFeaturesNA): 5200-wide edge embedding as a 325-k-tile image
@@ -72,6 +76,8 @@ def plan(n_enc: int, n_dec: int, vocab: int):
             vec(p + f"ln{i}_g", q + f"norm{i}.weight", H); vec(p + f"ln{i}_b", q + f"norm{i}.bias", H)
         bimg(p + "W1b_bimg", q + "W1.weight", H); bimg(p + "W2_bimg", q + "W2.weight", 0); bimg(p + "W3_bimg", q + "W3.weight", 0)
         bimg(p + "W11b_bimg", q + "W11.weight", H); bimg(p + "W12_bimg", q + "W12.weight", 0); bimg(p + "W13_bimg", q + "W13.weight", 0)
+        ximg(p + "W1b_ximg", q + "W1.weight", H); ximg(p + "W2_ximg", q + "W2.weight", 0); ximg(p + "W3_ximg", q + "W3.weight", 0)
+        ximg(p + "W11b_ximg", q + "W11.weight", H); ximg(p + "W12_ximg", q + "W12.weight", 0); ximg(p + "W13_ximg", q + "W13.weight", 0)
     for l in range(n_dec):
         p, q = f"dec{l}.", f"decoder_layers.{l}."
         for nm, c0 in (("W1a", 0), ("W1e", H), ("W1s", 2 * H), ("W1v", 3 * H)):
@@ -85,6 +91,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         for i in (1, 2):
             vec(p + f"ln{i}_g", q + f"norm{i}.weight", H); vec(p + f"ln{i}_b", q + f"norm{i}.bias", H)
         bimg(p + "W1e_bimg", q + "W1.weight", H); bimg(p + "W2_bimg", q + "W2.weight", 0); bimg(p + "W3_bimg", q + "W3.weight", 0)
+        ximg(p + "W1e_ximg", q + "W1.weight", H); ximg(p + "W2_ximg", q + "W2.weight", 0); ximg(p + "W3_ximg", q + "W3.weight", 0)
     return items, off
 
 
@@ -107,6 +114,7 @@ class PackedWeights:
         self.n_enc, self.n_dec, self.vocab = n_enc, n_dec, vocab
         if n_enc > hip.NAMP_MAX_LAYERS or n_dec > hip.NAMP_MAX_LAYERS:
             raise ValueError(f"at most {hip.NAMP_MAX_LAYERS} encoder/decoder layers are supported")
+        self.precision = "x3"            # per-edge GEMMs: "x3" split-bf16 (fp32-equivalent, default) | "fp32" exact MFMA | "bf16"
         self.items, total = plan(n_enc, n_dec, vocab)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.repack(state_dict)
@@ -139,6 +147,10 @@ class PackedWeights:
                           f"pack_image({name})")
             elif recipe[0] == "vec":
                 self.flat[off:off + n].copy_(src(recipe[1]).reshape(-1))
+            elif recipe[0] == "ximg":
+                w = src(recipe[1])
+                hip.check(L.namp_pack_image_x3(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
+                          f"pack_image_x3({name})")
             elif recipe[0] == "bimg":
                 w = src(recipe[1])
                 hip.check(L.namp_pack_image_bf16(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
@@ -158,7 +170,7 @@ class PackedWeights:
         m.n_enc, m.n_dec, m.vocab, m.reserved = self.n_enc, self.n_dec, self.vocab, 0
         for f in ("Wv_img", "Wv_b", "We_img", "We_b", "Wout_w", "Wout_b"):
             setattr(m, f, self.addr(f))
-        flags = hip.NAMP_FLAG_BF16 if getattr(self, "precision", "fp32") == "bf16" else 0
+        flags = {"bf16": hip.NAMP_FLAG_BF16, "x3": hip.NAMP_FLAG_X3, "fp32": 0}[getattr(self, "precision", "x3")]
         for l in range(self.n_enc):
             for f, _ in hip.NampEncLayerW._fields_:
                 setattr(m.enc[l], f, flags if f == "flags" else self.addr(f"enc{l}.{f}"))
@@ -167,12 +179,13 @@ class PackedWeights:
                 setattr(m.dec[l], f, flags if f == "flags" else self.addr(f"dec{l}.{f}"))
         for f, _ in hip.NampFeatW._fields_:
             setattr(m.feat, f, self.addr(f"feat.{f}"))
+        m.We_ximg = self.addr("We_ximg")
         self.struct = m
 
     def set_precision(self, precision: str):
         """"fp32" (parity mode, default) or "bf16" (per-edge GEMMs in bf16: throughput mode, BASELINE configs[2])."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("x3", "fp32", "bf16"):
+            raise ValueError("precision must be 'x3' (split-bf16, fp32-equivalent: the default), 'fp32' (exact fp32 MFMA) or 'bf16'")
         self.precision = precision
         self._build_struct()
 
