@@ -66,9 +66,23 @@ __device__ __forceinline__ f4 gelu4(f4 v) {
 #ifdef NAMP_ABL_NOGELU
   return v;
 #endif
-  f4 o;
-  o.x = gelu_erf(v.x); o.y = gelu_erf(v.y); o.z = gelu_erf(v.z); o.w = gelu_erf(v.w);
-  return o;
+  // gelu_erf() on four values, written on vectors so that the full-rate part (9 of the 13 operations) can be selected as
+  // packed fp32 (v_pk_mul_f32 / v_pk_fma_f32); the two transcendentals stay per element.  Same operation order per
+  // element as gelu_erf(): bit-identical results.
+  const f4 u = v * 0.84932180028801904f;
+  const f4 au = __builtin_elementwise_abs(u);
+  const f4 nu2 = -(u * u);
+  const f4 d = au * 0.27273943f + 1.0f;
+  f4 e, t;
+  e.x = __builtin_amdgcn_exp2f(nu2.x); e.y = __builtin_amdgcn_exp2f(nu2.y); e.z = __builtin_amdgcn_exp2f(nu2.z); e.w = __builtin_amdgcn_exp2f(nu2.w);
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y); t.z = __builtin_amdgcn_rcpf(d.z); t.w = __builtin_amdgcn_rcpf(d.w);
+  f4 q = t * 1.061405429f + -1.453152027f;
+  q = q * t + 1.421413741f;
+  q = q * t + -0.284496736f;
+  q = q * t + 0.254829592f;
+  const f4 y = -(q * t) * e + 1.0f;
+  const f4 h = v * 0.5f;
+  return __builtin_elementwise_abs(h) * y + h;
 }
 
 // acc[tn] (+)= W . x  over TK k-tiles.  `w` points at img[tk0][0][lane]; consecutive
