@@ -267,7 +267,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  * tables, logits, loss) are [B*N,128]-sized and stay with the caller's autograd; these entry points carry the
  * per-edge work.  Activations are recomputed in the backward pass, the reference's torch.utils.checkpoint policy
  * (na_model_utils.py:606,637).  mode: 0 = EncLayer message, 1 = DecLayer message, 2 = EncLayer edge update.
- * All images are fp32 fragment images (namp_pack_image); "t" images are those of the transposed blocks.
+ * All images are fp32 fragment images (namp_pack_image) — or, with x3 != 0, x3 images (namp_pack_image_x3: the GEMMs then
+ * run as split-bf16 products like the forward path's default mode); "t" images are those of the transposed blocks.
  *
  * namp_train_edge_fwd: the forward of one per-edge MLP from raw images.  mode 0/1: out = partial sums
  *   [B*N][ceil(K/16)][128] (as namp_enc_message / namp_dec_message; B_dec == B_enc); mode 2: out = per edge [B*N*K][128]
@@ -289,7 +290,7 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3_img, const float* b2, const float* b3,
                         const float* ln_g, const float* ln_b, float drop_p, uint32_t drop_seed, float* out,
-                        int B, int N, int K, void* stream);
+                        int x3, int B, int N, int K, void* stream);
 /* The whole EncLayer edge update with its tail (na_model_utils.py:236-240), forward = namp_train_edge_fwd(mode 2, ln_g, ln_b,
  * drop_p, drop_seed): out = LayerNorm3(h_E + dropout(message)); the dropout mask is a counter-based hash of (drop_seed, edge
  * row, channel), regenerated — not stored — by the backward launch.  Backward: g_out = dL/d(out) per edge row; recomputes
@@ -302,19 +303,19 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
                                const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
                                const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
                                uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int B, int N, int K, void* stream);
+                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int x3, int B, int N, int K, void* stream);
 int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int B, int N, int K, void* stream);
+                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int x3, int B, int N, int K, void* stream);
 /* dL/dPj = transpose of the neighbour gather, as a gather over the reverse adjacency: rev_edge [B*N*K] = edge ids sorted by
  * the table row they gathered (global row b*N + E_idx), rev_off [B*N+1] their offsets per row; out0[j] = sum of G1[e] over the
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */
 int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                             float* out0, float* out1, int G, void* stream);
 int namp_train_wgrad_chunks(long rows);
-int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream);
+int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long rows, float* dW_part, float* db_part, void* stream);
 int namp_train_feat_wgrad_chunks(long edges);
 long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_ws (atom-presence words per 64-edge tile) */
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,

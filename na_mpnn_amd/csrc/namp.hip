@@ -517,7 +517,7 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3_img, const float* b2, const float* b3,
                         const float* ln_g, const float* ln_b, float drop_p, uint32_t drop_seed, float* out,
-                        int B, int N, int K, void* stream) {
+                        int x3, int B, int N, int K, void* stream) {
   REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_fwd: drop_p=%g must be in [0,1)", (double)drop_p);
   REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "namp_train_edge_fwd: ln_g and ln_b go together");
   REQUIRE(mode == 2 || (ln_g == nullptr && drop_p == 0.f), "namp_train_edge_fwd: LayerNorm3 / dropout belong to mode 2");
@@ -534,13 +534,14 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.b2 = b2; a.b3 = b3;
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == MODE_ENC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_ENC_MESSAGE, s); rc = launch_edge<MODE_ENC_MSG, 0>(a, s); }
-  else if (mode == MODE_DEC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_DEC_MESSAGE, s); rc = launch_edge<MODE_DEC_MSG, 0>(a, s); }
+  const int prec = x3 ? PREC_X3 : PREC_F32;
+  if (mode == MODE_ENC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_ENC_MESSAGE, s); rc = launch_edge_prec<MODE_ENC_MSG, 0>(a, prec, s); }
+  else if (mode == MODE_DEC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_DEC_MESSAGE, s); rc = launch_edge_prec<MODE_DEC_MSG, 0>(a, prec, s); }
   else {
     a.hE_out = out; a.ln_g = ln_g; a.ln_b = ln_b;                                 // ln_g null: bare message
     if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
     ProfScope p_(NAMP_KIND_ENC_EDGE, s);
-    rc = launch_edge<MODE_ENC_EDGE, 0>(a, s);
+    rc = launch_edge_prec<MODE_ENC_EDGE, 0>(a, prec, s);
   }
   if (rc) return rc;
   CHECK_LAUNCH();

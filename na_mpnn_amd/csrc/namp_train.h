@@ -78,7 +78,8 @@ struct EdgeBwdArgs {
 // One wave = 16 consecutive edge rows of the flat [G*K] edge list (tiles may straddle residues: every
 // per-row operand is gathered per lane anyway).  8 waves per workgroup share the 2 x 64 KiB LDS weight ring;
 // the five images W1, W2, W3^T, W2^T, W1^T stream through it by LDS-DMA one GEMM ahead of their use.
-template <int MODE>
+// X3: the six / five GEMMs as split-bf16 products (chain_gemm_x3; the images are then x3 images), like the forward kernels
+template <int MODE, bool X3>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
   wait_dma_and_sync();
   // ---- recompute: z1, z2
-  chain_gemm<8, 8, false>(z1, x, w0, 8);
+  gemm128<X3, false, false>(z1, x, w0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
   __syncthreads();                                            // everyone is done with W1
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  chain_gemm<8, 8, false>(z2, x, w1, 8);
+  gemm128<X3, false, false>(z2, x, w1);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z2[t]);      // x <- a2 (only stored, for dW3), z2 <- gelu'(z2)
   // Row stores are issued right AFTER a ring barrier, never right before one: s_waitcnt vmcnt(0) also waits for store
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     f4 z3[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    chain_gemm<8, 8, false>(z3, x, w0, 8);
+    gemm128<X3, false, false>(z3, x, w0);
     asm volatile("" ::: "memory");       // the row loads below have kernel-constant addresses: do not hoist them (96 VGPRs) over the GEMMs
     const uint32_t key = drop_row_key(a.drop_seed, e);
     const float* hsrc = a.hE + e * NAMP_H + 4 * g;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   f4 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, wA, 8);
+  gemm128<X3, false, false>(acc, gr, wA);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
   wait_dma_and_sync();                                        // W2^T landed in slot B; slot A is free
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   // ---- g1 = (W2^T g2) * gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, wB, 8);
+  gemm128<X3, false, false>(acc, gr, wB);
   if (MODE == BWD_EDGE_LN) {
     const float* p1 = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t)
     acc[t] = (MODE == BWD_EDGE_LN && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm<8, 8, false>(acc, gr, wA, 8);
+  gemm128<X3, false, false>(acc, gr, wA);
   if (valid) {
     float* d = a.g_hE + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -406,6 +407,89 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
     for (int q = 0; q < 2; ++q) {
       const float s = xg_sum(bsum[q]);
       if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * (2 * wave + q) + n] = s;
+    }
+  }
+}
+
+// wgrad_x3_kernel: the same row contraction as split-bf16 products (namp_device.h, chain_gemm_x3): k-slot (g, j) of
+// v_mfma_f32_16x16x32_bf16 stands for row 8g + j of a 32-row step, so lane (n, g) reads column n of its 8 rows of G (A
+// operand) and of A (B operand), splits each value into bf16 hi + mid on the fly and issues hi*hi + hi*mid + mid*hi:
+// 48 bf16 MFMAs (768 pipe cycles) per 32 rows and wave instead of 128 fp32 MFMAs (4,096).  Waves form a 2 x 2 grid over the
+// 128 x 128 output (4 x 4 tiles each), which also halves the operand loads per wave.
+__device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& mid) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)v[j]; mid[j] = (__bf16)(v[j] - (float)hi[j]); }
+}
+
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
+                                                       long rows_per_chunk, float* __restrict__ dW_part,
+                                                       float* __restrict__ db_part) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int to0 = 4 * (wave >> 1), tc0 = 4 * (wave & 1);
+  const long r_begin = (long)blockIdx.x * rows_per_chunk;
+  long r_end = r_begin + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  f4 acc[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float gv[4][8], av[4][8], gn[4][8], an[4][8];
+  auto load = [&](long r0, float (&go)[4][8], float (&ao)[4][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long row = r0 + 8 * g + j;
+      const bool ok = row < r_end;
+      const long rr = ok ? row : r_begin;
+      const float* gp = G + rr * NAMP_H + 16 * to0 + n;
+      const float* ap = A + rr * NAMP_H + 16 * tc0 + n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float v = gp[16 * q]; go[q][j] = ok ? v : 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ao[t][j] = ap[16 * t];
+    }
+  };
+  if (r_begin < r_end) load(r_begin, gv, av);
+  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+    const bool more = r0 + 32 < r_end;
+    if (more) load(r0 + 32, gn, an);
+    bf8 gh[4], gm[4], ah[4], am[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      split8(gv[q], gh[q], gm[q]);
+      split8(av[q], ah[q], am[q]);
+      bsum[q] += ((gv[q][0] + gv[q][1]) + (gv[q][2] + gv[q][3])) + ((gv[q][4] + gv[q][5]) + (gv[q][6] + gv[q][7]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[q], ah[t], acc[q][t], 0, 0, 0);
+        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], am[t], acc[q][t], 0, 0, 0);
+        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], ah[t], acc[q][t], 0, 0, 0);
+      }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gv[q][j] = gn[q][j]; av[q][j] = an[q][j]; }
+    }
+  }
+  float* out = dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * (to0 + q) + 4 * g + r) * NAMP_H + 16 * (tc0 + t) + n] = acc[q][t][r];
+  if (db_part && (wave & 1) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float s = xg_sum(bsum[q]);
+      if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * (to0 + q) + n] = s;
     }
   }
 }

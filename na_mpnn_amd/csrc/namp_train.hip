@@ -45,10 +45,10 @@ int ensure_attributes() {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NAMP_IMG_BYTES);
       if (e != hipSuccess) g_attr_err = e;
     };
-    set((const void*)edge_chain_bwd_kernel<BWD_ENC_MSG>);
-    set((const void*)edge_chain_bwd_kernel<BWD_DEC_MSG>);
-    set((const void*)edge_chain_bwd_kernel<BWD_ROWS>);
-    set((const void*)edge_chain_bwd_kernel<BWD_EDGE_LN>);
+    set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, true>));
+    set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, true>));
+    set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, true>));
+    set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, true>));
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -63,7 +63,7 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int B, int N, int K, void* stream) {
+                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int x3, int B, int N, int K, void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
@@ -84,9 +84,14 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ENC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
-  else if (mode == 1) hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_DEC_MSG>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
-  else hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_ROWS>, dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);
+#define NAMP_LAUNCH_BWD(M)                                                                                              \
+  do {                                                                                                                    \
+    if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);        \
+    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, false>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);          \
+  } while (0)
+  if (mode == 0) NAMP_LAUNCH_BWD(BWD_ENC_MSG);
+  else if (mode == 1) NAMP_LAUNCH_BWD(BWD_DEC_MSG);
+  else NAMP_LAUNCH_BWD(BWD_ROWS);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -100,7 +105,7 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
                                const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
                                const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
                                uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int B, int N, int K, void* stream) {
+                               float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int x3, int B, int N, int K, void* stream) {
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
   REQUIRE_PTR(W3t_img); REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(ln_g);
   REQUIRE_PTR(g_out); REQUIRE_PTR(A1); REQUIRE_PTR(A2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(G3); REQUIRE_PTR(g_hE);
@@ -117,8 +122,11 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.g_Pa = g_Pa; a.g_Pj0 = g_Pc; a.dgb_part = dgb_part;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
-  hipLaunchKernelGGL(edge_chain_bwd_kernel<BWD_EDGE_LN>, dim3(namp_train_edge_update_bwd_groups(B, N, K)), dim3(512),
-                     2 * NAMP_IMG_BYTES, (hipStream_t)stream, a);
+  {
+    const int grid = namp_train_edge_update_bwd_groups(B, N, K);
+    hipStream_t s = (hipStream_t)stream;
+    NAMP_LAUNCH_BWD(BWD_EDGE_LN);
+  }
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -142,14 +150,16 @@ int namp_train_wgrad_chunks(long rows) {
   return (int)n;
 }
 
-int namp_train_wgrad(const float* G, const float* A, int gelu_A, long rows, float* dW_part, float* db_part, void* stream) {
+int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long rows, float* dW_part, float* db_part, void* stream) {
+  REQUIRE(!(gelu_A && x3), "namp_train_wgrad: the split-bf16 form takes activations (gelu_A = 0)");
   REQUIRE_PTR(G); REQUIRE_PTR(A); REQUIRE_PTR(dW_part);
   REQUIRE(rows >= 1, "namp_train_wgrad: rows=%ld", rows);
   const int nchunk = namp_train_wgrad_chunks(rows);
   long per = (rows + nchunk - 1) / nchunk;
-  per = (per + 15) / 16 * 16;
+  per = (per + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
-  if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  if (x3) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  else if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -94,13 +94,13 @@ _PROTOTYPES = {
     "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                   c_ip, c_ip, c_fp, c_fp,
                                   C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
-    "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, vp]),
+    "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, i32, vp]),
     "namp_train_edge_update_bwd_groups": (i32, [i32, i32, i32]),
-    "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 10 + [i32, i32, i32, vp]),
-    "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 19 + [i32, i32, i32, vp]),
+    "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 10 + [i32, i32, i32, i32, vp]),
+    "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 19 + [i32, i32, i32, i32, vp]),
     "namp_train_scatter_rows": (i32, [c_fp, c_ip, c_ip, vp, c_fp, c_fp, i32, vp]),
     "namp_train_wgrad_chunks": (i32, [C.c_long]),
-    "namp_train_wgrad": (i32, [c_fp, c_fp, i32, C.c_long, c_fp, c_fp, vp]),
+    "namp_train_wgrad": (i32, [c_fp, c_fp, i32, i32, C.c_long, c_fp, c_fp, vp]),
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
     "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, vp]),

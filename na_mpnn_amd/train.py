@@ -24,9 +24,27 @@ H = 128
 ENC_MSG, DEC_MSG, ENC_EDGE = 0, 1, 2
 
 
+# Evaluation of the per-edge GEMMs of the training kernels: True = split-bf16 products (fp32-equivalent to ~2^-16, the
+# default, like the inference path's "x3" mode); False = exact fp32 MFMA.  Set through forward_train from
+# model.message_precision ("fp32" selects the exact form).
+X3 = True
+
+
 def _image(block):
-    """Fragment image of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear weight."""
+    """Fragment image (fp32, or x3 when X3) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
+    weight."""
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
+    img = torch.empty(H * H, dtype=torch.float32, device=block.device)
+    if X3:
+        hip.check(hip.lib().namp_pack_image_x3(block.data_ptr(), block.stride(0), 0, img.data_ptr(), hip.current_stream()),
+                  "pack_image_x3")
+    else:
+        hip.check(hip.lib().namp_pack_image(block.data_ptr(), block.stride(0), 0, H, H, img.data_ptr(), hip.current_stream()),
+                  "pack_image")
+    return img
+
+
+def _image_f32(block):
     img = torch.empty(H * H, dtype=torch.float32, device=block.device)
     hip.check(hip.lib().namp_pack_image(block.data_ptr(), block.stride(0), 0, H, H, img.data_ptr(), hip.current_stream()),
               "pack_image")
@@ -44,7 +62,7 @@ def _wgrad(G, A, gelu_A, want_bias):
     n = L.namp_train_wgrad_chunks(rows)
     dW = torch.empty(n, H, H, device=G.device)
     db = torch.empty(n, H, device=G.device) if want_bias else None
-    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), rows, dW.data_ptr(), hip.ptr(db),
+    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), int(X3 and not gelu_A), rows, dW.data_ptr(), hip.ptr(db),
                                  hip.current_stream()), "train_wgrad")
     return dW.sum(0), (db.sum(0) if want_bias else None)
 
@@ -92,7 +110,7 @@ class _EdgeMLP(torch.autograd.Function):
         hip.check(L.namp_train_edge_fwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
-                                        None, None, 0.0, 0, out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
+                                        None, None, 0.0, 0, out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
         ctx.mode, ctx.rev = mode, rev
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
@@ -116,7 +134,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, B, N, K,
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, int(X3), B, N, K,
                                         hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
@@ -151,7 +169,7 @@ class _EdgeUpdate(torch.autograd.Function):
         hip.check(hip.lib().namp_train_edge_fwd(ENC_EDGE, h_E.data_ptr(), E_idx32.data_ptr(), None, None, None, Pa.data_ptr(),
                                                 Pc.data_ptr(), None, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(),
                                                 b2c.data_ptr(), b3c.data_ptr(), g_.data_ptr(), b_.data_ptr(), float(p), int(seed),
-                                                out.data_ptr(), B, N, K, hip.current_stream()), "train_edge_fwd")
+                                                out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
         ctx.p, ctx.seed, ctx.rev = float(p), int(seed), rev
         ctx.save_for_backward(h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32)
         return out
@@ -175,7 +193,7 @@ class _EdgeUpdate(torch.autograd.Function):
                                                img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
                                                g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
                                                G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
-                                               B, N, K, hip.current_stream()), "train_edge_update_bwd")
+                                               int(X3), B, N, K, hip.current_stream()), "train_edge_update_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
         dW3, db3 = _wgrad(G3, A2, False, True)
@@ -222,7 +240,7 @@ class _EdgeLinear(torch.autograd.Function):
         B, N, K, _ = x.shape
         x = x.contiguous()
         y = torch.empty_like(x)
-        hip.check(hip.lib().namp_edge_embed(_image(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
+        hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
                                             y.data_ptr(), B, N, K, hip.current_stream()), "edge_embed")
         ctx.save_for_backward(x, W)
         return y
@@ -234,7 +252,7 @@ class _EdgeLinear(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty_like(x)
         zero = torch.zeros(H, device=x.device)
-        hip.check(hip.lib().namp_edge_embed(_image_t(W).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, K,
+        hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach().t().contiguous()).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, K,
                                             hip.current_stream()), "edge_embed (dgrad)")
         dW, db = _wgrad(g.view(-1, H), x.view(-1, H), False, True)
         return gx, dW, db
@@ -333,6 +351,8 @@ def _ffn(x, dense):
 
 def forward_train(model, fd, decoding_randn=None):
     """Differentiable ProteinMPNN.forward of the training copy (na_model_utils.py:589-646) -> (log_probs, probs)."""
+    global X3
+    X3 = getattr(model, "message_precision", "x3") != "fp32"
     mask = fd["mask"]
     if not mask.is_cuda:
         raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
