@@ -57,6 +57,10 @@ int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stre
  * golden, bar 1e-3, arg-max unchanged).  The x3 image = bf16 fragment image of W_hi followed by that of W_mid (64 KiB). */
 #define NAMP_FLAG_X3 2
 int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream);     /* [128x128] block -> 64 KiB */
+/* The featuriser's edge_embedding.weight [128 x 5200] (model_utils.py:484) for the split-bf16 form of its GEMM: positional
+ * k-tile as an fp32 fragment tile, then one 48 KiB hi|mid block per group of 6 atom pairs; 128*5200 floats in all, the
+ * size of namp_pack_image's output for the same matrix. */
+int namp_pack_feat_x3(const float* W, int ld, float* img, void* stream);
 
 /* EncLayer parameters (inference/model_utils.py:659-679).  W1/W11 are split by input block:
  * a = h_V_i columns [0,128), b = h_E_ik [128,256), c = h_V_j [256,384). */
@@ -90,6 +94,8 @@ typedef struct NampDecLayerW {
  * 325-k-tile fragment image, embeddings.linear [16 x 66] + bias in plain layout, norm_edges. */
 typedef struct NampFeatW {
   const float *Wedge_img, *pos_w, *pos_b, *ln_g, *ln_b;
+  const float *Wedge_ximg;         /* optional (namp_pack_feat_x3): when set, the 5184 RBF columns of the embedding GEMM run as
+                                      split-bf16 products (and a requested h_E uses We_ximg); Wedge_img may then be NULL */
 } NampFeatW;
 
 typedef struct NampModelW {

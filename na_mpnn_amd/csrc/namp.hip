@@ -142,7 +142,8 @@ void set_lds_attributes() {
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<true>, SAMPLE_LDS);
-  set((const void*)edge_features_kernel, FEAT_LDS);
+  set((const void*)edge_features_kernel<false>, FEAT_LDS);
+  set((const void*)edge_features_kernel<true>, FEAT_LDS);
   set((const void*)knn_kernel, 8192 * 8 + 64);
 }
 
@@ -378,6 +379,14 @@ int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream
   REQUIRE_PTR(W); REQUIRE_PTR(img);
   REQUIRE(ld >= 128 && col0 >= 0 && col0 + 128 <= ld, "namp_pack_image_x3: block [128 x 128] at column %d does not fit ld=%d", col0, ld);
   hipLaunchKernelGGL(pack_image_x3_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_pack_feat_x3(const float* W, int ld, float* img, void* stream) {
+  REQUIRE_PTR(W); REQUIRE_PTR(img);
+  REQUIRE(ld >= 5200, "namp_pack_feat_x3: edge_embedding.weight rows hold 5200 columns, ld=%d", ld);
+  hipLaunchKernelGGL(pack_feat_x3_kernel, dim3((54 * 12288 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, img);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -749,7 +758,9 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
                    size_t ws_bytes, int B, int L, void* stream) {
   REQUIRE(w != nullptr, "namp_featurize: null weights");
   REQUIRE_PTR(X); REQUIRE_PTR(ws); OPTIONAL_PTR(E); OPTIONAL_PTR(h_E);
-  REQUIRE_PTR(w->feat.Wedge_img); REQUIRE_PTR(w->feat.pos_w); REQUIRE_PTR(w->feat.pos_b);
+  OPTIONAL_PTR(w->feat.Wedge_ximg);
+  if (!w->feat.Wedge_ximg) REQUIRE_PTR(w->feat.Wedge_img);
+  REQUIRE_PTR(w->feat.pos_w); REQUIRE_PTR(w->feat.pos_b);
   OPTIONAL_PTR(w->feat.ln_g); OPTIONAL_PTR(w->feat.ln_b);
   REQUIRE((w->feat.ln_g == nullptr) == (w->feat.ln_b == nullptr), "namp_featurize: norm_edges weight and bias go together");
   REQUIRE(w->feat.ln_g || !h_E, "namp_featurize: h_E needs norm_edges (pre-LayerNorm output is E only)");
@@ -763,7 +774,7 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
   int rc = check_dims(__func__, B, L, K);
   if (rc) return rc;
   if ((rc = ensure_attributes())) return rc;
-  if (h_E) { REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }
+  if (h_E) { if (w->feat.Wedge_ximg) REQUIRE_PTR(w->We_ximg); else REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }
   const int G = B * L;
   hipStream_t s = (hipStream_t)stream;
   Carver c(ws, ws_bytes);
@@ -779,12 +790,14 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);
     FeatArgs a = {};
     a.X18 = X18; a.M18 = M18; a.E_idx = E_idx; a.R_idx = R_idx; a.chain = chain_labels;
-    a.Wedge_img = w->feat.Wedge_img; a.pos_w = w->feat.pos_w; a.pos_b = w->feat.pos_b; a.ln_g = w->feat.ln_g; a.ln_b = w->feat.ln_b;
-    a.We_img = h_E ? w->We_img : nullptr; a.We_b = h_E ? w->We_b : nullptr; a.E_out = E; a.hE_out = h_E;
+    const bool x3 = w->feat.Wedge_ximg != nullptr;
+    a.Wedge_img = x3 ? w->feat.Wedge_ximg : w->feat.Wedge_img; a.pos_w = w->feat.pos_w; a.pos_b = w->feat.pos_b; a.ln_g = w->feat.ln_g; a.ln_b = w->feat.ln_b;
+    a.We_img = h_E ? (x3 ? w->We_ximg : w->We_img) : nullptr; a.We_b = h_E ? w->We_b : nullptr; a.E_out = E; a.hE_out = h_E;
     a.G = G; a.L = L; a.K = K;
     const EdgeGeom e = edge_geom(G, K);
     a.TPN = e.tpn;
-    hipLaunchKernelGGL(edge_features_kernel, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    if (x3) hipLaunchKernelGGL(edge_features_kernel<true>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    else hipLaunchKernelGGL(edge_features_kernel<false>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
   }
   CHECK_LAUNCH();
   return NAMP_OK;

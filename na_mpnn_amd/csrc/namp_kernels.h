@@ -41,6 +41,27 @@ __global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int co
   img[128 * 128 + e] = (__bf16)(v - (float)hi);
 }
 
+// Split-bf16 image of edge_embedding.weight [128 x 5200] for edge_features_kernel<true>: the positional k-tile stays an
+// fp32 fragment tile (2048 floats), then one 48 KiB block per RBF chunk c = 3a + bg (6 atom pairs = 3 bf16 K-steps of two
+// pairs): [hi: 3 steps x 8 tn x 64 lanes x 8 bf16][mid: same].  Slot j of lane (m, g) in step s is RBF 4g + (j&3) of pair
+// 2s + (j>>2) — each lane feeds the RBFs it generates for two consecutive atom pairs, no cross-lane traffic.
+__global__ void pack_feat_x3_kernel(const float* __restrict__ W, int ld, float* __restrict__ img) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < 2048) {
+    const int r = e & 3, lane = (e >> 2) & 63, tn = e >> 8;
+    img[e] = W[(size_t)(16 * tn + (lane & 15)) * ld + 4 * (lane >> 4) + r];
+  }
+  if (e >= 54 * 12288) return;
+  const int c = e / 12288, q = e - c * 12288;
+  const int j = q & 7, lane = (q >> 3) & 63, tn = (q >> 9) & 7, st = q >> 12;
+  const int col = 16 * (1 + 6 * c + 2 * st + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+  const float v = W[(size_t)(16 * tn + (lane & 15)) * ld + col];
+  __bf16* blk = (__bf16*)(img + 2048 + (size_t)c * 12288);
+  const __bf16 hi = (__bf16)v;
+  blk[q] = hi;
+  blk[12288 + q] = (__bf16)(v - (float)hi);
+}
+
 // ------------------------------------------------------------------------------------------
 // gather_cat_kernel — a1 + a3: out[row] = [ nbrs[row][0:C1] | nodes[b*N + idx[row]][0:C2] ]
 // (reference gather_nodes / cat_neighbors_nodes, inference/model_utils.py:713-732).
@@ -1777,7 +1798,7 @@ struct FeatArgs {
   const float* Wedge_img;                         // image of edge_embedding.weight [128 x 5200]: 325 k-tiles
   const float* pos_w; const float* pos_b;         // embeddings.linear [16 x 66], [16]
   const float* ln_g; const float* ln_b;           // norm_edges
-  const float* We_img; const float* We_b;         // optional fused W_e
+  const float* We_img; const float* We_b;         // optional fused W_e (x3 image for edge_features_kernel<true>)
   float* E_out;                                   // [G][K][128] or null
   float* hE_out;                                  // [G][K][128] or null (needs We_img)
   int G, L, K, TPN;
@@ -1786,6 +1807,7 @@ struct FeatArgs {
 #define FEAT_CHUNK_BYTES (6 * 8 * 64 * 16)        // 6 k-tiles x 8 tn x 1 KiB
 #define FEAT_LDS (2 * NAMP_IMG_BYTES)
 
+template <bool X3>
 __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1885,6 +1907,46 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
       const f4* w = (const f4*)(smem + slot * NAMP_IMG_BYTES) + lane;
       slot ^= 1;
       if (!wave_a) continue;                                         // wave-uniform: this residue lacks atom a
+      if constexpr (X3) {
+        // split-bf16 form: one K = 32 step covers the RBFs of two atom pairs; x = hi + mid, W = hi + mid (pack_feat_x3_kernel)
+        const bf8* wb = (const bf8*)w;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+          const int b0 = 6 * bg + 2 * st;
+          if (!((mj_s >> b0) & 3u)) continue;                        // wave-uniform: neither atom of the step is present
+          f4 xk[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int bb = b0 + h;
+            if ((mj_s >> bb) & 1u) {
+              const float dx = xi0 - xj[3 * bb], dy = xi1 - xj[3 * bb + 1], dz = xi2 - xj[3 * bb + 2];
+              const float D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);
+              const float mk = mia * (float)((mj >> bb) & 1u);
+              const float t0 = (D - mu0) * 0.8f, t1 = (D - mu1) * 0.8f, t2 = (D - mu2) * 0.8f, t3 = (D - mu3) * 0.8f;
+              xk[h].x = __expf(-(t0 * t0)) * mk; xk[h].y = __expf(-(t1 * t1)) * mk;
+              xk[h].z = __expf(-(t2 * t2)) * mk; xk[h].w = __expf(-(t3 * t3)) * mk;
+            } else {
+              xk[h] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          bf8 hi, mid;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              hi[4 * h + r] = (__bf16)xk[h][r];
+              mid[4 * h + r] = (__bf16)(xk[h][r] - (float)hi[4 * h + r]);
+            }
+#pragma unroll
+          for (int tn = 0; tn < 8; ++tn) {
+            const bf8 wh = wb[(st * 8 + tn) * 64], wm = wb[(FEAT_CHUNK_BYTES / 32) + (st * 8 + tn) * 64];
+            acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mid, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[tn], 0, 0, 0);
+            acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[tn], 0, 0, 0);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const int bb = 6 * bg + q;
@@ -1920,7 +1982,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) out[t] = *(const f4*)(a.We_b + 16 * t + 4 * g);
     wait_dma_and_sync();
-    chain_gemm<8, 8, false>(out, acc, (const f4*)smem + lane, 8);
+    gemm128<X3, false, false>(out, acc, (const f4*)smem + lane);
     if (valid) {
       float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll

@@ -43,7 +43,7 @@ class NampDecLayerW(C.Structure):
 
 
 class NampFeatW(C.Structure):
-    _fields_ = _fields(["Wedge_img", "pos_w", "pos_b", "ln_g", "ln_b"])
+    _fields_ = _fields(["Wedge_img", "pos_w", "pos_b", "ln_g", "ln_b", "Wedge_ximg"])
 
 
 class NampModelW(C.Structure):
@@ -66,6 +66,7 @@ _PROTOTYPES = {
     "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
     "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_pack_image_x3": (i32, [c_fp, i32, i32, c_fp, vp]),
+    "namp_pack_feat_x3": (i32, [c_fp, i32, c_fp, vp]),
     "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
     "namp_gather_rows_f32": (i32, [c_fp, c_ip, c_fp, C.c_long, i32, i32, i32, vp]),
     "namp_gather_edges_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),

@@ -55,6 +55,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
     # featuriser (ProteinFeaturesNA): 5200-wide edge embedding as a 325-k-tile image
     img("feat.Wedge_img", "features.edge_embedding.weight", 0, H, spec.EDGE_IN)
+    add("feat.Wedge_ximg", H * spec.EDGE_IN, ("fximg", "features.edge_embedding.weight"))
     vec("feat.pos_w", "features.embeddings.linear.weight", spec.NUM_POS * (2 * spec.MAX_REL + 2))
     vec("feat.pos_b", "features.embeddings.linear.bias", spec.NUM_POS)
     vec("feat.ln_g", "features.norm_edges.weight", H); vec("feat.ln_b", "features.norm_edges.bias", H)
@@ -151,6 +152,9 @@ class PackedWeights:
                 w = src(recipe[1])
                 hip.check(L.namp_pack_image_x3(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
                           f"pack_image_x3({name})")
+            elif recipe[0] == "fximg":
+                w = src(recipe[1])
+                hip.check(L.namp_pack_feat_x3(w.data_ptr(), w.shape[1], self.addr(name), stream), f"pack_feat_x3({name})")
             elif recipe[0] == "bimg":
                 w = src(recipe[1])
                 hip.check(L.namp_pack_image_bf16(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
@@ -179,6 +183,8 @@ class PackedWeights:
                 setattr(m.dec[l], f, flags if f == "flags" else self.addr(f"dec{l}.{f}"))
         for f, _ in hip.NampFeatW._fields_:
             setattr(m.feat, f, self.addr(f"feat.{f}"))
+        if flags == 0:
+            m.feat.Wedge_ximg = None                       # exact fp32 MFMA in the featuriser too
         m.We_ximg = self.addr("We_ximg")
         self.struct = m
 

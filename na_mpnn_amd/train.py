@@ -279,11 +279,16 @@ def _edge_embedding_fwd(fp, X, ints, top_k, ref_atom):
     dev = X.device
     Wd = fp.edge_embedding.weight.detach().contiguous()
     img = torch.empty(Wd.numel(), device=dev)
-    hip.check(L.namp_pack_image(Wd.data_ptr(), Wd.shape[1], 0, H, Wd.shape[1], img.data_ptr(), hip.current_stream()),
-              "pack_image(edge_embedding)")
     m = hip.NampModelW()
+    if X3:
+        hip.check(L.namp_pack_feat_x3(Wd.data_ptr(), Wd.shape[1], img.data_ptr(), hip.current_stream()), "pack_feat_x3(edge_embedding)")
+        m.feat.Wedge_ximg = img.data_ptr()
+    else:
+        hip.check(L.namp_pack_image(Wd.data_ptr(), Wd.shape[1], 0, H, Wd.shape[1], img.data_ptr(), hip.current_stream()),
+                  "pack_image(edge_embedding)")
+        m.feat.Wedge_img = img.data_ptr()
     pw, pb = fp.embeddings.linear.weight.detach().contiguous(), fp.embeddings.linear.bias.detach().contiguous()
-    m.feat.Wedge_img, m.feat.pos_w, m.feat.pos_b = img.data_ptr(), pw.data_ptr(), pb.data_ptr()
+    m.feat.pos_w, m.feat.pos_b = pw.data_ptr(), pb.data_ptr()
     m.feat.ln_g = m.feat.ln_b = None                          # pre-LayerNorm rows
     E_idx = torch.empty(B, Lr, K, dtype=torch.int32, device=dev)
     y = torch.empty(B, Lr, K, H, device=dev)
