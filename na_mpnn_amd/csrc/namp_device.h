@@ -62,6 +62,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // Ablation switches for tools/kbench.py (never defined in the shipped build).
 //   NAMP_ABL_NOGELU   : GELU -> identity          NAMP_ABL_LAYERS=n : stop the edge MLP after layer n
 //   NAMP_ABL_NOPROLOG : edge kernel reads no per-row operands (constants instead)
+//   NAMP_ABL_NOGEMM   : 128x128 tile GEMMs -> acc += x      NAMP_ABL_X1 : split-bf16 GEMMs keep only the hi.hi product
+//   NAMP_ABL_NOSTORE  : fused edge update keeps its rows in registers only   NAMP_ABL_NOLN : LayerNorms -> identity
+//   NAMP_ABL_NOTABLE2 : fused launches skip the second (message) table gather
+//   NAMP_ABL_NODMA    : no weight staging (LDS holds garbage)  NAMP_ABL_NOTAIL : fused residue tail -> plain store
 __device__ __forceinline__ f4 gelu4(f4 v) {
 #ifdef NAMP_ABL_NOGELU
   return v;
@@ -189,6 +193,11 @@ __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], co
 #pragma unroll
     for (int tn = 0; tn < 8; ++tn) {
       const bf8 wh = w[(s * 8 + tn) * 64], wm = w[(NAMP_BIMG_BYTES / 16) + (s * 8 + tn) * 64];
+#ifdef NAMP_ABL_X1
+      if (FLIP) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh, acc[tn], 0, 0, 0);
+      else      acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[tn], 0, 0, 0);
+      continue;
+#endif
       if (FLIP) {
         acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid, wh, acc[tn], 0, 0, 0);
         acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wm, acc[tn], 0, 0, 0);
@@ -205,6 +214,11 @@ __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], co
 // one 128 x 128 tile GEMM of the edge kernels out of a 64 KiB LDS slot: exact fp32 MFMA or the split-bf16 form
 template <bool X3, bool FLIP, bool ACT>
 __device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {
+#ifdef NAMP_ABL_NOGEMM
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] += ACT ? gelu4(x[t]) : x[t];
+  return;
+#endif
   if constexpr (X3) chain_gemm_x3<FLIP, ACT>(acc, x, (const bf8*)w);
   else chain_gemm<8, 8, FLIP, ACT>(acc, x, w, 8);
 }
@@ -246,6 +260,9 @@ __device__ __forceinline__ void chain_gemm_global(f4 (&acc)[NTN], const f4 (&x)[
 // 64 lanes x 16 B).  The LDS image is the global image verbatim (lane-linear), which is all
 // global_load_lds can do.  Completion: s_waitcnt vmcnt(0) in every issuing wave + a barrier.
 __device__ __forceinline__ void dma_to_lds(char* lds_dst, const float* gsrc, int nchunks, int wave, int nwaves, int lane) {
+#ifdef NAMP_ABL_NODMA
+  return;
+#endif
   for (int c = wave; c < nchunks; c += nwaves) {
     const char* g = (const char*)gsrc + (size_t)c * 1024 + lane * 16;
     char* d = lds_dst + c * 1024;
@@ -285,6 +302,9 @@ __device__ __forceinline__ float xg_sum(float v) {
 // (torch.nn.LayerNorm; reference model_utils.py:627-628,668-670).
 __device__ __forceinline__ void layernorm_row_T(f4 (&v)[8], const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, int g) {
+#ifdef NAMP_ABL_NOLN
+  return;
+#endif
   float s = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) s += (v[t].x + v[t].y) + (v[t].z + v[t].w);

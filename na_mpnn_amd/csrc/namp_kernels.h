@@ -678,7 +678,11 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] += acc[t];           // residual
     layernorm_row_T(x, a.ln_g, a.ln_b, g);                // x = updated h_E row: stored, and the message input
+#ifdef NAMP_ABL_NOSTORE
+    if (valid && a.G < 0) {
+#else
     if (valid) {
+#endif
       float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
@@ -702,6 +706,14 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       }
     }
     // message tables of this layer
+#ifdef NAMP_ABL_NOTABLE2
+    {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { acc[t] = x[t]; pjv[t] = x[t]; }
+      w_row = valid ? (1.0f / 30.0f) : 0.f;
+    }
+    if (false)
+#endif
     {
       const int j_loc = a.E_idx[erow];
       const float* pj;
@@ -833,6 +845,14 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(dp + 16 * t);
       }
+#ifdef NAMP_ABL_NOTAIL
+      if (tvalid) {
+        float* dst = a.tail.hV_out + (long)trow * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
+      }
+      return;
+#endif
       if (TAIL == 4 || TAIL == 8) {
         constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
         const ConsecutiveRows orow = {row0, npw, a.G};

@@ -78,6 +78,12 @@ def main():
         res[f"enc_msg_upd_p{npj}"] = timeit(lambda: L.namp_enc_message_update(
             e0, hE.data_ptr(), idx.data_ptr(), mask.data_ptr(), None, Pa.data_ptr(), Pc.data_ptr(), hV.data_ptr(),
             hV2.data_ptr(), proj, npj, B, N, K, s), args.reps)
+    e1 = P.enc_layer(1)
+    proj4 = (hip.NampProj * 4)(*[hip.NampProj(a(nm), None, None, T[i].data_ptr())
+                                 for i, nm in enumerate(["W11a_img", "W11c_img", "W1a_img", "W1c_img"])])
+    res["enc_edge_msg_upd_p4"] = timeit(lambda: L.namp_enc_edge_message_update(
+        e0, Pa.data_ptr(), Pc.data_ptr(), hE.data_ptr(), e1, idx.data_ptr(), mask.data_ptr(), None, Pa.data_ptr(), Pc.data_ptr(),
+        hV.data_ptr(), hV2.data_ptr(), proj4, 4, B, N, K, s), args.reps)
     proj = (hip.NampProj * 2)(hip.NampProj(a("W1a_img"), a("b1"), None, T[0].data_ptr()),
                               hip.NampProj(a("W1c_img"), None, None, T[1].data_ptr()))
     res["node_linear_p2"] = timeit(lambda: L.namp_node_linear(hV.data_ptr(), None, B, B, N, proj, 2, None, s), args.reps)
