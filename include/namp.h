@@ -290,7 +290,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
  * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated
  *   on the fly: X18 [B*L][18][3] (16 atoms + Cb + N_na), M18 [B*L][18] 0/1 floats, E_pos [B*L*K][16] the positional
- *   features, g_pre [B*L*K][128] = dL/d(pre-LayerNorm edge embedding); dW_part [namp_train_feat_wgrad_chunks][128][5200].
+ *   features, g_pre [B*L*K][128] = dL/d(pre-LayerNorm edge embedding); dW_part [namp_train_feat_wgrad_chunks][128][5200];
+ *   x3 != 0: the contraction over edges as split-bf16 products (as namp_train_wgrad).
  * namp_featurize with w->feat.ln_g == NULL writes the pre-LayerNorm rows to E (the training forward). */
 int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
@@ -325,7 +326,7 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
 int namp_train_feat_wgrad_chunks(long edges);
 long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_ws (atom-presence words per 64-edge tile) */
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
-                          float* dW_part, int32_t* tile_ws, int B, int L, int K, void* stream);
+                          float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream);
 
 /* Level-parallel form of the plain sampling branch (no symmetry groups, no pair_bias).  The step for residue i depends
  * only on the neighbours visited before it, so visits can be grouped into dependency levels and every level decoded in

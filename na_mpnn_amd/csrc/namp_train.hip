@@ -175,7 +175,7 @@ int namp_train_feat_wgrad_chunks(long edges) {
 long namp_train_feat_wgrad_ws_ints(long edges) { return edges <= 0 ? 0 : 2 * ((edges + FEATW_TILE - 1) / FEATW_TILE); }
 
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
-                          float* dW_part, int32_t* tile_ws, int B, int L, int K, void* stream) {
+                          float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream) {
   if (!tile_ws) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null tile workspace (namp_train_feat_wgrad_ws_ints int32s)");
   REQUIRE_PTR(X18); REQUIRE_PTR(M18); REQUIRE_PTR(E_pos); REQUIRE_PTR(g_pre); REQUIRE_PTR(dW_part);
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null E_idx");
@@ -187,8 +187,12 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   const long ntile = (E + FEATW_TILE - 1) / FEATW_TILE;
   hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M18, E_idx, E, L, K,
                      tile_ws);
-  hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
-                     tile_ws, E, per, L, K, dW_part);
+  if (x3)
+    hipLaunchKernelGGL(feat_wgrad_x3_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
+                       tile_ws, E, per, L, K, dW_part);
+  else
+    hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
+                       tile_ws, E, per, L, K, dW_part);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

@@ -104,7 +104,7 @@ _PROTOTYPES = {
     "namp_train_wgrad": (i32, [c_fp, c_fp, i32, i32, C.c_long, c_fp, c_fp, vp]),
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
-    "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, vp]),
+    "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, i32, vp]),
     "namp_sample_levels": (i32, [c_ip, c_ip, c_ip, c_ip, i32, i32, i32, i32, vp]),
     "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                          c_ip, C.POINTER(C.c_int32), i32,

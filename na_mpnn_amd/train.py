@@ -318,7 +318,8 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         Ep = E_pos.detach().contiguous()
         tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
         hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
-                                          part.data_ptr(), tws.data_ptr(), B, Lr, K, hip.current_stream()), "train_feat_wgrad")
+                                          part.data_ptr(), tws.data_ptr(), int(X3), B, Lr, K, hip.current_stream()),
+                  "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
         return None, part.sum(0), g_Epos, None, None, None
 
