@@ -31,14 +31,32 @@ def maxdiff(a, b):
     return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
 
 
+def test_split_bf16_and_exact_fp32_modes_agree(weights_np):
+    """The default evaluation of the per-edge and featuriser GEMMs (split-bf16 products) against exact fp32 MFMA on the
+    same complex: edge features, log-probs and arg-max — the two must differ by far less than the 1e-3 parity bar."""
+    dev = torch.device("cuda:0")
+    cx = synth.make_complex(seed=77, n=300, missing_atom_frac=0.03)
+    fd = fd_of(cx, dev)
+    m = make_model(weights_np, 48, dev)
+    out = {}
+    for prec in ("x3", "fp32"):
+        m.message_precision = prec
+        out[prec] = (m.featurize(fd)[1].clone(), m.score(fd)["log_probs"].clone())
+    assert maxdiff(out["x3"][0], out["fp32"][0].cpu()) < 1e-4            # measured 2.5e-5 at N=1000
+    assert maxdiff(out["x3"][1], out["fp32"][1].cpu()) < 2e-4            # measured 2e-5
+    assert torch.equal(out["x3"][1].argmax(-1), out["fp32"][1].argmax(-1))
+
+
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
 @pytest.mark.parametrize("n,k,tag,kw", [(97, 32, "n97_k32", dict(missing_atom_frac=0.05, masked_frac=0.04)),
                                          (150, 48, "n150_k48", {}), (32, 48, "n32_k48_LltK", {})])
-def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw):
+def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw, prec):
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, f"g4_fromX_{tag}.npz"))
     cx = synth.make_complex(seed=400 + n, n=n, **kw)
     fd = fd_of(cx, dev)
     m = make_model(weights_np, k, dev)
+    m.message_precision = prec
     V, E, E_idx = m.featurize(fd)
     # neighbour sets of every unmasked residue must agree with the reference.  (A masked residue's row of
     # the distance matrix is all-equal, so torch.topk's pick there is an arbitrary tie-break on either

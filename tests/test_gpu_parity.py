@@ -214,16 +214,22 @@ def run_encdec(L, dev, packed, d, B, N, K, joint=False):
     return hV, hE, logp, order
 
 
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
 @pytest.mark.parametrize("joint", [False, True])
 @pytest.mark.parametrize("n,tag,mf,batch", [(256, "n256", 0.05, 1), (40, "n40_LltK", 0.0, 1),
                                              (200, "b3_n200", 0.1, 3), (1000, "n1000", 0.0, 1)])
-def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch, joint):
+def test_encoder_decoder_goldens(L, dev, packed, golden_dir, n, tag, mf, batch, joint, prec):
     """a7+a8, the BASELINE metric scope: (V,E,E_idx) -> log_probs vs reference goldens (G3); as namp_encoder_fwd +
-    namp_decoder_fwd and as the single fused call namp_encdec_fwd (what bench.py times)."""
+    namp_decoder_fwd and as the single fused call namp_encdec_fwd (what bench.py times).  Both fp32-class evaluations of
+    the per-edge GEMMs: split-bf16 products (the default) and exact fp32 MFMA — same bars."""
     g = np.load(os.path.join(golden_dir, f"g3_encdec_{tag}.npz"))
     t, d = graph(dev, seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=mf)
     K = t["E_idx"].shape[-1]
-    hV, hE, logp, order = run_encdec(L, dev, packed, d, batch, n, K, joint)
+    packed.set_precision(prec)
+    try:
+        hV, hE, logp, order = run_encdec(L, dev, packed, d, batch, n, K, joint)
+    finally:
+        packed.set_precision("x3")
     stride = int(g["row_stride"])
     d_hv = maxdiff(hV[:, ::stride], torch.from_numpy(g["enc_hV_layers"][-1]))
     d_he = maxdiff(hE[:, ::max(1, n // 16)][:, :16], torch.from_numpy(g["enc_hE_rows"]))
