@@ -145,6 +145,7 @@ void set_lds_attributes() {
   set((const void*)edge_features_kernel<false>, FEAT_LDS);
   set((const void*)edge_features_kernel<true>, FEAT_LDS);
   set((const void*)knn_kernel, 8192 * 8 + 64);
+  set((const void*)knn_select_kernel, (8192 + 4096) * 8 + 1024 + 64);
 }
 
 int ensure_attributes() {
@@ -787,7 +788,11 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     hipLaunchKernelGGL(prep_atoms_kernel, dim3((G + 255) / 256), dim3(256), 0, s, X, X_m, protein_mask, dna_mask, rna_mask,
                        X18, M18, P, G, ref_atom);
     int Lp2 = 1; while (Lp2 < L) Lp2 <<= 1;
-    hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);
+    int Kp2 = 64; while (Kp2 < K) Kp2 <<= 1;
+    if (2 * Kp2 <= Lp2)      // selection pays when the final sort is at most half a row
+      hipLaunchKernelGGL(knn_select_kernel, dim3(G), dim3(256), ((size_t)L + Kp2) * 8 + 1024 + 64, s, P, mask, E_idx, L, K, Kp2);
+    else
+      hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);
     FeatArgs a = {};
     a.X18 = X18; a.M18 = M18; a.E_idx = E_idx; a.R_idx = R_idx; a.chain = chain_labels;
     const bool x3 = w->feat.Wedge_ximg != nullptr;

@@ -178,11 +178,21 @@ __device__ __forceinline__ void chain_gemm_bf16(f4 (&acc)[8], const f4 (&x)[8], 
 // build differs from the CPU reference by.  The "x3 image" of a block is its bf16 fragment image of W_hi followed by the
 // one of W_mid: 2 x 32 KiB = the size of the fp32 image, so the LDS ring and its DMA schedule are unchanged.
 // The register chain carries over as in the bf16 mode (k(s,g,j) = 32s + 16(j>>2) + 4g + (j&3)).
+// GELU beside bf16 MFMAs: the per-element form.  VALU and MFMA time add up on this chip whatever the interleaving
+// (tools/coexec_probe.hip), and packed fp32 operations beside MFMAs cost more than they save (measured -1.5 % per launch
+// for the scalar form here, +2 % for it in the fp32-MFMA kernels, which keep gelu4()).
+__device__ __forceinline__ f4 gelu4_scalar(const f4 v) {
+#ifdef NAMP_ABL_NOGELU
+  return v;
+#endif
+  return (f4){gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+}
+
 template <bool FLIP, bool ACT>
 __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const f4 a = ACT ? gelu4(x[2 * s]) : x[2 * s], b = ACT ? gelu4(x[2 * s + 1]) : x[2 * s + 1];
+    const f4 a = ACT ? gelu4_scalar(x[2 * s]) : x[2 * s], b = ACT ? gelu4_scalar(x[2 * s + 1]) : x[2 * s + 1];
     bf8 hi, mid;
     hi[0] = (__bf16)a.x; hi[1] = (__bf16)a.y; hi[2] = (__bf16)a.z; hi[3] = (__bf16)a.w;
     hi[4] = (__bf16)b.x; hi[5] = (__bf16)b.y; hi[6] = (__bf16)b.z; hi[7] = (__bf16)b.w;
@@ -190,22 +200,37 @@ __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], co
     mid[2] = (__bf16)(a.z - (float)hi[2]); mid[3] = (__bf16)(a.w - (float)hi[3]);
     mid[4] = (__bf16)(b.x - (float)hi[4]); mid[5] = (__bf16)(b.y - (float)hi[5]);
     mid[6] = (__bf16)(b.z - (float)hi[6]); mid[7] = (__bf16)(b.w - (float)hi[7]);
+    // product-major over groups of four channel tiles: the three products of one tile accumulate into the same registers,
+    // and a dependent MFMA issued right behind its producer waits out the whole pipeline (~2x the issue time); with four
+    // independent tiles between dependent issues the matrix pipe stays full
 #pragma unroll
-    for (int tn = 0; tn < 8; ++tn) {
-      const bf8 wh = w[(s * 8 + tn) * 64], wm = w[(NAMP_BIMG_BYTES / 16) + (s * 8 + tn) * 64];
+    for (int h = 0; h < 2; ++h) {
+      bf8 wh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wh[q] = w[(s * 8 + 4 * h + q) * 64];
 #ifdef NAMP_ABL_X1
-      if (FLIP) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh, acc[tn], 0, 0, 0);
-      else      acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[tn], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh[q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], hi, acc[4 * h + q], 0, 0, 0);
+      }
       continue;
 #endif
-      if (FLIP) {
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid, wh, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wm, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh, acc[tn], 0, 0, 0);
-      } else {
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mid, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[tn], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid, wh[q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], mid, acc[4 * h + q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf8 wm = w[(NAMP_BIMG_BYTES / 16) + (s * 8 + 4 * h + q) * 64];
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wm, acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[4 * h + q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh[q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], hi, acc[4 * h + q], 0, 0, 0);
       }
     }
   }

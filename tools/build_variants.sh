@@ -11,19 +11,8 @@ build() {
     hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/_variants/$name.o na_mpnn_amd/lib/obj/namp_train.o -o tools/_variants/$name.so &&
     rm -f tools/_variants/$name.o ) &
 }
-build nogelu -DNAMP_ABL_NOGELU
-build x1 -DNAMP_ABL_X1
-build nogemm -DNAMP_ABL_NOGEMM
-build nogemm_nogelu -DNAMP_ABL_NOGEMM -DNAMP_ABL_NOGELU
-build nodma -DNAMP_ABL_NODMA
-build notail -DNAMP_ABL_NOTAIL
-build noprolog -DNAMP_ABL_NOPROLOG
-build nostore -DNAMP_ABL_NOSTORE
-build noln -DNAMP_ABL_NOLN
-build notable2 -DNAMP_ABL_NOTABLE2
-build skel -DNAMP_ABL_NOGEMM -DNAMP_ABL_NOGELU -DNAMP_ABL_NOTAIL
-build skel_nostore -DNAMP_ABL_NOGEMM -DNAMP_ABL_NOGELU -DNAMP_ABL_NOTAIL -DNAMP_ABL_NOSTORE
-build skel_nostore_noprolog -DNAMP_ABL_NOGEMM -DNAMP_ABL_NOGELU -DNAMP_ABL_NOTAIL -DNAMP_ABL_NOSTORE -DNAMP_ABL_NOPROLOG -DNAMP_ABL_NOTABLE2
-build skel_min -DNAMP_ABL_NOGEMM -DNAMP_ABL_NOGELU -DNAMP_ABL_NOTAIL -DNAMP_ABL_NOSTORE -DNAMP_ABL_NOPROLOG -DNAMP_ABL_NOTABLE2 -DNAMP_ABL_NOLN -DNAMP_ABL_NODMA
+build gscalar -DNAMP_GELU_SCALAR
+build noslp -fno-slp-vectorize
+build gscalar_noslp -DNAMP_GELU_SCALAR -fno-slp-vectorize
 wait
 ls -la tools/_variants
