@@ -142,6 +142,9 @@ void set_lds_attributes() {
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<true>, SAMPLE_LDS);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_features_kernel<false>, FEAT_LDS);
   set((const void*)edge_features_kernel<true>, FEAT_LDS);
   set((const void*)knn_kernel, 8192 * 8 + 64);
@@ -204,6 +207,17 @@ int launch_edge_bf16_persistent(EdgeArgs a, hipStream_t s) {
   return NAMP_OK;
 }
 
+// split-bf16 mode on a grid larger than two waves of workgroups: persistent workgroups, ring turning across rounds
+template <int MODE>
+int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  const EdgeGeom e = edge_geom(a.G, a.K);
+  a.TPN = e.tpn;
+  hipLaunchKernelGGL((edge_mlp_x3_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 2 * NAMP_IMG_BYTES, s, a);
+  return NAMP_OK;
+}
+
 // bf16 STORAGE variant (h_E and the gathered tables in bf16 fragment order): large batches of the bf16 throughput mode
 template <int MODE>
 int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
@@ -236,6 +250,8 @@ int launch_edge_prec(const EdgeArgs& a, int prec, hipStream_t s) {
   if (prec == PREC_BF16 && TAIL == 0 && MODE != MODE_EMBED && edge_geom(a.G, a.K).grid > 2 * device_cus())
     return launch_edge_bf16_persistent<MODE == MODE_EMBED ? MODE_ENC_MSG : MODE>(a, s);
   if (prec == PREC_BF16) return launch_edge<MODE, TAIL, PREC_BF16>(a, s);
+  if (prec == PREC_X3 && TAIL == 0 && MODE != MODE_EMBED && edge_geom(a.G, a.K).grid > 2 * device_cus())
+    return launch_edge_x3_persistent<MODE == MODE_EMBED ? MODE_ENC_MSG : MODE>(a, s);
   if (prec == PREC_X3) return launch_edge<MODE, TAIL, PREC_X3>(a, s);
   return launch_edge<MODE, TAIL, PREC_F32>(a, s);
 }

@@ -999,6 +999,111 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 }
 
 // ------------------------------------------------------------------------------------------
+// edge_mlp_x3_persistent_kernel — the split-bf16 (parity) mode for LARGE batches.  The three 64 KiB x3 images cannot all
+// stay in LDS, so the 2-slot ring keeps turning — but across the workgroup's rounds of 12 tiles instead of once per
+// launch: W1 of round r+1 streams in under GEMM 3 of round r, the next round's h_E rows and table addresses are
+// requested one round ahead (edge_mlp_bf16_persistent_kernel's TileMeta chain), and launch ramp / first-image wait are
+// paid once per workgroup instead of once per 12 tiles.  Same arithmetic per row as edge_mlp_kernel<MODE, 0, PREC_X3>.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const long ntiles = (long)a.G * a.TPN;
+  const long stride = (long)gridDim.x * nwaves;
+  long base = (long)blockIdx.x * nwaves;                   // workgroup-uniform: every wave takes part in every barrier
+  char* slotA = smem;                                      // holds (or receives) W1 of the current round
+  char* slotB = smem + NAMP_IMG_BYTES;
+  TileMeta cur = tile_meta<MODE>(a, base + wave < ntiles ? base + wave : 0, m, g);
+  f4 xn[8];
+  {
+    const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
+  }
+  dma_to_lds(slotA, a.W1_img, 64, wave, nwaves, lane);
+  for (; base < ntiles; base += stride) {
+    const bool active = base + wave < ntiles;
+    f4 x[8], acc[8], pjv[8];
+    const TileMeta me = cur;
+    wait_dma_and_sync();                                   // W1 landed; everyone is done with the previous round's GEMM 3 (slotB)
+    dma_to_lds(slotB, a.W2_img, 64, wave, nwaves, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = xn[t];
+    {
+      const float* pa = a.Pa + me.pa_row * NAMP_H + 4 * g;
+      const float* pj = (me.pj_from1 ? a.Pj1 : a.Pj0) + me.pj_row * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+    }
+    // next round: metadata chain + h_E row, in flight under this round's GEMMs
+    const long nb = base + stride;
+    const bool more = nb < ntiles;                         // workgroup-uniform
+    cur = tile_meta<MODE>(a, nb + wave < ntiles ? nb + wave : (active ? base + wave : 0), m, g);
+    {
+      const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
+    }
+    gemm128<true, false, false>(acc, x, (const f4*)slotA + lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
+    wait_dma_and_sync();                                   // W2 landed; everyone is done with slotA (W1)
+    dma_to_lds(slotA, a.W3_img, 64, wave, nwaves, lane);
+    f4 (&y)[8] = pjv;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+    gemm128<true, false, true>(y, acc, (const f4*)slotB + lane);
+    wait_dma_and_sync();                                   // W3 landed; everyone is done with slotB (W2)
+    if (more) dma_to_lds(slotB, a.W1_img, 64, wave, nwaves, lane);   // next round's W1, under GEMM 3
+    if (MODE == MODE_ENC_EDGE) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+      gemm128<true, false, true>(acc, y, (const f4*)slotA + lane);
+      if (a.drop_thresh) {
+        const uint32_t key = drop_row_key(a.drop_seed, me.erow);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
+      }
+      if (a.ln_g) {
+        const float* src = a.hE + me.erow * NAMP_H + 4 * g;           // residual: re-read (L2), 32 registers less than keeping x
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
+        layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+      }
+      if (active && me.valid) {
+        float* dst = a.hE_out + me.erow * NAMP_H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float b = a.b3[16 * t + m];
+        acc[t] = (f4){b, b, b, b};
+      }
+      gemm128<true, true, true>(acc, y, (const f4*)slotA + lane);
+      float wr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
+      float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        s_ = xg_sum(s_);
+        if (active && g == 0) dst[16 * t] = s_;
+      }
+    }
+    char* tmp = slotA; slotA = slotB; slotB = tmp;         // next round's W1 sits in this round's slotB
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // dec_sample_kernel — the autoregressive sampler (ProteinMPNN.sample, non-symmetric branch,
 // inference/model_utils.py:126-218) as ONE persistent launch.  Sample streams are independent, so
 // there is no inter-workgroup traffic: a workgroup owns up to 4 streams (tile rows of the residue tail)
