@@ -316,24 +316,32 @@ __device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const i
 // g-lanes of a channel are summed at the end — the existing MFMA weight images are reused as is.
 // Tile row n is residue orow[n] (global row, < 0 = padding); rows need not be consecutive.
 // ------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// acc[n] += sum_k w[k] * x[k][n] for the R residues of the tile: two residues per v_pk_fma_f32 (the weight broadcast to
+// both halves) — this loop is instruction-issue bound, and the packed form halves its instruction count.
 template <int R>
 __device__ __forceinline__ void rows_fma(float (&acc)[R], const f4 (&wf)[8], const float* xT, const int g) {
+  f2 a2[R / 2];
+#pragma unroll
+  for (int q = 0; q < R / 2; ++q) a2[q] = (f2){acc[2 * q], acc[2 * q + 1]};
 #pragma unroll
   for (int tk = 0; tk < 8; ++tk) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* xp = xT + (16 * tk + 4 * g + r) * R;                 // R residues at this k
+      const f2 w2 = (f2){wf[tk][r], wf[tk][r]};
 #pragma unroll
       for (int q = 0; q < R; q += 4) {
         const f4 xv = *(const f4*)(xp + q);
-        acc[q + 0] = fmaf(wf[tk][r], xv.x, acc[q + 0]);
-        acc[q + 1] = fmaf(wf[tk][r], xv.y, acc[q + 1]);
-        acc[q + 2] = fmaf(wf[tk][r], xv.z, acc[q + 2]);
-        acc[q + 3] = fmaf(wf[tk][r], xv.w, acc[q + 3]);
+        a2[q / 2] = __builtin_elementwise_fma(w2, (f2){xv.x, xv.y}, a2[q / 2]);
+        a2[q / 2 + 1] = __builtin_elementwise_fma(w2, (f2){xv.z, xv.w}, a2[q / 2 + 1]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later k-tiles from being hoisted (register pressure)
   }
+#pragma unroll
+  for (int q = 0; q < R / 2; ++q) { acc[2 * q] = a2[q].x; acc[2 * q + 1] = a2[q].y; }
 }
 
 #define ROWS_TAIL_LDS_FLOATS(R) ((128 + 512 + 4 * 128 + 128) * (R) + 64)
