@@ -140,8 +140,10 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
-  set((const void*)dec_sample_kernel<false>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, false>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, false>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, true>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, true>, SAMPLE_LDS);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
@@ -879,7 +881,10 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   for (int l = 0; l < w->n_dec; ++l) {
     const NampDecLayerW* D = &w->dec[l];
     SampleLayer& L = a.l[l];
-    L.W1e_img = D->W1e_img; L.W2_img = D->W2_img; L.W3_img = D->W3_img; L.b2 = D->b2; L.b3 = D->b3; L.tok = D->tok;
+    const int prec = prec_of(D->flags) == PREC_X3 ? PREC_X3 : PREC_F32;       // the sampler has no bf16 mode: fp32-class only
+    L.W1e_img = pick_img(prec, D->W1e_img, nullptr, D->W1e_ximg); L.W2_img = pick_img(prec, D->W2_img, nullptr, D->W2_ximg);
+    L.W3_img = pick_img(prec, D->W3_img, nullptr, D->W3_ximg); L.b2 = D->b2; L.b3 = D->b3; L.tok = D->tok;
+    REQUIRE_PTR(L.W1e_img); REQUIRE_PTR(L.W2_img); REQUIRE_PTR(L.W3_img);
     L.Pfw = Pfw[l];
     L.Pa = (l == 0) ? Pa0 : Pa[l - 1];
     L.Pv = (l == 0) ? Pfw[0] : Pv[l - 1];
@@ -912,8 +917,12 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
                           ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  hipLaunchKernelGGL(dec_sample_kernel<false>, dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
-                     (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
+  if (prec_of(w->dec[0].flags) == PREC_X3)
+    hipLaunchKernelGGL((dec_sample_kernel<false, true>), dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
+                       (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
+  else
+    hipLaunchKernelGGL((dec_sample_kernel<false, false>), dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
+                       (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -948,12 +957,15 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   hipError_t e = hipMemsetAsync(S_out, 0xFF, (size_t)B_dec * N * sizeof(int32_t), s);          // every token "not drawn" (-1)
   if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_levels: hipMemsetAsync: %s", hipGetErrorString(e));
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
+  const bool x3 = prec_of(w->dec[0].flags) == PREC_X3;
   long off = 0;
   for (int l = 0; l < n_levels; ++l) {
     const int cnt = level_counts[l];
     if (cnt == 0) continue;
-    hipLaunchKernelGGL(dec_sample_kernel<true>, dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
-                       work + 2 * off, cnt);
+    if (x3) hipLaunchKernelGGL((dec_sample_kernel<true, true>), dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
+                               work + 2 * off, cnt);
+    else hipLaunchKernelGGL((dec_sample_kernel<true, false>), dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
+                            work + 2 * off, cnt);
     off += cnt;
   }
   CHECK_LAUNCH();

@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __rest
 // dependency levels (sample_levels_kernel: level = 1 + max level of the earlier neighbours) and launches one grid per level:
 // ~64 launches instead of 1000 sequential steps at N = 1000, K = 48, with every workgroup of the chip busy.  Same arithmetic
 // per residue, same uniform per visit, hence the same draws.
-template <bool LEVEL>
+template <bool LEVEL, bool X3 = false>
 __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
@@ -1401,21 +1401,21 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
       dma_to_lds(buf0, L.W1e_img, 64, wave, nwaves, lane);
       dma_to_lds(buf1, L.W2_img, 64, wave, nwaves, lane);
       wait_dma_and_sync();
-      chain_gemm<8, 8, false>(acc, x, w0, 8);
+      gemm128<X3, false, false>(acc, x, w0);
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
       __syncthreads();
       dma_to_lds(buf0, L.W3_img, 64, wave, nwaves, lane);
 #pragma unroll
       for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(L.b2 + 16 * q + 4 * g);
-      chain_gemm<8, 8, false, true>(x, acc, w1, 8);
+      gemm128<X3, false, true>(x, acc, w1);
       wait_dma_and_sync();
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float bq = L.b3[16 * q + m];
         acc[q] = (f4){bq, bq, bq, bq};
       }
-      chain_gemm<8, 8, true, true>(acc, x, w0, 8);
+      gemm128<X3, true, true>(acc, x, w0);
       float wr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);

@@ -17,6 +17,7 @@ for n, k, bs in ((1000, 48, 1), (1000, 32, 1), (400, 32, 30), (400, 32, 4), (97,
     fd.update({"batch_size": bs, "temperature": 0.1, "bias": torch.zeros(1, n, 33, device=dev), "symmetry_residues": [[]],
                "symmetry_weights": [[]], "randn": torch.randn(bs, n, device=dev)})
     m = model(k)
+    m.sample_level_parallel = "--sequential" not in sys.argv
     V, E, E_idx = m.featurize(fd)
     m.featurize = lambda fd_, _r=(V, E, E_idx): _r            # time the sampler, not the (torch-op) featuriser
     m.sample(fd); torch.cuda.synchronize()
