@@ -5,6 +5,7 @@
 #include "namp_kernels.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <initializer_list>
 #include <cstdio>
 #include <mutex>
@@ -807,7 +808,8 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
                        X18, M18, P, G, ref_atom);
     int Lp2 = 1; while (Lp2 < L) Lp2 <<= 1;
     int Kp2 = 64; while (Kp2 < K) Kp2 <<= 1;
-    if (2 * Kp2 <= Lp2)      // selection pays when the final sort is at most half a row
+    const bool full_sort = getenv("NAMP_KNN_FULL_SORT") != nullptr;      // debugging / test switch: sort whole rows
+    if (2 * Kp2 <= Lp2 && !full_sort)      // selection pays when the final sort is at most half a row
       hipLaunchKernelGGL(knn_select_kernel, dim3(G), dim3(256), ((size_t)L + Kp2) * 8 + 1024 + 64, s, P, mask, E_idx, L, K, Kp2);
     else
       hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);

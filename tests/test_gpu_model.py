@@ -350,6 +350,32 @@ def test_padded_batch_from_coordinates(weights_np):
         assert torch.equal(lp[b, :n].argmax(-1).cpu(), ref[b, :n].argmax(-1))
 
 
+@pytest.mark.parametrize("n,k,bs", [(300, 100, 1), (200, 130, 1), (1000, 64, 1), (1000, 65, 2), (5000, 48, 1), (8192, 48, 1),
+                                    (700, 30, 3), (129, 33, 1)])
+def test_knn_selection_equals_the_full_row_sort(weights_np, n, k, bs, monkeypatch):
+    """knn_select_kernel (radix select + small sort) against knn_kernel (bitonic sort of the whole row) on the same keys:
+    identical neighbour lists in identical order — with coincident residues (equal distances: ties go to the lower index),
+    masked residues (their substitute distance ties with the row maximum) and K from 30 to 130 (final sorts of 64, 128, 256
+    keys; K close to L falls back to the full sort on both sides)."""
+    dev = torch.device("cuda:0")
+    cxs = []
+    for b in range(bs):
+        cx = synth.make_complex(seed=900 + n + b, n=n, masked_frac=0.1)
+        dup = np.random.default_rng(n + b).integers(0, n, size=max(1, n // 10))
+        cx["X"][dup] = cx["X"][(dup + 7) % n]                       # coincident residues
+        cxs.append(cx)
+    from na_mpnn_amd import shard
+    fd = {k_: v.to(dev) for k_, v in shard.pad_batch(cxs).items()} if bs > 1 else fd_of(cxs[0], dev)
+    fd["batch_size"] = 1
+    m = make_model(weights_np, k, dev)
+    monkeypatch.delenv("NAMP_KNN_FULL_SORT", raising=False)
+    sel = m.featurize(fd)[2].clone()
+    monkeypatch.setenv("NAMP_KNN_FULL_SORT", "1")
+    full = m.featurize(fd)[2].clone()
+    assert sel.shape[-1] == min(k, n)
+    assert torch.equal(sel, full)
+
+
 @pytest.mark.parametrize("n,k,kw", [(1, 48, {}), (2, 48, {}), (3, 1, {}), (17, 16, {}), (40, 17, dict(masked_frac=0.3)),
                                     (33, 5, dict(missing_atom_frac=0.3)), (64, 64, {}), (65, 63, dict(n_chains=7)),
                                     (129, 48, dict(frac_protein=0.0, frac_dna=1.0)), (50, 48, dict(frac_protein=1.0, frac_dna=0.0)),
