@@ -57,6 +57,9 @@ int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stre
  * golden, bar 1e-3, arg-max unchanged).  The x3 image = bf16 fragment image of W_hi followed by that of W_mid (64 KiB). */
 #define NAMP_FLAG_X3 2
 int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream);     /* [128x128] block -> 64 KiB */
+/* x3 image of a general block [out_f x in_f] (out_f % 16 == 0, in_f % 32 == 0): the residue-level FFN weights
+ * (PositionWiseFeedForward W_in [512 x 128], W_out [128 x 512], model_utils.py:595-604); out_f*in_f floats of output. */
+int namp_pack_image_x3_general(const float* W, int ld, int col0, int out_f, int in_f, void* img, void* stream);
 /* The featuriser's edge_embedding.weight [128 x 5200] (model_utils.py:484) for the split-bf16 form of its GEMM: positional
  * k-tile as an fp32 fragment tile, then one 48 KiB hi|mid block per group of 6 atom pairs; 128*5200 floats in all, the
  * size of namp_pack_image's output for the same matrix. */
@@ -74,6 +77,9 @@ typedef struct NampEncLayerW {
   /* bf16 throughput mode: 32 KiB bf16 images of the six per-edge blocks (namp_pack_image_bf16) */
   const float *W1b_bimg, *W2_bimg, *W3_bimg, *W11b_bimg, *W12_bimg, *W13_bimg;
   const float *W1b_ximg, *W2_ximg, *W3_ximg, *W11b_ximg, *W12_ximg, *W13_ximg;   /* x3 images (namp_pack_image_x3) */
+  /* optional: x3 images of the residue-level blocks (namp_pack_image_x3_general for W_in / W_out).  When all that a launch
+   * needs are present, large batches (>= 64 residues per CU) run the residue update as split-bf16 products too. */
+  const float *Win_ximg, *Wout_ximg, *W1a_ximg, *W1c_ximg, *W11a_ximg, *W11c_ximg;
   int64_t flags;                                     /* NAMP_FLAG_BF16 / NAMP_FLAG_X3: precision of the per-edge GEMMs */
 } NampEncLayerW;
 
@@ -87,6 +93,7 @@ typedef struct NampDecLayerW {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *W1e_bimg, *W2_bimg, *W3_bimg;        /* bf16 images (throughput mode) */
   const float *W1e_ximg, *W2_ximg, *W3_ximg;        /* x3 images */
+  const float *Win_ximg, *Wout_ximg, *W1a_ximg, *W1v_ximg;   /* optional residue-level x3 images, as in NampEncLayerW */
   int64_t flags;
 } NampDecLayerW;
 

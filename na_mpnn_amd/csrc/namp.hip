@@ -325,7 +325,7 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
 int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                        const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
                        const float* hV, const float* partial, const int32_t* mask, float* hV_out,
-                       const NampProj* proj, int nproj, const int32_t* S, int G, int TPN, hipStream_t s) {
+                       const NampProj* proj, int nproj, const int32_t* S, int G, int TPN, hipStream_t s, bool x3 = false) {
   int rc = ensure_attributes();
   if (rc) return rc;
   NodeUpdateArgs a;
@@ -333,8 +333,10 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   a.partial = partial; a.G = G; a.TPN = TPN;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill: 64 accumulator VGPRs of hidden state next to 128 of weights)
-  if (G >= 32 * 2 * device_cus())
-    hipLaunchKernelGGL(node_update_multi_kernel<2>, dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
+  if (x3)                      // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
+    hipLaunchKernelGGL((node_update_multi_kernel<2, true>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
+  else if (G >= 32 * 2 * device_cus())
+    hipLaunchKernelGGL((node_update_multi_kernel<2, false>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
   else
     hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_TAIL_LDS, s, a);
   return NAMP_OK;
@@ -399,6 +401,17 @@ int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream
   REQUIRE_PTR(W); REQUIRE_PTR(img);
   REQUIRE(ld >= 128 && col0 >= 0 && col0 + 128 <= ld, "namp_pack_image_x3: block [128 x 128] at column %d does not fit ld=%d", col0, ld);
   hipLaunchKernelGGL(pack_image_x3_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_pack_image_x3_general(const float* W, int ld, int col0, int out_f, int in_f, void* img, void* stream) {
+  REQUIRE_PTR(W); REQUIRE_PTR(img);
+  REQUIRE(out_f > 0 && in_f > 0 && (out_f % 16) == 0 && (in_f % 32) == 0 && col0 >= 0 && ld >= col0 + in_f,
+          "namp_pack_image_x3_general: out_f=%d (x16) in_f=%d (x32) must fit ld=%d at column %d", out_f, in_f, ld, col0);
+  const int total = out_f * in_f;
+  hipLaunchKernelGGL(pack_image_x3_general_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, col0, out_f,
+                     in_f, (__bf16*)img);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -590,6 +603,35 @@ int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_im
   ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
   rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
                               proj, nproj, S, G, (K + 15) / 16, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+// Residue update of the unfused (large-batch) paths: as split-bf16 products when the precision is not exact fp32, the batch
+// takes the multi-tile kernel and the layer carries x3 images of the FFN and of every projected block; exact fp32 otherwise.
+static int node_update_auto(int64_t flags, const float* Win_ximg, const float* Wout_ximg, const float* const* proj_ximg,
+                            const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
+                            const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
+                            const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
+                            const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
+  bool x3 = prec_of(flags) != PREC_F32 && Win_ximg && Wout_ximg && G >= 32 * 2 * device_cus() && nproj <= 8;
+  for (int i = 0; x3 && i < nproj; ++i) x3 = proj_ximg && proj_ximg[i] != nullptr;
+  if (!x3)
+    return namp_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out, proj, nproj,
+                            S, G, K, stream);
+  REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_ximg); REQUIRE_PTR(b_in); REQUIRE_PTR(Wout_ximg); REQUIRE_PTR(b_out);
+  REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out); OPTIONAL_PTR(partial);
+  REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "node_update: bad dims G=%d K=%d", G, K);
+  NampProj px[8];
+  for (int i = 0; i < nproj; ++i) {
+    px[i] = proj[i]; px[i].img = proj_ximg[i];
+    REQUIRE_PTR(px[i].img); REQUIRE_PTR(px[i].out); OPTIONAL_PTR(px[i].bias); OPTIONAL_PTR(px[i].tok);
+    REQUIRE(!(px[i].tok && !S), "node_update: proj[%d].tok given but S is null", i);
+  }
+  ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
+  int rc = launch_node_update(ln1_g, ln1_b, Win_ximg, b_in, Wout_ximg, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out, px, nproj,
+                              S, G, (K + 15) / 16, (hipStream_t)stream, true);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -1071,8 +1113,9 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
         return rc;
     } else {
       if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[tm], P[tm + 1], partial, B, N, K, stream))) return rc;
-      if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b,
-                                 hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
+      const float* pex[4] = {L->W11a_ximg, L->W11c_ximg, last ? nullptr : w->enc[l + 1].W1a_ximg, last ? nullptr : w->enc[l + 1].W1c_ximg};
+      if ((rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img,
+                                 L->b_out, L->ln2_g, L->ln2_b, hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
         return rc;
     }
     if (!chain_edges || last) {
@@ -1146,8 +1189,9 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
       pe[3] = {Ln->W1c_img, nullptr, nullptr, P[1]};
       np = 4;
     }
-    if ((rc = namp_node_update(L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur],
-                               partial, mask, out, pe, np, nullptr, G, K, stream)))
+    const float* pex[4] = {L->W11a_ximg, L->W11c_ximg, last ? nullptr : w->enc[l + 1].W1a_ximg, last ? nullptr : w->enc[l + 1].W1c_ximg};
+    if ((rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out,
+                               L->ln2_g, L->ln2_b, hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
       return rc;
     if (last) cvt({P[2], P[3]}, {T16[2], T16[3]});
     else cvt({P[2], P[3], P[0], P[1]}, {T16[2], T16[3], T16[0], T16[1]});
@@ -1197,8 +1241,9 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
       pn[1] = {Dn->W1v_img, nullptr, Dn->tok, P[1]};
       np = 2;
     }
-    if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin, partial,
-                               mask, out, pn, np, S, G, K, stream)))
+    const float* pnx[2] = {last ? nullptr : w->dec[l + 1].W1a_ximg, last ? nullptr : w->dec[l + 1].W1v_ximg};
+    if ((rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out,
+                               D->ln2_g, D->ln2_b, hin, partial, mask, out, pn, np, S, G, K, stream)))
       return rc;
     if (!last) cvt({P[0], P[1]}, {T16[0], T16[1]});
     hin = out;
@@ -1415,8 +1460,9 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
     } else {
       if ((rc = namp_dec_message(D, h_E, E_idx, rank, PA[l & 1], PB[l & 1], Pfw[l], partial, B_dec, B_enc, N, K, stream)))
         return rc;
-      if ((rc = namp_node_update(D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin,
-                                 partial, mask, out, pn, np, S, Gd, K, stream)))
+      const float* pnx[2] = {last ? nullptr : w->dec[l + 1].W1a_ximg, last ? nullptr : w->dec[l + 1].W1v_ximg};
+      if ((rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img,
+                                 D->b_out, D->ln2_g, D->ln2_b, hin, partial, mask, out, pn, np, S, Gd, K, stream)))
         return rc;
     }
     hin = out;

@@ -188,6 +188,22 @@ __device__ __forceinline__ f4 gelu4_scalar(const f4 v) {
   return (f4){gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
 }
 
+// x = hi + mid (+ O(2^-16 x)) for the eight values a lane feeds into one K = 32 step (channel tiles 2s and 2s+1 of its row)
+__device__ __forceinline__ void split_x3(const f4 a, const f4 b, bf8& hi, bf8& mid) {
+  hi[0] = (__bf16)a.x; hi[1] = (__bf16)a.y; hi[2] = (__bf16)a.z; hi[3] = (__bf16)a.w;
+  hi[4] = (__bf16)b.x; hi[5] = (__bf16)b.y; hi[6] = (__bf16)b.z; hi[7] = (__bf16)b.w;
+  mid[0] = (__bf16)(a.x - (float)hi[0]); mid[1] = (__bf16)(a.y - (float)hi[1]);
+  mid[2] = (__bf16)(a.z - (float)hi[2]); mid[3] = (__bf16)(a.w - (float)hi[3]);
+  mid[4] = (__bf16)(b.x - (float)hi[4]); mid[5] = (__bf16)(b.y - (float)hi[5]);
+  mid[6] = (__bf16)(b.z - (float)hi[6]); mid[7] = (__bf16)(b.w - (float)hi[7]);
+}
+// acc += W . x for one fragment pair (hi, mid images of the same tile): the three split products
+__device__ __forceinline__ f4 mfma_x3(const bf8 wh, const bf8 wm, const bf8 hi, const bf8 mid, f4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc, 0, 0, 0);
+}
+
 template <bool FLIP, bool ACT>
 __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
 #pragma unroll

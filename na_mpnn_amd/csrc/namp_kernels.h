@@ -41,6 +41,21 @@ __global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int co
   img[128 * 128 + e] = (__bf16)(v - (float)hi);
 }
 
+// x3 image of a general block [OUT x IN] (multiples of 16 / 32): hi[s = IN/32][tn = OUT/16][lane][8 bf16] followed by mid in
+// the same order — pack_image_x3_kernel's layout for OUT = IN = 128.  Used by the residue-level kernels (W_in, W_out).
+__global__ void pack_image_x3_general_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN, __bf16* __restrict__ img) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= OUT * IN) return;
+  const int ntn = OUT >> 4;
+  const int j = e & 7, lane = (e >> 3) & 63, t = e >> 9;
+  const int tn = t % ntn, s = t / ntn;
+  const int n = 16 * tn + (lane & 15), k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  const float v = W[(size_t)n * ld + col0 + k];
+  const __bf16 hi = (__bf16)v;
+  img[e] = hi;
+  img[(size_t)OUT * IN + e] = (__bf16)(v - (float)hi);
+}
+
 // Split-bf16 image of edge_embedding.weight [128 x 5200] for edge_features_kernel<true>: the positional k-tile stays an
 // fp32 fragment tile (2048 floats), then one 48 KiB block per RBF chunk c = 3a + bg (6 atom pairs = 3 bf16 K-steps of two
 // pairs): [hi: 3 steps x 8 tn x 64 lanes x 8 bf16][mid: same].  Slot j of lane (m, g) in step s is RBF 4g + (j&3) of pair
@@ -1648,7 +1663,9 @@ __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a
 // projection fragment against the T output tiles.  Arithmetic per row is that of node_tail<true>.
 #define NODE_MULTI_LDS(T) (((2 * (T) * 16) + 8 * 16) * FFN_LD * 4)
 
-template <int T>
+// X3: Win_img / Wout_img / every projection image are x3 images (pack_image_x3_general_kernel / pack_image_x3_kernel) and
+// the three GEMM phases run as split-bf16 products: 144 bf16 MFMAs per tile instead of 384 fp32 MFMAs (5.3x fewer cycles).
+template <int T, bool X3 = false>
 __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = (float*)smem;                       // [T][16][FFN_LD]  LN1 outputs
@@ -1681,7 +1698,29 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
   __syncthreads();
   // ---- phase A: hidden = gelu(W_in x + b_in); wave w owns hidden units 64w .. 64w+63
   f4 hacc[T][4];
-  {
+  if constexpr (X3) {
+    bf8 wh[4][4], wm[4][4];
+    const bf8* w = (const bf8*)t.Win_img + (4 * wave) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) { wh[s][tn] = w[(s * 32 + tn) * 64]; wm[s][tn] = w[512 * 128 / 8 + (s * 32 + tn) * 64]; }
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hacc[q][c] = *(const f4*)(t.b_in + 64 * wave + 16 * c + 4 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* xr = xs + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
+        bf8 hi, mid;
+        split_x3(*(const f4*)xr, *(const f4*)(xr + 16), hi, mid);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma_x3(wh[s][tn], wm[s][tn], hi, mid, hacc[q][tn]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hacc[q][c] = gelu4(hacc[q][c]);
+    }
+  } else {
     f4 win[8][4];
     const f4* w = (const f4*)t.Win_img + (4 * wave) * 64 + lane;
 #pragma unroll
@@ -1706,23 +1745,42 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
   }
   // ---- phase B: W_out, then LayerNorm2 per tile
   {
-    f4 wo[4][8];
-    const f4* w = (const f4*)t.Wout_img + (4 * wave) * 8 * 64 + lane;
+    f4 wo[X3 ? 1 : 4][8];
+    bf8 woh[X3 ? 2 : 1][8], wom[X3 ? 2 : 1][8];
+    if constexpr (X3) {
+      const bf8* w = (const bf8*)t.Wout_img + (2 * wave) * 8 * 64 + lane;       // K-steps 2*wave, 2*wave+1: this wave's 64 hidden units
 #pragma unroll
-    for (int tk = 0; tk < 4; ++tk)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int tn = 0; tn < 8; ++tn) wo[tk][tn] = w[(tk * 8 + tn) * 64];
+        for (int tn = 0; tn < 8; ++tn) { woh[s][tn] = w[(s * 8 + tn) * 64]; wom[s][tn] = w[128 * 512 / 8 + (s * 8 + tn) * 64]; }
+    } else {
+      const f4* w = (const f4*)t.Wout_img + (4 * wave) * 8 * 64 + lane;
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) wo[X3 ? 0 : tk][tn] = w[(tk * 8 + tn) * 64];
+    }
 #pragma unroll
     for (int q = 0; q < T; ++q) {
       f4 oacc[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) oacc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (X3) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf8 hi, mid;
+          split_x3(hacc[q][2 * s], hacc[q][2 * s + 1], hi, mid);
+#pragma unroll
+          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma_x3(woh[s][tn], wom[s][tn], hi, mid, oacc[tn]);
+        }
+      } else {
 #pragma unroll
       for (int tk = 0; tk < 4; ++tk)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[tk][tn][r], hacc[q][tk][r], oacc[tn]);
+          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma4(wo[X3 ? 0 : tk][tn][r], hacc[q][tk][r], oacc[tn]);
+      }
       float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
 #pragma unroll
       for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = oacc[c];
@@ -1763,9 +1821,18 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
     const ProjDesc d = t.p[pi];
     {
       const int tn = wave;                                    // 8 waves <-> 8 channel tiles
-      f4 wf[8];
+      f4 wf[X3 ? 1 : 8];
+      bf8 wfh[X3 ? 4 : 1], wfm[X3 ? 4 : 1];
+      if constexpr (X3) {
 #pragma unroll
-      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)d.img)[(tk * 8 + tn) * 64 + lane];
+        for (int s = 0; s < 4; ++s) {
+          wfh[s] = ((const bf8*)d.img)[(s * 8 + tn) * 64 + lane];
+          wfm[s] = ((const bf8*)d.img)[NAMP_BIMG_BYTES / 16 + (s * 8 + tn) * 64 + lane];
+        }
+      } else {
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) wf[X3 ? 0 : tk] = ((const f4*)d.img)[(tk * 8 + tn) * 64 + lane];
+      }
       const f4 bias = d.bias ? *(const f4*)(d.bias + 16 * tn + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < T; ++q) {
@@ -1774,11 +1841,21 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         const int rr = valid ? row : (a.G - 1);
         f4 acc = bias;
         if (d.tok) acc += *(const f4*)(d.tok + (long)t.S[rr] * NAMP_H + 16 * tn + 4 * g);
+        if constexpr (X3) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float* yr = ys + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
+            bf8 hi, mid;
+            split_x3(*(const f4*)yr, *(const f4*)(yr + 16), hi, mid);
+            acc = mfma_x3(wfh[s], wfm[s], hi, mid, acc);
+          }
+        } else {
 #pragma unroll
         for (int tk = 0; tk < 8; ++tk) {
           const f4 xv = *(const f4*)(ys + (q * 16 + m) * FFN_LD + 16 * tk + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma4(wf[tk][r], xv[r], acc);
+          for (int r = 0; r < 4; ++r) acc = mfma4(wf[X3 ? 0 : tk][r], xv[r], acc);
+        }
         }
         if (valid) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
       }

@@ -32,14 +32,16 @@ class NampEncLayerW(C.Structure):
                         "Win_img", "b_in", "Wout_img", "b_out",
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
                         "W1b_bimg", "W2_bimg", "W3_bimg", "W11b_bimg", "W12_bimg", "W13_bimg",
-                        "W1b_ximg", "W2_ximg", "W3_ximg", "W11b_ximg", "W12_ximg", "W13_ximg"]) + [("flags", C.c_int64)]
+                        "W1b_ximg", "W2_ximg", "W3_ximg", "W11b_ximg", "W12_ximg", "W13_ximg",
+                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1c_ximg", "W11a_ximg", "W11c_ximg"]) + [("flags", C.c_int64)]
 
 
 class NampDecLayerW(C.Structure):
     _fields_ = _fields(["W1a_img", "W1e_img", "W1s_img", "W1v_img", "b1", "tok",
                         "W2_img", "b2", "W3_img", "b3", "Win_img", "b_in", "Wout_img", "b_out",
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b",
-                        "W1e_bimg", "W2_bimg", "W3_bimg", "W1e_ximg", "W2_ximg", "W3_ximg"]) + [("flags", C.c_int64)]
+                        "W1e_bimg", "W2_bimg", "W3_bimg", "W1e_ximg", "W2_ximg", "W3_ximg",
+                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1v_ximg"]) + [("flags", C.c_int64)]
 
 
 class NampFeatW(C.Structure):
@@ -67,6 +69,7 @@ _PROTOTYPES = {
     "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_pack_image_x3": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_pack_feat_x3": (i32, [c_fp, i32, c_fp, vp]),
+    "namp_pack_image_x3_general": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
     "namp_gather_nodes_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),
     "namp_gather_rows_f32": (i32, [c_fp, c_ip, c_fp, C.c_long, i32, i32, i32, vp]),
     "namp_gather_edges_f32": (i32, [c_fp, c_ip, c_fp, i32, i32, i32, i32, vp]),

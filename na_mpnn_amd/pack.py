@@ -49,6 +49,9 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     def ximg(name, key, col0):                      # 64 KiB x3 image (bf16 hi | bf16 mid) = 16384 float slots
         add(name, H * H, ("ximg", key, col0))
 
+    def xgimg(name, key, out_f, in_f):              # x3 image of a general block (residue-level FFN weights)
+        add(name, out_f * in_f, ("xgimg", key, out_f, in_f))
+
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
     ximg("We_ximg", "W_e.weight", 0)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
@@ -79,6 +82,9 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         bimg(p + "W11b_bimg", q + "W11.weight", H); bimg(p + "W12_bimg", q + "W12.weight", 0); bimg(p + "W13_bimg", q + "W13.weight", 0)
         ximg(p + "W1b_ximg", q + "W1.weight", H); ximg(p + "W2_ximg", q + "W2.weight", 0); ximg(p + "W3_ximg", q + "W3.weight", 0)
         ximg(p + "W11b_ximg", q + "W11.weight", H); ximg(p + "W12_ximg", q + "W12.weight", 0); ximg(p + "W13_ximg", q + "W13.weight", 0)
+        xgimg(p + "Win_ximg", q + "dense.W_in.weight", 4 * H, H); xgimg(p + "Wout_ximg", q + "dense.W_out.weight", H, 4 * H)
+        ximg(p + "W1a_ximg", q + "W1.weight", 0); ximg(p + "W1c_ximg", q + "W1.weight", 2 * H)
+        ximg(p + "W11a_ximg", q + "W11.weight", 0); ximg(p + "W11c_ximg", q + "W11.weight", 2 * H)
     for l in range(n_dec):
         p, q = f"dec{l}.", f"decoder_layers.{l}."
         for nm, c0 in (("W1a", 0), ("W1e", H), ("W1s", 2 * H), ("W1v", 3 * H)):
@@ -93,6 +99,8 @@ def plan(n_enc: int, n_dec: int, vocab: int):
             vec(p + f"ln{i}_g", q + f"norm{i}.weight", H); vec(p + f"ln{i}_b", q + f"norm{i}.bias", H)
         bimg(p + "W1e_bimg", q + "W1.weight", H); bimg(p + "W2_bimg", q + "W2.weight", 0); bimg(p + "W3_bimg", q + "W3.weight", 0)
         ximg(p + "W1e_ximg", q + "W1.weight", H); ximg(p + "W2_ximg", q + "W2.weight", 0); ximg(p + "W3_ximg", q + "W3.weight", 0)
+        xgimg(p + "Win_ximg", q + "dense.W_in.weight", 4 * H, H); xgimg(p + "Wout_ximg", q + "dense.W_out.weight", H, 4 * H)
+        ximg(p + "W1a_ximg", q + "W1.weight", 0); ximg(p + "W1v_ximg", q + "W1.weight", 3 * H)
     return items, off
 
 
@@ -152,6 +160,11 @@ class PackedWeights:
                 w = src(recipe[1])
                 hip.check(L.namp_pack_image_x3(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
                           f"pack_image_x3({name})")
+            elif recipe[0] == "xgimg":
+                _, key, out_f, in_f = recipe
+                w = src(key)
+                hip.check(L.namp_pack_image_x3_general(w.data_ptr(), w.shape[1], 0, out_f, in_f, self.addr(name), stream),
+                          f"pack_image_x3_general({name})")
             elif recipe[0] == "fximg":
                 w = src(recipe[1])
                 hip.check(L.namp_pack_feat_x3(w.data_ptr(), w.shape[1], self.addr(name), stream), f"pack_feat_x3({name})")
