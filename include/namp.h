@@ -328,6 +328,11 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */
 int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                             float* out0, float* out1, int G, void* stream);
+/* LayerNorm over the 128 channels of [rows][128] (features.norm_edges on the edge embedding, na_model_utils.py:509) and its
+ * backward: gx = dL/dx; dgb_part [namp_train_ln_rows_groups(rows)][2][128] = per-workgroup partial sums of d(weight), d(bias). */
+int namp_train_ln_rows_groups(long rows);
+int namp_train_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* out, long rows, void* stream);
+int namp_train_ln_rows_bwd(const float* x, const float* g, const float* gamma, float* gx, float* dgb_part, long rows, void* stream);
 int namp_train_wgrad_chunks(long rows);
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long rows, float* dW_part, float* db_part, void* stream);
 int namp_train_feat_wgrad_chunks(long edges);

@@ -784,6 +784,67 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// ln_rows_*_kernel: LayerNorm over the 128 channels of [rows][128] and its backward (norm_edges on the edge embedding,
+// na_model_utils.py:509: the one [E,128]-sized LayerNorm of the training step that is not fused into an edge kernel; the
+// stock op runs at ~1 TB/s on these 512-byte rows).  32 lanes x float4 per row, two rows per wave, grid-stride; eps = 1e-5,
+// biased variance.  Backward: gx = rstd (g.gamma - mean(g.gamma) - xhat mean(g.gamma.xhat)); d(gamma) = sum g.xhat and
+// d(beta) = sum g accumulate per thread over its rows and leave as per-workgroup partials dgb_part [groups][2][128].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out, long rows) {
+  const int c4 = threadIdx.x & 31;
+  const f4 ga = *(const f4*)(gamma + 4 * c4), be = *(const f4*)(beta + 4 * c4);
+  for (long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (long)gridDim.x * 8) {
+    f4 v = *(const f4*)(x + r * NAMP_H + 4 * c4);
+    const float mean = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+    v -= mean;
+    const float var = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 128.0f);
+    const float rstd = rsqrtf(var + 1e-5f);
+    *(f4*)(out + r * NAMP_H + 4 * c4) = v * rstd * ga + be;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ gamma, float* __restrict__ gx,
+                                                          float* __restrict__ dgb_part, long rows) {
+  __shared__ float red[8][2][128];
+  const int c4 = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const f4 ga = *(const f4*)(gamma + 4 * c4);
+  f4 dg = (f4){0.f, 0.f, 0.f, 0.f}, db = (f4){0.f, 0.f, 0.f, 0.f};
+  for (long r = (long)blockIdx.x * 8 + sub; r < rows; r += (long)gridDim.x * 8) {
+    f4 v = *(const f4*)(x + r * NAMP_H + 4 * c4);
+    const f4 gr = *(const f4*)(g + r * NAMP_H + 4 * c4);
+    const float mean = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+    v -= mean;
+    const float var = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 128.0f);
+    const float rstd = rsqrtf(var + 1e-5f);
+    const f4 xh = v * rstd;
+    const f4 gg = gr * ga;
+    const float m1 = half_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.0f / 128.0f);
+    const float m2 = half_wave_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.0f / 128.0f);
+    *(f4*)(gx + r * NAMP_H + 4 * c4) = (gg - m1 - xh * m2) * rstd;
+    dg += gr * xh;
+    db += gr;
+  }
+  *(f4*)&red[sub][0][4 * c4] = dg;
+  *(f4*)&red[sub][1][4 * c4] = db;
+  __syncthreads();
+  {
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][which][c];
+    dgb_part[((long)blockIdx.x * 2 + which) * NAMP_H + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // scatter_rows_kernel: dL/dPj[j] = sum over the edges e that gathered table row j of G1[e] — the transpose of the
 // neighbour gather, evaluated as a GATHER over the reverse adjacency (edges sorted by target once per step, shared by
 // all nine per-edge stages): one wave per target row streams its ~K incoming 512-B rows and sums them in registers.

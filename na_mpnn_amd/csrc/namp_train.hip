@@ -143,6 +143,31 @@ int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int3
   return NAMP_OK;
 }
 
+int namp_train_ln_rows_groups(long rows) {
+  if (rows <= 0) return 0;
+  long n = (rows + 63) / 64;               // >= 8 rows per sub-group pass, <= 8 workgroups per CU
+  if (n > 2048) n = 2048;
+  return (int)n;
+}
+
+int namp_train_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* out, long rows, void* stream) {
+  REQUIRE_PTR(x); REQUIRE_PTR(gamma); REQUIRE_PTR(beta); REQUIRE_PTR(out);
+  REQUIRE(rows >= 1, "namp_train_ln_rows_fwd: rows=%ld", rows);
+  hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(namp_train_ln_rows_groups(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out,
+                     rows);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_ln_rows_bwd(const float* x, const float* g, const float* gamma, float* gx, float* dgb_part, long rows, void* stream) {
+  REQUIRE_PTR(x); REQUIRE_PTR(g); REQUIRE_PTR(gamma); REQUIRE_PTR(gx); REQUIRE_PTR(dgb_part);
+  REQUIRE(rows >= 1, "namp_train_ln_rows_bwd: rows=%ld", rows);
+  hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(namp_train_ln_rows_groups(rows)), dim3(256), 0, (hipStream_t)stream, x, g, gamma, gx,
+                     dgb_part, rows);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
   long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 4 workgroups per CU
