@@ -293,6 +293,9 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   db3 = sum G3, db2 = sum G2, dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k] — the last two are accumulated by the
  *   launch itself with fp32 atomics into g_Pa / g_Pj0 (/ g_Pj1: rows that gathered Pfw) when those ZEROED [B*N][128]
  *   buffers are given (each optional; NULL: the caller reduces G1 — namp_train_scatter_rows does dL/dPj without atomics).
+ *   S3 / w3 (optional, modes 0/1 with K % 16 == 0; A2 and G3 may then be NULL and are not written): in a message mode
+ *   G3[i,k] = w_ik g_out[i], hence dW3 = g_out^T . S with S[i] = sum_k w_ik A2[i,k] and db3 = sum_i g_out[i] sum_k w_ik; the
+ *   launch writes per 16-row tile t = (i, k/16) the sums S3[t][128] and w3[t] — the caller adds a residue's K/16 tiles.
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
  * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated
@@ -322,7 +325,7 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int x3, int B, int N, int K, void* stream);
+                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N, int K, void* stream);
 /* dL/dPj = transpose of the neighbour gather, as a gather over the reverse adjacency: rev_edge [B*N*K] = edge ids sorted by
  * the table row they gathered (global row b*N + E_idx), rev_off [B*N+1] their offsets per row; out0[j] = sum of G1[e] over the
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */

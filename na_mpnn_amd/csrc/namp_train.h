@@ -63,6 +63,11 @@ struct EdgeBwdArgs {
   const float* g_node;         // MSG modes: dL/d(dh) per residue [G][128]; g3[e] = w_e * g_node[i]
   float* A1; float* A2;        // [E][128] activations gelu(z1), gelu(z2) (for wgrad)
   float* G1; float* G2; float* G3;   // [E][128] (G3 only written in MSG modes)
+  // MSG modes with tiles aligned to residues (K % 16 == 0), optional: in a message MODE the upstream gradient of row (i,k)
+  // is w_ik * g_node[i], so dW3 = sum_e G3[e]^T A2[e] = g_node^T . (sum_k w_ik A2[i,k]): the kernel then writes the
+  // weighted row sum of each 16-row tile (S3 [E/16][128], w3 [E/16] = sum of the tile's w) INSTEAD of the A2 and G3 rows —
+  // 2 x 590 MB of stores and the same again of weight-gradient reads less per launch at cfg5.
+  float* S3; float* w3;
   float* g_hE;                 // [E][128]
   float* g_Pa;                 // optional [G][128], ZEROED by the caller: += sum_k G1[i,k]   (fp32 atomics)
   float* g_Pj0; float* g_Pj1;  // optional [G][128], zeroed: += G1[e] at the row's gathered table (Pj0 / Pj1 like the forward)
@@ -79,8 +84,10 @@ struct EdgeBwdArgs {
 // per-row operand is gathered per lane anyway).  8 waves per workgroup share the 2 x 64 KiB LDS weight ring;
 // the five images W1, W2, W3^T, W2^T, W1^T stream through it by LDS-DMA one GEMM ahead of their use.
 // X3: the six / five GEMMs as split-bf16 products (chain_gemm_x3; the images are then x3 images), like the forward kernels
-template <int MODE, bool X3>
+// TSUM (message modes): write the per-tile weighted sums S3 / w3 instead of the A2 and G3 rows (see EdgeBwdArgs)
+template <int MODE, bool X3, bool TSUM = false>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
+  static_assert(!TSUM || MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG, "tile sums: message modes only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
   if (MODE == BWD_EDGE_LN) { if (threadIdx.x < 2 * NAMP_H) colsum[threadIdx.x] = 0.f; }
@@ -240,8 +247,27 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   char* bufB = (MODE == BWD_EDGE_LN) ? buf0 : buf1;
   wait_dma_and_sync();                                        // W3^T landed in slot A; slot B is free
   dma_to_lds(bufB, a.W2t_img, 64, wave, nwaves, lane);
-  if (MODE != BWD_EDGE_LN) store_rows(a.A2, x);
-  if (MODE != BWD_ROWS) store_rows(a.G3, gr);
+  if (TSUM) {
+    // weighted row sum of the tile's a2 over its 16 rows (lanes of equal g): 4 exchange steps per value
+    const long tile = ((long)blockIdx.x * nwaves + wave);
+    float ws = w_row;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ws += __shfl_xor(ws, o);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 v = x[t] * w_row;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+      }
+      if (m == 0 && tile * 16 < a.E) *(f4*)(a.S3 + tile * NAMP_H + 16 * t + 4 * g) = v;
+    }
+    if (lane == 0 && tile * 16 < a.E) a.w3[tile] = ws;
+  }
+  if (!TSUM) {
+    if (MODE != BWD_EDGE_LN) store_rows(a.A2, x);
+    if (MODE != BWD_ROWS) store_rows(a.G3, gr);
+  }
   // ---- g2 = (W3^T g3) * gelu'(z2)
   f4 acc[8];
 #pragma unroll

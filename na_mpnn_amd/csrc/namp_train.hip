@@ -47,6 +47,8 @@ int ensure_attributes() {
     };
     set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, true>));
     set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, true>));
+    set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, false, true>)); set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, true, true>));
+    set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, false, true>)); set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, true, true>));
     set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, true>));
     set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, true>));
   });
@@ -63,13 +65,22 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, int x3, int B, int N, int K, void* stream) {
+                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N, int K,
+                        void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
-  REQUIRE_PTR(A1); REQUIRE_PTR(A2); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
+  REQUIRE_PTR(A1); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_bwd: null E_idx");
-  if (mode != 2) REQUIRE_PTR(G3);
+  REQUIRE((S3 == nullptr) == (w3 == nullptr), "namp_train_edge_bwd: S3 and w3 go together");
+  if (S3) {
+    REQUIRE(mode != 2 && (K % 16) == 0, "namp_train_edge_bwd: tile sums (S3) need a message mode and K %% 16 == 0 (mode=%d, K=%d)", mode, K);
+    REQUIRE_PTR(S3);
+    if (((uintptr_t)w3 & 3) != 0) return fail(NAMP_EINVAL, "namp_train_edge_bwd: w3 must be 4-byte aligned");
+  } else {
+    REQUIRE_PTR(A2);
+    if (mode != 2) REQUIRE_PTR(G3);
+  }
   if (mode == 1) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_bwd: decoder message needs rank"); }
   REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_bwd: bad dims B=%d N=%d K=%d", B, N, K);
   int rc = ensure_attributes();
@@ -80,7 +91,7 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   if (mode == 2) a.g_rows = g_out; else a.g_node = g_out;
   REQUIRE(mode != 1 || (g_Pj0 == nullptr) == (g_Pj1 == nullptr), "namp_train_edge_bwd: decoder message needs g_Pj1 with g_Pj0");
   a.g_Pa = g_Pa; a.g_Pj0 = g_Pj0; a.g_Pj1 = g_Pj1;
-  a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE;
+  a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.S3 = S3; a.w3 = w3;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
@@ -89,8 +100,13 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
     if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);        \
     else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, false>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);          \
   } while (0)
-  if (mode == 0) NAMP_LAUNCH_BWD(BWD_ENC_MSG);
-  else if (mode == 1) NAMP_LAUNCH_BWD(BWD_DEC_MSG);
+#define NAMP_LAUNCH_BWD_TSUM(M)                                                                                         \
+  do {                                                                                                                    \
+    if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, true, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);  \
+    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, false, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);    \
+  } while (0)
+  if (mode == 0) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_ENC_MSG); else NAMP_LAUNCH_BWD(BWD_ENC_MSG); }
+  else if (mode == 1) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_DEC_MSG); else NAMP_LAUNCH_BWD(BWD_DEC_MSG); }
   else NAMP_LAUNCH_BWD(BWD_ROWS);
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -126,15 +126,20 @@ class _EdgeMLP(torch.autograd.Function):
         g = g.contiguous()
         img1, img2 = _image(W1b.detach()), _image(W2.detach())
         img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
-        A1, A2, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(5))
-        G3 = torch.empty(E, H, device=dev) if mode != ENC_EDGE else None
+        A1, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(4))
+        # message modes with tiles aligned to residues: dW3 = g^T . (sum_k w_ik a2[i,k]) from per-tile sums, no A2 / G3 rows
+        tile_sums = mode != ENC_EDGE and K % 16 == 0
+        A2 = None if tile_sums else torch.empty(E, H, device=dev)
+        G3 = torch.empty(E, H, device=dev) if (mode != ENC_EDGE and not tile_sums) else None
+        S3 = torch.empty(E // 16, H, device=dev) if tile_sums else None
+        w3 = torch.empty(E // 16, device=dev) if tile_sums else None
         b2c = b2.detach().contiguous()
         g_Pa = torch.zeros(B * N, H, device=dev)
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
-                                        g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, int(X3), B, N, K,
+                                        g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(X3), B, N, K,
                                         hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
@@ -145,7 +150,12 @@ class _EdgeMLP(torch.autograd.Function):
             g_Pj0, g_Pj1 = rev.scatter(G1)
         if mode == ENC_EDGE:
             G3 = g.view(E, H)
-        dW3, db3 = _wgrad(G3, A2, False, True)
+        if tile_sums:
+            g2d = g.view(B * N, H)
+            dW3 = g2d.t() @ S3.view(B * N, K // 16, H).sum(1)
+            db3 = (g2d * w3.view(B * N, K // 16).sum(1, keepdim=True)).sum(0)
+        else:
+            dW3, db3 = _wgrad(G3, A2, False, True)
         dW2, db2 = _wgrad(G2, A1, False, True)
         dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
