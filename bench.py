@@ -106,7 +106,17 @@ def gather_microbench(dev, reps=10):
     ms = e0.elapsed_time(e1) / reps
     nbytes = B * N * K * 1540 + B * N * 128 * 4
     gbs = nbytes / (ms * 1e-3) / 1e9
-    del hE, hV, idx, out
+    # the practical ceiling on this box: a device-to-device copy of the same order of bytes (3.1 GB read + written)
+    src, dst = out.view(-1)[: hE.numel()], hE.view(-1)
+    for _ in range(2):
+        dst.copy_(src)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * src.numel() * 4 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+    del hE, hV, idx, out, src, dst
     torch.cuda.empty_cache()
     traffic = None
     try:
@@ -116,7 +126,8 @@ def gather_microbench(dev, reps=10):
         pass
     return {"kernel": "gather_cat_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4),
-            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": traffic}
+            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": traffic,
+            "d2d_copy_GBps": round(copy_gbs, 1), "frac_of_d2d_copy": round(gbs / copy_gbs, 3)}
 
 
 def cpu_baseline(runner, budget_s=25.0):

@@ -351,7 +351,7 @@ int launch_gather(const float* nodes, const float* nbrs, const int32_t* idx, flo
     const long total = rows * ((C1 + C2) >> 2);
     long blocks = (total + 256L * 4 - 1) / (256L * 4);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
+    blocks = (blocks + 7) & ~7L;                       // a multiple of 8: one contiguous row range per XCD (gather_cat_kernel)
     hipLaunchKernelGGL(gather_cat_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
                        NK, N, C1, C2);
   } else {

@@ -89,15 +89,24 @@ __global__ void gather_cat_kernel(const float* __restrict__ nodes, const float* 
                                   const int32_t* __restrict__ idx, float* __restrict__ out,
                                   long rows, int NK /* N*K rows per batch */, int N, int C1, int C2) {
   const int s1 = C1 >> 2, slots = (C1 + C2) >> 2;
-  const long total = rows * slots;
-  const long stride = (long)gridDim.x * blockDim.x;
-  long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware row ranges: block b runs on XCD b % 8 (observed dispatch order; only speed depends on it), and each XCD has
+  // its own 4 MiB L2.  Giving every XCD one contiguous eighth of the (batch-major) rows keeps the node tables it gathers
+  // from — 512 KB per complex — resident in ITS L2; with rows dealt round-robin every L2 saw every table (at B = 64 the
+  // gathered rows then came from the fabric: 2.9 GB fetched per launch instead of 1.6).  gridDim.x is a multiple of 8.
+  const int xcd = blockIdx.x & 7, slot_b = blockIdx.x >> 3;
+  const long rows_per = (rows + 7) >> 3;
+  const long r0 = xcd * rows_per;
+  const long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+  const long base = r0 * slots;
+  const long total = r1 > r0 ? (r1 - r0) * slots : 0;
+  const long stride = (long)(gridDim.x >> 3) * blockDim.x;
+  long e0 = (long)slot_b * blockDim.x + threadIdx.x;
   for (; e0 < total; e0 += stride * UNROLL) {
     f4 v[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) {
+      const long e = base + e0 + u * stride;
+      if (e0 + u * stride < total) {
         const long row = e / slots;
         const int s = (int)(e - row * slots);
         if (s < s1) {
@@ -111,8 +120,7 @@ __global__ void gather_cat_kernel(const float* __restrict__ nodes, const float* 
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) *(f4*)(out + 4 * e) = v[u];
+      if (e0 + u * stride < total) *(f4*)(out + 4 * (base + e0 + u * stride)) = v[u];
     }
   }
 }
