@@ -164,7 +164,9 @@ int ensure_attributes() {
 // The message kernels update their own residues in-launch (fused tail) while the batch is small enough
 // that this beats a separate 16-residue-per-workgroup node_update launch: every workgroup of the fused
 // form re-streams the 768 KiB of FFN + projection weights for <= 12 residues.
-#define NAMP_FUSED_TAIL_MAX_RESIDUES 4096
+#ifndef NAMP_FUSED_TAIL_MAX_RESIDUES
+#define NAMP_FUSED_TAIL_MAX_RESIDUES 2500   // tools/batch_sweep.py: 3000 / 4000 residues run 5 / 10 % faster unfused, 2000 run 5 % slower
+#endif
 
 struct EdgeGeom { int tpn, nwaves, npw, grid; };
 EdgeGeom edge_geom(int G, int K) {
