@@ -610,14 +610,17 @@ int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_im
   return NAMP_OK;
 }
 
-// Residue update of the unfused (large-batch) paths: as split-bf16 products when the precision is not exact fp32, the batch
-// takes the multi-tile kernel and the layer carries x3 images of the FFN and of every projected block; exact fp32 otherwise.
+// Residue update of the unfused (large-batch) paths: as split-bf16 products (multi-tile kernel) when the precision is not exact
+// fp32 and the layer carries x3 images of the FFN and of every projected block; exact fp32 otherwise.
 static int node_update_auto(int64_t flags, const float* Win_ximg, const float* Wout_ximg, const float* const* proj_ximg,
                             const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                             const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
                             const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
                             const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
-  bool x3 = prec_of(flags) != PREC_F32 && Win_ximg && Wout_ximg && G >= 32 * 2 * device_cus() && nproj <= 8;
+#ifndef NAMP_NODE_X3_MIN_RESIDUES
+#define NAMP_NODE_X3_MIN_RESIDUES 2500   // the whole unfused regime: 3-12 % per forward at 3,000-16,000 residues (tools/batch_sweep.py)
+#endif
+  bool x3 = prec_of(flags) != PREC_F32 && Win_ximg && Wout_ximg && G >= NAMP_NODE_X3_MIN_RESIDUES && nproj <= 8;
   for (int i = 0; x3 && i < nproj; ++i) x3 = proj_ximg && proj_ximg[i] != nullptr;
   if (!x3)
     return namp_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out, proj, nproj,
