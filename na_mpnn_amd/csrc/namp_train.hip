@@ -186,8 +186,8 @@ int namp_train_ln_rows_bwd(const float* x, const float* g, const float* gamma, f
 
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
-  long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 4 workgroups per CU
-  if (n > 1024) n = 1024;
+  long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 2 workgroups per CU (the split-bf16
+  if (n > 512) n = 512;                    // kernel's occupancy): every chunk costs 64 KB of partials the caller has to add up
   return (int)n;
 }
 
