@@ -1,7 +1,7 @@
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01k
+O=$R/gpurun_out/r01l
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
