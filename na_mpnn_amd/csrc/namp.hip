@@ -351,10 +351,16 @@ int launch_gather(const float* nodes, const float* nbrs, const int32_t* idx, flo
   const int NK = rows_per_table ? rows_per_table : N * K;
   if (((C1 | C2) & 3) == 0) {
     const long total = rows * ((C1 + C2) >> 2);
-    long blocks = (total + 256L * 4 - 1) / (256L * 4);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+#ifndef NAMP_GATHER_UNROLL
+#define NAMP_GATHER_UNROLL 2      // rows in flight per thread: 1 / 2 / 4 / 8 measure 4.69 / 4.72 / 4.12 / 3.81 TB/s at the cfg3 shape
+#endif
+    long blocks = (total + 256L * NAMP_GATHER_UNROLL - 1) / (256L * NAMP_GATHER_UNROLL);
+#ifndef NAMP_GATHER_MAXBLK
+#define NAMP_GATHER_MAXBLK (256 * 16)
+#endif
+    if (blocks > NAMP_GATHER_MAXBLK) blocks = NAMP_GATHER_MAXBLK;
     blocks = (blocks + 7) & ~7L;                       // a multiple of 8: one contiguous row range per XCD (gather_cat_kernel)
-    hipLaunchKernelGGL(gather_cat_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
+    hipLaunchKernelGGL(gather_cat_kernel<NAMP_GATHER_UNROLL>, dim3((unsigned)blocks), dim3(256), 0, s, nodes, nbrs, idx, out, rows,
                        NK, N, C1, C2);
   } else {
     const long total = rows * (C1 + C2);
