@@ -114,6 +114,7 @@ typedef struct NampModelW {
   NampDecLayerW dec[NAMP_MAX_LAYERS];
   NampFeatW feat;
   const float* We_ximg;            /* x3 image of W_e (the embedding fused in front of EncLayer 0, namp_encdec_fwd) */
+  const float* Wv_ximg;            /* optional x3 image of W_v (with enc[0].W1a_ximg / W1c_ximg: namp_encdec_fwd's first launch as split-bf16 products) */
 } NampModelW;
 
 /* ---- a1/a3: neighbour gather ----------------------------------------------------------- */

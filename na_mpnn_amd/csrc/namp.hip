@@ -310,7 +310,7 @@ int check_proj(const char* fn, const NampProj* proj, int nproj, const int32_t* S
 }
 
 int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
-                       const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s) {
+                       const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s, bool x3 = false) {
   NodeLinearArgs a;
   a.X = X; a.S = S; a.G_out = G_out; a.G_src = G_src; a.N = N; a.nproj = nproj;
   a.pre.img = pre ? pre->img : nullptr; a.pre.bias = pre ? pre->bias : nullptr;
@@ -320,7 +320,8 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
     a.p[i].img = p.img; a.p[i].bias = p.bias; a.p[i].tok = p.tok; a.p[i].out = p.out;
   }
   const int units = ((G_out + 15) / 16) * nproj;
-  hipLaunchKernelGGL(node_linear_kernel, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  if (x3) hipLaunchKernelGGL(node_linear_kernel<true>, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(node_linear_kernel<false>, dim3((units + 3) / 4), dim3(256), 0, s, a);
   return NAMP_OK;
 }
 
@@ -1304,7 +1305,16 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   const NampEncLayerW* L0 = &w->enc[0];
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
-  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  if (prec_of(L0->flags) == PREC_X3 && w->Wv_ximg && L0->W1a_ximg && L0->W1c_ximg) {
+    // split-bf16 form of the first launch (two chained fp32 MFMA GEMMs per unit otherwise: 15 us of pure latency at cfg2)
+    OPTIONAL_PTR(w->Wv_ximg); OPTIONAL_PTR(L0->W1a_ximg); OPTIONAL_PTR(L0->W1c_ximg);
+    REQUIRE_PTR(V); REQUIRE_PTR(w->Wv_b); REQUIRE_PTR(L0->b1);
+    const NampProj prex = {w->Wv_ximg, w->Wv_b, nullptr, hv[0]};
+    const NampProj px[2] = {{L0->W1a_ximg, L0->b1, nullptr, P[0]}, {L0->W1c_ximg, nullptr, nullptr, P[1]}};
+    ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
+    launch_node_linear(V, nullptr, B * N, B * N, N, px, 2, &prex, s, true);
+    CHECK_LAUNCH();
+  } else if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
   if (E) { REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }    // embedded inside the first message launch
   int cur = 0;
   for (int l = 0; l < w->n_enc; ++l) {

@@ -252,6 +252,31 @@ __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], co
   }
 }
 
+// The split-bf16 contraction with the x3 image streamed straight from global memory (L2 resident): the 16 fragments of step
+// s+1 (hi and mid of 8 channel tiles) are requested before the MFMAs of step s issue — chain_gemm_global's schedule.
+__device__ __forceinline__ void chain_gemm_global_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* __restrict__ w) {
+  bf8 ch[8], cm[8], nh[8], nm[8];
+#pragma unroll
+  for (int tn = 0; tn < 8; ++tn) { ch[tn] = w[tn * 64]; cm[tn] = w[NAMP_BIMG_BYTES / 16 + tn * 64]; }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s + 1 < 4) {
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) { nh[tn] = w[((s + 1) * 8 + tn) * 64]; nm[tn] = w[NAMP_BIMG_BYTES / 16 + ((s + 1) * 8 + tn) * 64]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf8 hi, mid;
+    split_x3(x[2 * s], x[2 * s + 1], hi, mid);
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma_x3(ch[tn], cm[tn], hi, mid, acc[tn]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < 4) {
+#pragma unroll
+      for (int tn = 0; tn < 8; ++tn) { ch[tn] = nh[tn]; cm[tn] = nm[tn]; }
+    }
+  }
+}
+
 // one 128 x 128 tile GEMM of the edge kernels out of a 64 KiB LDS slot: exact fp32 MFMA or the split-bf16 form
 template <bool X3, bool FLIP, bool ACT>
 __device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {

@@ -1584,6 +1584,7 @@ struct NodeLinearArgs {
   ProjDesc p[8];
 };
 
+template <bool X3>       // X3: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products
 __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1609,7 +1610,8 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   if (a.pre.img) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = a.pre.bias ? *(const f4*)(a.pre.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-    chain_gemm_global<8, 8, false>(acc, x, (const f4*)a.pre.img + lane, 8);
+    if constexpr (X3) chain_gemm_global_x3(acc, x, (const bf8*)a.pre.img + lane);
+    else chain_gemm_global<8, 8, false>(acc, x, (const f4*)a.pre.img + lane, 8);
     if (pi == 0 && valid && a.pre.out) {
       float* dst = a.pre.out + (long)row * NAMP_H + 4 * g;
 #pragma unroll
@@ -1620,7 +1622,8 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = d.bias ? *(const f4*)(d.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-  chain_gemm_global<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
+  if constexpr (X3) chain_gemm_global_x3(acc, x, (const bf8*)d.img + lane);
+  else chain_gemm_global<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
   if (d.tok) {
     const float* tk = d.tok + (long)a.S[rr] * NAMP_H + 4 * g;
 #pragma unroll
