@@ -470,12 +470,15 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
       const long row = r0 + 8 * g + j;
       const bool ok = row < r_end;
       const long rr = ok ? row : r_begin;
-      const float* gp = G + rr * NAMP_H + 16 * to0 + n;
-      const float* ap = A + rr * NAMP_H + 16 * tc0 + n;
+      // one 16-byte load per row and operand: lane n takes columns 4n .. 4n+3 of the wave's 64-column half, i.e. MFMA tile q
+      // holds column 4n + q (not 16q + n) — a permutation of the output channels that the final store undoes.  256 contiguous
+      // bytes per row and instruction instead of four 64-byte pieces.
+      const f4 gq = *(const f4*)(G + rr * NAMP_H + 16 * to0 + 4 * n);
+      const f4 aq = *(const f4*)(A + rr * NAMP_H + 16 * tc0 + 4 * n);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const float v = gp[16 * q]; go[q][j] = ok ? v : 0.f; }
+      for (int q = 0; q < 4; ++q) go[q][j] = ok ? gq[q] : 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ao[t][j] = ap[16 * t];
+      for (int t = 0; t < 4; ++t) ao[t][j] = aq[t];
     }
   };
   if (r_begin < r_end) load(r_begin, gv, av);
@@ -510,12 +513,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(16 * (to0 + q) + 4 * g + r) * NAMP_H + 16 * (tc0 + t) + n] = acc[q][t][r];
+      for (int r = 0; r < 4; ++r) out[(16 * to0 + 4 * (4 * g + r) + q) * NAMP_H + 16 * tc0 + 4 * n + t] = acc[q][t][r];
   if (db_part && (wave & 1) == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float s = xg_sum(bsum[q]);
-      if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * (to0 + q) + n] = s;
+      if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * to0 + 4 * n + q] = s;
     }
   }
 }
