@@ -238,18 +238,24 @@ def train_bench(args, dev, rank, world, dist):
     bwd_ms = sum(v[0] for _, v in bwd); bwd_n = sum(v[1] for _, v in bwd)
     avg_s = bwd_ms / max(bwd_n, 1) * 1e-3
     edges = B * N * K
+    x3 = getattr(m, "message_precision", "x3") != "fp32"     # split-bf16 products: 3 bf16 MFMAs per algorithmic product
+    peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    algo_tf = BWD_FLOP_EDGE_ALGO * edges / avg_s / 1e12
     roofline = {"kernel": "edge_chain_bwd_kernel", "bound": "mfma",
-                "achieved": round(BWD_FLOP_EDGE_ALGO * edges / avg_s / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(BWD_FLOP_EDGE_ALGO * edges / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "executed_frac": round(BWD_FLOP_EDGE_EXEC * edges / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "achieved": round(algo_tf, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(algo_tf / peak, 4), "traffic": None,
+                "executed_frac": round(BWD_FLOP_EDGE_EXEC * (3 if x3 else 1) * edges / avg_s / 1e12 / peak, 4),
+                "frac_vs_fp32_mfma_peak": round(algo_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": bwd_n,
                 "note": "algorithmic = 3 data-gradient GEMMs per edge; executed adds the 2 recomputed forward GEMMs "
                         "(the reference's checkpoint-recompute policy); durations from the device trace of one step"}
     out = {"metric": "residues/sec trained (featurise + fwd + bwd + clip + Noam/Adam), N=1500 K=48 h=128", "value": round(value, 1),
            "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16x3 (per-edge GEMMs of forward, backward and weight gradients as split-bf16 products, fp32 accumulate; fp32 elsewhere)" if x3 else "f32",
+           "data": "synthetic",
            "config": {"workload": f"cfg5: B={B} x N={N} residues per rank, K={K}, H=128, 3+3 layers, dropout 0.1, coordinate noise 0.1, "
-                                  "label smoothing 0.1, fp32, seeded random-init weights; N > 1: data parallel, one RCCL "
+                                  "label smoothing 0.1, seeded random-init weights; N > 1: data parallel, one RCCL "
                                   "all-reduce of the 9.2 MB gradient bucket per step (the reference trains single-GPU)",
                       "global_batch": B * world, "seq_len": N, "parallelism": f"dp{world}"},
            "roofline": roofline,
@@ -323,8 +329,8 @@ def split_bench(args, dev, rank, world, dist):
     out = {"metric": "residues/sec (featurise + enc + dec forward from coordinates), design_test-sized split", "unit": "residues/s",
            "value": round(total_res * args.steps / elapsed, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"cfg4: {len(lengths)} complexes, {total_res} residues (N_i log-uniform 50..3000), K=48, fp32, one "
+           "dtype": "bf16x3 (GEMMs as split-bf16 products, fp32 accumulate: fp32-equivalent to 2^-16; fp32 elsewhere)" if getattr(m, "message_precision", "x3") == "x3" else "f32", "data": "synthetic",
+           "config": {"workload": f"cfg4: {len(lengths)} complexes, {total_res} residues (N_i log-uniform 50..3000), K=48, one "
                                   "score() from coordinates per token-bucket batch, LPT shards, no data-path collective",
                       "global_batch": len(lengths), "seq_len": int(np.median(lengths)), "parallelism": f"independent complexes x{world}"},
            "shard": {"rank0_complexes": len(mine), "rank0_batches": len(batches), "batch_tokens": args.batch_tokens, "rank0_residues": my_res, "ideal_residues_per_rank": total_res // world},
@@ -374,8 +380,8 @@ def design_bench(args, dev, rank, world, dist):
     res = {"metric": "sampled residues/sec (design: featurise + encode + autoregressive sample), 4oqu-sized complex",
            "value": round(world * bs * n * args.steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"cfg1: model.sample() on one {n}-residue RNA chain, K={K}, batch_size={bs}, T=0.1, fp32, from "
+           "vs_baseline": None, "dtype": "bf16x3 (GEMMs as split-bf16 products, fp32 accumulate: fp32-equivalent to 2^-16; fp32 elsewhere)" if getattr(m, "message_precision", "x3") == "x3" else "f32", "data": "synthetic",
+           "config": {"workload": f"cfg1: model.sample() on one {n}-residue RNA chain, K={K}, batch_size={bs}, T=0.1, from "
                                   "coordinates; level-parallel decoding", "global_batch": bs * world, "seq_len": n,
                       "parallelism": f"replicas x{world}"},
            "levels": out.get("levels")}
