@@ -427,6 +427,31 @@ def test_unfused_path_large_batch(L, dev, wt, packed):
     assert torch.equal(logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1))
 
 
+@pytest.mark.parametrize("joint", [False, True])
+@pytest.mark.parametrize("B,N,K,mf", [(3, 901, 30, 0.1), (2, 1333, 48, 0.0), (5, 611, 17, 0.2), (7, 777, 64, 0.05)])
+def test_unfused_regime_odd_shapes_against_the_oracle(L, dev, wt, packed, B, N, K, mf, joint):
+    """Calls of more than namp_fused_tail_max_residues() residues with tile counts that divide nothing (persistent
+    split-bf16 edge kernels with partly idle last rounds, the multi-tile split-bf16 residue update with a ragged last
+    workgroup, K not a multiple of 16): one complex of the batch against the oracle, and the exact-fp32 evaluation of the
+    same call against the default one."""
+    assert B * N > L.namp_fused_tail_max_residues()
+    t, d = graph(dev, seed=700 + N, batch=B, n=N, k=K, masked_frac=mf)
+    _, _, logp, _ = run_encdec(L, dev, packed, d, B, N, K, joint)
+    packed.set_precision("fp32")
+    try:
+        _, _, logp32, _ = run_encdec(L, dev, packed, d, B, N, K, joint)
+    finally:
+        packed.set_precision("x3")
+    assert maxdiff(logp, logp32) < 3e-4
+    b = B - 1
+    hV_r, hE_r = cpu_ref.encode_from_graph(wt, t["V"][b:b + 1], t["E"][b:b + 1], t["E_idx"][b:b + 1].long(), t["mask"][b:b + 1])
+    ref = cpu_ref.score_from_encoded(wt, hV_r, hE_r, t["E_idx"][b:b + 1].long(), t["S"][b:b + 1], t["mask"][b:b + 1],
+                                     t["chain_mask"][b:b + 1], t["randn"][b:b + 1])
+    assert maxdiff(logp[b:b + 1], ref["log_probs"]) < TOL_LOGP
+    valid = t["mask"][b].bool()
+    assert torch.equal(logp[b].argmax(-1).cpu()[valid], ref["log_probs"][0].argmax(-1)[valid])
+
+
 def test_abi_error_reporting(L, dev, packed):
     x = torch.zeros(64 * 128 + 4, device=dev)
     out = torch.zeros(64 * 128, device=dev)
