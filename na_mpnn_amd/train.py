@@ -361,6 +361,55 @@ def _ln(x, norm):
     return F.layer_norm(x, (H,), norm.weight, norm.bias, 1e-5)
 
 
+def _node_linear_call(x2, blocks, biases):
+    """y_q = x2 @ blocks[q]^T (+ biases[q]) for up to 8 [128 x 128] blocks in ONE node_linear launch -> list of [G,128]."""
+    G = x2.shape[0]
+    outs = [torch.empty(G, H, device=x2.device) for _ in blocks]
+    keep = [_image_f32(b_) for b_ in blocks]
+    bc = [None if b_ is None else b_.detach().contiguous() for b_ in biases]
+    proj = (hip.NampProj * len(blocks))(*[hip.NampProj(keep[q].data_ptr(), hip.ptr(bc[q]), None, outs[q].data_ptr())
+                                          for q in range(len(blocks))])
+    hip.check(hip.lib().namp_node_linear(x2.data_ptr(), None, 1, 1, G, proj, len(blocks), None, hip.current_stream()), "node_linear")
+    return outs
+
+
+class _NodeLinears(torch.autograd.Function):
+    """Several residue-level linear maps of the same input, y_q = x W_q^T + b_q with W_q [128 x 128] column blocks of the layers'
+    first-layer weights (the hoisted tables Pa / Pc / Pbw / Pfw, na_model_utils.py:218-236, 610-636, and W_v): one
+    node_linear_kernel launch forward, one for dL/dx, the row-contraction kernel for dL/dW_q.  (The stock GEMM picks a
+    32 x 32 tiling for these [24,000 x 128] x [128 x 128] products: 81 us each at cfg5.)"""
+
+    @staticmethod
+    def forward(ctx, x, nb, *wb):
+        Ws, bs = wb[:nb], wb[nb:]
+        x2 = x.contiguous().view(-1, H)
+        outs = _node_linear_call(x2, [w.detach() for w in Ws], bs)
+        ctx.nb, ctx.shape, ctx.has_b = nb, x.shape, [b is not None for b in bs]
+        ctx.save_for_backward(x2, *Ws)
+        return tuple(o.view(*x.shape[:-1], H) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x2, *Ws = ctx.saved_tensors
+        g2 = [g.contiguous().view(-1, H) for g in gs]
+        gx = None
+        for q, w in enumerate(Ws):                                  # dL/dx = sum_q g_q W_q
+            t = _node_linear_call(g2[q], [w.detach().t().contiguous()], [None])[0]
+            gx = t if gx is None else gx + t
+        gW, gb = [], []
+        for q in range(ctx.nb):
+            dW, db = _wgrad(g2[q], x2, False, ctx.has_b[q])
+            gW.append(dW); gb.append(db)
+        return (gx.view(ctx.shape), None, *gW, *gb)
+
+
+def _lin(x, *pairs):
+    """_lin(x, (W_a, b_a), (W_b, None), ...) -> tuple of x W^T + b for [128 x 128] blocks; HIP kernels on a HIP device."""
+    Ws = [p[0] for p in pairs]
+    bs = [p[1] for p in pairs]
+    return _NodeLinears.apply(x, len(Ws), *Ws, *bs)
+
+
 class _RowLayerNorm(torch.autograd.Function):
     """LayerNorm over the 128 channels of an [..,128] tensor with E-sized leading dimensions (norm_edges on the edge embedding,
     na_model_utils.py:509): HIP forward / backward (ln_rows_*_kernel) instead of the stock op, which runs at ~1 TB/s on
@@ -414,12 +463,12 @@ def forward_train(model, fd, decoding_randn=None):
     rev = ReverseAdjacency(E_idx) if torch.is_grad_enabled() else None
     for p in model.encoder_layers:                                                   # EncLayer, na_model_utils.py:218-241
         W1, W11 = p.W1.weight, p.W11.weight
-        Pa, Pc = F.linear(h_V, W1[:, :H], p.W1.bias), F.linear(h_V, W1[:, 2 * H:])
+        Pa, Pc = _lin(h_V, (W1[:, :H], p.W1.bias), (W1[:, 2 * H:], None))
         dh = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
                             E_idx, mask32, None, None, rev)
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
-        Pa, Pc = F.linear(h_V, W11[:, :H], p.W11.bias), F.linear(h_V, W11[:, 2 * H:])
+        Pa, Pc = _lin(h_V, (W11[:, :H], p.W11.bias), (W11[:, 2 * H:], None))
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # host RNG: follows torch.manual_seed
         h_E = _EdgeUpdate.apply(h_E, Pa, Pc, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight, p.W13.bias,
                                 p.norm3.weight, p.norm3.bias, E_idx, drop_p, seed, rev)
@@ -433,9 +482,9 @@ def forward_train(model, fd, decoding_randn=None):
     h_V_enc = h_V
     for p in model.decoder_layers:                                                   # DecLayer on the implicit h_ESV, :610-640
         W1 = p.W1.weight
-        Pa = F.linear(h_V, W1[:, :H], p.W1.bias)
-        Pbw = F.linear(h_S, W1[:, 2 * H:3 * H]) + F.linear(h_V, W1[:, 3 * H:])
-        Pfw = F.linear(h_V_enc, W1[:, 3 * H:])
+        Pa, Pv = _lin(h_V, (W1[:, :H], p.W1.bias), (W1[:, 3 * H:], None))
+        Pbw = _lin(h_S, (W1[:, 2 * H:3 * H], None))[0] + Pv
+        Pfw = _lin(h_V_enc, (W1[:, 3 * H:], None))[0]
         dh = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
                             E_idx, None, None, rank32, rev)
         h_V = _ln(h_V + drop(dh), p.norm1)
