@@ -8,14 +8,25 @@
 A "step" is one pass of the hot path — (V, E, E_idx, S, mask, decoding ranks) -> log_probs, i.e.
 W_v/W_e + 3 x EncLayer + decoder context + 3 x DecLayer + W_out + log_softmax — over
 one batch of synthetic graphs already resident in HBM.  Default workload = BASELINE.json configs[1]
-("cfg2": B=1, N=1000, K=48, H=128, 3+3 layers, fp32).  Every rank runs its own independent
+("cfg2": B=1, N=1000, K=48, H=128, 3+3 layers).  Every rank runs its own independent
 complexes (weak scaling, no data-path collective); one RCCL all-gather of the arg-max sequences at
 the end collates results for reporting, outside the timed region.
 
-Rank 0 prints ONE JSON line with the driver's contract keys plus
-  roofline      – dominant kernel, algorithmic FLOPs / HIP-event-measured duration vs fp32-MFMA peak
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this file under
+`torch.distributed.run` with N ranks (one per GPU, backend nccl = RCCL); under a launcher it uses
+the launcher's ranks and refuses a WORLD_SIZE that contradicts --gpus.
+
+The default cfg2 run times the path TWICE with the same K / W: the headline (`value`, `dtype` "f32")
+is the EXACT fp32 evaluation (v_mfma_f32_16x16x4_f32, what BASELINE configs[1] states); the `x3`
+object beside it is the split-bf16 evaluation (three bf16 products per fp32 product, fp32-equivalent
+to ~2^-16), the model's default.  Rank 0 prints ONE JSON line with the driver's contract keys plus
+  roofline      – dominant kernel, algorithmic FLOPs / HIP-event-measured duration vs the MFMA peak of its dtype
+  x3            – {value, ms_per_step, roofline, parity} of the split-bf16 evaluation (cfg2 only)
+  parity        – max |dlogp|, arg-max equality and sequence recovery vs the CPU oracle on the same inputs
   gather        – the standalone neighbour-gather (cat_neighbors_nodes) HBM figure, cfg3-shaped
-  cpu_baseline  – the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores
+  cpu_baseline  – the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores:
+                  best thread count, 1 thread, and the full forward from coordinates
+  secondary     – short runs of cfg3 (bf16, B=64), cfg5 (training step) and cfg1 (design call), N = 1 only
 """
 from __future__ import annotations
 
@@ -45,6 +56,7 @@ ALGO_FLOP = {"enc_message": 7_864_320, "enc_edge_update": 7_864_320, "dec_messag
              "enc_edge_dec_message": 7_864_320 + 9_437_184}    # last edge update + DecLayer 0 message
 EXEC_GEMMS = {"enc_message": 3, "enc_edge_update": 3, "dec_message": 3, "enc_edge_message": 6, "enc_edge_dec_message": 6}
 ALGO_FLOP_TOTAL = 78_684_416
+KERNEL_OF = {}      # launch kind -> kernel name when it is not edge_mlp_kernel (filled as kinds are added)
 # executed FLOP / residue of the hoisted formulation (three 128x128 GEMMs per edge)
 EXEC_FLOP_EDGE = 48 * 3 * 2 * 128 * 128
 
@@ -130,14 +142,37 @@ def gather_microbench(dev, reps=10):
             "d2d_copy_GBps": round(copy_gbs, 1), "frac_of_d2d_copy": round(gbs / copy_gbs, 3)}
 
 
+def seq_recovery(S_true, S_pred, mask):
+    """get_seq_rec of the reference (inference/data_utils.py:18-30): sum(match * mask) / sum(mask) per complex."""
+    match = (S_true == S_pred).to(torch.float32)
+    m = mask.to(torch.float32)
+    return (match * m).sum(-1) / m.sum(-1)
+
+
+def parity_vs_cpu(logp_gpu, ref_out, S_true, mask):
+    """Parity side-metric of BASELINE.json's `metric`: the designed (arg-max) sequence vs the CPU reference path's on
+    identical inputs — identical arg-max, and the sequence recovery (vs the native S) of both."""
+    lp, rp = logp_gpu.float().cpu(), ref_out["log_probs"]
+    seq_g, seq_c = lp.argmax(-1), rp.argmax(-1)
+    return {"max_abs_dlogp_vs_cpu": round(float((lp - rp).abs().max()), 7),
+            "argmax_equal": bool(torch.equal(seq_g, seq_c)),
+            "seq_recovery": {"gpu_vs_cpu_argmax": round(float(seq_recovery(seq_c, seq_g, mask).mean()), 6),
+                             "gpu_vs_native": round(float(seq_recovery(S_true, seq_g, mask).mean()), 6),
+                             "cpu_vs_native": round(float(seq_recovery(S_true, seq_c, mask).mean()), 6),
+                             "definition": "get_seq_rec, inference/data_utils.py:18-30 (random-init weights: recovery vs "
+                                           "the native sequence is chance level; the graded number is gpu_vs_cpu_argmax)"}}
+
+
 def cpu_baseline(runner, budget_s=25.0):
-    """The oracle on this box's host cores, same cfg2 inputs (bounded sample)."""
+    """The oracle on this box's host cores, same cfg2 inputs (bounded sample): best intra-op thread count, one thread,
+    and the full forward from coordinates (features + enc + dec: `cpu_ref.score`) — SURVEY 8(d) / BASELINE.md §3."""
     from oracle import cpu_ref
     w = {k: torch.from_numpy(v) for k, v in runner.w_np.items()}
     g = {k: torch.from_numpy(v[:1]) for k, v in runner.g_np.items()}
     E_idx = g["E_idx"].long()
     f = lambda: cpu_ref.encdec_from_graph(w, g["V"], g["E"], E_idx, g["S"], g["mask"], g["chain_mask"], g["randn"])
     n = g["V"].shape[1]
+    K = int(E_idx.shape[-1])
     ncpu = os.cpu_count() or 1
     # eager PyTorch on a many-core host is fastest well below the core count at this problem size:
     # try a few intra-op thread counts inside the time budget and report the best one.
@@ -156,10 +191,24 @@ def cpu_baseline(runner, budget_s=25.0):
             tried.append((min(nt, ncpu), min(times)))
             if best is None or min(times) < best[1]:
                 best = (min(nt, ncpu), min(times))
+        # one thread (the scalar-port figure)
+        torch.set_num_threads(1)
+        t0 = time.perf_counter(); f(); t_one = time.perf_counter() - t0
+        # full forward from coordinates: features (kNN, 18x18x16 RBFs, 5200 -> 128 embedding) + enc + dec
+        torch.set_num_threads(best[0])
+        cx = synth.make_complex(seed=77, n=n, n_chains=4)
+        fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+        fd["batch_size"] = 1
+        t0 = time.perf_counter(); cpu_ref.score(w, fd, K); t_full = time.perf_counter() - t0
     return out, {"value": round(n / best[1], 1), "unit": "residues/s", "cores": best[0], "kind": "port",
-                 "sample": f"oracle/cpu_ref.py enc+dec forward, B=1 N={n} K={E_idx.shape[-1]} fp32, eager PyTorch CPU, "
+                 "sample": f"oracle/cpu_ref.py enc+dec forward, B=1 N={n} K={K} fp32, eager PyTorch CPU, "
                            f"best of <=3 after 1 warm-up per thread count; tried (threads, s): "
-                           + ", ".join(f"({a}, {b:.3f})" for a, b in tried) + f"; host has {ncpu} logical cores"}
+                           + ", ".join(f"({a}, {b:.3f})" for a, b in tried) + f"; host has {ncpu} logical cores",
+                 "one_thread": {"value": round(n / t_one, 1), "unit": "residues/s", "cores": 1,
+                                "sample": f"same forward, torch.set_num_threads(1), one run ({t_one:.2f} s)"},
+                 "full_forward_from_X": {"value": round(n / t_full, 1), "unit": "residues/s", "cores": best[0],
+                                         "sample": f"oracle/cpu_ref.py score() from coordinates (features + enc + dec), one "
+                                                   f"synthetic {n}-residue complex, one run ({t_full:.2f} s)"}}
 
 
 # algorithmic FLOP / residue of one training step at K=48 (SURVEY §8(d) figures): forward (enc+dec 78.7 M + features
@@ -213,7 +262,7 @@ def train_bench(args, dev, rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -264,10 +313,10 @@ def train_bench(args, dev, rank, world, dist):
            "whole_step": {"algorithmic_tflops": round(TRAIN_FLOP_STEP * B * N / (ms_per_step * 1e-3) / 1e12, 2),
                           "final_loss": round(float(loss), 5),
                           "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}}
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_train_baseline(cxs[0], K, rti)
-        print(json.dumps(out), flush=True)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_train_baseline(cxs[0], K, rti)
+    torch.set_grad_enabled(False)
+    return out
 
 
 def split_bench(args, dev, rank, world, dist):
@@ -316,12 +365,12 @@ def split_bench(args, dev, rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_res = int(lengths.sum())
     t1 = time.perf_counter()
-    collated = shard.all_gather_ragged(result, len(lengths), device=dev)
+    collated = shard.all_gather_ragged(result, len(lengths), device=coll_device(dev, dist))
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t1) * 1e3
     n_coll = sum(int(x.numel()) for x in collated if x is not None)
@@ -337,8 +386,7 @@ def split_bench(args, dev, rank, world, dist):
            "collation": {"collective": "all_reduce(lengths) + all_gather(padded int32 sequences)", "ms": round(gather_ms, 3),
                          "residues_collated": n_coll}}
     assert n_coll == total_res, (n_coll, total_res)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    return out
 
 
 def design_bench(args, dev, rank, world, dist):
@@ -374,7 +422,7 @@ def design_bench(args, dev, rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = {"metric": "sampled residues/sec (design: featurise + encode + autoregressive sample), 4oqu-sized complex",
@@ -385,8 +433,8 @@ def design_bench(args, dev, rank, world, dist):
                                   "coordinates; level-parallel decoding", "global_batch": bs * world, "seq_len": n,
                       "parallelism": f"replicas x{world}"},
            "levels": out.get("levels")}
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if True:
             from oracle import cpu_ref
             torch.set_num_threads(min(8, os.cpu_count() or 1))
             w = {k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()}
@@ -398,7 +446,7 @@ def design_bench(args, dev, rank, world, dist):
             res["cpu_baseline"] = {"value": round(n / dt, 1), "unit": "residues/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"oracle/cpu_ref.py features + encode + sample(), one {n}-residue complex, batch_size 1, "
                                              f"eager PyTorch CPU ({dt:.2f} s)"}
-        print(json.dumps(res), flush=True)
+    return res
 
 
 def cpu_train_baseline(cx, K, rti, n=300):
@@ -425,6 +473,153 @@ def cpu_train_baseline(cx, K, rti, n=300):
                       f"eager PyTorch CPU, best of 3 ({', '.join(f'{t:.2f}s' for t in times)})"}
 
 
+def coll_device(dev, dist):
+    """Device of the collectives' buffers: the GPU under RCCL; host memory when the harness is exercised over gloo."""
+    return torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else dev
+
+
+def traffic_entry(workload, kind):
+    """HBM-side bytes per launch of `kind` from the committed PMC passes (tools/profile_round.sh regenerates
+    profiles/pmc_traffic.json every round and stamps the commit it profiled); bench.py cannot run rocprofv3 on itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None, None
+    src = {"file": "profiles/pmc_traffic.json", "commit": t.get("_commit"), "round": t.get("_round"),
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (MI355X_MICROARCH.md)"}
+    return (t.get(workload, {}) or {}).get(kind), src
+
+
+def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmup, profile_steps=None):
+    """Time `steps` passes of the encoder+decoder forward (one namp_encdec_fwd call each) at `precision`."""
+    cfg = WORKLOADS[workload]
+    B, N, K = cfg["B"], cfg["N"], cfg["K"]
+    cfg_idx = 1 if workload == "cfg2" else 2
+    runner = Runner(dev, B, N, K, seed=1 + cfg_idx + 1000 * rank, precision=precision)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        runner.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / steps * 1e3
+    value = world * B * N * steps / elapsed
+
+    # reporting-only collective: all-gather of the arg-max sequences (north_star: "RCCL all-gather ... only
+    # for throughput reporting"); outside the timed region.
+    seq = runner.logp.argmax(-1)
+    local = {rank * B + b: seq[b] for b in range(B)}              # complex id -> designed sequence
+    t1 = time.perf_counter()
+    collated = shard.all_gather_ragged(local, world * B, device=coll_device(dev, dist))
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    n_collated = sum(int(x.numel()) for x in collated if x is not None)
+    assert n_collated == world * B * N, (n_collated, world, B, N)
+
+    # per-kernel durations: the same steps again with the library's HIP-event hook on the launch stream (a second,
+    # event-instrumented pass: its sum sits a few percent above ms_per_step, which has no events between launches)
+    psteps = profile_steps or max(steps, 50)
+    runner.L.namp_profile_enable(1)
+    for _ in range(psteps):
+        runner.step()
+    prof = hip.profile_collect()
+    runner.L.namp_profile_enable(0)
+    per_kernel = {k: {"launches_per_step": c // psteps, "avg_ms": round(ms / max(c, 1), 5),
+                      "ms_per_step": round(ms / psteps, 5)} for k, (ms, c) in prof.items() if c}
+    dom = max((k for k in per_kernel if k in ALGO_FLOP), key=lambda k: per_kernel[k]["ms_per_step"])
+    avg_s = per_kernel[dom]["avg_ms"] * 1e-3
+    algo = ALGO_FLOP[dom] * B * N
+    traffic, traffic_source = traffic_entry(workload + ("" if precision == "x3" else "_" + precision), dom)
+    # fp32: exact fp32 MFMA (peak 157.3).  x3 / bf16: the products run on the bf16 pipe (dense peak 2500); x3 executes three
+    # bf16 products per fp32 product.  `achieved` stays the ALGORITHMIC rate (dense fp32 formulation of SURVEY 8(d)).
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    mult = 3 if precision == "x3" else 1
+    exec_flop = EXEC_FLOP_EDGE * B * N * EXEC_GEMMS[dom] // 3 * mult
+    roofline = {"kernel": f"{KERNEL_OF.get(dom, 'edge_mlp_kernel')}<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / peak, 4),
+                "traffic": traffic, "traffic_source": traffic_source, "flop_per_launch_algorithmic": algo,
+                "flop_per_launch_executed": exec_flop,
+                "executed_frac": round(exec_flop / avg_s / 1e12 / peak, 4),
+                "frac_vs_fp32_mfma_peak": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+    dtype = {"fp32": "f32", "x3": "bf16x3 (per-edge GEMMs as three bf16 products of split fp32 operands, fp32 accumulate: "
+                                   "fp32-equivalent to 2^-16; fp32 everywhere else)",
+             "bf16": "bf16 (per-edge GEMMs; fp32 accumulate, fp32 elsewhere)"}[precision]
+    out = {"metric": "residues/sec (enc+dec fwd), N~1000 K=48 h=128; seq-recovery vs CPU ref", "value": round(value, 1),
+           "unit": "residues/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": dtype, "data": "synthetic",
+           "config": {"workload": f"{workload}: B={B} x N={N} residues per rank, K={K}, H=128, 3 enc + 3 dec layers, "
+                                  f"per-edge GEMMs {precision}, seeded random-init weights, independent complexes per rank",
+                      "precision": precision, "global_batch": B * world, "seq_len": N, "parallelism": f"replicas x{world}"},
+           "roofline": roofline, "per_kernel": per_kernel,
+           "per_kernel_note": f"separate event-instrumented pass of {psteps} steps (HIP events around every launch)",
+           "whole_path": {"algorithmic_tflops": round(ALGO_FLOP_TOTAL * B * N / (ms_per_step * 1e-3) / 1e12, 3),
+                          "ms_per_step_instrumented_pass": round(sum(v["ms_per_step"] for v in per_kernel.values()), 5)},
+           "collation": {"collective": "all_reduce(lengths) + all_gather(padded int32 arg-max sequences), outside the timed region",
+                         "backend": (dist.get_backend() if dist is not None else None),
+                         "ranks": (dist.get_world_size() if dist is not None else 1),
+                         "collated_residues": n_collated, "expected_residues": world * B * N, "ms": round(gather_ms, 3)}}
+    return out, runner
+
+
+def secondary_runs(args, dev):
+    """Short runs of the other single-GPU workloads, so that their numbers are in the driver's record too (N = 1 only).
+    Each entry is a full bench line of that workload (its own metric / roofline / cpu_baseline) or {"error": ...}."""
+    import copy
+    res = []
+    for wl, steps, warm in (("cfg3", 6, 2), ("cfg5", 4, 2), ("cfg1", 10, 3)):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.workload = steps, warm, wl
+        t0 = time.perf_counter()
+        try:
+            if wl == "cfg3":
+                o, r = encdec_bench(a, dev, 0, 1, None, "cfg3", "bf16", steps, warm, profile_steps=steps)
+                lp = r.logp
+                o["checks"] = {"rows_normalised_max_err": round(float((lp.exp().sum(-1) - 1).abs().max()), 7),
+                               "finite": bool(torch.isfinite(lp).all())}
+                del r
+            elif wl == "cfg5":
+                o = train_bench(a, dev, 0, 1, None)
+            else:
+                o = design_bench(a, dev, 0, 1, None)
+        except Exception as e:          # a failing secondary must not take the headline down with it
+            o = {"workload": wl, "error": f"{type(e).__name__}: {e}"[:400]}
+        o["wall_s"] = round(time.perf_counter() - t0, 1)
+        res.append(o)
+        torch.cuda.empty_cache()
+    return res
+
+
+def respawn(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,8 +627,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--precision", choices=["x3", "fp32", "bf16"], default=None,
-                    help="per-edge GEMM evaluation: default x3 for cfg2 (parity mode: split-bf16 products, fp32-equivalent), "
-                         "bf16 for cfg3 (BASELINE configs[2]); fp32 = exact fp32 MFMA")
+                    help="per-edge GEMM evaluation of the headline: default fp32 for cfg2 (exact fp32 MFMA, BASELINE configs[1]; the "
+                         "x3 evaluation is timed beside it), bf16 for cfg3 (BASELINE configs[2]); x3 = split-bf16 products")
     ap.add_argument("--design-batch", type=int, default=1, help="cfg1: batch_size of the design call")
     ap.add_argument("--split-limit", type=int, default=0, help="cfg4: use only the first n complexes of the split")
     ap.add_argument("--batch-tokens", type=int, default=32000,
@@ -441,16 +636,27 @@ def main():
                          "measured 2.66 / 2.76 / 2.91 / 2.85 M residues/s at 8,000 / 16,000 / 32,000 / 64,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg5 / cfg1 runs appended to the default line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        respawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} contradicts the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # NAMP_BENCH_ONE_DEVICE=1 / NAMP_BENCH_BACKEND=gloo: validate the N>1 code path on a single-GPU box
     if os.environ.get("NAMP_BENCH_ONE_DEVICE") == "1":
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible "
+                         "(NAMP_BENCH_ONE_DEVICE=1 shares device 0 between ranks for harness tests)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -462,127 +668,60 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_gpus = world
     torch.set_grad_enabled(False)
+
+    def finish(out):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
 
     if args.workload == "cfg1":
         if args.steps == 50:
             args.steps = 20
-        design_bench(args, dev, rank, world, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish(design_bench(args, dev, rank, world, dist))
     if args.workload == "cfg4":
         if args.steps == 50:
             args.steps = 2
         args.warmup = min(args.warmup, 1)
-        split_bench(args, dev, rank, world, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish(split_bench(args, dev, rank, world, dist))
     if args.workload == "cfg5":
         if args.steps == 50:
             args.steps = 10                      # a training step is ~100x a cfg2 forward
-        train_bench(args, dev, rank, world, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    cfg = WORKLOADS[args.workload]
-    B, N, K = cfg["B"], cfg["N"], cfg["K"]
-    cfg_idx = 1 if args.workload == "cfg2" else 2
-    precision = args.precision or ("bf16" if args.workload == "cfg3" else "x3")
-    runner = Runner(dev, B, N, K, seed=1 + cfg_idx + 1000 * rank, precision=precision)
+        return finish(train_bench(args, dev, rank, world, dist))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        runner.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_gpus * B * N * args.steps / elapsed
-
-    # reporting-only collective: all-gather of the arg-max sequences (north_star: "RCCL all-gather ... only
-    # for throughput reporting"); outside the timed region.
-    seq = runner.logp.argmax(-1)
-    local = {rank * B + b: seq[b] for b in range(B)}              # complex id -> designed sequence
-    collated = shard.all_gather_ragged(local, world * B, device=dev)
-    n_collated = sum(int(x.numel()) for x in collated if x is not None)
-
-    # per-kernel durations: same steps again with the library's HIP-event hook on the launch stream
-    runner.L.namp_profile_enable(1)
-    for _ in range(args.steps):
-        runner.step()
-    prof = hip.profile_collect()
-    runner.L.namp_profile_enable(0)
-    per_kernel = {k: {"launches_per_step": c // args.steps, "avg_ms": round(ms / max(c, 1), 5),
-                      "ms_per_step": round(ms / args.steps, 5)} for k, (ms, c) in prof.items() if c}
-    dom = max((k for k in per_kernel if k in ALGO_FLOP), key=lambda k: per_kernel[k]["ms_per_step"])
-    avg_s = per_kernel[dom]["avg_ms"] * 1e-3
-    algo = ALGO_FLOP[dom] * B * N
-    # HBM-side bytes per launch from the committed PMC pass (profiles/r01_pmc.md); bench.py cannot run rocprofv3 on itself
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(args.workload, {}).get(dom)
-    except OSError:
-        pass
-    # fp32: exact fp32 MFMA (peak 157.3).  x3 / bf16: the products run on the bf16 pipe (dense peak 2500); x3 executes three
-    # bf16 products per fp32 product.  `achieved` stays the ALGORITHMIC rate (dense fp32 formulation of SURVEY 8(d)).
-    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    mult = 3 if precision == "x3" else 1
-    exec_flop = EXEC_FLOP_EDGE * B * N * EXEC_GEMMS[dom] // 3 * mult
-    roofline = {"kernel": f"edge_mlp_kernel<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / peak, 4),
-                "traffic": traffic, "flop_per_launch_algorithmic": algo,
-                "flop_per_launch_executed": exec_flop,
-                "executed_frac": round(exec_flop / avg_s / 1e12 / peak, 4),
-                "frac_vs_fp32_mfma_peak": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "avg_launch_ms": per_kernel[dom]["avg_ms"]}
-    dtype = {"fp32": "f32", "x3": "bf16x3 (per-edge GEMMs as three bf16 products of split fp32 operands, fp32 accumulate: "
-                                   "fp32-equivalent to 2^-16; fp32 everywhere else)",
-             "bf16": "bf16 (per-edge GEMMs; fp32 accumulate, fp32 elsewhere)"}[precision]
-
-    out = {"metric": "residues/sec (enc+dec fwd), N~1000 K=48 h=128", "value": round(value, 1), "unit": "residues/s",
-           "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": dtype, "data": "synthetic",
-           "config": {"workload": f"{args.workload}: B={B} x N={N} residues, K={K}, H=128, 3 enc + 3 dec layers, "
-                                  f"per-edge GEMMs {precision}, seeded random-init weights, per-rank independent complexes",
-                      "global_batch": B * n_gpus, "seq_len": N, "parallelism": f"replicas x{n_gpus}"},
-           "roofline": roofline, "per_kernel": per_kernel,
-           "whole_path": {"algorithmic_tflops": round(ALGO_FLOP_TOTAL * B * N / (ms_per_step * 1e-3) / 1e12, 3),
-                          "collated_residues": n_collated}}
-
-    if rank == 0:
-        if not args.no_gather and n_gpus == 1:
+    precision = args.precision or ("bf16" if args.workload == "cfg3" else "fp32")
+    out, runner = encdec_bench(args, dev, rank, world, dist, args.workload, precision, args.steps, args.warmup)
+    ref_out = None
+    if rank == 0 and world == 1:
+        if not args.no_gather:
             out["gather"] = gather_microbench(dev)
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline:
             ref_out, cb = cpu_baseline(runner)
             out["cpu_baseline"] = cb
-            lp = runner.logp[:1].cpu()
-            d = float((lp - ref_out["log_probs"]).abs().max())
-            out["parity"] = {"max_abs_dlogp_vs_cpu": round(d, 7),
-                             "argmax_equal": bool(torch.equal(lp.argmax(-1), ref_out["log_probs"].argmax(-1)))}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            g = runner.g_np
+            out["parity"] = parity_vs_cpu(runner.logp[:1], ref_out, torch.from_numpy(g["S"][:1]).long(), torch.from_numpy(g["mask"][:1]))
+    if args.workload == "cfg2" and args.precision is None:
+        # the split-bf16 evaluation (the model's default) on the same inputs, same K / W, every rank
+        del runner
+        x3, rx = encdec_bench(args, dev, rank, world, dist, "cfg2", "x3", args.steps, args.warmup)
+        xo = {k: x3[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "per_kernel", "whole_path")}
+        if ref_out is not None:
+            g = rx.g_np
+            xo["parity"] = parity_vs_cpu(rx.logp[:1], ref_out, torch.from_numpy(g["S"][:1]).long(), torch.from_numpy(g["mask"][:1]))
+        out["x3"] = xo
+        # compact copy inside `roofline`, which the driver's record keeps verbatim
+        out["roofline"]["also_measured_x3"] = {"value": xo["value"], "ms_per_step": xo["ms_per_step"],
+                                               "frac_vs_bf16_peak": xo["roofline"]["frac"],
+                                               "executed_frac": xo["roofline"]["executed_frac"],
+                                               "max_abs_dlogp_vs_cpu": xo.get("parity", {}).get("max_abs_dlogp_vs_cpu"),
+                                               "argmax_equal": xo.get("parity", {}).get("argmax_equal")}
+        del rx
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_runs(args, dev)
+    finish(out)
 
 
 if __name__ == "__main__":

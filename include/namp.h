@@ -46,7 +46,8 @@ const char* namp_last_error(void);
  * into fragment-image order.  out_f, in_f multiples of 16.  img: out_f*in_f floats. */
 int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float* img, void* stream);
 
-/* Precision of the per-edge message / edge-update GEMMs.  Default (flags = 0): fp32 MFMA, the parity mode.
+/* Precision of the per-edge message / edge-update GEMMs.  flags = 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the
+ * arithmetic BASELINE configs[1] names; the Python surface's default is NAMP_FLAG_X3 below (fp32-equivalent to 2^-16).
  * NAMP_FLAG_BF16: inputs and weights rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) — BASELINE
  * configs[2]'s throughput mode; ~1e-2 on log-probs, not parity-grade.  Residue-level math stays fp32. */
 #define NAMP_FLAG_BF16 1
@@ -205,6 +206,15 @@ size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K);
 int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_E, const int32_t* E_idx,
                        const int32_t* mask, const int32_t* mask_attend, float* h_V_out, float* h_E_out,
                        void* ws, size_t ws_bytes, int B, int N, int K, void* stream);
+
+/* DecLayer.forward (model_utils.py:636-657) as an operator on a MATERIALISED context, dropout inactive:
+ * h_ESV [B,N,K,384] = the reference's h_E argument ([h_E | h_S_j | h_V_j] in score() / sample(), model_utils.py:407-418);
+ * mask_attend optional float [B,N,K]; mask_V optional [B,N].  Exact fp32 MFMA.  The model itself never calls this
+ * (its decoder gathers the context implicitly: namp_decoder_fwd); it is the drop-in for callers that hold h_ESV.
+ * ws: namp_workspace_bytes(B, B, N, K). */
+int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_ESV, const int32_t* mask_V,
+                       const float* mask_attend, float* h_V_out, void* ws, size_t ws_bytes, int B, int N, int K,
+                       void* stream);
 
 /* ---- a11: graph construction + edge features ------------------------------------------------
  * ProteinFeaturesNA.forward, eval mode (model_utils.py:528-593) without the node one-hot (a 6-row table lookup

@@ -32,7 +32,7 @@ def _newer(target, deps):
     if not os.path.exists(target):
         return False
     t = os.path.getmtime(target)
-    return all(os.path.getmtime(os.path.join(CSRC, d)) <= t for d in deps)
+    return all(os.path.getmtime(os.path.join(CSRC, d)) < t for d in deps)     # equal mtimes: rebuild (mtime granularity)
 
 
 def _obj(unit):
@@ -56,14 +56,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print("[na_mpnn_amd.build]", " ".join(cmd), flush=True)
         procs.append((unit, subprocess.Popen(cmd, cwd=CSRC)))
-    for unit, p in procs:
-        try:
-            rc = p.wait(timeout=TIMEOUT_S)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            raise RuntimeError(f"hipcc timed out on {unit} after {TIMEOUT_S}s")
-        if rc != 0:
-            raise RuntimeError(f"hipcc failed on {unit} (exit {rc})")
+    try:
+        for unit, p in procs:
+            try:
+                rc = p.wait(timeout=TIMEOUT_S)
+            except subprocess.TimeoutExpired:
+                raise RuntimeError(f"hipcc timed out on {unit} after {TIMEOUT_S}s")
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {unit} (exit {rc})")
+    finally:
+        # never leave a compiler running behind a failure: it would overwrite lib/obj/*.o under a retry
+        for _, p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + [_obj(u) for u in UNITS] + ["-o", OUT]
     if verbose:
         print("[na_mpnn_amd.build]", " ".join(cmd), flush=True)

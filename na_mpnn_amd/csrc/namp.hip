@@ -1071,6 +1071,36 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
   return namp_enc_edge_update(w, h_E, E_idx, Pa2, Pc2, h_E_out, B, N, K, stream);
 }
 
+int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_ESV, const int32_t* mask_V,
+                       const float* mask_attend, float* h_V_out, void* ws, size_t ws_bytes, int B, int N, int K,
+                       void* stream) {
+  REQUIRE(w != nullptr, "namp_dec_layer_fwd: null weights");
+  REQUIRE_PTR(h_V); REQUIRE_PTR(h_ESV); REQUIRE_PTR(h_V_out); REQUIRE_PTR(ws); OPTIONAL_PTR(mask_attend);
+  REQUIRE_PTR(w->W1a_img); REQUIRE_PTR(w->W1e_img); REQUIRE_PTR(w->W1s_img); REQUIRE_PTR(w->W1v_img); REQUIRE_PTR(w->b1);
+  REQUIRE_PTR(w->W2_img); REQUIRE_PTR(w->W3_img); REQUIRE_PTR(w->b2); REQUIRE_PTR(w->b3);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  const int G = B * N, tpn = (K + 15) / 16;
+  Carver c(ws, ws_bytes);
+  float* Pa = c.take((size_t)G * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  if (!partial) return fail(NAMP_EWORKSPACE, "namp_dec_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
+  NampProj pa = {w->W1a_img, w->b1, nullptr, Pa};
+  if ((rc = namp_node_linear(h_V, nullptr, B, B, N, &pa, 1, nullptr, stream))) return rc;
+  DecCtxArgs a = {};
+  a.ctx = h_ESV; a.mask_attend = mask_attend; a.Pa = Pa;
+  a.W1e_img = w->W1e_img; a.W1s_img = w->W1s_img; a.W1v_img = w->W1v_img; a.W2_img = w->W2_img; a.W3_img = w->W3_img;
+  a.b2 = w->b2; a.b3 = w->b3; a.partial = partial; a.G = G; a.K = K; a.TPN = tpn;
+  {
+    ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
+    const long tiles = (long)G * tpn;
+    hipLaunchKernelGGL(dec_ctx_message_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    CHECK_LAUNCH();
+  }
+  return namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, partial,
+                          mask_V, h_V_out, nullptr, 0, nullptr, G, K, stream);
+}
+
 int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
                      const int32_t* mask, float* h_V, float* h_E, void* ws, size_t ws_bytes, int B, int N, int K,
                      void* stream) {

@@ -1877,6 +1877,70 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
 }
 
 // ------------------------------------------------------------------------------------------
+// dec_ctx_message_kernel — DecLayer.forward's message on a MATERIALISED context (model_utils.py:636-646): the
+// operator form the reference's sampler and score() call, h_ESV [G][K][384] = [h_E | h_S_j | h_V_j] given by the
+// caller.  First layer = Pa[i] (W1a . h_V_i + b1, hoisted) + the three 128-wide blocks of the row against
+// W1e / W1s / W1v; exact fp32 MFMA, weights streamed from L2 (this is the drop-in operator, not the hot path: the
+// model never materialises h_ESV).  One wave per 16-row tile; writes per-tile partial sums for node_update.
+// ------------------------------------------------------------------------------------------
+struct DecCtxArgs {
+  const float* ctx;            // [G][K][384]
+  const float* mask_attend;    // optional [G][K] (float, like the reference's argument)
+  const float* Pa;             // [G][128]
+  const float* W1e_img; const float* W1s_img; const float* W1v_img; const float* W2_img; const float* W3_img;
+  const float* b2; const float* b3;
+  float* partial;              // [G][TPN][128]
+  int G, K, TPN;
+};
+
+__global__ __launch_bounds__(256) void dec_ctx_message_kernel(const DecCtxArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long tile = (long)blockIdx.x * 4 + wave;
+  if (tile >= (long)a.G * a.TPN) return;
+  const int node = (int)(tile / a.TPN), kt = (int)(tile - (long)node * a.TPN);
+  const int m = lane & 15, g = lane >> 4;
+  const int k = 16 * kt + m;
+  const bool valid = k < a.K;
+  const long erow = (long)node * a.K + (valid ? k : 0);
+  f4 x[8], acc[8];
+  {
+    const float* pa = a.Pa + (long)node * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(pa + 16 * t);
+  }
+#pragma unroll 1
+  for (int blk = 0; blk < 3; ++blk) {
+    const float* src = a.ctx + erow * 384 + 128 * blk + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+    const float* img = blk == 0 ? a.W1e_img : blk == 1 ? a.W1s_img : a.W1v_img;
+    chain_gemm_global<8, 8, false>(acc, x, (const f4*)img + lane, 8);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { acc[t] = gelu4(acc[t]); x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g); }
+  chain_gemm_global<8, 8, false>(x, acc, (const f4*)a.W2_img + lane, 8);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    x[t] = gelu4(x[t]);
+    const float b = a.b3[16 * t + m];
+    acc[t] = (f4){b, b, b, b};
+  }
+  chain_gemm_global<8, 8, true>(acc, x, (const f4*)a.W3_img + lane, 8);
+  const float w_row = valid ? (a.mask_attend ? a.mask_attend[erow] : 1.0f) * (1.0f / 30.0f) : 0.f;
+  float wr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
+  float* dst = a.partial + ((long)node * a.TPN + kt) * NAMP_H + m;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+    s_ = xg_sum(s_);
+    if (g == 0) dst[16 * t] = s_;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // logits_kernel — log_softmax(W_out . h_V + b) over the 33-letter vocabulary
 // (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.
 // ------------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@ _PROTOTYPES = {
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),
     "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,
                                  vp, sz, i32, i32, i32, vp]),
+    "namp_dec_layer_fwd": (i32, [C.POINTER(NampDecLayerW), c_fp, c_fp, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, vp]),
     "namp_encoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_fp, c_fp,
                                vp, sz, i32, i32, i32, vp]),
     "namp_encdec_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,

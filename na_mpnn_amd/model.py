@@ -101,8 +101,17 @@ class ProteinMPNN(nn.Module):
         if (node_features, edge_features, hidden_dim) != (H, H, H):
             raise ValueError("the HIP kernels are specialised for node/edge/hidden width 128 "
                              "(the only configuration the reference instantiates)")
-        if not include_pred_na_N:
-            raise NotImplementedError("include_pred_na_N=0 is not supported")
+        # include_pred_na_N = 0 (training copy, na_model_utils.py:404-407,479-491): no virtual N_na atom; the edge embedding
+        # sees 17 x 17 atom pairs ([128 x 4640]).  The kernels keep their 18-atom layout: the weight is expanded to the
+        # 5200-column form with zero columns for every pair that involves atom 17, and atom 17 is marked absent on every
+        # residue, so its (structurally zero) k-tiles are skipped — bit-identical to a 17-atom evaluation.
+        self.include_pred_na_N = int(bool(include_pred_na_N))
+        if vocab != num_letters:
+            # the per-token tables (W1s . W_s, one row per letter) and the output head share one size in the kernels; the
+            # reference only ever builds vocab == num_letters (run.py:184-202, na_run.py:73-92)
+            raise ValueError(f"vocab ({vocab}) must equal num_letters ({num_letters})")
+        if num_decoder_layers > hip.NAMP_MAX_LAYERS or num_encoder_layers > hip.NAMP_MAX_LAYERS:
+            raise ValueError(f"at most {hip.NAMP_MAX_LAYERS} encoder / decoder layers are supported")
         self.model_type = model_type
         self.node_features, self.edge_features, self.hidden_dim = node_features, edge_features, hidden_dim
         self.vocab, self.num_letters = vocab, num_letters
@@ -117,7 +126,8 @@ class ProteinMPNN(nn.Module):
             eps(protein_augment_eps), eps(dna_augment_eps), eps(rna_augment_eps)
 
         self.W_v = nn.Linear(node_features, hidden_dim, bias=True)
-        self.features = _FeatureParams(edge_features, node_features, len(polytype_to_int), len(atom_dict) + 2)
+        self.features = _FeatureParams(edge_features, node_features, len(polytype_to_int),
+                                       len(atom_dict) + 1 + self.include_pred_na_N)
         self.W_e = nn.Linear(edge_features, hidden_dim, bias=True)
         self.W_s = nn.Embedding(vocab, hidden_dim)
         self.dropout = nn.Dropout(dropout)
@@ -130,6 +140,7 @@ class ProteinMPNN(nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws = None
+        self._tokens_ok = None
         # per-edge message / edge-update GEMMs: "x3" (default, parity mode) = three bf16 products of split operands with fp32
         # accumulation, fp32-equivalent to ~2^-16 (3e-5 on log-probs, arg-max unchanged) at 3/16 of the fp32 MFMA cost;
         # "fp32" = exact fp32 MFMA; "bf16" = plain bf16 inputs, BASELINE configs[2]'s throughput mode (~1e-2 on log-probs).
@@ -138,12 +149,29 @@ class ProteinMPNN(nn.Module):
     # ---------------------------------------------------------------------------------------
     # packed weights / workspace plumbing
     # ---------------------------------------------------------------------------------------
+    def edge_weight18(self):
+        """features.edge_embedding.weight in the kernels' 18-atom column layout [128 x 5200] (differentiable)."""
+        W = self.features.edge_embedding.weight
+        if self.include_pred_na_N:
+            return W
+        A = spec.N_ATOMS_AUG                                                   # 18; the model holds 17 x 17 pairs
+        a, b, r = torch.meshgrid(torch.arange(A - 1), torch.arange(A - 1), torch.arange(spec.NUM_RBF), indexing="ij")
+        cols = torch.cat((torch.arange(spec.NUM_POS), (spec.NUM_POS + (a * A + b) * spec.NUM_RBF + r).reshape(-1))).to(W.device)
+        return torch.zeros(W.shape[0], spec.EDGE_IN, dtype=W.dtype, device=W.device).index_copy(1, cols, W)
+
+    def _na_masks(self, fd):
+        """(dna_mask, rna_mask) as the featuriser kernels see them: they only decide the presence of the virtual N_na atom."""
+        if self.include_pred_na_N:
+            return fd["dna_mask"], fd["rna_mask"]
+        return torch.zeros_like(fd["dna_mask"]), torch.zeros_like(fd["rna_mask"])
+
     def _weights(self):
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is None or sig != self._packed_sig:
             dev = self.W_v.weight.device
             _require_device(self.W_v.weight, "model parameters")
             sd = {k: v for k, v in self.state_dict().items()}
+            sd["features.edge_embedding.weight"] = self.edge_weight18().detach()
             if self._packed is None or self._packed.flat.device != dev:
                 self._packed = PackedWeights(sd, len(self.encoder_layers), len(self.decoder_layers), self.num_letters, dev)
             else:
@@ -152,6 +180,18 @@ class ProteinMPNN(nn.Module):
         if getattr(self._packed, "precision", "x3") != self.message_precision:
             self._packed.set_precision(self.message_precision)
         return self._packed
+
+    def _check_tokens(self, S, what="S"):
+        """Token ids index the per-token tables inside the kernels: anything outside [0, vocab) would read out of bounds
+        where the reference's nn.Embedding raises (model_utils.py:402).  One device reduction + host read per NEW tensor
+        (same storage and version: already checked), so steady-state calls on a resident feature_dict stay asynchronous."""
+        key = (S.data_ptr(), S._version, tuple(S.shape), what)
+        if self._tokens_ok == key:
+            return
+        lo, hi = torch.aminmax(S)
+        if int(lo) < 0 or int(hi) >= self.vocab:
+            raise IndexError(f"na_mpnn_amd: token ids in '{what}' must lie in [0, {self.vocab}); got [{int(lo)}, {int(hi)}]")
+        self._tokens_ok = key
 
     def _workspace(self, B_enc, B_dec, N, K, device):
         need = hip.lib().namp_workspace_bytes(B_enc, B_dec, N, K)
@@ -200,7 +240,8 @@ class ProteinMPNN(nn.Module):
         E = torch.empty(B, L, K, self.edge_features, device=dev) if want_E else None
         hE = torch.empty(B, L, K, self.hidden_dim, device=dev) if want_hE else None
         ws = torch.empty(Lb.namp_featurize_workspace_bytes(B, L), dtype=torch.uint8, device=dev)
-        t = [_i32(fd[k]) for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask")]
+        dna_m, rna_m = self._na_masks(fd)
+        t = [_i32(fd[k]) for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + [_i32(dna_m), _i32(rna_m)]
         hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
                                     int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
                                     ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
@@ -231,7 +272,8 @@ class ProteinMPNN(nn.Module):
         C1p = X[:, :, ad["C1'"]]
         Nna = self._virtual(X[:, :, ad["O4'"]], C1p, X[:, :, ad["C2'"]], -0.56967352, 0.51055973, -0.53122153)
         X18 = torch.cat((X, Cb[:, :, None], Nna[:, :, None]), -2)
-        M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (fd["rna_mask"] + fd["dna_mask"])[:, :, None]), -1).float()
+        dna_m, rna_m = self._na_masks(fd)
+        M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (rna_m + dna_m)[:, :, None]), -1).float()
         P = Ca + X[:, :, ad[self.na_ref_atom]]
         mf = mask.float()
         m2 = mf[:, None, :] * mf[:, :, None]
@@ -257,7 +299,7 @@ class ProteinMPNN(nn.Module):
             d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
             pos = Wpos.t()[d] + bpos                                   # one-hot @ W^T == column select
             feat = torch.cat((pos, rbf.reshape(B, i1 - i0, K, -1)), -1)
-            E[:, i0:i1] = nn.functional.layer_norm(feat @ fp.edge_embedding.weight.t(), (self.edge_features,),
+            E[:, i0:i1] = nn.functional.layer_norm(feat @ self.edge_weight18().t(), (self.edge_features,),
                                                    fp.norm_edges.weight, fp.norm_edges.bias, 1e-5)
         return self._node_features(fd), E, E_idx
 
@@ -316,6 +358,7 @@ class ProteinMPNN(nn.Module):
         W = self._weights()
         B_enc, N, K = E_idx.shape
         B_dec = S.shape[0]
+        self._check_tokens(S)
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
         E32, S32, m32, r32 = _i32(E_idx), _i32(S), _i32(mask), _i32(rank)
         log_probs = torch.empty(B_dec, N, self.num_letters, device=h_V.device)
@@ -332,6 +375,7 @@ class ProteinMPNN(nn.Module):
         """encode() + decode_graph() for one decoder batch per complex, as ONE library call (namp_encdec_fwd): lets the
         kernels fuse across the encoder/decoder boundary.  Returns h_V, h_E, E_idx, log_probs(, logits)."""
         mask = feature_dict["mask"]
+        self._check_tokens(S)
         if self._hip_featuriser_ok():
             V, E, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
         else:
@@ -420,6 +464,12 @@ class ProteinMPNN(nn.Module):
         symmetric = not (len(sym) == 1 and len(sym[0]) == 0)
         B, L = S_true.shape
         dev = S_true.device
+        if len(self.decoder_layers) > 3:
+            raise NotImplementedError("sample(): the sampler kernels hold at most 3 decoder layers (score / training take up to "
+                                      f"{hip.NAMP_MAX_LAYERS}); this model has {len(self.decoder_layers)}")
+        self._check_tokens(S_true)
+        if fd.get("S_forced") is not None:
+            self._check_tokens(fd["S_forced"], "S_forced")
         h_V, h_E, E_idx = self.encode(fd)
         K = E_idx.shape[-1]
         chain_mask = mask * fd["chain_mask"]

@@ -96,7 +96,7 @@ def all_gather_ragged(local: dict, n_total: int, device=None, group=None):
     for k in keys:
         lens[k] = local[k].numel()
         owner[k] = rank
-    payload = torch.cat([local[k].reshape(-1).to(torch.int32) for k in keys]) if keys else \
+    payload = torch.cat([local[k].reshape(-1).to(device=device, dtype=torch.int32) for k in keys]) if keys else \
         torch.zeros(0, dtype=torch.int32, device=device)
     if world == 1:
         out, off = [None] * n_total, 0

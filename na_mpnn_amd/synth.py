@@ -32,6 +32,16 @@ def make_weights(seed: int = 0, num_encoder_layers: int = 3, num_decoder_layers:
     return out
 
 
+def make_weights_noN(seed: int = 0):
+    """make_weights() for a model built with include_pred_na_N=0 (na_model_utils.py:404-407): the edge embedding sees
+    17 x 17 atom pairs, i.e. features.edge_embedding.weight is [128 x 4640]; everything else is unchanged."""
+    w = make_weights(seed)
+    n_in = spec.NUM_POS + spec.NUM_RBF * 17 * 17
+    a = np.sqrt(6.0 / (n_in + spec.H))
+    w["features.edge_embedding.weight"] = np.random.default_rng(seed + 4640).uniform(-a, a, size=(spec.H, n_in)).astype(np.float32)
+    return w
+
+
 def random_walk_backbone(rng, n: int, step: float = 3.8):
     d = rng.standard_normal((n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)

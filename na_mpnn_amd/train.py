@@ -30,12 +30,12 @@ ENC_MSG, DEC_MSG, ENC_EDGE = 0, 1, 2
 X3 = True
 
 
-def _image(block):
-    """Fragment image (fp32, or x3 when X3) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
-    weight."""
+def _image(block, x3=None):
+    """Fragment image (fp32, or x3) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
+    weight.  x3 None: the module-level setting (forward passes); backward passes hand in the value their forward saved."""
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
     img = torch.empty(H * H, dtype=torch.float32, device=block.device)
-    if X3:
+    if (X3 if x3 is None else x3):
         hip.check(hip.lib().namp_pack_image_x3(block.data_ptr(), block.stride(0), 0, img.data_ptr(), hip.current_stream()),
                   "pack_image_x3")
     else:
@@ -51,18 +51,18 @@ def _image_f32(block):
     return img
 
 
-def _image_t(block):
-    return _image(block.detach().t().contiguous())
+def _image_t(block, x3=None):
+    return _image(block.detach().t().contiguous(), x3)
 
 
-def _wgrad(G, A, gelu_A, want_bias):
+def _wgrad(G, A, gelu_A, want_bias, x3=None):
     """sum over rows of G^T act(A) (and of G): [128,128] (, [128])."""
     L = hip.lib()
     rows = G.shape[0]
     n = L.namp_train_wgrad_chunks(rows)
     dW = torch.empty(n, H, H, device=G.device)
     db = torch.empty(n, H, device=G.device) if want_bias else None
-    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), int(X3 and not gelu_A), rows, dW.data_ptr(), hip.ptr(db),
+    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), int((X3 if x3 is None else x3) and not gelu_A), rows, dW.data_ptr(), hip.ptr(db),
                                  hip.current_stream()), "train_wgrad")
     return dW.sum(0), (db.sum(0) if want_bias else None)
 
@@ -111,7 +111,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
                                         None, None, 0.0, 0, out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.mode, ctx.rev = mode, rev
+        ctx.mode, ctx.rev, ctx.x3 = mode, rev, X3           # backward runs at the precision of ITS forward
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
 
@@ -124,8 +124,8 @@ class _EdgeMLP(torch.autograd.Function):
         dev = h_E.device
         L = hip.lib()
         g = g.contiguous()
-        img1, img2 = _image(W1b.detach()), _image(W2.detach())
-        img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
+        img1, img2 = _image(W1b.detach(), ctx.x3), _image(W2.detach(), ctx.x3)
+        img3t, img2t, img1t = _image_t(W3, ctx.x3), _image_t(W2, ctx.x3), _image_t(W1b, ctx.x3)
         A1, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(4))
         # message modes with tiles aligned to residues: dW3 = g^T . (sum_k w_ik a2[i,k]) from per-tile sums, no A2 / G3 rows
         tile_sums = mode != ENC_EDGE and K % 16 == 0
@@ -139,7 +139,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(X3), B, N, K,
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3), B, N, K,
                                         hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
@@ -155,9 +155,9 @@ class _EdgeMLP(torch.autograd.Function):
             dW3 = g2d.t() @ S3.view(B * N, K // 16, H).sum(1)
             db3 = (g2d * w3.view(B * N, K // 16).sum(1, keepdim=True)).sum(0)
         else:
-            dW3, db3 = _wgrad(G3, A2, False, True)
-        dW2, db2 = _wgrad(G2, A1, False, True)
-        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
+            dW3, db3 = _wgrad(G3, A2, False, True, x3=ctx.x3)
+        dW2, db2 = _wgrad(G2, A1, False, True, x3=ctx.x3)
+        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False, x3=ctx.x3)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
@@ -180,7 +180,7 @@ class _EdgeUpdate(torch.autograd.Function):
                                                 Pc.data_ptr(), None, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(),
                                                 b2c.data_ptr(), b3c.data_ptr(), g_.data_ptr(), b_.data_ptr(), float(p), int(seed),
                                                 out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.p, ctx.seed, ctx.rev = float(p), int(seed), rev
+        ctx.p, ctx.seed, ctx.rev, ctx.x3 = float(p), int(seed), rev, X3
         ctx.save_for_backward(h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32)
         return out
 
@@ -192,8 +192,8 @@ class _EdgeUpdate(torch.autograd.Function):
         dev = h_E.device
         L = hip.lib()
         g = g.contiguous()
-        img1, img2, img3 = _image(W1b.detach()), _image(W2.detach()), _image(W3.detach())
-        img3t, img2t, img1t = _image_t(W3), _image_t(W2), _image_t(W1b)
+        img1, img2, img3 = _image(W1b.detach(), ctx.x3), _image(W2.detach(), ctx.x3), _image(W3.detach(), ctx.x3)
+        img3t, img2t, img1t = _image_t(W3, ctx.x3), _image_t(W2, ctx.x3), _image_t(W1b, ctx.x3)
         A1, A2, G1, G2, G3, g_hE = (torch.empty(E, H, device=dev) for _ in range(6))
         g_Pa = torch.zeros(B * N, H, device=dev)
         part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
@@ -203,12 +203,12 @@ class _EdgeUpdate(torch.autograd.Function):
                                                img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
                                                g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
                                                G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
-                                               int(X3), B, N, K, hip.current_stream()), "train_edge_update_bwd")
+                                               int(ctx.x3), B, N, K, hip.current_stream()), "train_edge_update_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
-        dW3, db3 = _wgrad(G3, A2, False, True)
-        dW2, db2 = _wgrad(G2, A1, False, True)
-        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False)
+        dW3, db3 = _wgrad(G3, A2, False, True, x3=ctx.x3)
+        dW2, db2 = _wgrad(G2, A1, False, True, x3=ctx.x3)
+        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False, x3=ctx.x3)
         dgb = part.sum(0)
         return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
                 None, None, None, None)
@@ -252,6 +252,7 @@ class _EdgeLinear(torch.autograd.Function):
         y = torch.empty_like(x)
         hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
                                             y.data_ptr(), B, N, K, hip.current_stream()), "edge_embed")
+        ctx.x3 = X3
         ctx.save_for_backward(x, W)
         return y
 
@@ -264,7 +265,7 @@ class _EdgeLinear(torch.autograd.Function):
         zero = torch.zeros(H, device=x.device)
         hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach().t().contiguous()).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, K,
                                             hip.current_stream()), "edge_embed (dgrad)")
-        dW, db = _wgrad(g.view(-1, H), x.view(-1, H), False, True)
+        dW, db = _wgrad(g.view(-1, H), x.view(-1, H), False, True, x3=ctx.x3)
         return gx, dW, db
 
 
@@ -276,18 +277,19 @@ def _atom_frames(model, X, fd):
     C1p = X[:, :, ad["C1'"]]
     Nna = model._virtual(X[:, :, ad["O4'"]], C1p, X[:, :, ad["C2'"]], -0.56967352, 0.51055973, -0.53122153)
     X18 = torch.cat((X, Cb[:, :, None], Nna[:, :, None]), -2).contiguous()
-    M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (fd["rna_mask"] + fd["dna_mask"])[:, :, None]), -1)
+    dna_m, rna_m = model._na_masks(fd)                         # all-zero when the model has no virtual N_na atom
+    M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (rna_m + dna_m)[:, :, None]), -1)
     return X18, M18.float().contiguous()
 
 
-def _edge_embedding_fwd(fp, X, ints, top_k, ref_atom):
+def _edge_embedding_fwd(fp, W18, X, ints, top_k, ref_atom):
     """Fused HIP featuriser without its LayerNorm: y = edge_embedding([E_pos | RBF]) [B,L,K,128] and E_idx int32
     (na_model_utils.py:489-507); no autograd here, see _EdgeEmbeddingGrad."""
     L = hip.lib()
     B, Lr = X.shape[:2]
     K = int(min(top_k, Lr))
     dev = X.device
-    Wd = fp.edge_embedding.weight.detach().contiguous()
+    Wd = W18.detach().contiguous()                            # 18-atom column layout [128 x 5200] (model.edge_weight18)
     img = torch.empty(Wd.numel(), device=dev)
     m = hip.NampModelW()
     if X3:
@@ -314,6 +316,7 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, Wedge, E_pos, X18, M18, E_idx):
+        ctx.x3 = X3
         ctx.save_for_backward(Wedge, E_pos, X18, M18, E_idx)
         return y.view_as(y)
 
@@ -328,7 +331,7 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         Ep = E_pos.detach().contiguous()
         tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
         hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
-                                          part.data_ptr(), tws.data_ptr(), int(X3), B, Lr, K, hip.current_stream()),
+                                          part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
         return None, part.sum(0), g_Epos, None, None, None
@@ -339,10 +342,12 @@ def edge_embedding(model, fd):
     fp = model.features
     X = model._noised_X(fd).float().contiguous()
     X18, M18 = _atom_frames(model, X, fd)
-    ints = [fd[k].to(torch.int32).contiguous() for k in
-            ("X_m", "mask", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask")]
+    dna_m, rna_m = model._na_masks(fd)
+    ints = [fd[k].to(torch.int32).contiguous() for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + \
+        [dna_m.to(torch.int32).contiguous(), rna_m.to(torch.int32).contiguous()]
+    W18 = model.edge_weight18()                               # differentiable expansion when include_pred_na_N = 0
     with torch.no_grad():
-        y, E_idx = _edge_embedding_fwd(fp, X, ints, model.k_neighbors, model.atom_dict[model.na_ref_atom])
+        y, E_idx = _edge_embedding_fwd(fp, W18, X, ints, model.k_neighbors, model.atom_dict[model.na_ref_atom])
     # positional features as a torch expression (PositionalEncodings, na_model_utils.py:537-541) so that autograd
     # carries dL/dE_pos into embeddings.linear
     B, Lr, K = E_idx.shape
@@ -353,7 +358,7 @@ def edge_embedding(model, fd):
     same = (ch[:, :, None] == ch[bidx, j]).long()
     d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
     E_pos = _TableRows.apply(fp.embeddings.linear.weight.t(), d) + fp.embeddings.linear.bias     # [B,L,K,16]
-    y = _EdgeEmbeddingGrad.apply(y, fp.edge_embedding.weight, E_pos, X18, M18, E_idx)
+    y = _EdgeEmbeddingGrad.apply(y, W18, E_pos, X18, M18, E_idx)
     return y, E_idx
 
 
@@ -384,7 +389,7 @@ class _NodeLinears(torch.autograd.Function):
         Ws, bs = wb[:nb], wb[nb:]
         x2 = x.contiguous().view(-1, H)
         outs = _node_linear_call(x2, [w.detach() for w in Ws], bs)
-        ctx.nb, ctx.shape, ctx.has_b = nb, x.shape, [b is not None for b in bs]
+        ctx.nb, ctx.shape, ctx.has_b, ctx.x3 = nb, x.shape, [b is not None for b in bs], X3
         ctx.save_for_backward(x2, *Ws)
         return tuple(o.view(*x.shape[:-1], H) for o in outs)
 
@@ -398,7 +403,7 @@ class _NodeLinears(torch.autograd.Function):
             gx = t if gx is None else gx + t
         gW, gb = [], []
         for q in range(ctx.nb):
-            dW, db = _wgrad(g2[q], x2, False, ctx.has_b[q])
+            dW, db = _wgrad(g2[q], x2, False, ctx.has_b[q], x3=ctx.x3)
             gW.append(dW); gb.append(db)
         return (gx.view(ctx.shape), None, *gW, *gb)
 
@@ -587,8 +592,10 @@ def train_step(model, optimizer, fd, polymer_restype_masks, polymer_restype_nums
     mask_for_loss = mask * S_mask
     polymer_masks = {"protein": fd["protein_mask"], "dna": fd["dna_mask"], "rna": fd["rna_mask"]}
     log_probs, _ = forward_train(model, fd, decoding_randn)
+    # position-probability targets of the specificity model (na_run.py:229-230), when the batch carries them
     _, loss = loss_smoothed(S, log_probs, mask_for_loss, polymer_masks, polymer_restype_masks, polymer_restype_nums,
-                            weight=label_smoothing, tokens=loss_tokens, num_letters=log_probs.shape[-1])
+                            weight=label_smoothing, tokens=loss_tokens, num_letters=log_probs.shape[-1],
+                            ppm_mask=fd.get("ppm_mask"), aligned_ppm=fd.get("aligned_ppm"))
     loss.backward()
     if data_parallel:
         from . import shard

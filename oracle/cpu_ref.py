@@ -160,6 +160,10 @@ def features(w, fd, top_k):
     X18 = torch.cat((X, Cb[:, :, None, :], N_na[:, :, None, :]), -2)
     M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None],
                      (fd["rna_mask"] + fd["dna_mask"])[:, :, None]), -1)
+    if w["features.edge_embedding.weight"].shape[1] == 16 + 16 * 17 * 17:
+        # include_pred_na_N = 0 (model_utils.py:480-483,555-567; na_model_utils.py:404-407,479-491): no virtual N_na atom,
+        # 17 x 17 atom pairs, edge_embedding is [128 x 4640]
+        X18, M18 = X18[:, :, :17], M18[:, :, :17]
     _, E_idx = knn(Ca + ref_na, mask, top_k)
     R = rbf_all_pairs(X18, E_idx, M18)
     R_idx, chain = fd["R_idx"], fd["chain_labels"]
@@ -304,10 +308,14 @@ def restype_masks(restype_to_int, num_letters=33):
     return out, dict(POLYMER_RESTYPES)
 
 
-def loss_smoothed(S, log_probs, mask, polymer_masks, restype_mask, restype_num, weight=0.1, tokens=2000.0, num_letters=33):
-    """na_model_utils.py:111-146 with an empty ppm_mask: fp64 one-hot, (1-weight) on the polymer letters, plus
-    weight/num on the letters of the residue's own polymer; sum(loss*mask)/tokens."""
+def loss_smoothed(S, log_probs, mask, polymer_masks, restype_mask, restype_num, weight=0.1, tokens=2000.0, num_letters=33,
+                  ppm_mask=None, aligned_ppm=None):
+    """na_model_utils.py:111-146: fp64 one-hot — replaced by the aligned position-probability row where ppm_mask is set
+    (:134, the specificity model's target) —, (1-weight) on the polymer letters, plus weight/num on the letters of the
+    residue's own polymer; sum(loss*mask)/tokens."""
     onehot = F.one_hot(S, num_letters).to(torch.float64)
+    if ppm_mask is not None:
+        onehot[ppm_mask.bool()] = aligned_ppm[ppm_mask.bool()]
     eps = sum(polymer_masks[k][:, :, None] * restype_mask[k][None, None, :] * (weight / restype_num[k])
               for k in ("protein", "dna", "rna"))
     allm = restype_mask["protein"] + restype_mask["dna"] + restype_mask["rna"]
@@ -322,7 +330,7 @@ def noam_rate(step, model_size=128, factor=2, warmup=4000):
     return factor * (model_size ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5)))
 
 
-def train_loss_and_grads(w, fd, top_k, randn, restype_to_int, weight=0.1, tokens=2000.0):
+def train_loss_and_grads(w, fd, top_k, randn, restype_to_int, weight=0.1, tokens=2000.0, ppm_mask=None, aligned_ppm=None):
     """One training forward/backward of na_run.py:198-238 (dropout 0, no coordinate noise) on the restatement:
     returns loss (fp64 scalar), log_probs and {key: grad}."""
     wg = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
@@ -333,7 +341,8 @@ def train_loss_and_grads(w, fd, top_k, randn, restype_to_int, weight=0.1, tokens
         S_mask = 1 - torch.any(S[:, :, None] == no_loss[None, None, :], dim=-1).long()
         rm, rn = restype_masks(restype_to_int, log_probs.shape[-1])
         pm = {"protein": fd["protein_mask"], "dna": fd["dna_mask"], "rna": fd["rna_mask"]}
-        _, loss = loss_smoothed(S, log_probs, fd["mask"] * S_mask, pm, rm, rn, weight, tokens, log_probs.shape[-1])
+        _, loss = loss_smoothed(S, log_probs, fd["mask"] * S_mask, pm, rm, rn, weight, tokens, log_probs.shape[-1],
+                                ppm_mask=ppm_mask, aligned_ppm=aligned_ppm)
         loss.backward()
     return loss.detach(), log_probs.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in wg.items()}
 

@@ -120,6 +120,33 @@ def g2_layers(weights):
          enc_hV=hV[0].numpy(), enc_hE_rows=hE[0, ::16].numpy(), dec_hV=dV[0].numpy())
 
 
+def g4b_no_pred_na_N():
+    """include_pred_na_N = 0 (training copy only: na_model_utils.py:362,404-407,479-491,538): 17-atom featurisation,
+    forward from coordinates and one training step's loss / gradients of the feature parameters."""
+    weights = synth.make_weights_noN(0)
+    n, k = 60, 24
+    cx = synth.make_complex(seed=460, n=n, n_chains=3, masked_frac=0.04, missing_atom_frac=0.03)
+    fd = batchify(cx)
+    fd["S"] = fd["S"].long()
+    m = ref_train.ProteinMPNN(atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                              polytype_to_int=spec.polytype_to_int(), k_neighbors=k, dropout=0.0,
+                              protein_augment_eps=0.0, dna_augment_eps=0.0, rna_augment_eps=0.0, include_pred_na_N=0)
+    m.load_state_dict(tw(weights))
+    m.eval()
+    w = tw(weights)
+    V, E, E_idx = m.features(fd)
+    oV, oE, oI = cpu_ref.features(w, fd, k)
+    same(oV, V, "noN V"); same(oE, E, "noN E"); assert torch.equal(oI, E_idx)
+    torch.manual_seed(4321)
+    randn = torch.randn(fd["mask"].shape)
+    torch.manual_seed(4321)
+    lp, p = m(fd)
+    o_lp, o_p = cpu_ref.forward_train(w, fd, k, randn)
+    same(o_lp, lp, "noN forward")
+    save("g4b_noN_n60_k24", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), E_idx=E_idx[0].numpy().astype(np.int16),
+         E_rows=E[0, ::max(1, n // 8)].numpy()[:8], randn=randn.numpy(), log_probs=lp[0].numpy())
+
+
 def g3_encdec(weights, n, tag, masked_frac=0.0, batch=1):
     """encode-from-graph + score (the BASELINE metric scope), K=48."""
     g = synth.make_graph(seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=masked_frac)
@@ -276,10 +303,30 @@ def g7_inputs(n=72, n2=55, k=24):
     return fd, k
 
 
-def g7_training(weights):
+def g7b_ppm(fd, seed=702, frac=0.4):
+    """Position-probability targets for G7b (na_model_utils.py:134; na_run.py:229-230): ppm_mask on ~40 % of the unmasked
+    nucleotides, aligned_ppm rows = Dirichlet weights over the residue's own polymer letters (DNA 21..24 / RNA 26..29)."""
+    rng = np.random.default_rng(seed)
+    dna, rna, mask = fd["dna_mask"].numpy(), fd["rna_mask"].numpy(), fd["mask"].numpy()
+    B, L = mask.shape
+    ppm_mask = (((dna + rna) * mask) * (rng.random((B, L)) < frac)).astype(np.int64)
+    ppm = np.zeros((B, L, 33), np.float64)
+    w4 = rng.dirichlet(np.ones(4), size=(B, L))
+    ppm[:, :, 21:25] = w4 * dna[:, :, None]
+    ppm[:, :, 26:30] = w4 * rna[:, :, None]
+    return torch.from_numpy(ppm_mask), torch.from_numpy(ppm)
+
+
+def g7b_training(weights):
+    """G7 with a non-empty ppm_mask: the specificity model's training target (loss_smoothed's PPM branch)."""
+    g7_training(weights, ppm=True)
+
+
+def g7_training(weights, ppm=False):
     """Training step of the reference (na_run.py:198-238): train-mode forward through torch.utils.checkpoint
     (dropout 0, no coordinate noise), loss_smoothed, backward, one NoamOpt/Adam step."""
     fd, k = g7_inputs()
+    ppm_mask, aligned_ppm = g7b_ppm(fd) if ppm else (None, None)
     rti = spec.restype_to_int()
     m = ref_train_model(weights, k).train()
     for p in m.parameters():
@@ -297,11 +344,14 @@ def g7_training(weights):
         lp, _ = m(fd)
         _, loss = ref_train.loss_smoothed(S, lp, mask_for_loss, polymer_masks=pm, polymer_restype_masks=rm,
                                           polymer_restype_nums=rn, weight=0.1, tokens=2000.0, num_letters=33,
-                                          ppm_mask=torch.zeros_like(mask), aligned_ppm=torch.zeros(lp.shape, dtype=torch.float64))
+                                          ppm_mask=ppm_mask if ppm else torch.zeros_like(mask),
+                                          aligned_ppm=aligned_ppm if ppm else torch.zeros(lp.shape, dtype=torch.float64))
         opt.zero_grad()
         loss.backward()
     grads = {n_: p.grad.detach().clone() for n_, p in m.named_parameters()}
-    o_loss, o_lp, o_g = cpu_ref.train_loss_and_grads(tw(weights), fd, k, randn, rti)
+    o_loss, o_lp, o_g = cpu_ref.train_loss_and_grads(tw(weights), fd, k, randn, rti, ppm_mask=ppm_mask, aligned_ppm=aligned_ppm)
+    if ppm:
+        assert int(ppm_mask.sum()) >= 8, "G7b needs a non-trivial ppm_mask"
     same(o_lp, lp.detach(), "train-mode log_probs")
     assert float(o_loss) == float(loss), (float(o_loss), float(loss))
     worst = max(float((o_g[n_] - g).abs().max() / (g.abs().max() + 1e-30)) for n_, g in grads.items())
@@ -313,7 +363,7 @@ def g7_training(weights):
     names = sorted(grads)
     rng = np.random.default_rng(7)
     pick = {n_: rng.integers(0, grads[n_].numel(), 16) for n_ in names}
-    save("g7_training", names=np.array(names), randn=randn.numpy(), loss=np.float64(loss.item()), log_probs=lp.detach().numpy(),
+    save("g7b_training" if ppm else "g7_training", names=np.array(names), randn=randn.numpy(), loss=np.float64(loss.item()), log_probs=lp.detach().numpy(),
          grad_norm=np.array([float(grads[n_].double().norm()) for n_ in names]),
          grad_absmax=np.array([float(grads[n_].abs().max()) for n_ in names]),
          pick=np.stack([pick[n_] for n_ in names]),
@@ -328,7 +378,8 @@ def main():
     weights = synth.make_weights(0)
     if len(sys.argv) > 1:                       # e.g. `python oracle/make_goldens.py g7_training`: regenerate one fixture
         for name in sys.argv[1:]:
-            print(name); globals()[name](weights)
+            print(name)
+            globals()[name]() if name == "g4b_no_pred_na_N" else globals()[name](weights)
         return
     print("G1 gather"); g1_gather()
     print("G2 layers"); g2_layers(weights)
@@ -343,7 +394,9 @@ def main():
     g4_from_X(weights, 32, 48, "n32_k48_LltK")
     print("G5 sample"); g5_sample(weights)
     print("G6 sample variants (symmetry-tied, pair_bias)"); g6_sample_variants(weights)
+    print("G4b include_pred_na_N=0"); g4b_no_pred_na_N()
     print("G7 training step"); g7_training(weights)
+    print("G7b training step with a PPM target"); g7b_training(weights)
     print("all reference == oracle checks passed")
 
 

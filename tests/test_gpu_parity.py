@@ -184,6 +184,35 @@ def test_enc_layer_golden(L, dev, wt, packed, golden_dir):
     assert maxdiff(hV, rV) < TOL_ACT and maxdiff(hE, rE) < TOL_ACT
 
 
+def test_dec_layer_golden(L, dev, wt, packed, golden_dir):
+    """a5: DecLayer.forward as an operator on a MATERIALISED 384-wide context (model_utils.py:636-657) vs the reference
+    golden (G2 dec_hV: decoder_layers.2 on a seeded synthetic context with a partial mask_V), plus an explicit
+    mask_attend and odd shapes (K not a multiple of 16, ragged last workgroup) vs the oracle."""
+    g = np.load(os.path.join(golden_dir, "g2_layers.npz"))
+    t, d = graph(dev, seed=202, batch=1, n=128, k=48, masked_frac=0.1)
+    ctx = torch.from_numpy(np.random.default_rng(203).standard_normal((1, 128, 48, 384)).astype(np.float32))
+    ctx_d = ctx.to(dev)
+    out = torch.empty_like(d["V"])
+    ws = torch.empty(L.namp_workspace_bytes(1, 1, 128, 48), dtype=torch.uint8, device=dev)
+    hip.check(L.namp_dec_layer_fwd(packed.dec_layer(2), d["V"].data_ptr(), ctx_d.data_ptr(), d["mask"].data_ptr(), None,
+                                   out.data_ptr(), ws.data_ptr(), ws.numel(), 1, 128, 48, stream()))
+    dv = maxdiff(out[0], torch.from_numpy(g["dec_hV"]))
+    assert dv < TOL_ACT, dv
+    for (B, n, k, seed) in [(2, 37, 30, 5), (1, 21, 7, 6)]:
+        rng = np.random.default_rng(seed)
+        V = torch.from_numpy(rng.standard_normal((B, n, 128)).astype(np.float32))
+        c = torch.from_numpy(rng.standard_normal((B, n, k, 384)).astype(np.float32))
+        mV = torch.from_numpy(rng.integers(0, 2, (B, n)).astype(np.int32))
+        ma = torch.from_numpy(rng.integers(0, 2, (B, n, k)).astype(np.float32))
+        Vd, cd, mVd, mad = V.to(dev), c.to(dev), mV.to(dev), ma.to(dev)
+        o = torch.empty_like(Vd)
+        ws = torch.empty(L.namp_workspace_bytes(B, B, n, k), dtype=torch.uint8, device=dev)
+        hip.check(L.namp_dec_layer_fwd(packed.dec_layer(0), Vd.data_ptr(), cd.data_ptr(), mVd.data_ptr(), mad.data_ptr(),
+                                       o.data_ptr(), ws.data_ptr(), ws.numel(), B, n, k, stream()))
+        ref = cpu_ref.dec_layer(wt, "decoder_layers.0.", V, c, mV.float(), ma)
+        assert maxdiff(o, ref) < TOL_ACT, (B, n, k)
+
+
 def run_encdec(L, dev, packed, d, B, N, K, joint=False):
     hV = torch.empty(B, N, 128, device=dev)
     hE = torch.empty(B, N, K, 128, device=dev)
@@ -507,6 +536,17 @@ def test_cfg3_sized_batch(L, dev, wt, packed):
     d1 = {k_: v[31:32].contiguous() for k_, v in d.items()}
     _, _, logp1, _ = run_encdec(L, dev, packed, d1, 1, N, K)          # fused small-batch path on the same complex
     assert maxdiff(logp1, logp[31:32]) < 5e-5
+    # BASELINE configs[2] itself: the bf16 throughput mode AT this size, through the one-call path bench.py times (bf16
+    # MFMA + bf16 storage of h_E and the gathered tables).  Bar = the bf16 accuracy class on all 64,000 residues.
+    P = PackedWeights({k_: v.to(dev) for k_, v in wt.items()}, 3, 3, 33, dev)
+    P.set_precision("bf16")
+    _, _, lp16, _ = run_encdec(L, dev, P, d, B, N, K, joint=True)
+    assert torch.isfinite(lp16).all()
+    assert maxdiff(torch.logsumexp(lp16, -1), torch.zeros(B, N)) < 1e-5
+    err = maxdiff(lp16, logp.cpu())
+    agree = float((lp16.argmax(-1) == logp.argmax(-1)).float().mean())
+    print(f"cfg3-sized bf16: max|dlogp| vs parity mode = {err:.4f}, arg-max agreement = {agree:.4f}")
+    assert err < 0.15 and agree >= 0.97
 
 
 def test_bf16_throughput_mode(L, dev, wt, golden_dir):

@@ -129,3 +129,75 @@ def test_pad_batch_uses_the_reference_padding_values():
     assert (fd["R_idx"][0, 12:] == -100).all() and (fd["chain_labels"][2, 7:] == -1).all()
     assert np.array_equal(fd["X"][1].numpy(), cxs[1]["X"])
 
+
+
+def _model(**kw):
+    args = dict(num_letters=33, vocab=33, k_neighbors=8, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                polytype_to_int=spec.polytype_to_int())
+    args.update(kw)
+    return ProteinMPNN(**args)
+
+
+def test_token_range_and_constructor_checks():
+    """Token ids index per-token tables inside the kernels: the host wrappers refuse anything outside [0, vocab) like the
+    reference's nn.Embedding does; vocab != num_letters and too many layers are refused at construction."""
+    m = _model()
+    m._check_tokens(torch.tensor([[0, 5, 32]]))
+    with pytest.raises(IndexError, match=r"\[0, 33\)"):
+        m._check_tokens(torch.tensor([[0, 33]]))
+    with pytest.raises(IndexError):
+        m._check_tokens(torch.tensor([[-1, 3]]))
+    with pytest.raises(ValueError, match="vocab"):
+        _model(vocab=21)
+    with pytest.raises(ValueError, match="at most"):
+        _model(num_decoder_layers=9)
+
+
+def test_include_pred_na_N_0_parameter_surface():
+    """include_pred_na_N=0 (na_model_utils.py:404-407): edge embedding [128 x 4640]; its 18-atom expansion carries the
+    weights at the reference's (a*17+b) pairs and zeros on every pair that involves the absent virtual N_na atom."""
+    m = _model(include_pred_na_N=0)
+    W = m.features.edge_embedding.weight
+    assert tuple(W.shape) == (128, 16 + 16 * 17 * 17)
+    W18 = m.edge_weight18()
+    assert tuple(W18.shape) == (128, spec.EDGE_IN)
+    assert torch.equal(W18[:, :16], W[:, :16])
+    for a, b in [(0, 0), (3, 16), (16, 5), (16, 16)]:
+        assert torch.equal(W18[:, 16 + (a * 18 + b) * 16:16 + (a * 18 + b + 1) * 16], W[:, 16 + (a * 17 + b) * 16:16 + (a * 17 + b + 1) * 16])
+    for a, b in [(17, 0), (0, 17), (17, 17), (9, 17)]:
+        assert float(W18[:, 16 + (a * 18 + b) * 16:16 + (a * 18 + b + 1) * 16].abs().max()) == 0.0
+    W18.sum().backward()                                   # differentiable: the gradient lands in the [128 x 4640] parameter
+    assert W.grad is not None and float(W.grad.min()) == 1.0
+    # the default model is untouched
+    assert tuple(_model().features.edge_embedding.weight.shape) == (128, spec.EDGE_IN)
+
+
+def test_bench_respawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a launcher whose world size contradicts --gpus is refused instead of mislabelling the record
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="contradicts"):
+        bench.main()

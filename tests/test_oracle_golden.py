@@ -187,13 +187,30 @@ def g7_inputs():
     return fd, k
 
 
-def test_g7_training_step(golden_dir, weights_np):
+def g7b_ppm(fd, seed=702, frac=0.4):
+    """The PPM targets of golden G7b (same recipe as oracle/make_goldens.py:g7b_ppm)."""
+    rng = np.random.default_rng(seed)
+    dna, rna, mask = fd["dna_mask"].numpy(), fd["rna_mask"].numpy(), fd["mask"].numpy()
+    B, L = mask.shape
+    ppm_mask = (((dna + rna) * mask) * (rng.random((B, L)) < frac)).astype(np.int64)
+    ppm = np.zeros((B, L, 33), np.float64)
+    w4 = rng.dirichlet(np.ones(4), size=(B, L))
+    ppm[:, :, 21:25] = w4 * dna[:, :, None]
+    ppm[:, :, 26:30] = w4 * rna[:, :, None]
+    return torch.from_numpy(ppm_mask), torch.from_numpy(ppm)
+
+
+@pytest.mark.parametrize("tag", ["g7_training", "g7b_training"])
+def test_g7_training_step(golden_dir, weights_np, tag):
     """a12: loss and gradients of one training step (na_run.py:198-238) — the reference ran in train mode through
-    torch.utils.checkpoint; the oracle's plain autograd must give the same numbers."""
+    torch.utils.checkpoint; the oracle's plain autograd must give the same numbers.  g7b: with a non-empty ppm_mask
+    (loss_smoothed's position-probability target, na_model_utils.py:134)."""
     from na_mpnn_amd import spec
-    g = load(golden_dir, "g7_training")
+    g = load(golden_dir, tag)
     fd, k = g7_inputs()
-    loss, lp, grads = cpu_ref.train_loss_and_grads(tw(weights_np), fd, k, torch.from_numpy(g["randn"]), spec.restype_to_int())
+    pm, ppm = g7b_ppm(fd) if tag == "g7b_training" else (None, None)
+    loss, lp, grads = cpu_ref.train_loss_and_grads(tw(weights_np), fd, k, torch.from_numpy(g["randn"]), spec.restype_to_int(),
+                                                   ppm_mask=pm, aligned_ppm=ppm)
     exact(lp, g["log_probs"])
     assert float(loss) == float(g["loss"])
     names = [str(n) for n in g["names"]]
@@ -204,3 +221,19 @@ def test_g7_training_step(golden_dir, weights_np):
         assert abs(float(grads[n].double().norm()) - g["grad_norm"][i]) <= 1e-12 * max(1.0, g["grad_norm"][i])
     assert abs(cpu_ref.noam_rate(1) - float(g["lr_step1"])) < 1e-18
 
+
+
+def test_g4b_no_pred_na_N(golden_dir):
+    """include_pred_na_N = 0 (na_model_utils.py:404-407,479-491): 17-atom featurisation + the training copy's forward."""
+    from na_mpnn_amd import synth
+    g = load(golden_dir, "g4b_noN_n60_k24")
+    w = tw(synth.make_weights_noN(0))
+    assert w["features.edge_embedding.weight"].shape == (128, 16 + 16 * 17 * 17)
+    cx = synth.make_complex(seed=460, n=60, n_chains=3, masked_frac=0.04, missing_atom_frac=0.03)
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+    fd["S"] = fd["S"].long()
+    V, E, E_idx = cpu_ref.features(w, fd, 24)
+    assert np.array_equal(E_idx[0].numpy(), g["E_idx"].astype(np.int64))
+    exact(E[0, ::max(1, 60 // 8)][:8], g["E_rows"])
+    lp, _ = cpu_ref.forward_train(w, fd, 24, torch.from_numpy(g["randn"]))
+    exact(lp[0], g["log_probs"])
