@@ -159,14 +159,16 @@ def test_include_pred_na_N_0_parameter_surface():
     m = _model(include_pred_na_N=0)
     W = m.features.edge_embedding.weight
     assert tuple(W.shape) == (128, 16 + 16 * 17 * 17)
-    W18 = m.edge_weight18()
+    with torch.enable_grad():                              # other test modules switch autograd off globally at import
+        W18 = m.edge_weight18()
     assert tuple(W18.shape) == (128, spec.EDGE_IN)
     assert torch.equal(W18[:, :16], W[:, :16])
     for a, b in [(0, 0), (3, 16), (16, 5), (16, 16)]:
         assert torch.equal(W18[:, 16 + (a * 18 + b) * 16:16 + (a * 18 + b + 1) * 16], W[:, 16 + (a * 17 + b) * 16:16 + (a * 17 + b + 1) * 16])
     for a, b in [(17, 0), (0, 17), (17, 17), (9, 17)]:
-        assert float(W18[:, 16 + (a * 18 + b) * 16:16 + (a * 18 + b + 1) * 16].abs().max()) == 0.0
-    W18.sum().backward()                                   # differentiable: the gradient lands in the [128 x 4640] parameter
+        assert float(W18.detach()[:, 16 + (a * 18 + b) * 16:16 + (a * 18 + b + 1) * 16].abs().max()) == 0.0
+    with torch.enable_grad():
+        W18.sum().backward()                                   # differentiable: the gradient lands in the [128 x 4640] parameter
     assert W.grad is not None and float(W.grad.min()) == 1.0
     # the default model is untouched
     assert tuple(_model().features.edge_embedding.weight.shape) == (128, spec.EDGE_IN)
