@@ -53,10 +53,14 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
 # algorithmic FLOP / residue of the dense reference formulation, K=48, H=128
 ALGO_FLOP = {"enc_message": 7_864_320, "enc_edge_update": 7_864_320, "dec_message": 9_437_184,
              "enc_edge_message": 15_728_640,       # fused launch: edge update of layer l-1 + message of layer l
-             "enc_edge_dec_message": 7_864_320 + 9_437_184}    # last edge update + DecLayer 0 message
-EXEC_GEMMS = {"enc_message": 3, "enc_edge_update": 3, "dec_message": 3, "enc_edge_message": 6, "enc_edge_dec_message": 6}
+             "enc_edge_dec_message": 7_864_320 + 9_437_184,    # last edge update + DecLayer 0 message
+             # the persistent launch = the whole pass but the first residue-level launch (W_v + EncLayer 0's tables):
+             # W_e + 3 x (EncLayer message + FFN + edge update) + 3 x (DecLayer message + FFN) + W_out
+             "encdec_persistent": 78_684_416 - 32_768}
+EXEC_GEMMS = {"enc_message": 3, "enc_edge_update": 3, "dec_message": 3, "enc_edge_message": 6, "enc_edge_dec_message": 6,
+              "encdec_persistent": 28}           # 1 (W_e) + 9 + 9 + 9 per-edge 128 x 128 tile GEMMs
 ALGO_FLOP_TOTAL = 78_684_416
-KERNEL_OF = {}      # launch kind -> kernel name when it is not edge_mlp_kernel (filled as kinds are added)
+KERNEL_OF = {"encdec_persistent": "encdec_persistent_kernel"}      # launch kind -> kernel name when it is not edge_mlp_kernel
 # executed FLOP / residue of the hoisted formulation (three 128x128 GEMMs per edge)
 EXEC_FLOP_EDGE = 48 * 3 * 2 * 128 * 128
 

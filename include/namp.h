@@ -216,6 +216,16 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
                        const float* mask_attend, float* h_V_out, void* ws, size_t ws_bytes, int B, int N, int K,
                        void* stream);
 
+/* namp_encdec_fwd runs a small batch (at most one workgroup per CU; 3 + 3 layers; fp32-class precision) as ONE persistent
+ * launch after the node_linear launch: h_E stays in registers from the edge embedding to the last DecLayer, stages are
+ * separated by in-kernel grid barriers.  Results are bit-identical to the launch chain.  namp_set_persistent(0) (or the
+ * environment variable NAMP_PERSISTENT=0) selects the launch chain; returns the previous setting.  Two persistent launches
+ * are never in flight on different streams (the second caller gets the chain).
+ * namp_persistent_status: synchronous read-back of the barrier state of the last persistent launch that used `ws`
+ * (0 = every grid barrier completed; otherwise the code of the barrier that gave up — the outputs are then invalid). */
+int namp_set_persistent(int on);
+int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K, int32_t* code);
+
 /* ---- a11: graph construction + edge features ------------------------------------------------
  * ProteinFeaturesNA.forward, eval mode (model_utils.py:528-593) without the node one-hot (a 6-row table lookup
  * the caller does): virtual atoms, kNN on CA + ref atom with the reference's masking (E_idx int32 [B,L,K],
@@ -385,7 +395,8 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
 #define NAMP_KIND_FEATURES 8
 #define NAMP_KIND_ENC_EDGE_MESSAGE 9   /* namp_enc_edge_message_update: edge update of layer l-1 + message of layer l */
 #define NAMP_KIND_ENC_EDGE_DEC_MESSAGE 10   /* namp_encdec_fwd: last edge update + DecLayer 0 message */
-#define NAMP_NUM_KINDS 11
+#define NAMP_KIND_ENCDEC_PERSISTENT 11   /* namp_encdec_fwd: the whole encoder + decoder pass as one persistent launch */
+#define NAMP_NUM_KINDS 12
 int namp_profile_enable(int on);
 int namp_profile_collect(float* ms_per_kind, int32_t* launches_per_kind, int nkinds);
 

@@ -132,6 +132,8 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
+  set((const void*)(encdec_persistent_kernel<4, PREC_F32>), EDGE_TAIL_LDS);
+  set((const void*)(encdec_persistent_kernel<4, PREC_X3>), EDGE_TAIL_LDS);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
@@ -310,9 +312,9 @@ int check_proj(const char* fn, const NampProj* proj, int nproj, const int32_t* S
 }
 
 int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
-                       const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s, bool x3 = false) {
+                       const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s, bool x3 = false, unsigned* zero = nullptr) {
   NodeLinearArgs a;
-  a.X = X; a.S = S; a.G_out = G_out; a.G_src = G_src; a.N = N; a.nproj = nproj;
+  a.X = X; a.S = S; a.G_out = G_out; a.G_src = G_src; a.N = N; a.nproj = nproj; a.zero = zero;
   a.pre.img = pre ? pre->img : nullptr; a.pre.bias = pre ? pre->bias : nullptr;
   a.pre.tok = nullptr; a.pre.out = pre ? pre->out : nullptr;
   for (int i = 0; i < 8; ++i) {
@@ -387,6 +389,36 @@ struct Carver {
 };
 
 size_t tbl(size_t G) { return ((G * NAMP_HIDDEN * 4 + 255) & ~size_t(255)); }
+
+// ---- persistent forward (encdec_persistent_kernel): switch + in-flight guard ---------------------------------------------
+// Every workgroup of a persistent launch must be resident, and two such launches running at once on different streams could
+// each hold part of the chip while waiting for the rest.  Launches on ONE stream are ordered; a launch on another stream is
+// allowed only once the previous persistent launch has completed (hipEventQuery), otherwise the caller gets the launch chain.
+std::mutex g_persist_mutex;
+int g_persist_on = [] { const char* e = getenv("NAMP_PERSISTENT"); return (e && e[0] == '0') ? 0 : 1; }();
+struct PersistInFlight { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+PersistInFlight g_persist_dev[16];
+
+bool persist_acquire(hipStream_t s, int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  *dev_out = dev;
+  std::lock_guard<std::mutex> lk(g_persist_mutex);
+  if (!g_persist_on) return false;
+  PersistInFlight& f = g_persist_dev[dev];
+  if (!f.ev && hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { f.ev = nullptr; return false; }
+  if (f.pending && f.stream != s) {
+    if (hipEventQuery(f.ev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    f.pending = false;
+  }
+  return true;
+}
+
+void persist_mark(hipStream_t s, int dev) {
+  std::lock_guard<std::mutex> lk(g_persist_mutex);
+  PersistInFlight& f = g_persist_dev[dev];
+  if (f.ev && hipEventRecord(f.ev, s) == hipSuccess) { f.stream = s; f.pending = true; }
+}
 
 }  // namespace
 
@@ -1030,6 +1062,24 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
 
 
 
+int namp_set_persistent(int on) {
+  std::lock_guard<std::mutex> lk(g_persist_mutex);
+  const int prev = g_persist_on;
+  g_persist_on = on ? 1 : 0;
+  return prev;
+}
+
+int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K, int32_t* code) {
+  if (!ws || !code) return fail(NAMP_EINVAL, "namp_persistent_status: null pointer");
+  REQUIRE(ws_bytes >= NAMP_SYNC_WORDS * 4, "namp_persistent_status: workspace too small");
+  (void)B; (void)N; (void)K;
+  unsigned words[NAMP_SYNC_WORDS];
+  hipError_t e = hipMemcpy(words, ws, sizeof(words), hipMemcpyDeviceToHost);      // synchronous by design (a test / debug hook)
+  if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_persistent_status: hipMemcpy: %s", hipGetErrorString(e));
+  *code = (int32_t)words[NAMP_SYNC_TIMEOUT];
+  return NAMP_OK;
+}
+
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N, tpn = (K + 15) / 16;
@@ -1322,6 +1372,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   }
   hipStream_t s = (hipStream_t)stream;
   Carver c(ws, ws_bytes);
+  unsigned* sync = (unsigned*)c.take(NAMP_SYNC_WORDS);                      // first block of the workspace (namp_persistent_status)
   float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
   float* P[8];
   for (int i = 0; i < 8; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
@@ -1331,6 +1382,13 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   float* Pfw[NAMP_MAX_LAYERS];
   for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)G * NAMP_HIDDEN);
   if (!Pfw[w->n_dec - 1]) return fail(NAMP_EWORKSPACE, "namp_encdec_fwd: workspace too small (%zu bytes)", ws_bytes);
+
+  // one persistent launch for the whole pass when every workgroup of it is resident at once (see encdec_persistent_kernel)
+  const EdgeGeom eg = edge_geom(G, K);
+  int pdev = 0;
+  const bool persistent = w->n_enc == 3 && w->n_dec == 3 && eg.grid <= device_cus() && eg.npw <= 4 &&
+                          (rc = ensure_attributes()) == NAMP_OK && persist_acquire(s, &pdev);
+  if (rc) return rc;
 
   const NampEncLayerW* L0 = &w->enc[0];
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
@@ -1342,10 +1400,106 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
     const NampProj prex = {w->Wv_ximg, w->Wv_b, nullptr, hv[0]};
     const NampProj px[2] = {{L0->W1a_ximg, L0->b1, nullptr, P[0]}, {L0->W1c_ximg, nullptr, nullptr, P[1]}};
     ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
-    launch_node_linear(V, nullptr, B * N, B * N, N, px, 2, &prex, s, true);
+    launch_node_linear(V, nullptr, B * N, B * N, N, px, 2, &prex, s, true, persistent ? sync : nullptr);
     CHECK_LAUNCH();
-  } else if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  } else {
+    REQUIRE_PTR(w->Wv_img); REQUIRE_PTR(w->Wv_b); REQUIRE_PTR(L0->W1a_img); REQUIRE_PTR(L0->W1c_img); REQUIRE_PTR(L0->b1);
+    ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
+    launch_node_linear(V, nullptr, B * N, B * N, N, p0, 2, &pre, s, false, persistent ? sync : nullptr);
+    CHECK_LAUNCH();
+  }
   if (E) { REQUIRE_PTR(w->We_img); REQUIRE_PTR(w->We_b); }    // embedded inside the first message launch
+  if (persistent) {
+    PersistArgs PA_ = {};
+    PA_.sync = sync; PA_.embed = E ? 1 : 0;
+    REQUIRE_PTR(w->Wout_w); REQUIRE_PTR(w->Wout_b);
+    auto common = [&](StageArgs& st) {
+      st.hE = E ? E : h_E; st.E_idx = E_idx; st.mask = mask; st.rank = rank;
+      st.G = st.G_enc = G; st.N = N; st.K = K; st.TPN = eg.tpn;
+    };
+    int cur_ = 0;
+    for (int l = 0; l < 3; ++l) {
+      const NampEncLayerW* L = &w->enc[l];
+      const bool last = (l == 2);
+      StageArgs& st = PA_.st[l];
+      common(st);
+      const int tm = (l & 1) ? 4 : 0, tn = (l & 1) ? 0 : 4, te = (l & 1) ? 6 : 2, tp = (l & 1) ? 2 : 6;
+      st.Pa = P[tm]; st.Pj0 = P[tm + 1]; st.Pj1 = nullptr;
+      st.W1_img = pick_img(prec, L->W1b_img, nullptr, L->W1b_ximg); st.W2_img = pick_img(prec, L->W2_img, nullptr, L->W2_ximg);
+      st.W3_img = pick_img(prec, L->W3_img, nullptr, L->W3_ximg); st.b2 = L->b2; st.b3 = L->b3;
+      REQUIRE_PTR(st.W1_img); REQUIRE_PTR(st.W2_img); REQUIRE_PTR(st.W3_img); REQUIRE_PTR(st.b2); REQUIRE_PTR(st.b3);
+      if (l == 0) {
+        if (E) { st.eW1_img = pick_img(prec, w->We_img, nullptr, w->We_ximg); st.eb2 = w->We_b; REQUIRE_PTR(st.eW1_img); REQUIRE_PTR(st.eb2); }
+      } else {
+        const NampEncLayerW* Lp = &w->enc[l - 1];
+        st.ePa = P[tp]; st.ePj = P[tp + 1];
+        st.eW1_img = pick_img(prec, Lp->W11b_img, nullptr, Lp->W11b_ximg); st.eW2_img = pick_img(prec, Lp->W12_img, nullptr, Lp->W12_ximg);
+        st.eW3_img = pick_img(prec, Lp->W13_img, nullptr, Lp->W13_ximg); st.eb2 = Lp->b12; st.eb3 = Lp->b13;
+        st.ln_g = Lp->ln3_g; st.ln_b = Lp->ln3_b;
+        REQUIRE_PTR(st.eW1_img); REQUIRE_PTR(st.eW2_img); REQUIRE_PTR(st.eW3_img); REQUIRE_PTR(st.ln_g); REQUIRE_PTR(st.ln_b);
+      }
+      st.hE_out = nullptr;                                     // rows stay in registers
+      NampProj pe[8];
+      int np = 0;
+      pe[np++] = {L->W11a_img, L->b11, nullptr, P[te]};
+      pe[np++] = {L->W11c_img, nullptr, nullptr, P[te + 1]};
+      if (!last) {
+        const NampEncLayerW* Ln = &w->enc[l + 1];
+        pe[np++] = {Ln->W1a_img, Ln->b1, nullptr, P[tn]};
+        pe[np++] = {Ln->W1c_img, nullptr, nullptr, P[tn + 1]};
+      } else {
+        const NampDecLayerW* D0 = &w->dec[0];
+        for (int d = 0; d < 3; ++d) pe[np++] = {w->dec[d].W1v_img, nullptr, nullptr, Pfw[d]};
+        pe[np++] = {D0->W1a_img, D0->b1, nullptr, PA[0]};
+        pe[np++] = {D0->W1v_img, nullptr, D0->tok, PB[0]};
+      }
+      if ((rc = check_proj(__func__, pe, np, S))) return rc;
+      fill_tail(st.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur_], mask,
+                last ? h_V : hv[cur_ ^ 1], pe, np, S);
+      cur_ ^= 1;
+    }
+    const float* hin_ = h_V;
+    for (int l = 0; l < 3; ++l) {
+      const NampDecLayerW* D = &w->dec[l];
+      StageArgs& st = PA_.st[3 + l];
+      common(st);
+      st.Pa = PA[l & 1]; st.Pj0 = PB[l & 1]; st.Pj1 = Pfw[l];
+      st.W1_img = pick_img(prec, D->W1e_img, nullptr, D->W1e_ximg); st.W2_img = pick_img(prec, D->W2_img, nullptr, D->W2_ximg);
+      st.W3_img = pick_img(prec, D->W3_img, nullptr, D->W3_ximg); st.b2 = D->b2; st.b3 = D->b3;
+      REQUIRE_PTR(st.W1_img); REQUIRE_PTR(st.W2_img); REQUIRE_PTR(st.W3_img); REQUIRE_PTR(st.b2); REQUIRE_PTR(st.b3);
+      if (l == 0) {
+        const NampEncLayerW* Lp = &w->enc[2];
+        st.ePa = P[2]; st.ePj = P[3];                          // te of the last encoder layer (l = 2)
+        st.eW1_img = pick_img(prec, Lp->W11b_img, nullptr, Lp->W11b_ximg); st.eW2_img = pick_img(prec, Lp->W12_img, nullptr, Lp->W12_ximg);
+        st.eW3_img = pick_img(prec, Lp->W13_img, nullptr, Lp->W13_ximg); st.eb2 = Lp->b12; st.eb3 = Lp->b13;
+        st.ln_g = Lp->ln3_g; st.ln_b = Lp->ln3_b;
+        REQUIRE_PTR(st.eW1_img); REQUIRE_PTR(st.eW2_img); REQUIRE_PTR(st.eW3_img); REQUIRE_PTR(st.ln_g); REQUIRE_PTR(st.ln_b);
+        st.hE_out = h_E;                                       // the encoder's h_E leaves the registers once, here
+      }
+      NampProj pn[2] = {{}, {}};
+      int np = 0;
+      if (l < 2) {
+        const NampDecLayerW* Dn = &w->dec[l + 1];
+        pn[np++] = {Dn->W1a_img, Dn->b1, nullptr, PA[(l + 1) & 1]};
+        pn[np++] = {Dn->W1v_img, nullptr, Dn->tok, PB[(l + 1) & 1]};
+      }
+      if ((rc = check_proj(__func__, pn, np, S))) return rc;
+      fill_tail(st.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin_, mask, dhv[l & 1],
+                pn, np, S);
+      if (l == 2) { st.tail.head_w = w->Wout_w; st.tail.head_b = w->Wout_b; st.tail.log_probs = log_probs; st.tail.logits = logits; st.tail.vocab = w->vocab; }
+      hin_ = dhv[l & 1];
+    }
+    static_assert(sizeof(PersistArgs) <= 4000, "PersistArgs must fit the 4 KiB kernel-argument segment");
+    {
+      ProfScope prof_(NAMP_KIND_ENCDEC_PERSISTENT, s);
+      const dim3 grid(eg.grid), block(eg.nwaves * 64);
+      if (prec == PREC_X3) hipLaunchKernelGGL((encdec_persistent_kernel<4, PREC_X3>), grid, block, EDGE_TAIL_LDS, s, PA_);
+      else hipLaunchKernelGGL((encdec_persistent_kernel<4, PREC_F32>), grid, block, EDGE_TAIL_LDS, s, PA_);
+    }
+    CHECK_LAUNCH();
+    persist_mark(s, pdev);
+    return NAMP_OK;
+  }
   int cur = 0;
   for (int l = 0; l < w->n_enc; ++l) {
     const NampEncLayerW* L = &w->enc[l];

@@ -586,13 +586,19 @@ enum { PRE_NONE = 0, PRE_EMBED = 1, PRE_EDGE = 3 };
 // PREC: how the per-edge 128 x 128 GEMMs are evaluated — PREC_F32 exact fp32 MFMA; PREC_X3 split-bf16 (fp32-equivalent
 // to ~2^-16, the default parity mode: namp_device.h chain_gemm_x3); PREC_BF16 plain bf16 (throughput mode).
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_X3 = 2 };
-template <int MODE, int TAIL, int PREC = PREC_F32, int PRE = PRE_NONE>
-__global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
+// The body of edge_mlp_kernel as a device function, so that the persistent forward (encdec_persistent_kernel) can run the
+// stages of a whole encoder + decoder pass back to back on the SAME rows with h_E held in registers:
+//   PERSIST 0: the stand-alone launch (x is a scratch array);
+//   PERSIST 1: a stage of the persistent kernel that loads its rows from a.hE on entry;
+//   PERSIST 2: a stage that finds its rows in x (left there by the previous stage).
+// With PERSIST != 0 x is preserved (holds the — possibly updated — h_E row on exit), rows are stored only if a.hE_out is
+// given, and the kernel's LDS is re-used stage after stage (the caller separates stages by a grid barrier).
+template <int MODE, int TAIL, int PREC, int PRE, int PERSIST, class Args>
+__device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem) {
   constexpr bool BF16 = (PREC == PREC_BF16);
   constexpr bool X3 = (PREC == PREC_X3);
   static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32-class message + tail only");
   constexpr bool FUSE = (PRE == PRE_EDGE);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
   const int tid = threadIdx.x;
@@ -615,8 +621,9 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   const long erow = (long)node_enc * a.K + (valid ? k : 0);
 
   // ---- per-row operands: the h_E row (B operand of layer 1) and the hoisted first-layer terms
-  f4 x[8];
   f4 acc[8];
+  f4 ybuf[8];
+  f4 (&y)[8] = PERSIST ? ybuf : x;     // layer-2 pre-activations / residue-tail rows: x itself unless x must survive the stage
   f4 pjv[8];                       // gathered neighbour term, added after layer 1 (its latency hides under the MFMAs)
   float w_row = 0.f;
 #ifdef NAMP_ABL_NOPROLOG
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
   if (true) {
   } else if (MODE == MODE_EMBED) {
 #else
-  {
+  if (PERSIST != 2) {
     const float* src = a.hE + erow * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
@@ -685,8 +692,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-      chain_gemm_bf16<false, true>(x, acc, bw + (NAMP_BIMG_BYTES / 16));
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
     }
   } else {
   if (FUSE) {
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #ifdef NAMP_ABL_NOSTORE
     if (valid && a.G < 0) {
 #else
-    if (valid) {
+    if (valid && (PERSIST == 0 || a.hE_out != nullptr)) {
 #endif
       float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       gemm128<X3, false, false>(acc, x, w1);
 #pragma unroll
       for (int t = 0; t < 8; ++t) x[t] = acc[t];
-      if (valid) {
+      if (valid && (PERSIST == 0 || a.hE_out != nullptr)) {
         float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
         for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
@@ -790,8 +797,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 
   // ---- layer 2 (T); GELU of layer 1 is applied k-tile by k-tile inside the MFMA loop
 #pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  gemm128<X3, false, true>(x, acc, w1);           // x = layer-2 pre-activations
+  for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+  gemm128<X3, false, true>(y, acc, w1);           // y = layer-2 pre-activations
   wait_dma_and_sync();                                    // W3 has landed in buf0
   }
   }
@@ -814,8 +821,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
     // ---- layer 3 (T) + residual + LayerNorm3, written back row-wise
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    if (BF16) chain_gemm_bf16<false, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
-    else      gemm128<X3, false, true>(acc, x, w0);
+    if (BF16) chain_gemm_bf16<false, true>(acc, y, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
+    else      gemm128<X3, false, true>(acc, y, w0);
     if (a.drop_thresh) {                                           // training forward: dropout3 on the message
       const uint32_t key = drop_row_key(a.drop_seed, erow);
 #pragma unroll
@@ -841,8 +848,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const float b = a.b3[16 * t + m];
       acc[t] = (f4){b, b, b, b};
     }
-    if (BF16) chain_gemm_bf16<true, true>(acc, x, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
-    else      gemm128<X3, true, true>(acc, x, w0);
+    if (BF16) chain_gemm_bf16<true, true>(acc, y, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
+    else      gemm128<X3, true, true>(acc, y, w0);
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll
@@ -872,29 +879,159 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
       const int mm = tvalid ? m : 0;
       const float* hsrc = a.tail.hV + (long)(row0 + mm) * NAMP_H + 4 * g;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(hsrc + 16 * t);
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(hsrc + 16 * t);
       for (int q = 0; q < a.TPN; ++q) {
         const float* dp = dpart + (mm * a.TPN + q) * NAMP_H + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(dp + 16 * t);
+        for (int t = 0; t < 8; ++t) y[t] += *(const f4*)(dp + 16 * t);
       }
 #ifdef NAMP_ABL_NOTAIL
       if (tvalid) {
         float* dst = a.tail.hV_out + (long)trow * NAMP_H + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = x[t];
+        for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = y[t];
       }
       return;
 #endif
       if (TAIL == 4 || TAIL == 8) {
         constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
         const ConsecutiveRows orow = {row0, npw, a.G};
-        node_tail_rows<R>(a.tail, x, orow, (float*)smem, tid, wave, nwaves, lane);
+        node_tail_rows<R>(a.tail, y, orow, (float*)smem, tid, wave, nwaves, lane);
       } else {
-        node_tail<false>(a.tail, x, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+        node_tail<false>(a.tail, y, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
       }
     }
   }
+}
+
+template <int MODE, int TAIL, int PREC = PREC_F32, int PRE = PRE_NONE>
+__global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4 x[8];
+  edge_stage<MODE, TAIL, PREC, PRE, 0>(a, x, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// encdec_persistent_kernel — the WHOLE encoder + decoder forward of a small batch (one wave of workgroups: at most one
+// workgroup per CU, every workgroup resident) as ONE launch.  A workgroup keeps the rows it owns — the K neighbours of its
+// <= 12/TPN residues — in registers from the edge embedding to the last DecLayer: h_E is read once (as E) and written once
+// (the encoder's output), instead of 5 reads + 4 writes over the seven launches of the fused chain.  Stages
+//   S0  h_E = W_e.E + b_e ; EncLayer 0 message + residue tail          (tables for S1)
+//   S1  EncLayer 0 edge update ; EncLayer 1 message + tail
+//   ..  (n_enc stages)
+//   Sd0 last edge update (h_E stored) ; DecLayer 0 message + tail
+//   Sd1.. DecLayer l message + tail ; the last one evaluates the output head
+// are the bodies of the fused launches (edge_stage).  What a residue tail writes — h_V' and the first-layer tables the
+// NEXT stage gathers from OTHER workgroups' residues — crosses workgroups, so stages are separated by a grid barrier:
+// every wave drains its stores, one lane releases at agent scope and arrives on a counter (two-level: per group of
+// workgroups, then across groups), polls relaxed, and one agent-scope acquire drops the CU's stale L1 lines
+// (cdna_hip_programming.md, Guideline 16).  Residency comes from the grid size alone (<= number of CUs, one 133 KB-LDS
+// workgroup per CU); every spin is bounded and reports through sync[SYNC_TIMEOUT] instead of hanging.
+// The counters are zeroed by the launch that precedes this one in the stream (node_linear_kernel, NodeLinearArgs.zero).
+// ------------------------------------------------------------------------------------------
+#define NAMP_PERSIST_MAX_STAGES 16
+#define NAMP_SYNC_GROUPS 8
+#define NAMP_SYNC_WORDS 64          // [0..7] group arrival counters, [8] top counter, [16..23] group generations, [32] timeout code
+#define NAMP_SYNC_TOP 8
+#define NAMP_SYNC_GEN 16
+#define NAMP_SYNC_TIMEOUT 32
+#ifndef NAMP_SPIN_LIMIT
+#define NAMP_SPIN_LIMIT (1u << 22)  // polls (each followed by s_sleep): several seconds — a hang becomes a reported failure
+#endif
+
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ bool spin_until_ge(gu32* word, unsigned target, gu32* tmo, unsigned code) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > NAMP_SPIN_LIMIT) {
+      __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  return true;
+}
+
+// epoch = 1, 2, ... within one launch.  Group g = blockIdx % 8 (the observed XCD of the block: a speed choice only).
+__device__ __forceinline__ void grid_barrier(unsigned* sync, const unsigned epoch, const int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its own stores have left
+  __syncthreads();
+  if (tid == 0) {
+    gu32* sy = (gu32*)sync;
+    const int grp = blockIdx.x % NAMP_SYNC_GROUPS;
+    const unsigned ngroups = gridDim.x < NAMP_SYNC_GROUPS ? gridDim.x : NAMP_SYNC_GROUPS;
+    const unsigned in_group = (gridDim.x - grp + NAMP_SYNC_GROUPS - 1) / NAMP_SYNC_GROUPS;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the write-back has completed before the arrival (G16 pitfall 12)
+    const unsigned old = __hip_atomic_fetch_add(sy + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == in_group * epoch) {                           // last arriver of the group: arrive on the top counter,
+      __hip_atomic_fetch_add(sy + NAMP_SYNC_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      spin_until_ge(sy + NAMP_SYNC_TOP, ngroups * epoch, sy + NAMP_SYNC_TIMEOUT, 0x100u + epoch);
+      __hip_atomic_store(sy + NAMP_SYNC_GEN + grp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... release the group
+    } else {
+      spin_until_ge(sy + NAMP_SYNC_GEN + grp, epoch, sy + NAMP_SYNC_TIMEOUT, 0x200u + epoch);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// One stage's arguments: the members of EdgeArgs the fused fp32-class message stages read, under the same names (edge_stage is
+// templated on the argument type), without the members of other modes — six of these must fit the 4 KiB kernel-argument
+// segment.  The stage functions read them straight from that segment (scalar loads at the point of use); copying them
+// into registers up front cost 540 spilled SGPRs.
+struct StageArgs {
+  const float* hE; float* hE_out; const int32_t* E_idx; const int32_t* mask; const int32_t* rank;
+  const float* Pa; const float* Pj0; const float* Pj1;
+  const float* W1_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
+  const float* ln_g; const float* ln_b;
+  const float* ePa; const float* ePj; const float* eW1_img; const float* eW2_img; const float* eW3_img;
+  const float* eb2; const float* eb3;
+  NodeTail tail;
+  int G, G_enc, N, K, TPN;
+  // members of EdgeArgs that no persistent stage uses
+  static constexpr const int32_t* mask_attend = nullptr;
+  static constexpr const float* b1 = nullptr;
+  static constexpr uint32_t drop_thresh = 0, drop_seed = 0;
+  static constexpr float drop_scale = 1.0f;
+  static constexpr const __bf16* hE16 = nullptr;
+  static constexpr __bf16* hE16_out = nullptr;
+  static constexpr float* partial = nullptr;
+};
+
+struct PersistArgs {
+  StageArgs st[6];                      // 3 EncLayer + 3 DecLayer stages
+  unsigned* sync;                       // NAMP_SYNC_WORDS zeroed words
+  int embed;                            // stage 0 starts from E (h_E = W_e.E + b_e) rather than from an embedded h_E
+};
+
+// The stage arguments are read from the kernel-argument segment itself at the point of use (through the segment pointer,
+// not through the by-value parameter, whose address cannot be taken without the compiler copying the 3.6 KB into scratch).
+__device__ __forceinline__ const PersistArgs* persist_kernargs() {
+  return (const PersistArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// TAIL as in edge_mlp_kernel (4 = up to 4 residues per workgroup, K in 33..48).  The stage sequence is written out for
+// 3 + 3 layers (the reference's only configuration, design_model.json; other depths take the launch chain).
+template <int TAIL, int PREC>
+__global__ __launch_bounds__(768) void encdec_persistent_kernel(const PersistArgs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PersistArgs* P = persist_kernargs();
+  const int tid = threadIdx.x;
+  f4 x[8];
+  if (P->embed) edge_stage<MODE_ENC_MSG, TAIL, PREC, PRE_EMBED, 1>(P->st[0], x, smem);
+  else          edge_stage<MODE_ENC_MSG, TAIL, PREC, PRE_NONE, 1>(P->st[0], x, smem);
+  grid_barrier(P->sync, 1, tid);
+  edge_stage<MODE_ENC_MSG, TAIL, PREC, PRE_EDGE, 2>(P->st[1], x, smem);
+  grid_barrier(P->sync, 2, tid);
+  edge_stage<MODE_ENC_MSG, TAIL, PREC, PRE_EDGE, 2>(P->st[2], x, smem);
+  grid_barrier(P->sync, 3, tid);
+  edge_stage<MODE_DEC_MSG, TAIL, PREC, PRE_EDGE, 2>(P->st[3], x, smem);
+  grid_barrier(P->sync, 4, tid);
+  edge_stage<MODE_DEC_MSG, TAIL, PREC, PRE_NONE, 2>(P->st[4], x, smem);
+  grid_barrier(P->sync, 5, tid);
+  edge_stage<MODE_DEC_MSG, TAIL, PREC, PRE_NONE, 2>(P->st[5], x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1582,6 +1719,7 @@ struct NodeLinearArgs {
   ProjDesc pre;        // optional first stage: h = pre.img . X + pre.bias (stored to pre.out), the
                        // projections then apply to h (h_V = W_v.V + b feeding enc0's tables in one launch)
   ProjDesc p[8];
+  unsigned* zero;      // optional: 64 words cleared by this launch (the grid-barrier state of the persistent launch that follows)
 };
 
 template <bool X3>       // X3: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products
@@ -1590,6 +1728,7 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int unit = blockIdx.x * 4 + wave;
   const int ntiles = (a.G_out + 15) >> 4;
+  if (a.zero && blockIdx.x == 0 && threadIdx.x < 64) a.zero[threadIdx.x] = 0u;
   if (unit >= ntiles * a.nproj) return;
   const int tile = unit / a.nproj, pi = unit - tile * a.nproj;
   const int m = lane & 15, g = lane >> 4;

@@ -119,6 +119,8 @@ _PROTOTYPES = {
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),
     "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,
                                  vp, sz, i32, i32, i32, vp]),
+    "namp_set_persistent": (i32, [i32]),
+    "namp_persistent_status": (i32, [vp, sz, i32, i32, i32, C.POINTER(C.c_int32)]),
     "namp_dec_layer_fwd": (i32, [C.POINTER(NampDecLayerW), c_fp, c_fp, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, vp]),
     "namp_encoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_fp, c_fp,
                                vp, sz, i32, i32, i32, vp]),
@@ -129,7 +131,7 @@ _PROTOTYPES = {
 }
 
 KERNEL_KINDS = ["gather", "node_linear", "edge_embed", "enc_message", "enc_edge_update", "node_update",
-                "dec_message", "logits", "features", "enc_edge_message", "enc_edge_dec_message"]
+                "dec_message", "logits", "features", "enc_edge_message", "enc_edge_dec_message", "encdec_persistent"]
 
 _lib = None
 

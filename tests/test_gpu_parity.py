@@ -592,3 +592,47 @@ def test_bf16_throughput_mode(L, dev, wt, golden_dir):
             assert torch.isfinite(lp_x).all()
             assert maxdiff(lp_x[valid], lp_f[valid]) < 0.15, (b, n, k)
             assert float((lp_x.argmax(-1) == lp_f.argmax(-1))[valid].float().mean()) >= 0.97, (b, n, k)
+
+
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
+@pytest.mark.parametrize("B,N,K,mf", [(1, 1000, 48, 0.0), (1, 333, 40, 0.1), (2, 400, 48, 0.05), (1, 37, 35, 0.0), (1, 1024, 48, 0.0)])
+def test_persistent_forward_equals_launch_chain(L, dev, wt, B, N, K, mf, prec):
+    """namp_encdec_fwd as ONE persistent launch (h_E in registers across all six layers, in-kernel grid barriers) against
+    the seven-launch chain on the same inputs: every output bit-identical, every grid barrier completed — repeated, so
+    that a stale table line (a missing acquire) or a lost arrival would show."""
+    t, d = graph(dev, seed=900 + N + K, batch=B, n=N, k=K, masked_frac=mf)
+    KK = t["E_idx"].shape[-1]
+    P = PackedWeights({k_: v.to(dev) for k_, v in wt.items()}, 3, 3, 33, dev)
+    P.set_precision(prec)
+    order = torch.argsort((d["mask"] * d["chain_mask"] + 0.0001) * torch.abs(d["randn"]))
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(N, device=dev).expand(B, -1))
+    rank = rank.to(torch.int32)
+    ws = torch.empty(2 * L.namp_workspace_bytes(B, B, N, KK), dtype=torch.uint8, device=dev)
+
+    def run():
+        hV = torch.full((B, N, 128), float("nan"), device=dev)
+        hE = torch.full((B, N, KK, 128), float("nan"), device=dev)
+        logp = torch.full((B, N, 33), float("nan"), device=dev)
+        logits = torch.full((B, N, 33), float("nan"), device=dev)
+        hip.check(L.namp_encdec_fwd(P.model(), d["V"].data_ptr(), d["E"].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(),
+                                    d["S"].data_ptr(), rank.data_ptr(), hV.data_ptr(), hE.data_ptr(), logp.data_ptr(), logits.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), B, N, KK, stream()))
+        torch.cuda.synchronize()
+        return hV, hE, logp, logits
+
+    prev = L.namp_set_persistent(0)
+    try:
+        ref = run()
+        L.namp_set_persistent(1)
+        code = C.c_int32(-1)
+        for rep in range(4):
+            ws.fill_(0xCD)                                     # poison the barrier state: the launch must re-initialise it
+            got = run()
+            hip.check(L.namp_persistent_status(ws.data_ptr(), ws.numel(), B, N, KK, C.byref(code)))
+            assert code.value == 0, hex(code.value)
+            for a_, b_, name in zip(got, ref, ("h_V", "h_E", "log_probs", "logits")):
+                assert torch.equal(a_, b_), (name, rep, float((a_ - b_).abs().max()))
+    finally:
+        L.namp_set_persistent(prev)
+    assert torch.isfinite(ref[2]).all()
