@@ -723,6 +723,18 @@ def main():
                                                "argmax_equal": xo.get("parity", {}).get("argmax_equal")}
         del rx
         torch.cuda.empty_cache()
+        if world == 1 and not args.no_secondary:
+            # the opt-in one-launch form of the same pass (encdec_persistent_kernel), for the record: slower than the chain
+            Lb = hip.lib()
+            prev = Lb.namp_set_persistent(1)
+            try:
+                pz, rp = encdec_bench(args, dev, rank, world, dist, "cfg2", "x3", args.steps, args.warmup)
+                out["x3_persistent_launch"] = {"value": pz["value"], "ms_per_step": pz["ms_per_step"], "per_kernel": pz["per_kernel"],
+                                               "note": "namp_set_persistent(1): the whole pass as node_linear + ONE persistent launch "
+                                                       "(six stages, five grid barriers); bit-identical outputs; off by default"}
+                del rp
+            finally:
+                Lb.namp_set_persistent(prev)
         if rank == 0 and world == 1 and not args.no_secondary:
             out["secondary"] = secondary_runs(args, dev)
     finish(out)

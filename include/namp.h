@@ -216,11 +216,12 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
                        const float* mask_attend, float* h_V_out, void* ws, size_t ws_bytes, int B, int N, int K,
                        void* stream);
 
-/* namp_encdec_fwd runs a small batch (at most one workgroup per CU; 3 + 3 layers; fp32-class precision) as ONE persistent
- * launch after the node_linear launch: h_E stays in registers from the edge embedding to the last DecLayer, stages are
- * separated by in-kernel grid barriers.  Results are bit-identical to the launch chain.  namp_set_persistent(0) (or the
- * environment variable NAMP_PERSISTENT=0) selects the launch chain; returns the previous setting.  Two persistent launches
- * are never in flight on different streams (the second caller gets the chain).
+/* namp_encdec_fwd can run a small batch (at most one workgroup per CU; K in 33..48; 3 + 3 layers; fp32-class precision) as
+ * ONE persistent launch after the node_linear launch: h_E stays in registers from the edge embedding to the last DecLayer,
+ * stages are separated by in-kernel grid barriers.  Results are bit-identical to the launch chain.  OFF by default — on
+ * MI355X the barriers cost more than the launch boundaries they replace —; namp_set_persistent(1) or the
+ * environment variable NAMP_PERSISTENT=1 selects it; returns the previous setting.  Two persistent launches are never in
+ * flight on different streams (the second caller gets the chain).
  * namp_persistent_status: synchronous read-back of the barrier state of the last persistent launch that used `ws`
  * (0 = every grid barrier completed; otherwise the code of the barrier that gave up — the outputs are then invalid). */
 int namp_set_persistent(int on);

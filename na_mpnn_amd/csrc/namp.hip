@@ -25,6 +25,9 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+// namp_persist.hip (its own translation unit: the persistent kernel takes minutes to compile)
+__attribute__((visibility("hidden"))) int namp_internal_launch_persistent(const struct PersistArgs* a, int x3, int grid, int block, hipStream_t s);
+
 // error text setter for namp_train.hip (same thread-local buffer; not part of the ABI)
 __attribute__((visibility("hidden"))) int namp_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 
@@ -132,8 +135,6 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
-  set((const void*)(encdec_persistent_kernel<4, PREC_F32>), EDGE_TAIL_LDS);
-  set((const void*)(encdec_persistent_kernel<4, PREC_X3>), EDGE_TAIL_LDS);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
@@ -395,7 +396,9 @@ size_t tbl(size_t G) { return ((G * NAMP_HIDDEN * 4 + 255) & ~size_t(255)); }
 // each hold part of the chip while waiting for the rest.  Launches on ONE stream are ordered; a launch on another stream is
 // allowed only once the previous persistent launch has completed (hipEventQuery), otherwise the caller gets the launch chain.
 std::mutex g_persist_mutex;
-int g_persist_on = [] { const char* e = getenv("NAMP_PERSISTENT"); return (e && e[0] == '0') ? 0 : 1; }();
+// Off by default: measured on MI355X (profiles/r02_persistent.md) the six in-kernel grid barriers cost more (9 us each) than
+// the launch boundaries and h_E round trips they replace (cfg2, x3: 0.360 ms persistent vs 0.332 ms for the chain).
+int g_persist_on = [] { const char* e = getenv("NAMP_PERSISTENT"); return (e && e[0] == '1') ? 1 : 0; }();
 struct PersistInFlight { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
 PersistInFlight g_persist_dev[16];
 
@@ -1386,8 +1389,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   // one persistent launch for the whole pass when every workgroup of it is resident at once (see encdec_persistent_kernel)
   const EdgeGeom eg = edge_geom(G, K);
   int pdev = 0;
-  const bool persistent = w->n_enc == 3 && w->n_dec == 3 && eg.grid <= device_cus() && eg.npw <= 4 &&
-                          (rc = ensure_attributes()) == NAMP_OK && persist_acquire(s, &pdev);
+  const bool persistent = w->n_enc == 3 && w->n_dec == 3 && eg.grid <= device_cus() && eg.npw <= 4 && persist_acquire(s, &pdev);
   if (rc) return rc;
 
   const NampEncLayerW* L0 = &w->enc[0];
@@ -1489,12 +1491,10 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
       if (l == 2) { st.tail.head_w = w->Wout_w; st.tail.head_b = w->Wout_b; st.tail.log_probs = log_probs; st.tail.logits = logits; st.tail.vocab = w->vocab; }
       hin_ = dhv[l & 1];
     }
-    static_assert(sizeof(PersistArgs) <= 4000, "PersistArgs must fit the 4 KiB kernel-argument segment");
     {
       ProfScope prof_(NAMP_KIND_ENCDEC_PERSISTENT, s);
-      const dim3 grid(eg.grid), block(eg.nwaves * 64);
-      if (prec == PREC_X3) hipLaunchKernelGGL((encdec_persistent_kernel<4, PREC_X3>), grid, block, EDGE_TAIL_LDS, s, PA_);
-      else hipLaunchKernelGGL((encdec_persistent_kernel<4, PREC_F32>), grid, block, EDGE_TAIL_LDS, s, PA_);
+      if ((rc = namp_internal_launch_persistent(&PA_, prec == PREC_X3 ? 1 : 0, eg.grid, eg.nwaves * 64, s)))
+        return fail(NAMP_ELAUNCH, "namp_encdec_fwd: persistent launch setup failed (%d)", rc);
     }
     CHECK_LAUNCH();
     persist_mark(s, pdev);

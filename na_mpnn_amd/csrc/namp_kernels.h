@@ -8,7 +8,7 @@
 //   W: [OUT x *] row-major with leading dimension ld; the block is columns [col0, col0+IN).
 //   img[tk][tn][lane][r], tk < IN/16, tn < OUT/16.
 // ------------------------------------------------------------------------------------------
-__global__ void pack_image_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN,
+static __global__ void pack_image_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN,
                                   float* __restrict__ img) {
   const int total = OUT * IN;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -21,7 +21,7 @@ __global__ void pack_image_kernel(const float* __restrict__ W, int ld, int col0,
 }
 
 // bf16 fragment image of a [128 x 128] block (namp_device.h, bf16 throughput mode)
-__global__ void pack_image_bf16_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
+static __global__ void pack_image_bf16_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 128 * 128) return;
   const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 7, s = e >> 12;
@@ -30,7 +30,7 @@ __global__ void pack_image_bf16_kernel(const float* __restrict__ W, int ld, int 
 }
 
 // x3 image (namp_device.h, chain_gemm_x3): bf16 fragment image of W_hi = bf16(W), then the one of W_mid = bf16(W - W_hi)
-__global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
+static __global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 128 * 128) return;
   const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 7, s = e >> 12;
@@ -43,7 +43,7 @@ __global__ void pack_image_x3_kernel(const float* __restrict__ W, int ld, int co
 
 // x3 image of a general block [OUT x IN] (multiples of 16 / 32): hi[s = IN/32][tn = OUT/16][lane][8 bf16] followed by mid in
 // the same order — pack_image_x3_kernel's layout for OUT = IN = 128.  Used by the residue-level kernels (W_in, W_out).
-__global__ void pack_image_x3_general_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN, __bf16* __restrict__ img) {
+static __global__ void pack_image_x3_general_kernel(const float* __restrict__ W, int ld, int col0, int OUT, int IN, __bf16* __restrict__ img) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= OUT * IN) return;
   const int ntn = OUT >> 4;
@@ -60,7 +60,7 @@ __global__ void pack_image_x3_general_kernel(const float* __restrict__ W, int ld
 // fp32 fragment tile (2048 floats), then one 48 KiB block per RBF chunk c = 3a + bg (6 atom pairs = 3 bf16 K-steps of two
 // pairs): [hi: 3 steps x 8 tn x 64 lanes x 8 bf16][mid: same].  Slot j of lane (m, g) in step s is RBF 4g + (j&3) of pair
 // 2s + (j>>2) — each lane feeds the RBFs it generates for two consecutive atom pairs, no cross-lane traffic.
-__global__ void pack_feat_x3_kernel(const float* __restrict__ W, int ld, float* __restrict__ img) {
+static __global__ void pack_feat_x3_kernel(const float* __restrict__ W, int ld, float* __restrict__ img) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < 2048) {
     const int r = e & 3, lane = (e >> 2) & 63, tn = e >> 8;
@@ -128,7 +128,7 @@ __global__ void gather_cat_kernel(const float* __restrict__ nodes, const float* 
 }
 
 // scalar fallback for channel counts that are not multiples of 4 (e.g. the C=1 mask gather)
-__global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes, const float* __restrict__ nbrs,
+static __global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes, const float* __restrict__ nbrs,
                                          const int32_t* __restrict__ idx, float* __restrict__ out,
                                          long rows, int NK, int N, int C1, int C2) {
   const int ct = C1 + C2;
@@ -377,7 +377,15 @@ struct ConsecutiveRows {
   __device__ __forceinline__ int operator()(int n) const { return (n < nrows && row0 + n < G) ? row0 + n : -1; }
 };
 
-template <int R, typename RowFn>
+// SC1: outputs are stored WRITE-THROUGH (sc1, agent scope) — what another workgroup of the same launch gathers after a grid
+// barrier must not sit dirty in this XCD's L2 (persistent forward; no release fence is needed then, Guideline 16 R1).
+template <bool SC1>
+__device__ __forceinline__ void st_out(float* p, const float v) {
+  if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <int R, typename RowFn, bool SC1 = false>
 __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const RowFn orow, float* lds,
                                                const int tid, const int wave, const int nwaves, const int lane) {
   float* xT = lds;                    // [128][R]    x = LN1(...)          (k-major, residue-minor)
@@ -464,7 +472,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
     const float mk = (a.mask && orw >= 0) ? (float)a.mask[orw] : 1.0f;
     const float y = (d * rstd * a.ln2_g[c_] + a.ln2_b[c_]) * mk;
     yT[c_ * R + n_] = y;
-    if (orw >= 0) a.hV_out[(long)orw * NAMP_H + c_] = y;
+    if (orw >= 0) st_out<SC1>(a.hV_out + (long)orw * NAMP_H + c_, y);
   }
   if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
@@ -499,7 +507,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
           if (orw >= 0) {
             float o = acc[n] + b;
             if (pd.tok) o += pd.tok[(long)a.S[orw] * NAMP_H + c];
-            pd.out[(long)orw * NAMP_H + c] = o;
+            st_out<SC1>(pd.out + (long)orw * NAMP_H + c, o);
           }
         }
       }
@@ -896,7 +904,7 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
       if (TAIL == 4 || TAIL == 8) {
         constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
         const ConsecutiveRows orow = {row0, npw, a.G};
-        node_tail_rows<R>(a.tail, y, orow, (float*)smem, tid, wave, nwaves, lane);
+        node_tail_rows<R, ConsecutiveRows, (PERSIST != 0)>(a.tail, y, orow, (float*)smem, tid, wave, nwaves, lane);
       } else {
         node_tail<false>(a.tail, y, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
       }
@@ -923,8 +931,8 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 //   Sd1.. DecLayer l message + tail ; the last one evaluates the output head
 // are the bodies of the fused launches (edge_stage).  What a residue tail writes — h_V' and the first-layer tables the
 // NEXT stage gathers from OTHER workgroups' residues — crosses workgroups, so stages are separated by a grid barrier:
-// every wave drains its stores, one lane releases at agent scope and arrives on a counter (two-level: per group of
-// workgroups, then across groups), polls relaxed, and one agent-scope acquire drops the CU's stale L1 lines
+// the tail stores them write-through (sc1), every wave drains its stores, one lane arrives on a counter (two-level: per
+// group of workgroups, then across groups), polls relaxed, and one agent-scope acquire drops the CU's stale L1 lines
 // (cdna_hip_programming.md, Guideline 16).  Residency comes from the grid size alone (<= number of CUs, one 133 KB-LDS
 // workgroup per CU); every spin is bounded and reports through sync[SYNC_TIMEOUT] instead of hanging.
 // The counters are zeroed by the launch that precedes this one in the stream (node_linear_kernel, NodeLinearArgs.zero).
@@ -955,15 +963,20 @@ __device__ __forceinline__ bool spin_until_ge(gu32* word, unsigned target, gu32*
 
 // epoch = 1, 2, ... within one launch.  Group g = blockIdx % 8 (the observed XCD of the block: a speed choice only).
 __device__ __forceinline__ void grid_barrier(unsigned* sync, const unsigned epoch, const int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its own stores have left
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its own (write-through) stores have completed
   __syncthreads();
+#ifdef NAMP_ABL_NOGRIDBARRIER
+  return;
+#endif
   if (tid == 0) {
     gu32* sy = (gu32*)sync;
     const int grp = blockIdx.x % NAMP_SYNC_GROUPS;
     const unsigned ngroups = gridDim.x < NAMP_SYNC_GROUPS ? gridDim.x : NAMP_SYNC_GROUPS;
     const unsigned in_group = (gridDim.x - grp + NAMP_SYNC_GROUPS - 1) / NAMP_SYNC_GROUPS;
+#ifdef NAMP_PERSIST_RELEASE_FENCE                                 // plain table stores + release fence instead of sc1 stores (A/B)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the write-back has completed before the arrival (G16 pitfall 12)
+#endif
     const unsigned old = __hip_atomic_fetch_add(sy + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1 == in_group * epoch) {                           // last arriver of the group: arrive on the top counter,
       __hip_atomic_fetch_add(sy + NAMP_SYNC_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1349,7 +1362,7 @@ __device__ __forceinline__ void bf16_row_to_f32(f4 (&out)[8], const __bf16* __re
 
 // fp32 [rows][128] (plain channel order) -> bf16 fragment order, for up to 4 tables per launch
 struct CvtTables { const float* src[4]; __bf16* dst[4]; int n; long rows; };
-__global__ void cvt_tables_bf16_kernel(const CvtTables c) {
+static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte output piece: (row, g, s)
   if (e >= c.rows * 16) return;
   const long row = e >> 4;
@@ -1449,7 +1462,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
 // sample_levels_kernel: dependency level of every visit of the plain sampling branch.  One wave per stream walks its
 // decoding order once: level(i) = 1 + max level of the neighbours visited before i (0 if none) — lanes cover the K
 // neighbours, levels live in LDS.  level_out[b][t] is indexed by VISIT t.
-__global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __restrict__ E_idx, const int32_t* __restrict__ order,
+static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __restrict__ E_idx, const int32_t* __restrict__ order,
                                                           const int32_t* __restrict__ rank, int32_t* __restrict__ level_out,
                                                           int B_enc, int N, int K) {
   extern __shared__ int lv[];                                    // [N]
@@ -1787,7 +1800,7 @@ struct NodeUpdateArgs {
   int G, TPN;
 };
 
-__global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a) {
+static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2032,7 +2045,7 @@ struct DecCtxArgs {
   int G, K, TPN;
 };
 
-__global__ __launch_bounds__(256) void dec_ctx_message_kernel(const DecCtxArgs a) {
+static __global__ __launch_bounds__(256) void dec_ctx_message_kernel(const DecCtxArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long tile = (long)blockIdx.x * 4 + wave;
@@ -2083,7 +2096,7 @@ __global__ __launch_bounds__(256) void dec_ctx_message_kernel(const DecCtxArgs a
 // logits_kernel — log_softmax(W_out . h_V + b) over the 33-letter vocabulary
 // (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ hV, const float* __restrict__ W,
+static __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ hV, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ log_probs,
                                                      float* __restrict__ logits_out, int G, int V) {
   const int lane = threadIdx.x & 63;
@@ -2122,7 +2135,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ h
 // prep_atoms_kernel: per residue, the 18-atom frame (16 real + virtual Cb + virtual N_na, model_utils.py:548-569),
 // its 0/1 atom mask as a bit field, and the kNN reference point P = CA + C1' (model_utils.py:573).
 // Atom order is the reference's atom_dict (run.py:15-19): N, CA, C, O, OP1, OP2, P, O5', C5', C4', O4', C3', O3', C2', O2', C1'.
-__global__ void prep_atoms_kernel(const float* __restrict__ X, const int32_t* __restrict__ X_m,
+static __global__ void prep_atoms_kernel(const float* __restrict__ X, const int32_t* __restrict__ X_m,
                                   const int32_t* __restrict__ protein_mask, const int32_t* __restrict__ dna_mask,
                                   const int32_t* __restrict__ rna_mask, float* __restrict__ X18,
                                   uint32_t* __restrict__ M18, float* __restrict__ P, int G, int ref_atom) {
@@ -2155,7 +2168,7 @@ __global__ void prep_atoms_kernel(const float* __restrict__ X, const int32_t* __
 // residues, row maximum, then a bitonic sort of 64-bit keys (distance bits << 32 | index) in LDS and the K
 // smallest are written in ascending order (ties: unmasked before masked, then by index; torch.topk leaves them unspecified).
 // The distance uses the reference's operation order with contraction off so that near-ties round identically.
-__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
+static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
                                                   int32_t* __restrict__ E_idx, int L, int Lp2, int K) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2217,7 +2230,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, c
 // most); those <= Kp2 candidates are compacted, sorted (one wave with cross-lane exchanges when Kp2 = 64, the bitonic
 // network in LDS otherwise) and the first K written.  Keys are unique (index in the low bits), so the result is the
 // sorted row's prefix exactly.  O(L) per pass instead of O(L log^2 L): 13x fewer LDS passes at L = 3000.
-__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
+static __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
                                                          int32_t* __restrict__ E_idx, int L, int K, int Kp2) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
