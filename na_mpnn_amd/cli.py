@@ -2,8 +2,8 @@
 
 Mirrors the contract of /root/reference/inference/run.py — the flags of :519-555, the mode defaults of
 :559-583, ``seqs/<name>.fa`` with the header lines of :445-455 / :501-511 and ``specificity/<name>.npz`` with the
-keys of :426-443 — on top of ``na_mpnn_amd.model.ProteinMPNN`` and ``na_mpnn_amd.pdbio`` (no prody).  Not provided:
-backbone PDB output (prody writer).
+keys of :426-443, ``backbones/<name>_<id>.pdb`` (:475-491) — on top of ``na_mpnn_amd.model.ProteinMPNN`` and
+``na_mpnn_amd.pdbio`` (no prody; PDB and mmCIF input).
 
     python -m na_mpnn_amd.cli --mode design --pdb_path in.pdb --out_folder out/ [--checkpoint_na_mpnn ckpt.pt]
 
@@ -55,11 +55,14 @@ def build_parser():
     a("--design_na_only", type=int, default=0)
     a("--k_neighbors", type=int, default=None)
     a("--catch_failed_inferences", type=int, default=0)
+    a("--output_pdbs", type=int, default=1, help="1 - write backbones/<name>_<id>.pdb with the designed residue names")
     a("--output_sequences", type=int, default=1)
     a("--output_specificity", type=int, default=0)
     a("--load_residues_with_missing_atoms", type=int, default=0)
     a("--mode", type=str, default=None)
     a("--device", type=str, default="cuda:0")
+    a("--forced_draws_npz", type=str, default="", help="testing: npz with 'randn' [batches*batch_size, L] (decoding-order noise) and "
+      "'S_forced' [batches*batch_size, L] (the tokens every draw is forced to) — makes a run reproducible across devices")
     return p
 
 
@@ -150,6 +153,8 @@ def main(argv=None):
 
     base = args.out_folder if args.out_folder.endswith("/") else args.out_folder + "/"
     os.makedirs(base + "seqs", exist_ok=True)
+    if args.output_pdbs:
+        os.makedirs(base + "backbones", exist_ok=True)
     if args.output_specificity:
         os.makedirs(base + "specificity", exist_ok=True)
     if args.fixed_pos_by_pdb:
@@ -207,16 +212,22 @@ def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bia
                    "symmetry_residues": sym_res, "symmetry_weights": sym_w})
         if pair_bias_AA is not None:
             fd["pair_bias"] = make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0], pair_bias_AA)
-        S_l, lp_l, sp_l, loss_l = [], [], [], []
+        S_l, lp_l, sp_l, loss_l, lpr_l = [], [], [], [], []
         cmask = (fd["mask"] * fd["chain_mask"]).float()
-        for _ in range(args.number_of_batches):
+        forced = np.load(args.forced_draws_npz) if args.forced_draws_npz else None
+        for ib in range(args.number_of_batches):
             fd["randn"] = torch.randn(args.batch_size, L, device=device)
+            if forced is not None:
+                rows = slice(ib * args.batch_size, (ib + 1) * args.batch_size)
+                fd["randn"] = torch.from_numpy(forced["randn"][rows]).to(device)
+                fd["S_forced"] = torch.from_numpy(forced["S_forced"][rows]).to(device)
             out = model.sample(fd)
             onehot = torch.nn.functional.one_hot(out["S"], 33)
             lpr = -(onehot * out["log_probs"]).sum(-1)                                   # get_score, data_utils.py:36-52
+            lpr_l.append(lpr)
             loss_l.append((lpr * cmask).sum(-1) / (cmask.sum(-1) + 1e-8))
             S_l.append(out["S"]); lp_l.append(out["log_probs"]); sp_l.append(out["sampling_probs"])
-        S_stack, sp_stack, loss_stack = torch.cat(S_l), torch.cat(sp_l), torch.cat(loss_l)
+        S_stack, sp_stack, loss_stack, lpr_stack = torch.cat(S_l), torch.cat(sp_l), torch.cat(loss_l), torch.cat(lpr_l)
         rec = ((fd["S"][:1] == S_stack) * cmask).sum(-1) / cmask.sum(-1)               # get_seq_rec, data_utils.py:18-30
 
     rna_flag = P["rna_mask_for_token_conversion"]
@@ -229,6 +240,13 @@ def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bia
         entries.append('>{}, id={}, T={}, seed={}, overall_confidence={} seq_rec={}\n{}'.format(
             name, ix if args.zero_indexed else ix + 1, args.temperature, seed, conf, srec,
             seq_string(S_stack[ix].cpu().numpy(), rna_flag, int_to_str, dna_to_rna, P["chain_letters"])))
+        if args.output_pdbs:                                                          # run.py:475-491
+            one_to_three = {v: k for k, v in spec.RESTYPE_3TO1.items()}
+            chars = [dna_to_rna.get(int_to_str[int(t)], int_to_str[int(t)]) if rna_flag[i] == 1 else int_to_str[int(t)]
+                     for i, t in enumerate(S_stack[ix].cpu().numpy())]
+            lp_res = lpr_stack[ix].cpu().numpy()
+            pdbio.write_backbone_pdb(base + "backbones/" + name + "_" + str(ix if args.zero_indexed else ix + 1) + ".pdb" + args.file_ending,
+                                     P, [one_to_three[c] for c in chars], np.exp(-lp_res) * (lp_res > 0.01).astype(np.float32))
     if args.output_sequences:
         with open(base + "seqs/" + name + ".fa" + args.file_ending, "w") as fh:
             fh.write("\n".join(entries))

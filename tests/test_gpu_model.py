@@ -365,6 +365,42 @@ def test_cli_design_and_specificity(tmp_path, weights_np):
     assert list(z["encoded_residues"][:2]) == [f"A{cx['R_idx'][0]}", f"A{cx['R_idx'][1]}"]
 
 
+@pytest.mark.parametrize("ext", ["pdb", "cif"])
+def test_cli_output_files_byte_level(tmp_path, golden_dir, ext):
+    """f3: the design CLI's OUTPUT FILES against fixtures written with the reference's format strings from the CPU oracle's
+    sample() (oracle/make_cli_fixture.py): with the oracle's draws forced (`--forced_draws_npz`), seqs/<name>.fa is
+    byte-identical (headers of run.py:445-455 / :501-511, 4-digit confidence / recovery, chain-separated sequences with the
+    RNA letter conversion), specificity/<name>.npz has the keys, dtypes and values of run.py:426-443, and backbones/ carries
+    the designed residue names (run.py:475-491) — from the PDB and from the mmCIF form of the same complex."""
+    from na_mpnn_amd import cli, pdbio
+    gd = os.path.join(golden_dir, "cli")
+    out = os.path.join(str(tmp_path), "out")
+    cli.main(["--pdb_path", os.path.join(gd, "input." + ext), "--out_folder", out, "--random_init_seed", "0", "--seed", "7",
+              "--batch_size", "2", "--temperature", "1.0", "--fixed_residues", "A0 A1", "--output_specificity", "1",
+              "--forced_draws_npz", os.path.join(gd, "forced_draws.npz")])
+    got = open(os.path.join(out, "seqs", "input.fa"), "rb").read()
+    want = open(os.path.join(gd, "expected.fa"), "rb").read()
+    assert got == want, (got.decode(), want.decode())
+    z = np.load(os.path.join(out, "specificity", "input.npz"), allow_pickle=True)
+    e = np.load(os.path.join(gd, "expected_specificity.npz"), allow_pickle=True)
+    assert sorted(z.files) == sorted(e.files)
+    for k in e.files:
+        assert z[k].dtype == e[k].dtype and z[k].shape == e[k].shape, k
+        if k == "predicted_ppm":
+            assert np.abs(z[k] - e[k]).max() < 1e-4
+        elif z[k].dtype == object:
+            assert z[k].item() == e[k].item(), k
+        else:
+            assert np.array_equal(z[k], e[k]), k
+    forced = np.load(os.path.join(gd, "forced_draws.npz"))
+    P = pdbio.parse_pdb(os.path.join(gd, "input.pdb"))
+    for ix in (1, 2):
+        Q = pdbio.parse_pdb(os.path.join(out, "backbones", f"input_{ix}.pdb"), na_shared_tokens=True)
+        assert np.array_equal(Q["X_m"], P["X_m"]) and np.abs(Q["X"] - P["X"]).max() < 1e-3
+        assert np.array_equal(Q["S"], forced["S_forced"][ix - 1])        # designed residue names, re-parsed to tokens
+        assert len(Q["other_atoms"]) == (1 if ext == "pdb" else 0)       # the ligand travels (the mmCIF fixture has none)
+
+
 def test_padded_batch_from_coordinates(weights_np):
     """G8: B=3 complexes of different length padded with mask=0 tails, through the drop-in surface's training-style
     forward (B > 1): every real residue must match the same complex run alone (padding invariance) and the oracle."""

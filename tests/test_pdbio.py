@@ -68,3 +68,75 @@ def test_reference_example_files():
     q = pdbio.parse_pdb(os.path.join(REF_EXAMPLES, "1am9.pdb"))
     assert len(q["S"]) == 389 and len(set(q["chain_letters"])) == 8          # 313 aa + 76 nt, 8 chains
     assert q["protein_mask"].sum() == 313 and q["dna_mask"].sum() == 72 and q["mask"].sum() == 385
+
+
+def test_mmcif_reader_equals_pdb_reader(tmp_path, golden_dir):
+    """The `_atom_site` reader (auth_* identifiers, quoted atom names like "C1'", '?' insertion codes) gives the same parse
+    as the PDB reader on the same complex — committed fixture pair + a fresh round trip with insertion codes."""
+    a = pdbio.parse_pdb(os.path.join(golden_dir, "cli", "input.pdb"))
+    b = pdbio.parse_pdb(os.path.join(golden_dir, "cli", "input.cif"))
+    for k in ("X", "X_m", "mask", "S", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask", "R_polymer_type"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["chain_letters"] == b["chain_letters"] and a["icodes"] == b["icodes"]
+    assert len(a["other_atoms"]) == 1 and a["other_atoms"][0].resname == "MG"          # the water is not an "other atom"
+    cx = synth.make_complex(seed=23, n=30, n_chains=2)
+    names = [INT_TO_RES[int(s)] for s in cx["S"]]
+    letters = ["AB"[c] for c in cx["chain_labels"]]
+    R = cx["R_idx"].copy(); R[5] = R[4]; ic = [""] * 30; ic[5] = "A"
+    p = os.path.join(str(tmp_path), "y.cif")
+    pdbio.write_mmcif(p, cx["X"], cx["X_m"], names, letters, R, ic)
+    P = pdbio.parse_pdb(p, na_shared_tokens=False)
+    assert np.array_equal(P["X_m"], cx["X_m"]) and np.abs(P["X"] - cx["X"]).max() < 6e-4
+    assert np.array_equal(P["S"], cx["S"]) and P["icodes"][5] == "A" and P["R_idx"][5] == R[4]
+    assert pdbio.renumber(P["R_idx"])[5] == R[4] + 1
+    # a second model and an altloc B copy are ignored
+    txt = open(p).read().splitlines()
+    row = [l for l in txt if l.startswith("ATOM")][0].split()
+    row[4] = "B"; alt = " ".join(row)
+    row[4] = "."; row[-1] = "2"; model2 = " ".join(row)
+    open(p, "w").write("\n".join(txt[:-1] + [alt, model2, "#"]) + "\n")
+    assert len(pdbio.parse_pdb(p)["S"]) == 30
+
+
+def test_legacy_atom_names_and_name_tables(tmp_path):
+    """Pre-remediation nucleic atom names (O1P / O2P / C1*): the reference's prody selection does not rename them, so by
+    default such residues lose their reference atom / backbone completeness exactly as they do there; the opt-in
+    normalisation recovers them.  Residue names outside prody's protein / nucleic tables are not polymer residues."""
+    cx = synth.make_complex(seed=24, n=20, n_chains=1, frac_protein=0.0, frac_dna=1.0)
+    names = [INT_TO_RES[int(s)] for s in cx["S"]]
+    path = os.path.join(str(tmp_path), "old.pdb")
+    pdbio.write_pdb(path, cx["X"], cx["X_m"], names, ["A"] * 20, cx["R_idx"])
+    txt = open(path).read().replace(" OP1", " O1P").replace(" OP2", " O2P").replace("'", "*")
+    open(path, "w").write(txt)
+    assert len(pdbio.parse_pdb(path)["S"]) == 0                        # no C1' atom anywhere: nothing to anchor a residue
+    P = pdbio.parse_pdb(path, normalize_legacy_names=True, na_shared_tokens=False)
+    assert len(P["S"]) == 20 and P["dna_mask"].sum() == 20 and np.array_equal(P["S"], cx["S"])
+    # a modified nucleotide (PSU) is not in prody's nucleic table: it is an "other atom", not a residue
+    pdbio.write_pdb(path, cx["X"], cx["X_m"], ["PSU" if i == 3 else n for i, n in enumerate(names)], ["A"] * 20, cx["R_idx"])
+    Q = pdbio.parse_pdb(path)
+    assert len(Q["S"]) == 19 and {a.resname for a in Q["other_atoms"]} == {"PSU"}
+
+
+def test_backbone_pdb_writer_round_trip(tmp_path, golden_dir):
+    """run.py:475-491: backbone atoms with the designed residue names and per-residue confidences in the B-factor column,
+    followed by the input's non-polymer, non-water atoms; re-reading the file gives the same coordinates."""
+    P = pdbio.parse_pdb(os.path.join(golden_dir, "cli", "input.pdb"), na_shared_tokens=False)
+    L = len(P["S"])
+    new_names = ["GLY" if P["protein_mask"][i] else ("DA" if P["dna_mask"][i] else "U") for i in range(L)]
+    conf = np.linspace(0.05, 0.95, L)
+    out = os.path.join(str(tmp_path), "bb.pdb")
+    pdbio.write_backbone_pdb(out, P, new_names, conf)
+    lines = open(out).read().splitlines()
+    assert lines[-1] == "END" and all(len(l) == 78 for l in lines[:-1])
+    atom_lines = [l for l in lines if l.startswith("ATOM")]
+    assert len(atom_lines) == int(P["X_m"].sum()) and lines[-2].startswith("HETATM") and lines[-2][17:20] == " MG"
+    assert not any("HOH" in l for l in lines)
+    Q = pdbio.parse_pdb(out, na_shared_tokens=False)
+    assert np.array_equal(Q["X_m"], P["X_m"]) and np.abs(Q["X"] - P["X"]).max() < 1e-3
+    rti = spec.restype_to_int(False)
+    assert np.array_equal(Q["S"], np.array([rti[n] for n in new_names]))
+    first = {}
+    for l in atom_lines:
+        first.setdefault((l[21], int(l[22:26])), float(l[60:66]))
+    got = np.array([first[(c, int(r))] for c, r in zip(P["chain_letters"], P["R_idx"])])
+    assert np.abs(got - conf).max() < 0.006                            # %6.2f
