@@ -239,6 +239,8 @@ def train_bench(args, dev, rank, world, dist):
                     restype_to_int=rti, polytype_to_int=spec.polytype_to_int())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()})
     m.to(dev).train()
+    if getattr(args, "precision", None):
+        m.message_precision = args.precision          # "bf16" = the mixed-precision mode (na_run.py MIXED_PRECISION)
     cxs = [synth.make_complex(seed=5000 + 100 * rank + b, n=N, n_chains=4) for b in range(B)]
     fd = {k: torch.from_numpy(np.stack([c[k] for c in cxs])).to(dev) for k in cxs[0]}
     fd["S"] = fd["S"].long()
@@ -291,13 +293,14 @@ def train_bench(args, dev, rank, world, dist):
     bwd_ms = sum(v[0] for _, v in bwd); bwd_n = sum(v[1] for _, v in bwd)
     avg_s = bwd_ms / max(bwd_n, 1) * 1e-3
     edges = B * N * K
-    x3 = getattr(m, "message_precision", "x3") != "fp32"     # split-bf16 products: 3 bf16 MFMAs per algorithmic product
+    mp = getattr(m, "message_precision", "x3")
+    x3 = mp != "fp32"                                       # bf16 pipe; "x3": 3 bf16 MFMAs per algorithmic product, "bf16": 1
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
     algo_tf = BWD_FLOP_EDGE_ALGO * edges / avg_s / 1e12
     roofline = {"kernel": "edge_chain_bwd_kernel", "bound": "mfma",
                 "achieved": round(algo_tf, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(algo_tf / peak, 4), "traffic": None,
-                "executed_frac": round(BWD_FLOP_EDGE_EXEC * (3 if x3 else 1) * edges / avg_s / 1e12 / peak, 4),
+                "executed_frac": round(BWD_FLOP_EDGE_EXEC * (3 if mp == "x3" else 1) * edges / avg_s / 1e12 / peak, 4),
                 "frac_vs_fp32_mfma_peak": round(algo_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": bwd_n,
                 "note": "algorithmic = 3 data-gradient GEMMs per edge; executed adds the 2 recomputed forward GEMMs "
@@ -305,7 +308,9 @@ def train_bench(args, dev, rank, world, dist):
     out = {"metric": "residues/sec trained (featurise + fwd + bwd + clip + Noam/Adam), N=1500 K=48 h=128", "value": round(value, 1),
            "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16x3 (per-edge GEMMs of forward, backward and weight gradients as split-bf16 products, fp32 accumulate; fp32 elsewhere)" if x3 else "f32",
+           "dtype": {"x3": "bf16x3 (per-edge GEMMs of forward, backward and weight gradients as split-bf16 products, fp32 accumulate; fp32 elsewhere)",
+                     "bf16": "bf16 mixed precision (per-edge GEMMs as plain bf16 products, fp32 accumulate; fp32 master weights, "
+                             "residue-level math, loss and optimiser)", "fp32": "f32"}[mp],
            "data": "synthetic",
            "config": {"workload": f"cfg5: B={B} x N={N} residues per rank, K={K}, H=128, 3+3 layers, dropout 0.1, coordinate noise 0.1, "
                                   "label smoothing 0.1, seeded random-init weights; N > 1: data parallel, one RCCL "
@@ -598,7 +603,13 @@ def secondary_runs(args, dev):
                                "finite": bool(torch.isfinite(lp).all())}
                 del r
             elif wl == "cfg5":
+                a.precision = None
                 o = train_bench(a, dev, 0, 1, None)
+                a2 = copy.copy(a)
+                a2.precision, a2.no_cpu_baseline = "bf16", True
+                o2 = train_bench(a2, dev, 0, 1, None)            # the mixed-precision mode of the same step
+                o["mixed_precision_bf16"] = {k: o2[k] for k in ("value", "ms_per_step", "dtype", "hip_kernel_share", "roofline")}
+                o["mixed_precision_bf16"]["final_loss"] = o2["whole_step"]["final_loss"]
             else:
                 o = design_bench(a, dev, 0, 1, None)
         except Exception as e:          # a failing secondary must not take the headline down with it

@@ -620,7 +620,7 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.b2 = b2; a.b3 = b3;
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   hipStream_t s = (hipStream_t)stream;
-  const int prec = x3 ? PREC_X3 : PREC_F32;
+  const int prec = x3 == 2 ? PREC_BF16 : x3 ? PREC_X3 : PREC_F32;        // x3 = 2: plain bf16 products (mixed-precision training)
   if (mode == MODE_ENC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_ENC_MESSAGE, s); rc = launch_edge_prec<MODE_ENC_MSG, 0>(a, prec, s); }
   else if (mode == MODE_DEC_MSG) { a.partial = out; ProfScope p_(NAMP_KIND_DEC_MESSAGE, s); rc = launch_edge_prec<MODE_DEC_MSG, 0>(a, prec, s); }
   else {

@@ -289,6 +289,15 @@ __device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4
   else chain_gemm<8, 8, FLIP, ACT>(acc, x, w, 8);
 }
 
+// The training kernels' tile GEMM by precision code (the `x3` argument of the namp_train_* entry points): 0 exact fp32 MFMA,
+// 1 split-bf16 products, 2 plain bf16 products (mixed-precision training: na_run.py trains under autocast); ACT is never
+// used there (activations come from gelu_val_grad).  The bf16 image is the first 32 KiB of the 64 KiB slot.
+template <int PREC, bool FLIP>
+__device__ __forceinline__ void gemm128p(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {
+  if constexpr (PREC == 2) chain_gemm_bf16<FLIP, false>(acc, x, (const bf8*)w);
+  else gemm128<PREC == 1, FLIP, false>(acc, x, w);
+}
+
 // Same contraction with the weight image streamed straight from global memory (L2 / L1 resident):
 // fragments of step tk+1 are requested before the MFMAs of step tk issue, so one L2 round trip is
 // always covered by 4*NTN MFMAs.  Used where each fragment is consumed once per wave or where the

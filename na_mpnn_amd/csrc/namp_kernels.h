@@ -1150,6 +1150,13 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
+      if (a.drop_thresh) {                                        // training forward: dropout3 on the message
+        const uint32_t key = drop_row_key(a.drop_seed, me.erow);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
+      }
       if (a.ln_g) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] += x[t];               // residual: the row is still in registers

@@ -85,8 +85,10 @@ struct EdgeBwdArgs {
 // the five images W1, W2, W3^T, W2^T, W1^T stream through it by LDS-DMA one GEMM ahead of their use.
 // X3: the six / five GEMMs as split-bf16 products (chain_gemm_x3; the images are then x3 images), like the forward kernels
 // TSUM (message modes): write the per-tile weighted sums S3 / w3 instead of the A2 and G3 rows (see EdgeBwdArgs)
-template <int MODE, bool X3, bool TSUM = false>
+// PREC: 0 exact fp32 MFMA, 1 split-bf16 products (X3), 2 plain bf16 products (mixed-precision mode; 32 KiB images)
+template <int MODE, int PREC, bool TSUM = false>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
+  constexpr int IMG_KB = (PREC == 2) ? 32 : 64;
   static_assert(!TSUM || MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG, "tile sums: message modes only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
@@ -134,15 +136,15 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
 
-  dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
-  dma_to_lds(buf1, a.W2_img, 64, wave, nwaves, lane);
+  dma_to_lds(buf0, a.W1_img, IMG_KB, wave, nwaves, lane);
+  dma_to_lds(buf1, a.W2_img, IMG_KB, wave, nwaves, lane);
   wait_dma_and_sync();
   // ---- recompute: z1, z2
-  gemm128<X3, false, false>(z1, x, w0);
+  gemm128p<PREC, false>(z1, x, w0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
   __syncthreads();                                            // everyone is done with W1
-  dma_to_lds(buf0, MODE == BWD_EDGE_LN ? a.W3_img : a.W3t_img, 64, wave, nwaves, lane);
+  dma_to_lds(buf0, MODE == BWD_EDGE_LN ? a.W3_img : a.W3t_img, IMG_KB, wave, nwaves, lane);
   // activations and their derivatives from ONE evaluation each: x <- a1 = gelu(z1), z1 <- gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z1[t]);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-  gemm128<X3, false, false>(z2, x, w1);
+  gemm128p<PREC, false>(z2, x, w1);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z2[t]);      // x <- a2 (only stored, for dW3), z2 <- gelu'(z2)
   // Row stores are issued right AFTER a ring barrier, never right before one: s_waitcnt vmcnt(0) also waits for store
@@ -175,12 +177,12 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   if (MODE == BWD_EDGE_LN) {
     // z3 = W3 a2 + b3 (a2 is still in x), then backwards through LayerNorm3 and the dropout mask
     wait_dma_and_sync();                                      // W3 landed in buf0; W2 (buf1) is free
-    dma_to_lds(buf1, a.W3t_img, 64, wave, nwaves, lane);
+    dma_to_lds(buf1, a.W3t_img, IMG_KB, wave, nwaves, lane);
     store_rows(a.A2, x);
     f4 z3[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
-    gemm128<X3, false, false>(z3, x, w0);
+    gemm128p<PREC, false>(z3, x, w0);
     asm volatile("" ::: "memory");       // the row loads below have kernel-constant addresses: do not hoist them (96 VGPRs) over the GEMMs
     const uint32_t key = drop_row_key(a.drop_seed, e);
     const float* hsrc = a.hE + e * NAMP_H + 4 * g;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   char* bufA = (MODE == BWD_EDGE_LN) ? buf1 : buf0;
   char* bufB = (MODE == BWD_EDGE_LN) ? buf0 : buf1;
   wait_dma_and_sync();                                        // W3^T landed in slot A; slot B is free
-  dma_to_lds(bufB, a.W2t_img, 64, wave, nwaves, lane);
+  dma_to_lds(bufB, a.W2t_img, IMG_KB, wave, nwaves, lane);
   if (TSUM) {
     // weighted row sum of the tile's a2 over its 16 rows (lanes of equal g): 4 exchange steps per value
     const long tile = ((long)blockIdx.x * nwaves + wave);
@@ -272,16 +274,16 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   f4 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  gemm128<X3, false, false>(acc, gr, wA);
+  gemm128p<PREC, false>(acc, gr, wA);
 #pragma unroll
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
   wait_dma_and_sync();                                        // W2^T landed in slot B; slot A is free
-  dma_to_lds(bufA, a.W1t_img, 64, wave, nwaves, lane);
+  dma_to_lds(bufA, a.W1t_img, IMG_KB, wave, nwaves, lane);
   store_rows(a.G2, gr);
   // ---- g1 = (W2^T g2) * gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  gemm128<X3, false, false>(acc, gr, wB);
+  gemm128p<PREC, false>(acc, gr, wB);
   if (MODE == BWD_EDGE_LN) {
     const float* p1 = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t)
     acc[t] = (MODE == BWD_EDGE_LN && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
-  gemm128<X3, false, false>(acc, gr, wA);
+  gemm128p<PREC, false>(acc, gr, wA);
   if (valid) {
     float* d = a.g_hE + e * NAMP_H + 4 * g;
 #pragma unroll
@@ -447,6 +449,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& mid) {
   for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)v[j]; mid[j] = (__bf16)(v[j] - (float)hi[j]); }
 }
 
+// MID = false: plain bf16 products (hi . hi only) — the mixed-precision mode
+template <bool MID>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
                                                        long rows_per_chunk, float* __restrict__ dW_part,
                                                        float* __restrict__ db_part) {
@@ -496,8 +500,10 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[q], ah[t], acc[q][t], 0, 0, 0);
-        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], am[t], acc[q][t], 0, 0, 0);
+        if (MID) {
+          acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[q], ah[t], acc[q][t], 0, 0, 0);
+          acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], am[t], acc[q][t], 0, 0, 0);
+        }
         acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], ah[t], acc[q][t], 0, 0, 0);
       }
     if (more) {

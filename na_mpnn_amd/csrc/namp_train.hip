@@ -45,12 +45,11 @@ int ensure_attributes() {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NAMP_IMG_BYTES);
       if (e != hipSuccess) g_attr_err = e;
     };
-    set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, true>));
-    set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, true>));
-    set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, false, true>)); set((const void*)(edge_chain_bwd_kernel<BWD_ENC_MSG, true, true>));
-    set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, false, true>)); set((const void*)(edge_chain_bwd_kernel<BWD_DEC_MSG, true, true>));
-    set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_ROWS, true>));
-    set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, false>)); set((const void*)(edge_chain_bwd_kernel<BWD_EDGE_LN, true>));
+#define NAMP_SET3(M, ...) set((const void*)(edge_chain_bwd_kernel<M, 0 __VA_ARGS__>)); set((const void*)(edge_chain_bwd_kernel<M, 1 __VA_ARGS__>)); \
+                          set((const void*)(edge_chain_bwd_kernel<M, 2 __VA_ARGS__>))
+    NAMP_SET3(BWD_ENC_MSG); NAMP_SET3(BWD_DEC_MSG); NAMP_SET3(BWD_ROWS); NAMP_SET3(BWD_EDGE_LN);
+#define NAMP_COMMA ,
+    NAMP_SET3(BWD_ENC_MSG, NAMP_COMMA true); NAMP_SET3(BWD_DEC_MSG, NAMP_COMMA true);
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -95,15 +94,18 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
+  // x3: precision code — 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain bf16 products (mixed precision)
 #define NAMP_LAUNCH_BWD(M)                                                                                              \
   do {                                                                                                                    \
-    if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);        \
-    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, false>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);          \
+    if (x3 == 2) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 2>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);      \
+    else if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 1>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);      \
+    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 0>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);              \
   } while (0)
 #define NAMP_LAUNCH_BWD_TSUM(M)                                                                                         \
   do {                                                                                                                    \
-    if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, true, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);  \
-    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, false, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);    \
+    if (x3 == 2) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 2, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a); \
+    else if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 1, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a); \
+    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 0, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);        \
   } while (0)
   if (mode == 0) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_ENC_MSG); else NAMP_LAUNCH_BWD(BWD_ENC_MSG); }
   else if (mode == 1) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_DEC_MSG); else NAMP_LAUNCH_BWD(BWD_DEC_MSG); }
@@ -199,7 +201,8 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
   long per = (rows + nchunk - 1) / nchunk;
   per = (per + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
-  if (x3) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  else if (x3) hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   CHECK_LAUNCH();

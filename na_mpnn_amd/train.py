@@ -24,10 +24,14 @@ H = 128
 ENC_MSG, DEC_MSG, ENC_EDGE = 0, 1, 2
 
 
-# Evaluation of the per-edge GEMMs of the training kernels: True = split-bf16 products (fp32-equivalent to ~2^-16, the
-# default, like the inference path's "x3" mode); False = exact fp32 MFMA.  Set through forward_train from
-# model.message_precision ("fp32" selects the exact form).
-X3 = True
+# Evaluation of the per-edge GEMMs of the training kernels (forward, backward, weight gradients) — the `x3` argument of the
+# namp_train_* entry points: 1 = split-bf16 products (fp32-equivalent to ~2^-16, the default, like the inference path's
+# "x3" mode); 0 = exact fp32 MFMA; 2 = plain bf16 products with fp32 accumulation — the MIXED-PRECISION mode, mirroring the
+# reference's training under torch.cuda.amp.autocast (na_run.py:21,216-238; master weights, residue-level math, losses
+# and the optimiser stay fp32, and torch's GradScaler can be used unchanged around loss.backward()).  Set through
+# forward_train from model.message_precision ("fp32" / "x3" / "bf16").
+X3 = 1
+PREC_CODE = {"fp32": 0, "x3": 1, "bf16": 2}
 
 
 def _image(block, x3=None):
@@ -35,7 +39,11 @@ def _image(block, x3=None):
     weight.  x3 None: the module-level setting (forward passes); backward passes hand in the value their forward saved."""
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
     img = torch.empty(H * H, dtype=torch.float32, device=block.device)
-    if (X3 if x3 is None else x3):
+    prec = int(X3 if x3 is None else x3)
+    if prec == 2:                                              # 32 KiB bf16 image in the first half of the buffer
+        hip.check(hip.lib().namp_pack_image_bf16(block.data_ptr(), block.stride(0), 0, img.data_ptr(), hip.current_stream()),
+                  "pack_image_bf16")
+    elif prec == 1:
         hip.check(hip.lib().namp_pack_image_x3(block.data_ptr(), block.stride(0), 0, img.data_ptr(), hip.current_stream()),
                   "pack_image_x3")
     else:
@@ -62,7 +70,7 @@ def _wgrad(G, A, gelu_A, want_bias, x3=None):
     n = L.namp_train_wgrad_chunks(rows)
     dW = torch.empty(n, H, H, device=G.device)
     db = torch.empty(n, H, device=G.device) if want_bias else None
-    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), int((X3 if x3 is None else x3) and not gelu_A), rows, dW.data_ptr(), hip.ptr(db),
+    hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), (0 if gelu_A else int(X3 if x3 is None else x3)), rows, dW.data_ptr(), hip.ptr(db),
                                  hip.current_stream()), "train_wgrad")
     return dW.sum(0), (db.sum(0) if want_bias else None)
 
@@ -292,7 +300,7 @@ def _edge_embedding_fwd(fp, W18, X, ints, top_k, ref_atom):
     Wd = W18.detach().contiguous()                            # 18-atom column layout [128 x 5200] (model.edge_weight18)
     img = torch.empty(Wd.numel(), device=dev)
     m = hip.NampModelW()
-    if X3:
+    if X3:                                                    # the feature GEMM: split products in both reduced-precision modes
         hip.check(L.namp_pack_feat_x3(Wd.data_ptr(), Wd.shape[1], img.data_ptr(), hip.current_stream()), "pack_feat_x3(edge_embedding)")
         m.feat.Wedge_ximg = img.data_ptr()
     else:
@@ -331,7 +339,7 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         Ep = E_pos.detach().contiguous()
         tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
         hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
-                                          part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
+                                          part.data_ptr(), tws.data_ptr(), int(bool(ctx.x3)), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
         return None, part.sum(0), g_Epos, None, None, None
@@ -451,7 +459,7 @@ def _ffn(x, dense):
 def forward_train(model, fd, decoding_randn=None):
     """Differentiable ProteinMPNN.forward of the training copy (na_model_utils.py:589-646) -> (log_probs, probs)."""
     global X3
-    X3 = getattr(model, "message_precision", "x3") != "fp32"
+    X3 = PREC_CODE[getattr(model, "message_precision", "x3")]
     mask = fd["mask"]
     if not mask.is_cuda:
         raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
@@ -582,8 +590,12 @@ def polymer_restype_tables(restype_to_int, num_letters, device):
 
 
 def train_step(model, optimizer, fd, polymer_restype_masks, polymer_restype_nums, tokens_with_no_loss, label_smoothing=0.1,
-               loss_tokens=2000.0, gradient_norm=0.0, decoding_randn=None, data_parallel=False):
-    """One optimisation step of na_run.py:198-238 (fp32): forward, label-smoothed loss, backward, clip, Noam/Adam.
+               loss_tokens=2000.0, gradient_norm=0.0, decoding_randn=None, data_parallel=False, scaler=None):
+    """One optimisation step of na_run.py:198-238: forward, label-smoothed loss, backward, clip, Noam/Adam.
+    Mixed precision (the reference's MIXED_PRECISION branch, :216-238): set ``model.message_precision = "bf16"`` — the
+    per-edge GEMMs of forward, backward and weight gradients then run as plain bf16 products with fp32 accumulation, master
+    weights / residue-level math / loss / optimiser stay fp32 — and optionally pass the reference's ``scaler``
+    (torch GradScaler): ``scaler.scale(loss).backward(); clip; scaler.step(optimizer); scaler.update()`` like :232-238.
     ``data_parallel`` (an extension; torch.distributed initialised, one process per GPU): gradients are averaged over
     the ranks with one all-reduce before clipping, so every rank applies the same update."""
     optimizer.zero_grad()
@@ -596,11 +608,15 @@ def train_step(model, optimizer, fd, polymer_restype_masks, polymer_restype_nums
     _, loss = loss_smoothed(S, log_probs, mask_for_loss, polymer_masks, polymer_restype_masks, polymer_restype_nums,
                             weight=label_smoothing, tokens=loss_tokens, num_letters=log_probs.shape[-1],
                             ppm_mask=fd.get("ppm_mask"), aligned_ppm=fd.get("aligned_ppm"))
-    loss.backward()
+    (scaler.scale(loss) if scaler is not None else loss).backward()
     if data_parallel:
         from . import shard
         shard.allreduce_gradients(model.parameters())          # one RCCL all-reduce of the 9.2 MB gradient bucket
     if gradient_norm > 0.0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_norm)
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
     return loss.detach(), log_probs.detach()
