@@ -286,7 +286,7 @@ def train_bench(args, dev, rank, world, dist):
         if t_us > 0:
             kern[ev.key] = (t_us / 1e3, ev.count)
     ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "wgrad_kernel", "feat_wgrad", "edge_features",
-                                                                  "edge_mlp_kernel", "edge_mlp_x3_persistent", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
+                                                                  "edge_mlp_kernel", "edge_mlp_x3_persistent", "edge_mlp_bf16", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
                                                                   "prep_atoms", "wgrad_x3", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
     total_dev_ms = sum(v[0] for v in kern.values())
     bwd = [(k, v) for k, v in ours.items() if "edge_chain_bwd" in k]
@@ -319,6 +319,8 @@ def train_bench(args, dev, rank, world, dist):
            "roofline": roofline,
            "per_kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(ours.items(), key=lambda kv: -kv[1][0])},
            "device_ms_per_step": round(total_dev_ms, 3), "hip_kernel_share": round(sum(v[0] for v in ours.values()) / total_dev_ms, 3),
+           "other_kernels_ms_per_step": {k[:90]: [round(v[0], 3), v[1]] for k, v in sorted(((k, v) for k, v in kern.items() if k not in ours),
+                                                                                    key=lambda kv: -kv[1][0])[:16]},
            "whole_step": {"algorithmic_tflops": round(TRAIN_FLOP_STEP * B * N / (ms_per_step * 1e-3) / 1e12, 2),
                           "final_loss": round(float(loss), 5),
                           "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}}

@@ -116,6 +116,7 @@ typedef struct NampModelW {
   NampFeatW feat;
   const float* We_ximg;            /* x3 image of W_e (the embedding fused in front of EncLayer 0, namp_encdec_fwd) */
   const float* Wv_ximg;            /* optional x3 image of W_v (with enc[0].W1a_ximg / W1c_ximg: namp_encdec_fwd's first launch as split-bf16 products) */
+  const float* We_bimg;            /* optional bf16 image of W_e: the edge embedding of the bf16 throughput mode on bf16 MFMA */
 } NampModelW;
 
 /* ---- a1/a3: neighbour gather ----------------------------------------------------------- */
@@ -318,6 +319,9 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   S3 / w3 (optional, modes 0/1 with K % 16 == 0; A2 and G3 may then be NULL and are not written): in a message mode
  *   G3[i,k] = w_ik g_out[i], hence dW3 = g_out^T . S with S[i] = sum_k w_ik A2[i,k] and db3 = sum_i g_out[i] sum_k w_ik; the
  *   launch writes per 16-row tile t = (i, k/16) the sums S3[t][128] and w3[t] — the caller adds a residue's K/16 tiles.
+ *   The `x3` argument of the namp_train_* entry points is a precision code: 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain
+ *   bf16 products (mixed-precision training).  For namp_train_edge_bwd, adding 4 makes the launch ADD its dL/dh_E to the rows
+ *   already in g_hE (another consumer's gradient of the same h_E) instead of overwriting them.
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
  * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated

@@ -142,6 +142,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)dec_sample_kernel<false, false>, SAMPLE_LDS);
@@ -1257,9 +1258,10 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   cvt({P[0], P[1]}, {T16[0], T16[1]});
   {
     EdgeArgs a = {};
-    a.hE = E; a.hE16_out = h16; a.W1_img = w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
+    a.hE = E; a.hE16_out = h16; a.W1_img = w->We_bimg ? w->We_bimg : w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
     ProfScope prof_(NAMP_KIND_EDGE_EMBED, s);
-    if ((rc = launch_edge<MODE_EMBED>(a, s))) return rc;
+    // bf16 MFMA for the embedding too (the fp32 MFMA form is MFMA-bound: 8,192 pipe cycles per tile against 512)
+    if ((rc = (w->We_bimg ? launch_edge<MODE_EMBED, 0, PREC_BF16>(a, s) : launch_edge<MODE_EMBED>(a, s)))) return rc;
   }
   int cur = 0;
   for (int l = 0; l < w->n_enc; ++l) {

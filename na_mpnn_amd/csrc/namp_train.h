@@ -78,6 +78,7 @@ struct EdgeBwdArgs {
   float* dgb_part;             // [gridDim.x][2][128]: per-workgroup sums of g*xhat (-> d ln weight) and g (-> d ln bias)
   long E;                      // G * K rows
   int G, N, K;
+  int acc_hE;                  // message modes: g_hE already holds another consumer's dL/dh_E — add to it instead of overwriting
 };
 
 // One wave = 16 consecutive edge rows of the flat [G*K] edge list (tiles may straddle residues: every
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   // ---- dL/dh_E = W1b^T g1 (+ the residual path of the edge update)
 #pragma unroll
   for (int t = 0; t < 8; ++t)
-    acc[t] = (MODE == BWD_EDGE_LN && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+    acc[t] = ((MODE == BWD_EDGE_LN || a.acc_hE) && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
   gemm128p<PREC, false>(acc, gr, wA);
   if (valid) {
     float* d = a.g_hE + e * NAMP_H + 4 * g;

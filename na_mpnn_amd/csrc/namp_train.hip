@@ -92,6 +92,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.g_Pa = g_Pa; a.g_Pj0 = g_Pj0; a.g_Pj1 = g_Pj1;
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.S3 = S3; a.w3 = w3;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
+  a.acc_hE = (x3 & 4) ? 1 : 0;                               // bit 2 of the precision argument: accumulate into g_hE
+  x3 &= 3;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
   // x3: precision code — 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain bf16 products (mixed precision)

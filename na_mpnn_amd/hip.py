@@ -53,7 +53,7 @@ class NampModelW(C.Structure):
                 ("Wv_img", c_fp), ("Wv_b", c_fp), ("We_img", c_fp), ("We_b", c_fp),
                 ("Wout_w", c_fp), ("Wout_b", c_fp),
                 ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS),
-                ("feat", NampFeatW), ("We_ximg", c_fp), ("Wv_ximg", c_fp)]
+                ("feat", NampFeatW), ("We_ximg", c_fp), ("Wv_ximg", c_fp), ("We_bimg", c_fp)]
 
 
 class NampProj(C.Structure):

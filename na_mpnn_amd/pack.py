@@ -53,7 +53,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         add(name, out_f * in_f, ("xgimg", key, out_f, in_f))
 
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
-    ximg("We_ximg", "W_e.weight", 0); ximg("Wv_ximg", "W_v.weight", 0)
+    ximg("We_ximg", "W_e.weight", 0); ximg("Wv_ximg", "W_v.weight", 0); bimg("We_bimg", "W_e.weight", 0)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
     # featuriser (ProteinFeaturesNA): 5200-wide edge embedding as a 325-k-tile image
@@ -200,6 +200,7 @@ class PackedWeights:
             m.feat.Wedge_ximg = None                       # exact fp32 MFMA in the featuriser too
         m.We_ximg = self.addr("We_ximg")
         m.Wv_ximg = self.addr("Wv_ximg")
+        m.We_bimg = self.addr("We_bimg")
         self.struct = m
 
     def set_precision(self, precision: str):

@@ -75,6 +75,27 @@ def _wgrad(G, A, gelu_A, want_bias, x3=None):
     return dW.sum(0), (db.sum(0) if want_bias else None)
 
 
+def _wgrad_many(pairs, x3=None):
+    """Several row contractions over the SAME rows in one go: pairs = [(G, A, want_bias), ...] -> [(dW, db or None), ...].
+    The per-chunk partials of all of them land in one buffer and are reduced by ONE sum (a stage's three weight gradients
+    otherwise cost six small reductions)."""
+    L = hip.lib()
+    rows = pairs[0][0].shape[0]
+    n = L.namp_train_wgrad_chunks(rows)
+    k = len(pairs)
+    dev = pairs[0][0].device
+    prec = int(X3 if x3 is None else x3)
+    tmp = torch.empty(k, n, H, H, device=dev)
+    tmpb = torch.empty(k, n, H, device=dev)
+    for q, (G, A, wb) in enumerate(pairs):
+        assert G.shape[0] == rows
+        hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), 0, prec, rows, tmp[q].data_ptr(), tmpb[q].data_ptr() if wb else None,
+                                     hip.current_stream()), "train_wgrad")
+    dW = tmp.sum(1)
+    db = tmpb.sum(1) if any(wb for _, _, wb in pairs) else None
+    return [(dW[q], (db[q] if wb else None)) for q, (_, _, wb) in enumerate(pairs)]
+
+
 class ReverseAdjacency:
     """Edges grouped by the table row they gather (global row b*N + E_idx[b,i,k]) — the transpose of the neighbour
     gather, built once per step and shared by all per-edge stages' backward passes."""
@@ -121,20 +142,33 @@ class _EdgeMLP(torch.autograd.Function):
                                         None, None, 0.0, 0, out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
         ctx.mode, ctx.rev, ctx.x3 = mode, rev, X3           # backward runs at the precision of ITS forward
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
-        return out if mode == ENC_EDGE else out.sum(1).view(B, N, H)
+        ctx.set_materialize_grads(False)
+        if mode == ENC_EDGE:
+            return out
+        # second output: h_E itself, for the NEXT consumer of the same edge rows (EncLayer's edge update, the next DecLayer).
+        # Its gradient then arrives HERE, and the backward launch adds its own dL/dh_E onto those rows in place — autograd
+        # would otherwise sum the consumers' [E,128] gradients with a separate 1.8 GB pass each.
+        return out.sum(1).view(B, N, H), h_E.view_as(h_E)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         mode = ctx.mode
         h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32 = ctx.saved_tensors
         B, N, K = E_idx32.shape
         E = B * N * K
         dev = h_E.device
         L = hip.lib()
+        if g is None:                                        # only the pass-through output was used downstream
+            g = torch.zeros(B, N, H, device=dev) if mode != ENC_EDGE else torch.zeros(B, N, K, H, device=dev)
         g = g.contiguous()
         img1, img2 = _image(W1b.detach(), ctx.x3), _image(W2.detach(), ctx.x3)
         img3t, img2t, img1t = _image_t(W3, ctx.x3), _image_t(W2, ctx.x3), _image_t(W1b, ctx.x3)
-        A1, G1, G2, g_hE = (torch.empty(E, H, device=dev) for _ in range(4))
+        A1, G1, G2 = (torch.empty(E, H, device=dev) for _ in range(3))
+        acc = g_pass is not None and g_pass.is_contiguous() and g_pass.dtype == torch.float32 and g_pass.numel() == E * H
+        if g_pass is not None and not acc:
+            g_pass = g_pass.contiguous().float()
+            acc = True
+        g_hE = g_pass.view(E, H) if acc else torch.empty(E, H, device=dev)     # accumulate in place onto the later consumer's gradient
         # message modes with tiles aligned to residues: dW3 = g^T . (sum_k w_ik a2[i,k]) from per-tile sums, no A2 / G3 rows
         tile_sums = mode != ENC_EDGE and K % 16 == 0
         A2 = None if tile_sums else torch.empty(E, H, device=dev)
@@ -147,8 +181,8 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3), B, N, K,
-                                        hip.current_stream()), "train_edge_bwd")
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3) | (4 if acc else 0),
+                                        B, N, K, hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
             r = rank32.view(-1)
@@ -162,10 +196,9 @@ class _EdgeMLP(torch.autograd.Function):
             g2d = g.view(B * N, H)
             dW3 = g2d.t() @ S3.view(B * N, K // 16, H).sum(1)
             db3 = (g2d * w3.view(B * N, K // 16).sum(1, keepdim=True)).sum(0)
+            (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         else:
-            dW3, db3 = _wgrad(G3, A2, False, True, x3=ctx.x3)
-        dW2, db2 = _wgrad(G2, A1, False, True, x3=ctx.x3)
-        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False, x3=ctx.x3)
+            (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
@@ -214,9 +247,7 @@ class _EdgeUpdate(torch.autograd.Function):
                                                int(ctx.x3), B, N, K, hip.current_stream()), "train_edge_update_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
-        dW3, db3 = _wgrad(G3, A2, False, True, x3=ctx.x3)
-        dW2, db2 = _wgrad(G2, A1, False, True, x3=ctx.x3)
-        dW1b, _ = _wgrad(G1, h_E.view(E, H), False, False, x3=ctx.x3)
+        (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         dgb = part.sum(0)
         return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
                 None, None, None, None)
@@ -409,10 +440,8 @@ class _NodeLinears(torch.autograd.Function):
         for q, w in enumerate(Ws):                                  # dL/dx = sum_q g_q W_q
             t = _node_linear_call(g2[q], [w.detach().t().contiguous()], [None])[0]
             gx = t if gx is None else gx + t
-        gW, gb = [], []
-        for q in range(ctx.nb):
-            dW, db = _wgrad(g2[q], x2, False, ctx.has_b[q], x3=ctx.x3)
-            gW.append(dW); gb.append(db)
+        res = _wgrad_many([(g2[q], x2, ctx.has_b[q]) for q in range(ctx.nb)], x3=ctx.x3)      # one reduction for all blocks
+        gW, gb = [r[0] for r in res], [r[1] for r in res]
         return (gx.view(ctx.shape), None, *gW, *gb)
 
 
@@ -477,8 +506,8 @@ def forward_train(model, fd, decoding_randn=None):
     for p in model.encoder_layers:                                                   # EncLayer, na_model_utils.py:218-241
         W1, W11 = p.W1.weight, p.W11.weight
         Pa, Pc = _lin(h_V, (W1[:, :H], p.W1.bias), (W1[:, 2 * H:], None))
-        dh = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
-                            E_idx, mask32, None, None, rev)
+        dh, h_E = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
+                                 E_idx, mask32, None, None, rev)           # h_E: passed through to the edge update below
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
         Pa, Pc = _lin(h_V, (W11[:, :H], p.W11.bias), (W11[:, 2 * H:], None))
@@ -498,8 +527,8 @@ def forward_train(model, fd, decoding_randn=None):
         Pa, Pv = _lin(h_V, (W1[:, :H], p.W1.bias), (W1[:, 3 * H:], None))
         Pbw = _lin(h_S, (W1[:, 2 * H:3 * H], None))[0] + Pv
         Pfw = _lin(h_V_enc, (W1[:, 3 * H:], None))[0]
-        dh = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
-                            E_idx, None, None, rank32, rev)
+        dh, h_E = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
+                                 E_idx, None, None, rank32, rev)          # h_E: passed through to the next DecLayer
         h_V = _ln(h_V + drop(dh), p.norm1)
         h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
     logits = model.W_out(h_V)
