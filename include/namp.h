@@ -321,7 +321,9 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   launch writes per 16-row tile t = (i, k/16) the sums S3[t][128] and w3[t] — the caller adds a residue's K/16 tiles.
  *   The `x3` argument of the namp_train_* entry points is a precision code: 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain
  *   bf16 products (mixed-precision training).  For namp_train_edge_bwd, adding 4 makes the launch ADD its dL/dh_E to the rows
- *   already in g_hE (another consumer's gradient of the same h_E) instead of overwriting them.
+ *   already in g_hE (another consumer's gradient of the same h_E) instead of overwriting them; adding 8 (both backward
+ *   entry points, K % 16 == 0) makes g_Pa a [B*N*K/16][128] buffer of per-tile sums written with plain stores — the caller adds
+ *   a residue's K/16 tiles — instead of a zeroed [B*N][128] buffer accumulated with fp32 atomics (deterministic).
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
  *   c < namp_train_wgrad_chunks(rows); the caller adds the chunks.  dW_part [chunks][128][128], db_part [chunks][128] or NULL.
  * namp_train_feat_wgrad: gradient of features.edge_embedding.weight [128 x 5200] with the RBF features regenerated

@@ -78,6 +78,7 @@ struct EdgeBwdArgs {
   float* dgb_part;             // [gridDim.x][2][128]: per-workgroup sums of g*xhat (-> d ln weight) and g (-> d ln bias)
   long E;                      // G * K rows
   int G, N, K;
+  int gpa_tiles;               // g_Pa is [E/16][128] per-tile sums (K % 16 == 0: a tile = one residue), plain stores — deterministic
   int acc_hE;                  // message modes: g_hE already holds another consumer's dL/dh_E — add to it instead of overwriting
 };
 
@@ -306,7 +307,20 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
       }
     }
   }
-  if (a.g_Pa) {
+  if (a.g_Pa && a.gpa_tiles) {
+    // tiles aligned to residues: the tile's 16 rows belong to ONE residue — sum them (butterfly over the 16 lanes of a
+    // channel group) and store the tile's row; the caller adds a residue's K/16 tiles.  No atomics: the summation order is fixed.
+    const long tile = (long)blockIdx.x * nwaves + wave;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f4 v = valid ? gr[t] : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+      }
+      if (m == 0 && tile * 16 < a.E) *(f4*)(a.g_Pa + tile * NAMP_H + 16 * t + 4 * g) = v;
+    }
+  } else if (a.g_Pa) {
     // rows of a tile are consecutive edges: residues are non-decreasing, usually one or two per tile -> reduce over the
     // rows of the first / the last residue with two masked butterflies and add once per residue; other shapes (K < 8) go row by row
     const int n_first = __shfl(node, g << 4), n_last = __shfl(node, (g << 4) | 15);

@@ -93,6 +93,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.S3 = S3; a.w3 = w3;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   a.acc_hE = (x3 & 4) ? 1 : 0;                               // bit 2 of the precision argument: accumulate into g_hE
+  a.gpa_tiles = (x3 & 8) ? 1 : 0;                            // bit 3: g_Pa holds per-tile sums [E/16][128] (needs K % 16 == 0)
+  REQUIRE(!a.gpa_tiles || (K % 16) == 0, "namp_train_edge_bwd: per-tile g_Pa sums need K %% 16 == 0 (K=%d)", K);
   x3 &= 3;
   const int grid = (int)((a.E + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
@@ -142,6 +144,9 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.g_Pa = g_Pa; a.g_Pj0 = g_Pc; a.dgb_part = dgb_part;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
+  a.gpa_tiles = (x3 & 8) ? 1 : 0;
+  REQUIRE(!a.gpa_tiles || (K % 16) == 0, "namp_train_edge_update_bwd: per-tile g_Pa sums need K %% 16 == 0 (K=%d)", K);
+  x3 &= 3;
   {
     const int grid = namp_train_edge_update_bwd_groups(B, N, K);
     hipStream_t s = (hipStream_t)stream;

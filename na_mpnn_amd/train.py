@@ -34,12 +34,33 @@ X3 = 1
 PREC_CODE = {"fp32": 0, "x3": 1, "bf16": 2}
 
 
-def _image(block, x3=None):
-    """Fragment image (fp32, or x3) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
-    weight.  x3 None: the module-level setting (forward passes); backward passes hand in the value their forward saved."""
+# Fragment images made during ONE training step (forward_train and the backward pass that follows it), keyed by (storage
+# address, strides, precision, transposed): a stage's forward images (W1b, W2, W3) are needed again by its backward launch,
+# which recomputes the chain — pack them once.  The cache belongs to the step token forward_train creates: a new step starts
+# empty, and calls outside forward_train (tests driving one autograd Function) never touch it.
+_IMG_CACHE = {}
+_STEP = None                      # token of the step being recorded by forward_train (None outside)
+_CACHE_STEP = None                # token the cache's entries belong to
+
+
+def _image(block, x3=None, transposed=False, step=None):
+    """Fragment image (fp32, or x3 / bf16) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
+    weight (or of its transpose).  x3 None: the module-level setting (forward passes); backward passes hand in the value
+    their forward saved."""
+    prec = int(X3 if x3 is None else x3)
+    step = _STEP if step is None else step
+    use_cache = step is not None and step is _CACHE_STEP
+    key = (block.data_ptr(), block.stride(0), block.stride(1), block._version, prec, transposed, block.device.index)
+    if use_cache:
+        hit = _IMG_CACHE.get(key)
+        if hit is not None:
+            return hit
+    if transposed:
+        block = block.detach().t().contiguous()
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
     img = torch.empty(H * H, dtype=torch.float32, device=block.device)
-    prec = int(X3 if x3 is None else x3)
+    if use_cache:
+        _IMG_CACHE[key] = img
     if prec == 2:                                              # 32 KiB bf16 image in the first half of the buffer
         hip.check(hip.lib().namp_pack_image_bf16(block.data_ptr(), block.stride(0), 0, img.data_ptr(), hip.current_stream()),
                   "pack_image_bf16")
@@ -59,8 +80,8 @@ def _image_f32(block):
     return img
 
 
-def _image_t(block, x3=None):
-    return _image(block.detach().t().contiguous(), x3)
+def _image_t(block, x3=None, step=None):
+    return _image(block.detach(), x3, transposed=True, step=step)
 
 
 def _wgrad(G, A, gelu_A, want_bias, x3=None):
@@ -140,7 +161,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
                                         None, None, 0.0, 0, out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.mode, ctx.rev, ctx.x3 = mode, rev, X3           # backward runs at the precision of ITS forward
+        ctx.mode, ctx.rev, ctx.x3, ctx.step = mode, rev, X3, _STEP     # backward runs at the precision of ITS forward
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         ctx.set_materialize_grads(False)
         if mode == ENC_EDGE:
@@ -161,8 +182,8 @@ class _EdgeMLP(torch.autograd.Function):
         if g is None:                                        # only the pass-through output was used downstream
             g = torch.zeros(B, N, H, device=dev) if mode != ENC_EDGE else torch.zeros(B, N, K, H, device=dev)
         g = g.contiguous()
-        img1, img2 = _image(W1b.detach(), ctx.x3), _image(W2.detach(), ctx.x3)
-        img3t, img2t, img1t = _image_t(W3, ctx.x3), _image_t(W2, ctx.x3), _image_t(W1b, ctx.x3)
+        img1, img2 = _image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step)
+        img3t, img2t, img1t = _image_t(W3, ctx.x3, ctx.step), _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
         A1, G1, G2 = (torch.empty(E, H, device=dev) for _ in range(3))
         acc = g_pass is not None and g_pass.is_contiguous() and g_pass.dtype == torch.float32 and g_pass.numel() == E * H
         if g_pass is not None and not acc:
@@ -176,12 +197,13 @@ class _EdgeMLP(torch.autograd.Function):
         S3 = torch.empty(E // 16, H, device=dev) if tile_sums else None
         w3 = torch.empty(E // 16, device=dev) if tile_sums else None
         b2c = b2.detach().contiguous()
-        g_Pa = torch.zeros(B * N, H, device=dev)
+        gpa_tiles = K % 16 == 0                                # deterministic per-tile sums instead of fp32 atomics
+        g_Pa = torch.empty(E // 16, H, device=dev) if gpa_tiles else torch.zeros(B * N, H, device=dev)
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3) | (4 if acc else 0),
+                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3) | (4 if acc else 0) | (8 if gpa_tiles else 0),
                                         B, N, K, hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
@@ -199,6 +221,8 @@ class _EdgeMLP(torch.autograd.Function):
             (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         else:
             (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
+        if gpa_tiles:
+            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
@@ -221,7 +245,7 @@ class _EdgeUpdate(torch.autograd.Function):
                                                 Pc.data_ptr(), None, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(),
                                                 b2c.data_ptr(), b3c.data_ptr(), g_.data_ptr(), b_.data_ptr(), float(p), int(seed),
                                                 out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
-        ctx.p, ctx.seed, ctx.rev, ctx.x3 = float(p), int(seed), rev, X3
+        ctx.p, ctx.seed, ctx.rev, ctx.x3, ctx.step = float(p), int(seed), rev, X3, _STEP
         ctx.save_for_backward(h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32)
         return out
 
@@ -233,10 +257,12 @@ class _EdgeUpdate(torch.autograd.Function):
         dev = h_E.device
         L = hip.lib()
         g = g.contiguous()
-        img1, img2, img3 = _image(W1b.detach(), ctx.x3), _image(W2.detach(), ctx.x3), _image(W3.detach(), ctx.x3)
-        img3t, img2t, img1t = _image_t(W3, ctx.x3), _image_t(W2, ctx.x3), _image_t(W1b, ctx.x3)
+        img1, img2, img3 = (_image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step),
+                            _image(W3.detach(), ctx.x3, step=ctx.step))
+        img3t, img2t, img1t = _image_t(W3, ctx.x3, ctx.step), _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
         A1, A2, G1, G2, G3, g_hE = (torch.empty(E, H, device=dev) for _ in range(6))
-        g_Pa = torch.zeros(B * N, H, device=dev)
+        gpa_tiles = K % 16 == 0
+        g_Pa = torch.empty(E // 16, H, device=dev) if gpa_tiles else torch.zeros(B * N, H, device=dev)
         part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
         b2c, b3c, lw = b2.detach().contiguous(), b3.detach().contiguous(), ln_w.detach().contiguous()
         hip.check(L.namp_train_edge_update_bwd(h_E.data_ptr(), E_idx32.data_ptr(), Pa.data_ptr(), Pc.data_ptr(), img1.data_ptr(),
@@ -244,7 +270,9 @@ class _EdgeUpdate(torch.autograd.Function):
                                                img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
                                                g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
                                                G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
-                                               int(ctx.x3), B, N, K, hip.current_stream()), "train_edge_update_bwd")
+                                               int(ctx.x3) | (8 if gpa_tiles else 0), B, N, K, hip.current_stream()), "train_edge_update_bwd")
+        if gpa_tiles:
+            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
         (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
@@ -487,8 +515,17 @@ def _ffn(x, dense):
 
 def forward_train(model, fd, decoding_randn=None):
     """Differentiable ProteinMPNN.forward of the training copy (na_model_utils.py:589-646) -> (log_probs, probs)."""
-    global X3
+    global X3, _STEP, _CACHE_STEP
     X3 = PREC_CODE[getattr(model, "message_precision", "x3")]
+    _STEP = _CACHE_STEP = object()                           # a new step: its own (empty) image cache
+    _IMG_CACHE.clear()
+    try:
+        return _forward_train(model, fd, decoding_randn)
+    finally:
+        _STEP = None
+
+
+def _forward_train(model, fd, decoding_randn):
     mask = fd["mask"]
     if not mask.is_cuda:
         raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
