@@ -359,6 +359,11 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */
 int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                             float* out0, float* out1, int G, void* stream);
+/* Mixed-precision mode (precision code 2): the backward entry points write A1, A2, G1, G2, G3 as bf16 [E][128] row tensors
+ * (plain channel order; the float* parameters then point at bf16 storage), namp_train_wgrad takes them with bit 4 (G is
+ * bf16; required) / bit 5 (A is bf16) added to its precision argument, and the table-gradient gather reads G1 here. */
+int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                                 float* out0, float* out1, int G, void* stream);
 /* LayerNorm over the 128 channels of [rows][128] (features.norm_edges on the edge embedding, na_model_utils.py:509) and its
  * backward: gx = dL/dx; dgb_part [namp_train_ln_rows_groups(rows)][2][128] = per-workgroup partial sums of d(weight), d(bias). */
 int namp_train_ln_rows_groups(long rows);

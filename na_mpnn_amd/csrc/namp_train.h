@@ -42,6 +42,19 @@ __device__ __forceinline__ f4 gelu_split4(f4& z) {
   return (f4){v0, v1, v2, v3};
 }
 
+// Row tensors of the MIXED-PRECISION mode (precision code 2): A1, A2, G1, G2, G3 are [E][128] bf16 in plain channel order —
+// half the bytes for the launch's stores, for the row contractions (namp_train_wgrad) and for the table-gradient gather.
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf4 to_bf4(const f4 v) { bf4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w; return o; }
+__device__ __forceinline__ f4 from_bf4(const bf4 v) { return (f4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+template <bool BF> __device__ __forceinline__ void st_row4(float* base, const long off, const f4 v) {
+  if (BF) *(bf4*)((__bf16*)base + off) = to_bf4(v); else *(f4*)(base + off) = v;
+}
+template <bool BF> __device__ __forceinline__ f4 ld_row4(const float* base, const long off) {
+  if (BF) return from_bf4(*(const bf4*)((const __bf16*)base + off));
+  return *(const f4*)(base + off);
+}
+
 enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2, BWD_EDGE_LN = 3 };
 
 struct EdgeBwdArgs {
@@ -91,6 +104,7 @@ struct EdgeBwdArgs {
 template <int MODE, int PREC, bool TSUM = false>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
   constexpr int IMG_KB = (PREC == 2) ? 32 : 64;
+  constexpr bool RB = (PREC == 2);            // bf16 row tensors (A1, A2, G1, G2, G3)
   static_assert(!TSUM || MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG, "tile sums: message modes only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
@@ -151,13 +165,11 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z1[t]);
   if (valid) {
-    float* d1 = a.A1 + e * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) *(f4*)(d1 + 16 * t) = x[t];
+    for (int t = 0; t < 8; ++t) st_row4<RB>(a.A1, e * NAMP_H + 4 * g + 16 * t, x[t]);
     if (MODE == BWD_EDGE_LN) {       // 6-GEMM variant: gelu'(z1) waits in its own G1 row (L2) instead of 32 VGPRs
-      float* p1 = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(p1 + 16 * t) = z1[t];
+      for (int t = 0; t < 8; ++t) st_row4<RB>(a.G1, e * NAMP_H + 4 * g + 16 * t, z1[t]);
     }
   }
 #pragma unroll
@@ -169,9 +181,8 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   // acknowledgements (gfx9 has one counter), and a store issued after the barrier has a whole GEMM to retire.
   auto store_rows = [&](float* base, const f4 (&v)[8]) {
     if (valid) {
-      float* d = base + e * NAMP_H + 4 * g;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = v[t];
+      for (int t = 0; t < 8; ++t) st_row4<RB>(base, e * NAMP_H + 4 * g + 16 * t, v[t]);
     }
   };
   // ---- upstream gradient rows
@@ -287,9 +298,8 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   gemm128p<PREC, false>(acc, gr, wB);
   if (MODE == BWD_EDGE_LN) {
-    const float* p1 = a.G1 + e * NAMP_H + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) gr[t] = valid ? acc[t] * *(const f4*)(p1 + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 8; ++t) gr[t] = valid ? acc[t] * ld_row4<RB>(a.G1, e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
   } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z1[t];
@@ -540,6 +550,77 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
     for (int q = 0; q < 4; ++q) {
       const float s = xg_sum(bsum[q]);
       if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * to0 + 4 * n + q] = s;
+    }
+  }
+}
+
+// wgrad_bf16_kernel: the row contraction of the mixed-precision mode on bf16 row tensors (G always bf16; A bf16 — A1 / A2 —
+// or fp32 — h_E, residue-level inputs): the loaded values ARE the MFMA operands (no split), 8 bytes per row, lane and operand.
+template <bool A_BF16>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const __bf16* __restrict__ G, const void* __restrict__ Av, long rows,
+                                                         long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int to0 = 4 * (wave >> 1), tc0 = 4 * (wave & 1);
+  const long r_begin = (long)blockIdx.x * rows_per_chunk;
+  long r_end = r_begin + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  f4 acc[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  bf8 gv[4], av[4], gn[4], an[4];
+  auto load = [&](long r0, bf8 (&go)[4], bf8 (&ao)[4]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long row = r0 + 8 * g + j;
+      const bool ok = row < r_end;
+      const long rr = ok ? row : r_begin;
+      const bf4 gq = *(const bf4*)(G + rr * NAMP_H + 16 * to0 + 4 * n);       // columns 4n .. 4n+3 of the wave's 64-column half
+      bf4 aq;
+      if (A_BF16) aq = *(const bf4*)((const __bf16*)Av + rr * NAMP_H + 16 * tc0 + 4 * n);
+      else aq = to_bf4(*(const f4*)((const float*)Av + rr * NAMP_H + 16 * tc0 + 4 * n));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) go[q][j] = ok ? gq[q] : (__bf16)0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ao[t][j] = aq[t];
+    }
+  };
+  if (r_begin < r_end) load(r_begin, gv, av);
+  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+    const bool more = r0 + 32 < r_end;
+    if (more) load(r0 + 32, gn, an);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sq += (float)gv[q][j];
+      bsum[q] += sq;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gv[q], av[t], acc[q][t], 0, 0, 0);
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { gv[q] = gn[q]; av[q] = an[q]; }
+    }
+  }
+  float* out = dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * to0 + 4 * (4 * g + r) + q) * NAMP_H + 16 * tc0 + 4 * n + t] = acc[q][t][r];
+  if (db_part && (wave & 1) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float s_ = xg_sum(bsum[q]);
+      if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * to0 + 4 * n + q] = s_;
     }
   }
 }
@@ -901,6 +982,7 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
 // Deterministic, no atomics (the atomic scatter inside edge_chain_bwd_kernel cost 0.85 ms per launch at cfg5, this
 // 0.2 ms).  sel (DecLayer): per edge 1 = the row gathered Pbw -> out0, 0 = Pfw -> out1.
 // ------------------------------------------------------------------------------------------
+template <bool BF>        // BF: G1 is a bf16 row tensor (mixed-precision mode)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ G1, const int32_t* __restrict__ rev_edge,
                                                            const int32_t* __restrict__ rev_off, const uint8_t* __restrict__ sel,
                                                            float* __restrict__ out0, float* __restrict__ out1, int G) {
@@ -912,7 +994,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
   for (int p = beg + half; p < end; p += 2) {
     const int e = rev_edge[p];
-    const f4 v = *(const f4*)(G1 + (long)e * NAMP_H + 4 * c4);
+    const f4 v = ld_row4<BF>(G1, (long)e * NAMP_H + 4 * c4);
     if (!sel || sel[e]) s0 += v; else s1 += v;
   }
 #pragma unroll

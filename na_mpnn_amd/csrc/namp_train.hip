@@ -156,16 +156,28 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   return NAMP_OK;
 }
 
-int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
-                            float* out0, float* out1, int G, void* stream) {
+static int scatter_rows_impl(const void* G1, bool bf16_rows, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                             float* out0, float* out1, int G, void* stream) {
   REQUIRE_PTR(G1); REQUIRE_PTR(out0);
   if (!rev_edge || !rev_off) return fail(NAMP_EINVAL, "namp_train_scatter_rows: null reverse adjacency");
   REQUIRE((sel == nullptr) == (out1 == nullptr), "namp_train_scatter_rows: sel and out1 go together");
   REQUIRE(G >= 1, "namp_train_scatter_rows: G=%d", G);
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, G1, rev_edge, rev_off, sel, out0,
-                     out1, G);
+  if (bf16_rows) hipLaunchKernelGGL(scatter_rows_kernel<true>, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)G1,
+                                    rev_edge, rev_off, sel, out0, out1, G);
+  else hipLaunchKernelGGL(scatter_rows_kernel<false>, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)G1, rev_edge,
+                          rev_off, sel, out0, out1, G);
   CHECK_LAUNCH();
   return NAMP_OK;
+}
+
+int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                            float* out0, float* out1, int G, void* stream) {
+  return scatter_rows_impl(G1, false, rev_edge, rev_off, sel, out0, out1, G, stream);
+}
+
+int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
+                                 float* out0, float* out1, int G, void* stream) {
+  return scatter_rows_impl(G1, true, rev_edge, rev_off, sel, out0, out1, G, stream);
 }
 
 int namp_train_ln_rows_groups(long rows) {
@@ -201,14 +213,20 @@ int namp_train_wgrad_chunks(long rows) {
 }
 
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long rows, float* dW_part, float* db_part, void* stream) {
-  REQUIRE(!(gelu_A && x3), "namp_train_wgrad: the split-bf16 form takes activations (gelu_A = 0)");
+  REQUIRE(!(gelu_A && (x3 & 3)), "namp_train_wgrad: the split-bf16 form takes activations (gelu_A = 0)");
   REQUIRE_PTR(G); REQUIRE_PTR(A); REQUIRE_PTR(dW_part);
   REQUIRE(rows >= 1, "namp_train_wgrad: rows=%ld", rows);
   const int nchunk = namp_train_wgrad_chunks(rows);
   long per = (rows + nchunk - 1) / nchunk;
   per = (per + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
-  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  // bits 4 / 5 of the precision argument: G / A are bf16 row tensors (the mixed-precision backward's outputs)
+  const bool g16 = (x3 & 16) != 0, a16 = (x3 & 32) != 0;
+  x3 &= 3;
+  REQUIRE(!(g16 || a16) || (x3 == 2 && g16), "namp_train_wgrad: bf16 row tensors belong to precision code 2, and G must be one of them");
+  if (g16 && a16) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3(nchunk), dim3(256), 0, s, (const __bf16*)G, (const void*)A, rows, per, dW_part, db_part);
+  else if (g16) hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3(nchunk), dim3(256), 0, s, (const __bf16*)G, (const void*)A, rows, per, dW_part, db_part);
+  else if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else if (x3) hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);

@@ -110,7 +110,12 @@ def _wgrad_many(pairs, x3=None):
     tmpb = torch.empty(k, n, H, device=dev)
     for q, (G, A, wb) in enumerate(pairs):
         assert G.shape[0] == rows
-        hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), 0, prec, rows, tmp[q].data_ptr(), tmpb[q].data_ptr() if wb else None,
+        code = prec
+        if G.dtype == torch.bfloat16:                       # the mixed-precision backward's bf16 row tensors
+            code |= 16 | (32 if A.dtype == torch.bfloat16 else 0)
+        elif A.dtype == torch.bfloat16:
+            A = A.float()
+        hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), 0, code, rows, tmp[q].data_ptr(), tmpb[q].data_ptr() if wb else None,
                                      hip.current_stream()), "train_wgrad")
     dW = tmp.sum(1)
     db = tmpb.sum(1) if any(wb for _, _, wb in pairs) else None
@@ -136,8 +141,9 @@ class ReverseAdjacency:
         """-> sum of G1 rows per gathered table row [G,128] (two outputs when sel, uint8 per edge, is given)."""
         out0 = torch.empty(self.G, H, device=G1.device)
         out1 = torch.empty(self.G, H, device=G1.device) if sel is not None else None
-        hip.check(hip.lib().namp_train_scatter_rows(G1.data_ptr(), self.edges.data_ptr(), self.offsets.data_ptr(), hip.ptr(sel),
-                                                    out0.data_ptr(), hip.ptr(out1), self.G, hip.current_stream()), "scatter_rows")
+        fn = hip.lib().namp_train_scatter_rows_bf16 if G1.dtype == torch.bfloat16 else hip.lib().namp_train_scatter_rows
+        hip.check(fn(G1.data_ptr(), self.edges.data_ptr(), self.offsets.data_ptr(), hip.ptr(sel),
+                     out0.data_ptr(), hip.ptr(out1), self.G, hip.current_stream()), "scatter_rows")
         return out0, out1
 
 
@@ -184,7 +190,8 @@ class _EdgeMLP(torch.autograd.Function):
         g = g.contiguous()
         img1, img2 = _image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step)
         img3t, img2t, img1t = _image_t(W3, ctx.x3, ctx.step), _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
-        A1, G1, G2 = (torch.empty(E, H, device=dev) for _ in range(3))
+        rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
+        A1, G1, G2 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(3))
         acc = g_pass is not None and g_pass.is_contiguous() and g_pass.dtype == torch.float32 and g_pass.numel() == E * H
         if g_pass is not None and not acc:
             g_pass = g_pass.contiguous().float()
@@ -192,8 +199,8 @@ class _EdgeMLP(torch.autograd.Function):
         g_hE = g_pass.view(E, H) if acc else torch.empty(E, H, device=dev)     # accumulate in place onto the later consumer's gradient
         # message modes with tiles aligned to residues: dW3 = g^T . (sum_k w_ik a2[i,k]) from per-tile sums, no A2 / G3 rows
         tile_sums = mode != ENC_EDGE and K % 16 == 0
-        A2 = None if tile_sums else torch.empty(E, H, device=dev)
-        G3 = torch.empty(E, H, device=dev) if (mode != ENC_EDGE and not tile_sums) else None
+        A2 = None if tile_sums else torch.empty(E, H, device=dev, dtype=rdt)
+        G3 = torch.empty(E, H, device=dev, dtype=rdt) if (mode != ENC_EDGE and not tile_sums) else None
         S3 = torch.empty(E // 16, H, device=dev) if tile_sums else None
         w3 = torch.empty(E // 16, device=dev) if tile_sums else None
         b2c = b2.detach().contiguous()
@@ -213,7 +220,7 @@ class _EdgeMLP(torch.autograd.Function):
         else:
             g_Pj0, g_Pj1 = rev.scatter(G1)
         if mode == ENC_EDGE:
-            G3 = g.view(E, H)
+            G3 = g.view(E, H).to(rdt)
         if tile_sums:
             g2d = g.view(B * N, H)
             dW3 = g2d.t() @ S3.view(B * N, K // 16, H).sum(1)
@@ -260,7 +267,9 @@ class _EdgeUpdate(torch.autograd.Function):
         img1, img2, img3 = (_image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step),
                             _image(W3.detach(), ctx.x3, step=ctx.step))
         img3t, img2t, img1t = _image_t(W3, ctx.x3, ctx.step), _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
-        A1, A2, G1, G2, G3, g_hE = (torch.empty(E, H, device=dev) for _ in range(6))
+        rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
+        A1, A2, G1, G2, G3 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(5))
+        g_hE = torch.empty(E, H, device=dev)
         gpa_tiles = K % 16 == 0
         g_Pa = torch.empty(E // 16, H, device=dev) if gpa_tiles else torch.zeros(B * N, H, device=dev)
         part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
