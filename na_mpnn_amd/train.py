@@ -519,6 +519,11 @@ class _RowLayerNorm(torch.autograd.Function):
 
 
 def _ffn(x, dense):
+    """PositionWiseFeedForward (na_model_utils.py:286-296).  Mixed-precision mode: under bf16 autocast like the reference's
+    training loop (na_run.py:217) — the two [B*N,128] x [128,512] library GEMMs run on the bf16 matrix pipe."""
+    if X3 == 2 and x.is_cuda:
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            return dense.W_out(F.gelu(dense.W_in(x))).float()
     return dense.W_out(F.gelu(dense.W_in(x)))
 
 
