@@ -107,7 +107,9 @@ typedef struct NampFeatW {
 } NampFeatW;
 
 typedef struct NampModelW {
-  int32_t n_enc, n_dec, vocab, reserved;
+  int32_t n_enc, n_dec, vocab;
+  int32_t reserved;                /* 0; 2 = namp_featurize evaluates its GEMM as plain bf16 products on the x3 image's hi half
+                                      (mixed-precision training, feat.Wedge_ximg set) */
   const float *Wv_img, *Wv_b;      /* W_v (model_utils.py:35,88) */
   const float *We_img, *We_b;      /* W_e (model_utils.py:48,89) */
   const float *Wout_w, *Wout_b;    /* W_out [vocab x 128] plain layout (model_utils.py:65) */

@@ -152,8 +152,9 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES);
-  set((const void*)edge_features_kernel<false>, FEAT_LDS);
-  set((const void*)edge_features_kernel<true>, FEAT_LDS);
+  set((const void*)edge_features_kernel<0>, FEAT_LDS);
+  set((const void*)edge_features_kernel<1>, FEAT_LDS);
+  set((const void*)edge_features_kernel<2>, FEAT_LDS);
   set((const void*)knn_kernel, 8192 * 8 + 64);
   set((const void*)knn_select_kernel, (8192 + 4096) * 8 + 1024 + 64);
 }
@@ -911,8 +912,10 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     a.G = G; a.L = L; a.K = K;
     const EdgeGeom e = edge_geom(G, K);
     a.TPN = e.tpn;
-    if (x3) hipLaunchKernelGGL(edge_features_kernel<true>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
-    else hipLaunchKernelGGL(edge_features_kernel<false>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    // NampModelW.reserved == 2 with an x3 image: plain bf16 products on its hi half (mixed-precision training)
+    if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    else hipLaunchKernelGGL(edge_features_kernel<0>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
   }
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -2368,7 +2368,8 @@ struct FeatArgs {
 #define FEAT_XJ_BYTES (54 * 16 * 4)               // one wave's 16 neighbour frames
 #define FEAT_LDS (2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES + 256)
 
-template <bool X3>
+// X3: 0 exact fp32 MFMA; 1 split-bf16 products; 2 plain bf16 products on the x3 image's hi half (mixed-precision training)
+template <int X3>
 __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2508,12 +2509,14 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
             bf8 wh[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) wh[q] = wb[(st * 8 + 4 * h + q) * 64];
+            if (X3 == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], mid, acc[4 * h + q], 0, 0, 0);
+              for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], mid, acc[4 * h + q], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const bf8 wm = wb[(FEAT_CHUNK_BYTES / 32) + (st * 8 + 4 * h + q) * 64];
-              acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[4 * h + q], 0, 0, 0);
+              for (int q = 0; q < 4; ++q) {
+                const bf8 wm = wb[(FEAT_CHUNK_BYTES / 32) + (st * 8 + 4 * h + q) * 64];
+                acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[4 * h + q], 0, 0, 0);
+              }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], hi, acc[4 * h + q], 0, 0, 0);
@@ -2556,7 +2559,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) out[t] = *(const f4*)(a.We_b + 16 * t + 4 * g);
     wait_dma_and_sync();
-    gemm128<X3, false, false>(out, acc, (const f4*)smem + lane);
+    gemm128<X3 != 0, false, false>(out, acc, (const f4*)smem + lane);
     if (valid) {
       float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll

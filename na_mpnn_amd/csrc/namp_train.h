@@ -782,6 +782,7 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
 // than the fp32 form; results differ from it by the split's 2^-16 per product.
 #define FEATW_LDT 72            // bf16 elements per channel row of the transposed planes (64 edges + pad: conflict-free b128 writes)
 
+template <bool MID>      // MID = false: hi . hi products only (mixed-precision mode)
 __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                             const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
                                                             const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
@@ -890,13 +891,17 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
           const bf8 ah = *(const bf8*)(gh + (16 * t + n) * FEATW_LDT + row0);
           const bf8 am = *(const bf8*)(gm + (16 * t + n) * FEATW_LDT + row0);
           if (live0) {
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[0], acc[0][t], 0, 0, 0);
+            if (MID) {
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[0][t], 0, 0, 0);
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[0], acc[0][t], 0, 0, 0);
+            }
             acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], acc[0][t], 0, 0, 0);
           }
           if (live1) {
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[1][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[1], acc[1][t], 0, 0, 0);
+            if (MID) {
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[1][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[1], acc[1][t], 0, 0, 0);
+            }
             acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], acc[1][t], 0, 0, 0);
           }
         }

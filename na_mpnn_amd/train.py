@@ -371,6 +371,7 @@ def _edge_embedding_fwd(fp, W18, X, ints, top_k, ref_atom):
     if X3:                                                    # the feature GEMM: split products in both reduced-precision modes
         hip.check(L.namp_pack_feat_x3(Wd.data_ptr(), Wd.shape[1], img.data_ptr(), hip.current_stream()), "pack_feat_x3(edge_embedding)")
         m.feat.Wedge_ximg = img.data_ptr()
+        m.reserved = 2 if X3 == 2 else 0                       # mixed precision: plain bf16 products on the hi half
     else:
         hip.check(L.namp_pack_image(Wd.data_ptr(), Wd.shape[1], 0, H, Wd.shape[1], img.data_ptr(), hip.current_stream()),
                   "pack_image(edge_embedding)")
@@ -407,7 +408,7 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         Ep = E_pos.detach().contiguous()
         tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
         hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
-                                          part.data_ptr(), tws.data_ptr(), int(bool(ctx.x3)), B, Lr, K, hip.current_stream()),
+                                          part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
         return None, part.sum(0), g_Epos, None, None, None
