@@ -366,6 +366,24 @@ int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int3
  * bf16; required) / bit 5 (A is bf16) added to its precision argument, and the table-gradient gather reads G1 here. */
 int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                                  float* out0, float* out1, int G, void* stream);
+/* Residue tail of EncLayer / DecLayer in training (na_model_utils.py:236-247, 268-283), one launch each way:
+ *     x1 = LayerNorm1(h_V + dropout1(dh));  z = W_in x1 + b_in;  y = x1 + dropout2(W_out gelu(z) + b_out);  out = mask * LayerNorm2(y)
+ * (dh = the K-sum of the messages / 30; both dropouts are counter-based hashes of (seed, row, channel), regenerated in
+ * backward; GEMMs as split-bf16 products).  Win_ximg / Wout_ximg: namp_pack_image_x3_general of W_in [512 x 128] / W_out
+ * [128 x 512]; WoutT_ximg / WinT_ximg: the same of their transposes.  Forward keeps x1 [G][128], z [4][G][128] (hidden units in
+ * four 128-wide blocks, block-major) and y [G][128] for the backward launch, which writes dL/dh_V, dL/d(dh), the row tensors
+ * g_f [G][128], g_z and h = gelu(z) [4][G][128] — dW_out[:, 128q:] = g_f^T h_q, dW_in[128q:, :] = g_z_q^T x1, db_out = sum g_f,
+ * db_in_q = sum g_z_q through namp_train_wgrad — and part [namp_train_tail_groups(G)][4][128]: per-workgroup sums of d ln2 weight,
+ * d ln2 bias, d ln1 weight, d ln1 bias. */
+int namp_train_tail_groups(int G);
+int namp_train_tail_fwd(const float* h_V, const float* dh, const int32_t* mask, const float* ln1_g, const float* ln1_b,
+                        const float* Win_ximg, const float* b_in, const float* Wout_ximg, const float* b_out, const float* ln2_g,
+                        const float* ln2_b, float drop_p, uint32_t seed1, uint32_t seed2, float* out, float* x1, float* z, float* y,
+                        int G, void* stream);
+int namp_train_tail_bwd(const float* h_V, const float* dh, const int32_t* mask, const float* ln1_g, const float* ln2_g,
+                        const float* WoutT_ximg, const float* WinT_ximg, float drop_p, uint32_t seed1, uint32_t seed2,
+                        const float* x1, const float* z, const float* y, const float* g_out, float* g_hV, float* g_dh, float* g_f,
+                        float* g_z, float* h, float* part, int G, void* stream);
 /* LayerNorm over the 128 channels of [rows][128] (features.norm_edges on the edge embedding, na_model_utils.py:509) and its
  * backward: gx = dL/dx; dgb_part [namp_train_ln_rows_groups(rows)][2][128] = per-workgroup partial sums of d(weight), d(bias). */
 int namp_train_ln_rows_groups(long rows);

@@ -1010,3 +1010,312 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Residue tail of EncLayer / DecLayer in TRAINING (na_model_utils.py:236-247, 268-283), fused per workgroup:
+//     x1  = LayerNorm1(h_V + dropout1(dh))                    dh = sum_k message / 30 (from the edge kernels)
+//     z   = W_in x1 + b_in ;  f = W_out gelu(z) + b_out
+//     out = mask * LayerNorm2(x1 + dropout2(f))
+// tail_train_fwd_kernel: T 16-row tiles per workgroup, 8 waves — wave w owns hidden units 64w .. 64w+63 through both GEMMs
+// (x3 images in registers, applied to all T tiles; partial W_out outputs reduced through LDS), exactly the schedule of
+// node_update_multi_kernel<T, true>; both dropouts are counter-based hashes of (seed, row, channel) regenerated by the
+// backward launch.  It keeps x1, z (block-major [4][G][128]) and y = x1 + dropout2(f) for the backward launch.
+// tail_train_bwd_kernel: the same schedule run backwards — LayerNorm2 backward on the rows, g_h = W_out^T g_f (image of
+// W_out^T, shape of W_in's), g_z = g_h * gelu'(z), g_x1 = g_y + W_in^T g_z (image of W_in^T, shape of W_out's, partials through
+// LDS), LayerNorm1 backward; writes dL/dh_V, dL/d(dh), and the row tensors g_f, g_z, h = gelu(z) (block-major) from which the
+// row-contraction kernel forms dW_in, dW_out, db_in, db_out; LayerNorm weight / bias gradients as per-workgroup partial sums.
+// ------------------------------------------------------------------------------------------
+struct TailTrainArgs {
+  const float* hV; const float* dh; const int32_t* mask;
+  const float* ln1_g; const float* ln1_b; const float* b_in; const float* b_out; const float* ln2_g; const float* ln2_b;
+  const float* WA_ximg;          // fwd: W_in  [512 x 128];  bwd: W_out^T [512 x 128]
+  const float* WB_ximg;          // fwd: W_out [128 x 512];  bwd: W_in^T  [128 x 512]
+  float* out; float* x1; float* z; float* y;                       // fwd outputs (bwd: x1, z, y are inputs)
+  const float* g_out; float* g_hV; float* g_dh; float* g_f; float* g_z; float* h; float* part;   // bwd
+  uint32_t drop_thresh, seed1, seed2; float drop_scale;
+  int G;
+};
+
+#ifndef FFN_LD
+#define FFN_LD 132             // padded row stride (floats) of the LDS tiles (as in namp_kernels.h)
+#endif
+#define TAIL_T 2
+#define TAIL_LDS (((2 * TAIL_T * 16) + 8 * 16) * FFN_LD * 4)
+
+// per-wave GEMM "A": out[q][4 tiles of this wave's 64 hidden units] = W (512 x 128 image) . rows of tile q (from LDS, fp32)
+template <int T>
+__device__ __forceinline__ void tail_gemm_A(f4 (&hacc)[T][4], const float* rows, const float* img, const int wave, const int lane) {
+  const int m = lane & 15, g = lane >> 4;
+  bf8 wh[4][4], wm[4][4];
+  const bf8* w = (const bf8*)img + (4 * wave) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) { wh[s][tn] = w[(s * 32 + tn) * 64]; wm[s][tn] = w[512 * 128 / 8 + (s * 32 + tn) * 64]; }
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float* xr = rows + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
+      bf8 hi, mid;
+      split_x3(*(const f4*)xr, *(const f4*)(xr + 16), hi, mid);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma_x3(wh[s][tn], wm[s][tn], hi, mid, hacc[q][tn]);
+    }
+  }
+}
+
+// per-wave GEMM "B" for ONE tile: partial[16 x 128] = W (128 x 512 image, this wave's two K-steps) . v (this wave's 64 units)
+__device__ __forceinline__ void tail_gemm_B(f4 (&oacc)[8], const f4 (&v)[4], const bf8 (&woh)[2][8], const bf8 (&wom)[2][8]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf8 hi, mid;
+    split_x3(v[2 * s], v[2 * s + 1], hi, mid);
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma_x3(woh[s][tn], wom[s][tn], hi, mid, oacc[tn]);
+  }
+}
+
+__device__ __forceinline__ void tail_load_B(bf8 (&woh)[2][8], bf8 (&wom)[2][8], const float* img, const int wave, const int lane) {
+  const bf8* w = (const bf8*)img + (2 * wave) * 8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) { woh[s][tn] = w[(s * 8 + tn) * 64]; wom[s][tn] = w[128 * 512 / 8 + (s * 8 + tn) * 64]; }
+}
+
+__global__ __launch_bounds__(512) void tail_train_fwd_kernel(const TailTrainArgs a) {
+  constexpr int T = TAIL_T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                       // [T][16][FFN_LD]  x1 = LN1(...)
+  float* ys = xs + T * 16 * FFN_LD;               // (unused in forward)
+  float* ps = ys + T * 16 * FFN_LD;               // [8][16][FFN_LD]  per-wave partial FFN outputs of the tile in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 16 * T;
+  // ---- phase 0: pre = h_V + dropout1(dh), LayerNorm1, one wave per tile
+  for (int q = wave; q < T; q += 8) {
+    const int row = row0 + 16 * q + m;
+    const int rr = row < a.G ? row : (a.G - 1);
+    f4 x[8];
+    const float* src = a.hV + (long)rr * NAMP_H + 4 * g;
+    const float* dsrc = a.dh + (long)rr * NAMP_H + 4 * g;
+    const uint32_t key = drop_row_key(a.seed1, rr);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      f4 d = *(const f4*)(dsrc + 16 * c);
+      if (a.drop_thresh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] *= drop_factor(key, 16 * c + 4 * g + r, a.drop_thresh, a.drop_scale);
+      }
+      x[c] = *(const f4*)(src + 16 * c) + d;
+    }
+    layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+      if (row < a.G) *(f4*)(a.x1 + (long)row * NAMP_H + 16 * c + 4 * g) = x[c];
+    }
+  }
+  __syncthreads();
+  // ---- phase A: z = W_in x1 + b_in (kept for the backward launch), hidden = gelu(z)
+  f4 hacc[T][4];
+#pragma unroll
+  for (int q = 0; q < T; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hacc[q][c] = *(const f4*)(a.b_in + 64 * wave + 16 * c + 4 * g);
+  tail_gemm_A<T>(hacc, xs, a.WA_ximg, wave, lane);
+  const long blk_off = (long)(wave >> 1) * a.G * NAMP_H + 64 * (wave & 1);      // block-major [4][G][128]
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const int row = row0 + 16 * q + m;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (row < a.G) *(f4*)(a.z + blk_off + (long)row * NAMP_H + 16 * c + 4 * g) = hacc[q][c];
+      hacc[q][c] = gelu4(hacc[q][c]);
+    }
+  }
+  // ---- phase B: f = W_out hidden + b_out, y = x1 + dropout2(f), LayerNorm2, mask
+  {
+    bf8 woh[2][8], wom[2][8];
+    tail_load_B(woh, wom, a.WB_ximg, wave, lane);
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      f4 oacc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) oacc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+      tail_gemm_B(oacc, hacc[q], woh, wom);
+      float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = oacc[c];
+      __syncthreads();
+      {   // thread -> (row = tid/32, 4 channels)
+        const int r = tid >> 5, c = (tid & 31) * 4;
+        const int orow = row0 + 16 * q + r;
+        const bool ok = orow < a.G;
+        f4 f = *(const f4*)(a.b_out + c);
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) f += *(const f4*)(ps + (w2 * 16 + r) * FFN_LD + c);
+        if (a.drop_thresh) {
+          const uint32_t key = drop_row_key(a.seed2, ok ? orow : 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] *= drop_factor(key, c + e, a.drop_thresh, a.drop_scale);
+        }
+        f4 v = *(const f4*)(xs + (q * 16 + r) * FFN_LD + c) + f;
+        if (ok) *(f4*)(a.y + (long)orow * NAMP_H + c) = v;
+        float s_ = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s_ += __shfl_xor(s_, o);
+        const float mean = s_ * (1.0f / 128.0f);
+        v -= mean;
+        float qq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) qq += __shfl_xor(qq, o);
+        const float rstd = rsqrtf(qq * (1.0f / 128.0f) + 1e-5f);
+        const float mk = (a.mask && ok) ? (float)a.mask[orow] : 1.0f;
+        const f4 o4 = (v * rstd * *(const f4*)(a.ln2_g + c) + *(const f4*)(a.ln2_b + c)) * mk;
+        if (ok) *(f4*)(a.out + (long)orow * NAMP_H + c) = o4;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void tail_train_bwd_kernel(const TailTrainArgs a) {
+  constexpr int T = TAIL_T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* gf = (float*)smem;                       // [T][16][FFN_LD]  g_f = dropout2-mask * g_y
+  float* gy = gf + T * 16 * FFN_LD;               // [T][16][FFN_LD]  g_y = dL/dy
+  float* ps = gy + T * 16 * FFN_LD;               // [8][16][FFN_LD]  per-wave partials of W_in^T g_z
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 16 * T;
+  const int r = tid >> 5, c = (tid & 31) * 4;     // row layout: thread -> (row, 4 channels)
+  f4 dg2 = (f4){0.f, 0.f, 0.f, 0.f}, db2 = dg2, dg1 = dg2, db1 = dg2;
+  // ---- phase 0: LayerNorm2 backward on the rows; g_f = dropout2 mask * g_y
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const int orow = row0 + 16 * q + r;
+    const bool ok = orow < a.G;
+    const long ro = (long)(ok ? orow : 0) * NAMP_H + c;
+    f4 v = *(const f4*)(a.y + ro);
+    const float mk = a.mask ? (float)a.mask[ok ? orow : 0] : 1.0f;
+    f4 go = ok ? *(const f4*)(a.g_out + ro) * mk : (f4){0.f, 0.f, 0.f, 0.f};
+    float s_ = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) s_ += __shfl_xor(s_, o);
+    const float mean = s_ * (1.0f / 128.0f);
+    v -= mean;
+    float qq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) qq += __shfl_xor(qq, o);
+    const float rstd = rsqrtf(qq * (1.0f / 128.0f) + 1e-5f);
+    const f4 xhat = v * rstd;
+    dg2 += go * xhat; db2 += go;
+    const f4 gg = go * *(const f4*)(a.ln2_g + c);
+    float m1 = (gg.x + gg.y) + (gg.z + gg.w), m2 = (gg.x * xhat.x + gg.y * xhat.y) + (gg.z * xhat.z + gg.w * xhat.w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    m1 *= (1.0f / 128.0f); m2 *= (1.0f / 128.0f);
+    const f4 gyv = (gg - m1 - xhat * m2) * rstd;
+    f4 gfv = gyv;
+    if (a.drop_thresh) {
+      const uint32_t key = drop_row_key(a.seed2, ok ? orow : 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gfv[e] *= drop_factor(key, c + e, a.drop_thresh, a.drop_scale);
+    }
+    *(f4*)(gy + (q * 16 + r) * FFN_LD + c) = gyv;
+    *(f4*)(gf + (q * 16 + r) * FFN_LD + c) = gfv;
+    if (ok) *(f4*)(a.g_f + ro) = gfv;
+  }
+  __syncthreads();
+  // ---- phase A: g_h = W_out^T g_f (this wave's 64 hidden units); g_z = g_h * gelu'(z); h = gelu(z)
+  f4 gz[T][4];
+#pragma unroll
+  for (int q = 0; q < T; ++q)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) gz[q][cc] = (f4){0.f, 0.f, 0.f, 0.f};
+  tail_gemm_A<T>(gz, gf, a.WA_ximg, wave, lane);
+  const long blk_off = (long)(wave >> 1) * a.G * NAMP_H + 64 * (wave & 1);
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const int row = row0 + 16 * q + m;
+    const bool ok = row < a.G;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const long off = blk_off + (long)(ok ? row : 0) * NAMP_H + 16 * cc + 4 * g;
+      f4 zz = *(const f4*)(a.z + off);
+      const f4 hv = gelu_split4(zz);                 // zz <- gelu'(z)
+      gz[q][cc] = ok ? gz[q][cc] * zz : (f4){0.f, 0.f, 0.f, 0.f};
+      if (ok) { *(f4*)(a.g_z + off) = gz[q][cc]; *(f4*)(a.h + off) = hv; }
+    }
+  }
+  // ---- phase B: g_x1 = g_y + W_in^T g_z, LayerNorm1 backward
+  {
+    bf8 woh[2][8], wom[2][8];
+    tail_load_B(woh, wom, a.WB_ximg, wave, lane);
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      f4 oacc[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) oacc[cc] = (f4){0.f, 0.f, 0.f, 0.f};
+      tail_gemm_B(oacc, gz[q], woh, wom);
+      float* dst = ps + (wave * 16 + m) * FFN_LD + 4 * g;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) *(f4*)(dst + 16 * cc) = oacc[cc];
+      __syncthreads();
+      {
+        const int orow = row0 + 16 * q + r;
+        const bool ok = orow < a.G;
+        const long ro = (long)(ok ? orow : 0) * NAMP_H + c;
+        f4 gx = *(const f4*)(gy + (q * 16 + r) * FFN_LD + c);
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) gx += *(const f4*)(ps + (w2 * 16 + r) * FFN_LD + c);
+        // recompute pre = h_V + dropout1(dh) and its LayerNorm1 statistics
+        f4 d = *(const f4*)(a.dh + ro);
+        f4 dm = (f4){1.f, 1.f, 1.f, 1.f};
+        if (a.drop_thresh) {
+          const uint32_t key = drop_row_key(a.seed1, ok ? orow : 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dm[e] = drop_factor(key, c + e, a.drop_thresh, a.drop_scale);
+        }
+        f4 v = *(const f4*)(a.hV + ro) + d * dm;
+        float s_ = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s_ += __shfl_xor(s_, o);
+        const float mean = s_ * (1.0f / 128.0f);
+        v -= mean;
+        float qq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) qq += __shfl_xor(qq, o);
+        const float rstd = rsqrtf(qq * (1.0f / 128.0f) + 1e-5f);
+        const f4 xhat = v * rstd;
+        if (!ok) gx = (f4){0.f, 0.f, 0.f, 0.f};
+        dg1 += gx * xhat; db1 += gx;
+        const f4 gg = gx * *(const f4*)(a.ln1_g + c);
+        float m1 = (gg.x + gg.y) + (gg.z + gg.w), m2 = (gg.x * xhat.x + gg.y * xhat.y) + (gg.z * xhat.z + gg.w * xhat.w);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        m1 *= (1.0f / 128.0f); m2 *= (1.0f / 128.0f);
+        const f4 gp = (gg - m1 - xhat * m2) * rstd;
+        if (ok) { *(f4*)(a.g_hV + ro) = gp; *(f4*)(a.g_dh + ro) = gp * dm; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- LayerNorm weight / bias gradients: this thread holds the sums over its T rows; add the 16 row-threads of a channel in
+  // a fixed order through LDS (ps is free): [kind][row-thread][128] -> thread (kind = tid / 128, channel = tid % 128)
+  float* red = ps;
+  *(f4*)(red + (0 * 16 + r) * NAMP_H + c) = dg2; *(f4*)(red + (1 * 16 + r) * NAMP_H + c) = db2;
+  *(f4*)(red + (2 * 16 + r) * NAMP_H + c) = dg1; *(f4*)(red + (3 * 16 + r) * NAMP_H + c) = db1;
+  __syncthreads();
+  {
+    const int kind = tid >> 7, ch = tid & 127;
+    float s_ = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) s_ += red[(kind * 16 + rr) * NAMP_H + ch];
+    a.part[(long)blockIdx.x * 4 * NAMP_H + tid] = s_;
+  }
+}

@@ -180,6 +180,61 @@ int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const 
   return scatter_rows_impl(G1, true, rev_edge, rev_off, sel, out0, out1, G, stream);
 }
 
+int namp_train_tail_groups(int G) { return G < 1 ? 0 : (G + 16 * TAIL_T - 1) / (16 * TAIL_T); }
+
+static int tail_attr() {
+  static std::once_flag once;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [] {
+    hipError_t e = hipFuncSetAttribute((const void*)tail_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tail_train_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
+    err = e;
+  });
+  if (err != hipSuccess) return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(tail_train): %s", hipGetErrorString(err));
+  return NAMP_OK;
+}
+
+int namp_train_tail_fwd(const float* h_V, const float* dh, const int32_t* mask, const float* ln1_g, const float* ln1_b,
+                        const float* Win_ximg, const float* b_in, const float* Wout_ximg, const float* b_out, const float* ln2_g,
+                        const float* ln2_b, float drop_p, uint32_t seed1, uint32_t seed2, float* out, float* x1, float* z, float* y,
+                        int G, void* stream) {
+  REQUIRE_PTR(h_V); REQUIRE_PTR(dh); REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_ximg); REQUIRE_PTR(b_in);
+  REQUIRE_PTR(Wout_ximg); REQUIRE_PTR(b_out); REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(out); REQUIRE_PTR(x1);
+  REQUIRE_PTR(z); REQUIRE_PTR(y);
+  REQUIRE(G >= 1, "namp_train_tail_fwd: G=%d", G);
+  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_tail_fwd: drop_p=%g must be in [0,1)", (double)drop_p);
+  int rc = tail_attr();
+  if (rc) return rc;
+  TailTrainArgs a = {};
+  a.hV = h_V; a.dh = dh; a.mask = mask; a.ln1_g = ln1_g; a.ln1_b = ln1_b; a.b_in = b_in; a.b_out = b_out; a.ln2_g = ln2_g; a.ln2_b = ln2_b;
+  a.WA_ximg = Win_ximg; a.WB_ximg = Wout_ximg; a.out = out; a.x1 = x1; a.z = z; a.y = y; a.G = G;
+  if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.seed1 = seed1; a.seed2 = seed2; a.drop_scale = 1.0f / (1.0f - drop_p); }
+  hipLaunchKernelGGL(tail_train_fwd_kernel, dim3(namp_train_tail_groups(G)), dim3(512), TAIL_LDS, (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_tail_bwd(const float* h_V, const float* dh, const int32_t* mask, const float* ln1_g, const float* ln2_g,
+                        const float* WoutT_ximg, const float* WinT_ximg, float drop_p, uint32_t seed1, uint32_t seed2,
+                        const float* x1, const float* z, const float* y, const float* g_out, float* g_hV, float* g_dh, float* g_f,
+                        float* g_z, float* h, float* part, int G, void* stream) {
+  REQUIRE_PTR(h_V); REQUIRE_PTR(dh); REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln2_g); REQUIRE_PTR(WoutT_ximg); REQUIRE_PTR(WinT_ximg);
+  REQUIRE_PTR(x1); REQUIRE_PTR(z); REQUIRE_PTR(y); REQUIRE_PTR(g_out); REQUIRE_PTR(g_hV); REQUIRE_PTR(g_dh); REQUIRE_PTR(g_f);
+  REQUIRE_PTR(g_z); REQUIRE_PTR(h); REQUIRE_PTR(part);
+  REQUIRE(G >= 1, "namp_train_tail_bwd: G=%d", G);
+  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_tail_bwd: drop_p=%g must be in [0,1)", (double)drop_p);
+  int rc = tail_attr();
+  if (rc) return rc;
+  TailTrainArgs a = {};
+  a.hV = h_V; a.dh = dh; a.mask = mask; a.ln1_g = ln1_g; a.ln2_g = ln2_g; a.WA_ximg = WoutT_ximg; a.WB_ximg = WinT_ximg;
+  a.x1 = (float*)x1; a.z = (float*)z; a.y = (float*)y; a.g_out = g_out; a.g_hV = g_hV; a.g_dh = g_dh; a.g_f = g_f; a.g_z = g_z; a.h = h;
+  a.part = part; a.G = G;
+  if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.seed1 = seed1; a.seed2 = seed2; a.drop_scale = 1.0f / (1.0f - drop_p); }
+  hipLaunchKernelGGL(tail_train_bwd_kernel, dim3(namp_train_tail_groups(G)), dim3(512), TAIL_LDS, (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_ln_rows_groups(long rows) {
   if (rows <= 0) return 0;
   long n = (rows + 63) / 64;               // >= 8 rows per sub-group pass, <= 8 workgroups per CU

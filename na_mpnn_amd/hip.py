@@ -104,6 +104,9 @@ _PROTOTYPES = {
     "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 21 + [i32, i32, i32, i32, vp]),
     "namp_train_scatter_rows": (i32, [c_fp, c_ip, c_ip, vp, c_fp, c_fp, i32, vp]),
     "namp_train_scatter_rows_bf16": (i32, [c_fp, c_ip, c_ip, vp, c_fp, c_fp, i32, vp]),
+    "namp_train_tail_groups": (i32, [i32]),
+    "namp_train_tail_fwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 8 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 4 + [i32, vp]),
+    "namp_train_tail_bwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 4 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 10 + [i32, vp]),
     "namp_train_ln_rows_groups": (i32, [C.c_long]),
     "namp_train_ln_rows_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),
     "namp_train_ln_rows_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),

@@ -519,6 +519,86 @@ class _RowLayerNorm(torch.autograd.Function):
         return gx, s[0], s[1]
 
 
+def _ximage_general(W, transposed=False, step=None):
+    """x3 image of a general [out_f x in_f] block (residue-level FFN weights; namp_pack_image_x3_general), cached per step."""
+    step = _STEP if step is None else step
+    use_cache = step is not None and step is _CACHE_STEP
+    key = (W.data_ptr(), W.stride(0), W.stride(1), W._version, "xg", transposed, W.device.index)
+    if use_cache and key in _IMG_CACHE:
+        return _IMG_CACHE[key]
+    Wc = (W.detach().t() if transposed else W.detach()).contiguous().float()
+    img = torch.empty(Wc.numel(), dtype=torch.float32, device=W.device)
+    hip.check(hip.lib().namp_pack_image_x3_general(Wc.data_ptr(), Wc.shape[1], 0, Wc.shape[0], Wc.shape[1], img.data_ptr(),
+                                                   hip.current_stream()), "pack_image_x3_general")
+    if use_cache:
+        _IMG_CACHE[key] = img
+    return img
+
+
+class _NodeTail(torch.autograd.Function):
+    """The residue tail of EncLayer / DecLayer (na_model_utils.py:236-247, 268-283) as one HIP launch each way:
+    out = mask * LayerNorm2(x1 + dropout2(W_out gelu(W_in x1 + b_in) + b_out)),  x1 = LayerNorm1(h_V + dropout1(dh)).
+    Dropout masks are counter-based hashes regenerated in backward; x1, z and the pre-LayerNorm2 rows are kept (37 MB per layer at
+    cfg5) instead of being recomputed; the four weight gradients go through the row-contraction kernel."""
+
+    @staticmethod
+    def forward(ctx, h_V, dh, mask32, ln1_w, ln1_b, W_in, b_in, W_out, b_out, ln2_w, ln2_b, p, seed1, seed2):
+        L = hip.lib()
+        shape = h_V.shape
+        hv, d = h_V.contiguous().view(-1, H), dh.contiguous().view(-1, H)
+        G = hv.shape[0]
+        dev = hv.device
+        out, x1, y = (torch.empty(G, H, device=dev) for _ in range(3))
+        z = torch.empty(4, G, H, device=dev)
+        c = lambda t: t.detach().contiguous()
+        l1w, l1b, l2w, l2b, bi, bo = c(ln1_w), c(ln1_b), c(ln2_w), c(ln2_b), c(b_in), c(b_out)
+        img_in, img_out = _ximage_general(W_in), _ximage_general(W_out)      # named: they must outlive the launch's enqueue
+        hip.check(L.namp_train_tail_fwd(hv.data_ptr(), d.data_ptr(), hip.ptr(mask32), l1w.data_ptr(), l1b.data_ptr(),
+                                        img_in.data_ptr(), bi.data_ptr(), img_out.data_ptr(),
+                                        bo.data_ptr(), l2w.data_ptr(), l2b.data_ptr(), float(p), int(seed1), int(seed2),
+                                        out.data_ptr(), x1.data_ptr(), z.data_ptr(), y.data_ptr(), G, hip.current_stream()),
+                  "train_tail_fwd")
+        ctx.p, ctx.seeds, ctx.shape, ctx.x3, ctx.step = float(p), (int(seed1), int(seed2)), shape, X3, _STEP
+        ctx.save_for_backward(hv, d, mask32, ln1_w, ln2_w, W_in, W_out, x1, z, y)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        hv, d, mask32, ln1_w, ln2_w, W_in, W_out, x1, z, y = ctx.saved_tensors
+        L = hip.lib()
+        G = hv.shape[0]
+        dev = hv.device
+        g = g.contiguous().view(G, H)
+        g_hV, g_dh, g_f = (torch.empty(G, H, device=dev) for _ in range(3))
+        g_z, h = torch.empty(4, G, H, device=dev), torch.empty(4, G, H, device=dev)
+        part = torch.empty(L.namp_train_tail_groups(G), 4, H, device=dev)
+        l1w, l2w = ln1_w.detach().contiguous(), ln2_w.detach().contiguous()
+        img_outT, img_inT = _ximage_general(W_out, True, ctx.step), _ximage_general(W_in, True, ctx.step)
+        hip.check(L.namp_train_tail_bwd(hv.data_ptr(), d.data_ptr(), hip.ptr(mask32), l1w.data_ptr(), l2w.data_ptr(),
+                                        img_outT.data_ptr(), img_inT.data_ptr(),
+                                        ctx.p, ctx.seeds[0], ctx.seeds[1], x1.data_ptr(), z.data_ptr(), y.data_ptr(), g.data_ptr(),
+                                        g_hV.data_ptr(), g_dh.data_ptr(), g_f.data_ptr(), g_z.data_ptr(), h.data_ptr(), part.data_ptr(),
+                                        G, hip.current_stream()), "train_tail_bwd")
+        res = _wgrad_many([(g_f, h[q], q == 0) for q in range(4)] + [(g_z[q], x1, True) for q in range(4)], x3=ctx.x3)
+        dW_out = torch.cat([res[q][0] for q in range(4)], 1)              # [128, 512]: column block q = g_f^T h_q
+        db_out = res[0][1]
+        dW_in = torch.cat([res[4 + q][0] for q in range(4)], 0)           # [512, 128]: row block q = g_z_q^T x1
+        db_in = torch.cat([res[4 + q][1] for q in range(4)], 0)
+        dln = part.sum(0)
+        return (g_hV.view(ctx.shape), g_dh.view(ctx.shape), None, dln[2], dln[3], dW_in, db_in, dW_out, db_out, dln[0], dln[1],
+                None, None, None)
+
+
+def _tail(h_V, dh, mask32, maskf, p, drop, drop_p):
+    """Residue tail of one layer: the fused HIP launches in the split-bf16 / mixed-precision modes, stock ops in exact fp32."""
+    if X3 and h_V.is_cuda:
+        s1, s2 = (torch.randint(0, 2 ** 31 - 1, (2,)).tolist() if drop_p > 0 else (0, 0))      # host RNG: follows torch.manual_seed
+        return _NodeTail.apply(h_V, dh, mask32, p.norm1.weight, p.norm1.bias, p.dense.W_in.weight, p.dense.W_in.bias,
+                               p.dense.W_out.weight, p.dense.W_out.bias, p.norm2.weight, p.norm2.bias, drop_p, s1, s2)
+    h_V = _ln(h_V + drop(dh), p.norm1)
+    return maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
+
+
 def _ffn(x, dense):
     """PositionWiseFeedForward (na_model_utils.py:286-296).  Mixed-precision mode: under bf16 autocast like the reference's
     training loop (na_run.py:217) — the two [B*N,128] x [128,512] library GEMMs run on the bf16 matrix pipe."""
@@ -560,8 +640,7 @@ def _forward_train(model, fd, decoding_randn):
         Pa, Pc = _lin(h_V, (W1[:, :H], p.W1.bias), (W1[:, 2 * H:], None))
         dh, h_E = _EdgeMLP.apply(ENC_MSG, h_E, Pa, Pc, None, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
                                  E_idx, mask32, None, None, rev)           # h_E: passed through to the edge update below
-        h_V = _ln(h_V + drop(dh), p.norm1)
-        h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
+        h_V = _tail(h_V, dh, mask32, maskf, p, drop, drop_p)
         Pa, Pc = _lin(h_V, (W11[:, :H], p.W11.bias), (W11[:, 2 * H:], None))
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # host RNG: follows torch.manual_seed
         h_E = _EdgeUpdate.apply(h_E, Pa, Pc, W11[:, H:2 * H], p.W12.weight, p.W12.bias, p.W13.weight, p.W13.bias,
@@ -581,8 +660,7 @@ def _forward_train(model, fd, decoding_randn):
         Pfw = _lin(h_V_enc, (W1[:, 3 * H:], None))[0]
         dh, h_E = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
                                  E_idx, None, None, rank32, rev)          # h_E: passed through to the next DecLayer
-        h_V = _ln(h_V + drop(dh), p.norm1)
-        h_V = maskf * _ln(h_V + drop(_ffn(h_V, p.dense)), p.norm2)
+        h_V = _tail(h_V, dh, mask32, maskf, p, drop, drop_p)
     logits = model.W_out(h_V)
     return F.log_softmax(logits, dim=-1), F.softmax(logits, dim=-1)
 
