@@ -287,7 +287,7 @@ def train_bench(args, dev, rank, world, dist):
             kern[ev.key] = (t_us / 1e3, ev.count)
     ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "wgrad_kernel", "feat_wgrad", "edge_features",
                                                                   "edge_mlp_kernel", "edge_mlp_x3_persistent", "edge_mlp_bf16", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
-                                                                  "prep_atoms", "wgrad_x3", "wgrad_bf16", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
+                                                                  "prep_atoms", "wgrad_x3", "wgrad_bf16", "tail_train", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
     total_dev_ms = sum(v[0] for v in kern.values())
     bwd = [(k, v) for k, v in ours.items() if "edge_chain_bwd" in k]
     bwd_ms = sum(v[0] for _, v in bwd); bwd_n = sum(v[1] for _, v in bwd)

@@ -364,6 +364,10 @@ int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int3
 /* Mixed-precision mode (precision code 2): the backward entry points write A1, A2, G1, G2, G3 as bf16 [E][128] row tensors
  * (plain channel order; the float* parameters then point at bf16 storage), namp_train_wgrad takes them with bit 4 (G is
  * bf16; required) / bit 5 (A is bf16) added to its precision argument, and the table-gradient gather reads G1 here. */
+/* n <= 8 row contractions over the SAME rows in one launch (fp32 row tensors; precision code 1 or 2): G[q], A[q], dW_part[q],
+ * db_part[q] (may be NULL) are host arrays of device pointers, each pair as in namp_train_wgrad. */
+int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, float* const* dW_part,
+                           float* const* db_part, void* stream);
 int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                                  float* out0, float* out1, int G, void* stream);
 /* Residue tail of EncLayer / DecLayer in training (na_model_utils.py:236-247, 268-283), one launch each way:

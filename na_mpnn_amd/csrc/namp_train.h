@@ -476,9 +476,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& mid) {
 
 // MID = false: plain bf16 products (hi . hi only) — the mixed-precision mode
 template <bool MID>
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
-                                                       long rows_per_chunk, float* __restrict__ dW_part,
-                                                       float* __restrict__ db_part) {
+__device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const float* __restrict__ A, long rows,
+                                              long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -552,6 +551,25 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
       if (g == 0) db_part[(long)blockIdx.x * NAMP_H + 16 * to0 + 4 * n + q] = s;
     }
   }
+}
+
+template <bool MID>
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
+                                                       long rows_per_chunk, float* __restrict__ dW_part,
+                                                       float* __restrict__ db_part) {
+  wgrad_x3_body<MID>(G, A, rows, rows_per_chunk, dW_part, db_part);
+}
+
+// Up to 8 contractions over the SAME rows in one launch (blockIdx.y = which): a residue tail's eight [24,000-row] weight-gradient
+// blocks would otherwise be eight launches of 47 workgroups each.
+struct WgradMulti { const float* G[8]; const float* A[8]; float* dW[8]; float* db[8]; };
+template <bool MID>
+__global__ __launch_bounds__(256) void wgrad_x3_multi_kernel(const WgradMulti m, long rows, long rows_per_chunk) {
+  const float* G = m.G[0]; const float* A = m.A[0]; float* dW = m.dW[0]; float* db = m.db[0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q)
+    if ((int)blockIdx.y == q) { G = m.G[q]; A = m.A[q]; dW = m.dW[q]; db = m.db[q]; }     // static indices: no kernarg spill
+  wgrad_x3_body<MID>(G, A, rows, rows_per_chunk, dW, db);
 }
 
 // wgrad_bf16_kernel: the row contraction of the mixed-precision mode on bf16 row tensors (G always bf16; A bf16 — A1 / A2 —

@@ -289,6 +289,28 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
   return NAMP_OK;
 }
 
+int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, float* const* dW_part,
+                           float* const* db_part, void* stream) {
+  REQUIRE(G && A && dW_part && db_part, "namp_train_wgrad_multi: null pointer table");
+  REQUIRE(n >= 1 && n <= 8, "namp_train_wgrad_multi: n=%d must be in [1,8]", n);
+  REQUIRE(x3 == 1 || x3 == 2, "namp_train_wgrad_multi: precision code %d (1 = split-bf16, 2 = bf16 products of fp32 rows)", x3);
+  REQUIRE(rows >= 1, "namp_train_wgrad_multi: rows=%ld", rows);
+  WgradMulti m = {};
+  for (int q = 0; q < 8; ++q) {
+    const int s_ = q < n ? q : 0;
+    REQUIRE_PTR(G[s_]); REQUIRE_PTR(A[s_]); REQUIRE_PTR(dW_part[s_]);
+    m.G[q] = G[s_]; m.A[q] = A[s_]; m.dW[q] = dW_part[s_]; m.db[q] = db_part[s_];
+  }
+  const int nchunk = namp_train_wgrad_chunks(rows);
+  long per = (rows + nchunk - 1) / nchunk;
+  per = (per + 31) / 32 * 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per);
+  else hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_feat_wgrad_chunks(long edges) {
   if (edges <= 0) return 0;
   long n = (edges + 4095) / 4096;          // finer chunks than the dense cost needs: the block sparsity makes workgroups uneven

@@ -112,6 +112,8 @@ _PROTOTYPES = {
     "namp_train_ln_rows_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),
     "namp_train_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_wgrad": (i32, [c_fp, c_fp, i32, i32, C.c_long, c_fp, c_fp, vp]),
+    "namp_train_wgrad_multi": (i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, i32, C.c_long, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), vp]),
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
     "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, i32, vp]),

@@ -108,7 +108,19 @@ def _wgrad_many(pairs, x3=None):
     prec = int(X3 if x3 is None else x3)
     tmp = torch.empty(k, n, H, H, device=dev)
     tmpb = torch.empty(k, n, H, device=dev)
-    for q, (G, A, wb) in enumerate(pairs):
+    if prec in (1, 2) and all(G.dtype == torch.float32 and A.dtype == torch.float32 for G, A, _ in pairs):
+        # fp32 row tensors, split-bf16 / bf16 products: up to 8 contractions per launch
+        for q0 in range(0, k, 8):
+            grp = pairs[q0:q0 + 8]
+            arr = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
+            hip.check(L.namp_train_wgrad_multi(arr([G.data_ptr() for G, _, _ in grp]), arr([A.data_ptr() for _, A, _ in grp]), len(grp),
+                                               prec, rows, arr([tmp[q0 + i].data_ptr() for i in range(len(grp))]),
+                                               arr([(tmpb[q0 + i].data_ptr() if grp[i][2] else None) for i in range(len(grp))]),
+                                               hip.current_stream()), "train_wgrad_multi")
+        pairs_done = True
+    else:
+        pairs_done = False
+    for q, (G, A, wb) in enumerate(() if pairs_done else pairs):
         assert G.shape[0] == rows
         code = prec
         if G.dtype == torch.bfloat16:                       # the mixed-precision backward's bf16 row tensors
