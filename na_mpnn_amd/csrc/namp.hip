@@ -213,6 +213,7 @@ int launch_edge_bf16_persistent(EdgeArgs a, hipStream_t s) {
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
+  if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
   hipLaunchKernelGGL((edge_mlp_bf16_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
   return NAMP_OK;
 }
@@ -224,6 +225,7 @@ int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
+  if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
   hipLaunchKernelGGL((edge_mlp_x3_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 2 * NAMP_IMG_BYTES, s, a);
   return NAMP_OK;
 }
@@ -235,6 +237,8 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   if (rc) return rc;
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
+  if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
+  // 12 waves per CU; 16 (1,024 threads, 128 VGPRs) measured the same: the launch is instruction-issue bound, not latency bound
   hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
   return NAMP_OK;
 }
@@ -340,7 +344,7 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   fill_tail(a.t, ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, hV, mask, hV_out, proj, nproj, S);
   a.partial = partial; a.G = G; a.TPN = TPN;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
-  // 4 tiles would halve the stream again but spill: 64 accumulator VGPRs of hidden state next to 128 of weights)
+  // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
   if (x3)                      // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
     hipLaunchKernelGGL((node_update_multi_kernel<2, true>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
   else if (G >= 32 * 2 * device_cus())
@@ -830,8 +834,10 @@ int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const floa
   if (!Wout_b || !log_probs) return fail(NAMP_EINVAL, "namp_logits_log_softmax: null pointer");
   REQUIRE(G >= 1 && vocab >= 1 && vocab <= 64, "namp_logits_log_softmax: vocab=%d must be in [1,64]", vocab);
   ProfScope prof_(NAMP_KIND_LOGITS, (hipStream_t)stream);
-  hipLaunchKernelGGL(logits_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, h_V, Wout_w, Wout_b,
-                     log_probs, logits, G, vocab);
+  int per_wg = (G + 2 * device_cus() - 1) / (2 * device_cus());            // ~2 workgroups per CU; W_out is staged once per workgroup
+  per_wg = (per_wg + 3) / 4 * 4;
+  hipLaunchKernelGGL(logits_kernel, dim3((G + per_wg - 1) / per_wg), dim3(256), (size_t)32 * vocab * 16, (hipStream_t)stream, h_V,
+                     Wout_w, Wout_b, log_probs, logits, G, vocab, per_wg);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

@@ -65,6 +65,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 //   NAMP_ABL_NOGEMM   : 128x128 tile GEMMs -> acc += x      NAMP_ABL_X1 : split-bf16 GEMMs keep only the hi.hi product
 //   NAMP_ABL_NOSTORE  : fused edge update keeps its rows in registers only   NAMP_ABL_NOLN : LayerNorms -> identity
 //   NAMP_ABL_NOTABLE2 : fused launches skip the second (message) table gather
+//   NAMP_ABL_NOLDSW   : bf16 chain GEMMs take their weight fragment from registers (no ds_read)
 //   NAMP_ABL_NODMA    : no weight staging (LDS holds garbage)  NAMP_ABL_NOTAIL : fused residue tail -> plain store
 __device__ __forceinline__ f4 gelu4(f4 v) {
 #ifdef NAMP_ABL_NOGELU
@@ -160,9 +161,18 @@ __device__ __forceinline__ void chain_gemm_bf16(f4 (&acc)[8], const f4 (&x)[8], 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const bf8 xb = pack_bf16<ACT>(x[2 * s], x[2 * s + 1]);
+#ifdef NAMP_ABL_NOGEMM
+    acc[s].x += (float)xb[0] + (float)xb[5]; acc[s + 4].y += (float)xb[2] + (float)xb[7];
+    acc[s].z += (float)xb[1] + (float)xb[4]; acc[s + 4].w += (float)xb[3] + (float)xb[6];
+    continue;
+#endif
 #pragma unroll
     for (int tn = 0; tn < 8; ++tn) {
+#ifdef NAMP_ABL_NOLDSW
+      bf8 wf = xb; wf[0] = (__bf16)(float)(s * 8 + tn);
+#else
       const bf8 wf = w[(s * 8 + tn) * 64];
+#endif
       if (FLIP) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, wf, acc[tn], 0, 0, 0);
       else      acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb, acc[tn], 0, 0, 0);
     }

@@ -568,7 +568,8 @@ struct EdgeArgs {
   const float* eb2; const float* eb3;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // ENC_EDGE, training only: dropout on the message (thresh 0 = off)
   // bf16 STORAGE (throughput mode on large batches, edge_mlp_bf16s_kernel): rows of 128 bf16 in fragment order
-  // [g][s][j] <-> channel 32s + 16(j>>2) + 4g + (j&3), i.e. lane (m, g) owns one contiguous 64-byte segment of its row
+  // [s][g][j] <-> channel 32s + 16(j>>2) + 4g + (j&3): 16-byte piece (s, g) is what lane (m, g) feeds into MFMA step s, and the four
+  // lanes of a row cover one contiguous 64-byte segment per load / store instruction
   const __bf16* hE16; __bf16* hE16_out;
   const __bf16* Pa16; const __bf16* Pj016; const __bf16* Pj116;
   float* partial;              // MSG modes without the fused tail: [G][TPN][128]
@@ -812,10 +813,10 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   }
   if (MODE == MODE_EMBED) {
     if (valid) {
-      if (a.hE16_out) {                 // bf16 storage in fragment order: this lane's 32 channels are one 64-byte segment
-        bf8* dst = (bf8*)(a.hE16_out + erow * NAMP_H + 32 * g);
+      if (a.hE16_out) {                 // bf16 storage in fragment order: piece (s, g) of the row = this lane's operand of MFMA step s
+        bf8* dst = (bf8*)(a.hE16_out + erow * NAMP_H) + g;
 #pragma unroll
-        for (int sq = 0; sq < 4; ++sq) dst[sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
       } else {
         float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1065,8 +1066,8 @@ struct TileMeta {
 template <int MODE>
 __device__ __forceinline__ TileMeta tile_meta(const EdgeArgs& a, long tile, int m, int g) {
   TileMeta t;
-  t.node = (int)(tile / a.TPN);
-  t.kt = (int)(tile - (long)t.node * a.TPN);
+  t.node = (int)((unsigned)tile / (unsigned)a.TPN);       // G * TPN < 2^31 (checked by the launchers): no 64-bit division
+  t.kt = (int)tile - t.node * a.TPN;
   const int b_dec = t.node / a.N;
   const int i_loc = t.node - b_dec * a.N;
   const int node_enc = (MODE == MODE_DEC_MSG) ? ((b_dec % (a.G_enc / a.N)) * a.N + i_loc) : t.node;
@@ -1352,16 +1353,18 @@ struct SampleRows {             // tile row n -> residue of stream (b0 + n) at t
 
 // ------------------------------------------------------------------------------------------
 // bf16 STORAGE variant of the persistent throughput kernel.  With bf16 MFMA the large-batch launches are bound by the
-// bytes of h_E and of the gathered table rows, so those are kept in bf16 too — in FRAGMENT ORDER: position [g][s][j] of a
+// bytes of h_E and of the gathered table rows, so those are kept in bf16 too — in FRAGMENT ORDER: position [s][g][j] of a
 // row holds channel 32s + 16(j>>2) + 4g + (j&3), which is at once (i) the 8 values lane (m, g) feeds into MFMA step s and
-// (ii) its fp32 accumulators (tile 2s + (j>>2), element j&3).  Every per-row access is therefore one contiguous 64-byte
-// segment per lane (256 B per row, four 16-byte loads), GEMM-1 operands need no conversion at all, and the edge update
-// writes rows in the order the next launch reads them.  fp32 accumulation, fp32 LayerNorm / K-sum / residue tail.
+// (ii) its fp32 accumulators (tile 2s + (j>>2), element j&3).  A row access is four 16-byte loads / stores per lane, and in
+// each of them the four lanes (g = 0..3) of a row cover 64 contiguous bytes (the first layout, [g][s][j], gave every lane its
+// own 64-byte segment: 16 bytes out of every 64 per instruction, four times the memory requests — the updated rows'
+// stores ran at 2.4 TB/s).  GEMM-1 operands need no conversion at all, and the edge update writes rows in the order the next
+// launch reads them.  fp32 accumulation, fp32 LayerNorm / K-sum / residue tail.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bf16_row_to_f32(f4 (&out)[8], const __bf16* __restrict__ seg) {
+__device__ __forceinline__ void bf16_row_to_f32(f4 (&out)[8], const __bf16* __restrict__ row, const int g) {
 #pragma unroll
   for (int sq = 0; sq < 4; ++sq) {
-    const bf8 v = *(const bf8*)(seg + 8 * sq);
+    const bf8 v = ((const bf8*)row)[4 * sq + g];
     out[2 * sq] = (f4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     out[2 * sq + 1] = (f4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
   }
@@ -1373,11 +1376,11 @@ static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte output piece: (row, g, s)
   if (e >= c.rows * 16) return;
   const long row = e >> 4;
-  const int g = (int)(e >> 2) & 3, sq = (int)e & 3;
+  const int sq = (int)(e >> 2) & 3, g = (int)e & 3;                  // consecutive threads write consecutive pieces
   for (int q = 0; q < c.n; ++q) {
     const float* s0 = c.src[q] + row * NAMP_H + 32 * sq + 4 * g;
     const f4 lo = *(const f4*)s0, hi = *(const f4*)(s0 + 16);
-    *(bf8*)(c.dst[q] + row * NAMP_H + 32 * g + 8 * sq) = pack_bf16<false>(lo, hi);
+    *(bf8*)(c.dst[q] + row * NAMP_H + 8 * (4 * sq + g)) = pack_bf16<false>(lo, hi);
   }
 }
 
@@ -1394,9 +1397,9 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
   TileMeta cur = tile_meta<MODE>(a, tile < ntiles ? tile : 0, m, g);
   bf8 xn[4];
   {
-    const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H + 32 * g);
+    const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
 #pragma unroll
-    for (int sq = 0; sq < 4; ++sq) xn[sq] = src[sq];
+    for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
   }
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
@@ -1410,20 +1413,39 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
     for (int sq = 0; sq < 4; ++sq) xb[sq] = xn[sq];
     const TileMeta me = cur;
     f4 acc[8], pjv[8];
-    bf16_row_to_f32(acc, a.Pa16 + me.pa_row * NAMP_H + 32 * g);
-    bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H + 32 * g);
+#ifdef NAMP_ABL_NOPROLOG
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc[t] = (f4){0.01f * lane, 0.02f, 0.03f * t, 0.04f}; pjv[t] = (f4){0.1f, 0.01f * lane, 0.3f, 0.2f * t}; }
+    const long nt = tile + stride;
+    cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
+#else
+    bf16_row_to_f32(acc, a.Pa16 + me.pa_row * NAMP_H, g);
+    bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H, g);
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
     {
-      const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H + 32 * g);
+      const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
 #pragma unroll
-      for (int sq = 0; sq < 4; ++sq) xn[sq] = src[sq];
+      for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
     }
+#endif
     // layer 1: the stored row IS the MFMA operand
+#ifdef NAMP_ABL_NOGEMM
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) { acc[sq].x += (float)xb[sq][0]; acc[sq + 4].y += (float)xb[sq][7]; }
+#else
 #pragma unroll
     for (int sq = 0; sq < 4; ++sq)
 #pragma unroll
-      for (int tn = 0; tn < 8; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[(sq * 8 + tn) * 64], xb[sq], acc[tn], 0, 0, 0);
+      for (int tn = 0; tn < 8; ++tn) {
+#ifdef NAMP_ABL_NOLDSW
+        bf8 wf = xb[sq]; wf[0] = (__bf16)(float)(sq * 8 + tn);
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[sq], acc[tn], 0, 0, 0);
+#else
+        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[(sq * 8 + tn) * 64], xb[sq], acc[tn], 0, 0, 0);
+#endif
+      }
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
     f4 (&y)[8] = pjv;
@@ -1441,9 +1463,9 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
       }
       layernorm_row_T(acc, a.ln_g, a.ln_b, g);
       if (me.valid) {
-        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H + 32 * g);
+        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + g;
 #pragma unroll
-        for (int sq = 0; sq < 4; ++sq) dst[sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
       }
     } else {
 #pragma unroll
@@ -2101,37 +2123,46 @@ static __global__ __launch_bounds__(256) void dec_ctx_message_kernel(const DecCt
 
 // ------------------------------------------------------------------------------------------
 // logits_kernel — log_softmax(W_out . h_V + b) over the 33-letter vocabulary
-// (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.
+// (model_utils.py:420-421).  One wave per residue; lane t < V owns logit t.  W_out is staged once per workgroup in LDS as
+// [channel / 4][token] 16-byte pieces, so the 32 reads of a dot product are conflict-free ds_read_b128 (read straight from
+// global memory, lane t walks row t: 33 cache lines per load instruction — 195 us for 64,000 residues, now 1/8 of that);
+// a workgroup serves `per_wg` residues.  Same summation order as before: results unchanged.
 // ------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ hV, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ log_probs,
-                                                     float* __restrict__ logits_out, int G, int V) {
+                                                     float* __restrict__ logits_out, int G, int V, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4* wl = (f4*)smem;                                                      // [32][V]
   const int lane = threadIdx.x & 63;
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= G) return;
-  const float* h = hV + (long)node * NAMP_H;
-  float z = -INFINITY;
-  if (lane < V) {
-    const float* w = W + (long)lane * NAMP_H;
+  for (int idx = threadIdx.x; idx < 32 * V; idx += 256) {
+    const int c4 = idx / V, t = idx - c4 * V;
+    wl[idx] = *(const f4*)(W + (long)t * NAMP_H + 4 * c4);
+  }
+  __syncthreads();
+  const int first = blockIdx.x * per_wg, last = min(G, first + per_wg);
+  const float b = lane < V ? bias[lane] : 0.f;
+  const f4* wt = wl + (lane < V ? lane : 0);
+  for (int node = first + (threadIdx.x >> 6); node < last; node += 4) {
+    const float* h = hV + (long)node * NAMP_H;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < NAMP_H; c += 4) {
-      const f4 wv = *(const f4*)(w + c);
-      const f4 hv = *(const f4*)(h + c);
+    for (int c4 = 0; c4 < NAMP_H / 4; ++c4) {
+      const f4 wv = wt[c4 * V];
+      const f4 hv = *(const f4*)(h + 4 * c4);
       s0 = fmaf(wv.x, hv.x, s0); s1 = fmaf(wv.y, hv.y, s1);
       s2 = fmaf(wv.z, hv.z, s2); s3 = fmaf(wv.w, hv.w, s3);
     }
-    z = (s0 + s1) + (s2 + s3) + bias[lane];
-  }
-  float mx = z;
+    const float z = lane < V ? (s0 + s1) + (s2 + s3) + b : -INFINITY;
+    float mx = z;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float e = (lane < V) ? expf(z - mx) : 0.f;
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = (lane < V) ? expf(z - mx) : 0.f;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
-  if (lane < V) {
-    log_probs[(long)node * V + lane] = (z - mx) - logf(e);
-    if (logits_out) logits_out[(long)node * V + lane] = z;
+    for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+    if (lane < V) {
+      log_probs[(long)node * V + lane] = (z - mx) - logf(e);
+      if (logits_out) logits_out[(long)node * V + lane] = z;
+    }
   }
 }
 

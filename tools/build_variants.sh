@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build ablation variants of libnamp_hip.so into tools/_variants/ (git-ignored; ships with the gpurun snapshot).
-# Only namp.hip is recompiled per variant; the training objects come from the regular build (na_mpnn_amd/lib/obj).
+# Only namp.hip is recompiled per variant; the other objects come from the regular build (na_mpnn_amd/lib/obj).
+#   tools/build_variants.sh name:-DFLAG[,-DFLAG2] ...        (default: the bf16 storage kernel's ablation set)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_variants
@@ -8,11 +9,16 @@ mkdir -p tools/_variants
 build() {
   name=$1; shift
   ( timeout 1500 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c na_mpnn_amd/csrc/namp.hip -o tools/_variants/$name.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/_variants/$name.o na_mpnn_amd/lib/obj/namp_train.o -o tools/_variants/$name.so &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/_variants/$name.o na_mpnn_amd/lib/obj/namp_train.o na_mpnn_amd/lib/obj/namp_persist.o -o tools/_variants/$name.so &&
     rm -f tools/_variants/$name.o ) &
 }
-build gscalar -DNAMP_GELU_SCALAR
-build noslp -fno-slp-vectorize
-build gscalar_noslp -DNAMP_GELU_SCALAR -fno-slp-vectorize
+if [ $# -eq 0 ]; then
+  set -- nogelu:-DNAMP_ABL_NOGELU nogemm:-DNAMP_ABL_NOGEMM noldsw:-DNAMP_ABL_NOLDSW noprolog:-DNAMP_ABL_NOPROLOG \
+         nogemm_nogelu:-DNAMP_ABL_NOGEMM,-DNAMP_ABL_NOGELU skeleton:-DNAMP_ABL_NOGEMM,-DNAMP_ABL_NOGELU,-DNAMP_ABL_NOPROLOG
+fi
+for v in "$@"; do
+  name=${v%%:*}; flags=${v#*:}
+  build $name ${flags//,/ }
+done
 wait
 ls -la tools/_variants
