@@ -149,9 +149,12 @@ int namp_node_linear(const float* X, const int32_t* S, int B_out, int B_src, int
 int namp_edge_embed(const float* We_img, const float* We_b, const float* E, float* h_E,
                     int B, int N, int K, void* stream);
 
-/* Message phase of EncLayer (model_utils.py:684-690): partial[n][t][:] = sum over the t-th
- * 16-neighbour tile of mask_i*mask_j/30 * W3.gelu(W2.gelu(W1.[h_V_i|h_E_ik|h_V_j])).
- * Pa = W1a.h_V + b1 and Pc = W1c.h_V come from namp_node_linear.  partial: [B*N][ceil(K/16)][128].
+/* Message phase of EncLayer (model_utils.py:684-690).  The last layer of the message MLP is linear and is followed by a
+ * weighted sum over the K neighbours, so it is applied AFTER that sum, once per residue, by the residue kernel:
+ *     sum_k w_k (W3 a_k + b3) = W3 (sum_k w_k a_k) + b3 sum_k w_k,   a_k = gelu(W2.gelu(W1.[h_V_i|h_E_ik|h_V_j])), w_k = mask_i*mask_j/30.
+ * partial holds, for T = ceil(K/16) 16-neighbour tiles per residue,  [B*N][T][128] floats  sum_{k in tile} w_k a_k  followed by
+ * [B*N][T] floats  sum_{k in tile} w_k  — (B*N*T*129 floats in all); namp_node_update(..., partial, W3_img, b3, ...) finishes it.
+ * Pa = W1a.h_V + b1 and Pc = W1c.h_V come from namp_node_linear.
  * mask_attend may be NULL (then mask_i*mask_j, as every reference call site passes). */
 int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
                      const int32_t* mask_attend, const float* Pa, const float* Pc, float* partial,
@@ -161,12 +164,15 @@ int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_
 int namp_enc_edge_update(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx,
                          const float* Pa, const float* Pc, float* h_E_out, int B, int N, int K, void* stream);
 /* Residue tail shared by EncLayer / DecLayer (model_utils.py:690-697, 646-656):
- * h_V' = mask * LN2(x + FFN(x)),  x = LN1(h_V + sum_t partial[n][t]),
+ * h_V' = mask * LN2(x + FFN(x)),  x = LN1(h_V + dh),
+ *   dh = m3 . sum_t partial[n][t] + m3_b * sum_t wsum[n][t]   when m3_img (fp32 image of the message MLP's W3, + bias m3_b) is given
+ *        (partial as written by namp_enc_message / namp_dec_message: K-sums followed by their weight sums),
+ *   dh = sum_t partial[n][t]                                   when m3_img is NULL (partial [G][T][128] holds whole messages),
  * fused with nproj (0..8) projections of h_V' (as namp_node_linear) that the next edge kernels gather. */
 int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                      const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
-                     const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream);
+                     const float* h_V, const float* partial, const float* m3_img, const float* m3_b, const int32_t* mask,
+                     float* h_V_out, const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream);
 /* Message phase of DecLayer on the implicit context h_ESV (model_utils.py:416-418, 640-646):
  * first layer = W1e.h_E_ik + Pa[i] + (rank[j]<rank[i] ? Pbw[j] : Pfw[j]).  Decoder batch b uses
  * encoder batch b % B_enc (the reference's .repeat(B_decoder, ...), model_utils.py:399-404). */
@@ -308,19 +314,19 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  * All images are fp32 fragment images (namp_pack_image) — or, with x3 != 0, x3 images (namp_pack_image_x3: the GEMMs then
  * run as split-bf16 products like the forward path's default mode); "t" images are those of the transposed blocks.
  *
- * namp_train_edge_fwd: the forward of one per-edge MLP from raw images.  mode 0/1: out = partial sums
- *   [B*N][ceil(K/16)][128] (as namp_enc_message / namp_dec_message; B_dec == B_enc); mode 2: out = per edge [B*N*K][128]
+ * namp_train_edge_fwd: the forward of one per-edge MLP from raw images.  mode 0/1: out = the K-sums of the layer-2 activations
+ *   and their weight sums, [B*N][ceil(K/16)][128] + [B*N][ceil(K/16)] floats (as namp_enc_message / namp_dec_message;
+ *   B_dec == B_enc; W3_img / b3 are not read: the caller applies layer 3 per residue, dh = W3 . sum_t S[t] + b3 sum_t w[t]);
+ *   mode 2: out = per edge [B*N*K][128]
  *   either the bare message W13.gelu(W12.gelu(W11.[..])) + b13 (ln_g NULL, drop_p 0) or the finished edge update (below).
- * namp_train_edge_bwd: given g_out = dL/d(sum_k message) [B*N][128] (modes 0/1; the 1/30 scale and mask_attend are
- *   applied inside) or dL/d(message) per edge [B*N*K][128] (mode 2), recompute the chain and write per edge row
- *   the activations A1 = gelu(z1), A2 = gelu(z2), the gradients G1 = dL/dz1, G2 = dL/dz2, G3 = dL/dz3 (modes 0/1 only;
- *   mode 2: G3 == g_out) and g_hE = dL/dh_E.  Then dW3 = G3^T A2, dW2 = G2^T A1, dW1b = G1^T h_E (namp_train_wgrad),
- *   db3 = sum G3, db2 = sum G2, dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k] — the last two are accumulated by the
+ * namp_train_edge_bwd: given g_out = dL/d(sum_k w_k a2_k) [B*N][128] (modes 0/1: the gradient of the K-sum the forward wrote,
+ *   i.e. W3^T dL/d(dh); the 1/30 scale and mask_attend are applied inside; W3t_img, A2, G3, S3, w3 are not used and may be NULL)
+ *   or dL/d(message) per edge [B*N*K][128] (mode 2), recompute the chain and write per edge row the activations
+ *   A1 = gelu(z1), A2 = gelu(z2) (mode 2), the gradients G1 = dL/dz1, G2 = dL/dz2 (mode 2: G3 == g_out) and g_hE = dL/dh_E.
+ *   Then dW2 = G2^T A1, dW1b = G1^T h_E (mode 2 also dW3 = G3^T A2) by namp_train_wgrad, db2 = sum G2;
+ *   dL/dPa[i] = sum_k G1[i,k], dL/dPj[j] += G1[i,k] — the last two are accumulated by the
  *   launch itself with fp32 atomics into g_Pa / g_Pj0 (/ g_Pj1: rows that gathered Pfw) when those ZEROED [B*N][128]
  *   buffers are given (each optional; NULL: the caller reduces G1 — namp_train_scatter_rows does dL/dPj without atomics).
- *   S3 / w3 (optional, modes 0/1 with K % 16 == 0; A2 and G3 may then be NULL and are not written): in a message mode
- *   G3[i,k] = w_ik g_out[i], hence dW3 = g_out^T . S with S[i] = sum_k w_ik A2[i,k] and db3 = sum_i g_out[i] sum_k w_ik; the
- *   launch writes per 16-row tile t = (i, k/16) the sums S3[t][128] and w3[t] — the caller adds a residue's K/16 tiles.
  *   The `x3` argument of the namp_train_* entry points is a precision code: 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain
  *   bf16 products (mixed-precision training).  For namp_train_edge_bwd, adding 4 makes the launch ADD its dL/dh_E to the rows
  *   already in g_hE (another consumer's gradient of the same h_E) instead of overwriting them; adding 8 (both backward

@@ -300,6 +300,7 @@ void fill_tail(NodeTail& t, const float* ln1_g, const float* ln1_b, const float*
   t.hV = hV; t.mask = mask; t.ln1_g = ln1_g; t.ln1_b = ln1_b; t.Win_img = Win_img; t.b_in = b_in;
   t.Wout_img = Wout_img; t.b_out = b_out; t.ln2_g = ln2_g; t.ln2_b = ln2_b; t.hV_out = hV_out; t.S = S;
   t.head_w = nullptr; t.head_b = nullptr; t.log_probs = nullptr; t.logits = nullptr; t.vocab = 0;
+  t.m3_img = nullptr; t.m3_b = nullptr;
   t.nproj = nproj;
   for (int i = 0; i < 8; ++i) {
     if (i < nproj) { t.p[i].img = proj[i].img; t.p[i].bias = proj[i].bias; t.p[i].tok = proj[i].tok; t.p[i].out = proj[i].out; }
@@ -336,12 +337,14 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
 
 int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                        const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                       const float* hV, const float* partial, const int32_t* mask, float* hV_out,
-                       const NampProj* proj, int nproj, const int32_t* S, int G, int TPN, hipStream_t s, bool x3 = false) {
+                       const float* hV, const float* partial, const float* m3_img, const float* m3_b, const int32_t* mask,
+                       float* hV_out, const NampProj* proj, int nproj, const int32_t* S, int G, int TPN, hipStream_t s,
+                       bool x3 = false) {
   int rc = ensure_attributes();
   if (rc) return rc;
   NodeUpdateArgs a;
   fill_tail(a.t, ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, hV, mask, hV_out, proj, nproj, S);
+  a.t.m3_img = partial ? m3_img : nullptr; a.t.m3_b = m3_b;      // (x3: the x3 image of W3)
   a.partial = partial; a.G = G; a.TPN = TPN;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
@@ -642,16 +645,17 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
 
 int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                      const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                     const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
-                     const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
+                     const float* h_V, const float* partial, const float* m3_img, const float* m3_b, const int32_t* mask,
+                     float* h_V_out, const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
   REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_img); REQUIRE_PTR(b_in); REQUIRE_PTR(Wout_img);
   REQUIRE_PTR(b_out); REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out);
-  OPTIONAL_PTR(partial);
+  OPTIONAL_PTR(partial); OPTIONAL_PTR(m3_img); OPTIONAL_PTR(m3_b);
+  REQUIRE(!m3_img || (partial && m3_b), "namp_node_update: m3_img needs partial (K-sums + weight sums) and m3_b");
   REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_node_update: bad dims G=%d K=%d", G, K);
   int rc = check_proj(__func__, proj, nproj, S);
   if (rc) return rc;
   ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
-  rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out,
+  rc = launch_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, m3_img, m3_b, mask, h_V_out,
                               proj, nproj, S, G, (K + 15) / 16, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
@@ -663,16 +667,18 @@ int namp_node_update(const float* ln1_g, const float* ln1_b, const float* Win_im
 static int node_update_auto(int64_t flags, const float* Win_ximg, const float* Wout_ximg, const float* const* proj_ximg,
                             const float* ln1_g, const float* ln1_b, const float* Win_img, const float* b_in,
                             const float* Wout_img, const float* b_out, const float* ln2_g, const float* ln2_b,
-                            const float* h_V, const float* partial, const int32_t* mask, float* h_V_out,
+                            const float* h_V, const float* partial, const float* m3_img, const float* m3_ximg, const float* m3_b,
+                            const int32_t* mask, float* h_V_out,
                             const NampProj* proj, int nproj, const int32_t* S, int G, int K, void* stream) {
 #ifndef NAMP_NODE_X3_MIN_RESIDUES
 #define NAMP_NODE_X3_MIN_RESIDUES 2500   // the whole unfused regime: 3-12 % per forward at 3,000-16,000 residues (tools/batch_sweep.py)
 #endif
-  bool x3 = prec_of(flags) != PREC_F32 && Win_ximg && Wout_ximg && G >= NAMP_NODE_X3_MIN_RESIDUES && nproj <= 8;
+  bool x3 = prec_of(flags) != PREC_F32 && Win_ximg && Wout_ximg && G >= NAMP_NODE_X3_MIN_RESIDUES && nproj <= 8 && (!m3_img || m3_ximg);
   for (int i = 0; x3 && i < nproj; ++i) x3 = proj_ximg && proj_ximg[i] != nullptr;
   if (!x3)
-    return namp_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out, proj, nproj,
-                            S, G, K, stream);
+    return namp_node_update(ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, h_V, partial, m3_img, m3_b, mask, h_V_out,
+                            proj, nproj, S, G, K, stream);
+  OPTIONAL_PTR(m3_ximg); OPTIONAL_PTR(m3_b);
   REQUIRE_PTR(ln1_g); REQUIRE_PTR(ln1_b); REQUIRE_PTR(Win_ximg); REQUIRE_PTR(b_in); REQUIRE_PTR(Wout_ximg); REQUIRE_PTR(b_out);
   REQUIRE_PTR(ln2_g); REQUIRE_PTR(ln2_b); REQUIRE_PTR(h_V); REQUIRE_PTR(h_V_out); OPTIONAL_PTR(partial);
   REQUIRE(G >= 1 && K >= 1 && K <= NAMP_MAX_K, "node_update: bad dims G=%d K=%d", G, K);
@@ -683,8 +689,8 @@ static int node_update_auto(int64_t flags, const float* Win_ximg, const float* W
     REQUIRE(!(px[i].tok && !S), "node_update: proj[%d].tok given but S is null", i);
   }
   ProfScope prof_(NAMP_KIND_NODE_UPDATE, (hipStream_t)stream);
-  int rc = launch_node_update(ln1_g, ln1_b, Win_ximg, b_in, Wout_ximg, b_out, ln2_g, ln2_b, h_V, partial, mask, h_V_out, px, nproj,
-                              S, G, (K + 15) / 16, (hipStream_t)stream, true);
+  int rc = launch_node_update(ln1_g, ln1_b, Win_ximg, b_in, Wout_ximg, b_out, ln2_g, ln2_b, h_V, partial, m3_img ? m3_ximg : nullptr,
+                              m3_b, mask, h_V_out, px, nproj, S, G, (K + 15) / 16, (hipStream_t)stream, true);
   if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -739,6 +745,7 @@ int namp_enc_message_update(const NampEncLayerW* w, const float* h_E, const int3
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
+  a.tail.m3_img = w->W3_img; a.tail.m3_b = w->b3;                    // layer 3 of the message MLP runs per residue (NodeTail)
   ProfScope prof_(NAMP_KIND_ENC_MESSAGE, (hipStream_t)stream);
   rc = launch_edge_tail<MODE_ENC_MSG>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
@@ -783,6 +790,7 @@ int namp_enc_edge_message_update(const NampEncLayerW* w_prev, const float* ePa, 
   a.G = a.G_enc = B * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, nullptr);
+  a.tail.m3_img = w->W3_img; a.tail.m3_b = w->b3;
   ProfScope prof_(NAMP_KIND_ENC_EDGE_MESSAGE, (hipStream_t)stream);
   rc = launch_edge_tail_fused<MODE_ENC_MSG>(a, prec, (hipStream_t)stream);
   if (rc) return rc;
@@ -820,6 +828,7 @@ int namp_dec_message_update(const NampDecLayerW* w, const float* h_E, const int3
   a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
   fill_tail(a.tail, w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, mask,
             h_V_out, proj, nproj, S);
+  a.tail.m3_img = w->W3_img; a.tail.m3_b = w->b3;
   a.tail.head_w = head_w; a.tail.head_b = head_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = vocab;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
   rc = launch_edge_tail<MODE_DEC_MSG>(a, prec, (hipStream_t)stream);
@@ -1096,8 +1105,8 @@ int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K,
 size_t namp_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N, tpn = (K + 15) / 16;
-  const size_t enc = (2 + 8 + tpn) * tbl(Ge);
-  const size_t dec = (2 + 4 + tpn) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
+  const size_t enc = (2 + 8 + tpn + 1) * tbl(Ge);            // (+1: the K-sums' weight sums behind `partial`)
+  const size_t dec = (2 + 4 + tpn + 1) * tbl(Gd) + NAMP_MAX_LAYERS * tbl(Ge);
   return (enc > dec ? enc : dec) + 4096;
 }
 
@@ -1114,7 +1123,7 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
   Carver c(ws, ws_bytes);
   float* Pa = c.take((size_t)G * NAMP_HIDDEN);
   float* Pc = c.take((size_t)G * NAMP_HIDDEN);
-  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * (NAMP_HIDDEN + 1) + 3);      // K-sums [G][tpn][128] + weight sums [G][tpn]
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_enc_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
   NampProj p1[2] = {{w->W1a_img, w->b1, nullptr, Pa}, {w->W1c_img, nullptr, nullptr, Pc}};
   if ((rc = namp_node_linear(h_V, nullptr, B, B, N, p1, 2, nullptr, stream))) return rc;
@@ -1128,7 +1137,7 @@ int namp_enc_layer_fwd(const NampEncLayerW* w, const float* h_V, const float* h_
   } else {
     if ((rc = namp_enc_message(w, h_E, E_idx, mask, mask_attend, Pa, Pc, partial, B, N, K, stream))) return rc;
     if ((rc = namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V,
-                               partial, mask, h_V_out, p2, 2, nullptr, G, K, stream)))
+                               partial, w->W3_img, w->b3, mask, h_V_out, p2, 2, nullptr, G, K, stream)))
       return rc;
   }
   return namp_enc_edge_update(w, h_E, E_idx, Pa2, Pc2, h_E_out, B, N, K, stream);
@@ -1146,7 +1155,7 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
   const int G = B * N, tpn = (K + 15) / 16;
   Carver c(ws, ws_bytes);
   float* Pa = c.take((size_t)G * NAMP_HIDDEN);
-  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * (NAMP_HIDDEN + 1) + 3);      // K-sums [G][tpn][128] + weight sums [G][tpn]
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_dec_layer_fwd: workspace too small (%zu bytes)", ws_bytes);
   NampProj pa = {w->W1a_img, w->b1, nullptr, Pa};
   if ((rc = namp_node_linear(h_V, nullptr, B, B, N, &pa, 1, nullptr, stream))) return rc;
@@ -1161,7 +1170,7 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
     CHECK_LAUNCH();
   }
   return namp_node_update(w->ln1_g, w->ln1_b, w->Win_img, w->b_in, w->Wout_img, w->b_out, w->ln2_g, w->ln2_b, h_V, partial,
-                          mask_V, h_V_out, nullptr, 0, nullptr, G, K, stream);
+                          nullptr, nullptr, mask_V, h_V_out, nullptr, 0, nullptr, G, K, stream);     // partial holds whole messages here
 }
 
 int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx,
@@ -1177,7 +1186,7 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
   float* P[8];
   for (int i = 0; i < 8; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
-  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * (NAMP_HIDDEN + 1) + 3);      // K-sums [G][tpn][128] + weight sums [G][tpn]
   if (!partial) return fail(NAMP_EWORKSPACE, "namp_encoder_fwd: workspace too small (%zu bytes)", ws_bytes);
   const bool fused = G <= NAMP_FUSED_TAIL_MAX_RESIDUES;
   const bool chain_edges = fused && (w->enc[0].flags & NAMP_FLAG_BF16) == 0;
@@ -1220,7 +1229,8 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
       if ((rc = namp_enc_message(L, h_E, E_idx, mask, nullptr, P[tm], P[tm + 1], partial, B, N, K, stream))) return rc;
       const float* pex[4] = {L->W11a_ximg, L->W11c_ximg, last ? nullptr : w->enc[l + 1].W1a_ximg, last ? nullptr : w->enc[l + 1].W1c_ximg};
       if ((rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img,
-                                 L->b_out, L->ln2_g, L->ln2_b, hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
+                                 L->b_out, L->ln2_g, L->ln2_b, hv[cur], partial, L->W3_img, L->W3_ximg, L->b3, mask, out, pe, np, nullptr, G, K,
+                                 stream)))
         return rc;
     }
     if (!chain_edges || last) {
@@ -1247,7 +1257,7 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   for (int i = 0; i < 6; ++i) P[i] = c.take((size_t)G * NAMP_HIDDEN);
   float* Pfw[NAMP_MAX_LAYERS];
   for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)G * NAMP_HIDDEN);
-  float* partial = c.take((size_t)G * tpn * NAMP_HIDDEN);
+  float* partial = c.take((size_t)G * tpn * (NAMP_HIDDEN + 1) + 3);      // K-sums [G][tpn][128] + weight sums [G][tpn]
   __bf16* T16[4 + NAMP_MAX_LAYERS];                       // bf16 tables: 0,1 message / Pa,Pbw; 2,3 edge update; 4.. Pfw_l
   for (int i = 0; i < 4 + w->n_dec; ++i) T16[i] = (__bf16*)c.take((size_t)G * NAMP_HIDDEN / 2);
   if (!T16[3 + w->n_dec]) return fail(NAMP_EWORKSPACE, "namp_encdec_fwd: workspace too small (%zu bytes)", ws_bytes);
@@ -1297,7 +1307,8 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     }
     const float* pex[4] = {L->W11a_ximg, L->W11c_ximg, last ? nullptr : w->enc[l + 1].W1a_ximg, last ? nullptr : w->enc[l + 1].W1c_ximg};
     if ((rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out,
-                               L->ln2_g, L->ln2_b, hv[cur], partial, mask, out, pe, np, nullptr, G, K, stream)))
+                               L->ln2_g, L->ln2_b, hv[cur], partial, L->W3_img, L->W3_ximg, L->b3, mask, out, pe, np, nullptr, G, K,
+                               stream)))
       return rc;
     if (last) cvt({P[2], P[3]}, {T16[2], T16[3]});
     else cvt({P[2], P[3], P[0], P[1]}, {T16[2], T16[3], T16[0], T16[1]});
@@ -1349,7 +1360,7 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     }
     const float* pnx[2] = {last ? nullptr : w->dec[l + 1].W1a_ximg, last ? nullptr : w->dec[l + 1].W1v_ximg};
     if ((rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out,
-                               D->ln2_g, D->ln2_b, hin, partial, mask, out, pn, np, S, G, K, stream)))
+                               D->ln2_g, D->ln2_b, hin, partial, D->W3_img, D->W3_ximg, D->b3, mask, out, pn, np, S, G, K, stream)))
       return rc;
     if (!last) cvt({P[0], P[1]}, {T16[0], T16[1]});
     hin = out;
@@ -1469,6 +1480,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
       if ((rc = check_proj(__func__, pe, np, S))) return rc;
       fill_tail(st.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur_], mask,
                 last ? h_V : hv[cur_ ^ 1], pe, np, S);
+      st.tail.m3_img = L->W3_img; st.tail.m3_b = L->b3;
       cur_ ^= 1;
     }
     const float* hin_ = h_V;
@@ -1499,6 +1511,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
       if ((rc = check_proj(__func__, pn, np, S))) return rc;
       fill_tail(st.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin_, mask, dhv[l & 1],
                 pn, np, S);
+      st.tail.m3_img = D->W3_img; st.tail.m3_b = D->b3;
       if (l == 2) { st.tail.head_w = w->Wout_w; st.tail.head_b = w->Wout_b; st.tail.log_probs = log_probs; st.tail.logits = logits; st.tail.vocab = w->vocab; }
       hin_ = dhv[l & 1];
     }
@@ -1540,6 +1553,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
     a.G = a.G_enc = G; a.N = N; a.K = K;
     fill_tail(a.tail, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out, L->ln2_g, L->ln2_b, hv[cur], mask, out,
               pe, np, S);
+    a.tail.m3_img = L->W3_img; a.tail.m3_b = L->b3;
     if (l == 0 && E) {      // h_E = W_e.E + b_e (model_utils.py:89) in front of the first message phase
       a.hE = E; a.hE_out = h_E; a.eW1_img = pick_img(prec, w->We_img, nullptr, w->We_ximg); a.eb2 = w->We_b;
       REQUIRE_PTR(a.eW1_img);
@@ -1595,6 +1609,7 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
       if ((rc = check_proj(__func__, pn, np, S))) return rc;
       fill_tail(a.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b, hin, mask, out,
                 pn, np, S);
+      a.tail.m3_img = D->W3_img; a.tail.m3_b = D->b3;
       if (last) { a.tail.head_w = w->Wout_w; a.tail.head_b = w->Wout_b; a.tail.log_probs = log_probs; a.tail.logits = logits; a.tail.vocab = w->vocab; }
       ProfScope prof_(NAMP_KIND_ENC_EDGE_DEC_MESSAGE, s);
       rc = launch_edge_tail_fused<MODE_DEC_MSG>(a, prec, s);
@@ -1624,7 +1639,7 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
   float* PB[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
   float* Pa = PA[0];
   float* Pbw = PB[0];
-  float* partial = c.take((size_t)Gd * tpn * NAMP_HIDDEN);
+  float* partial = c.take((size_t)Gd * tpn * (NAMP_HIDDEN + 1) + 3);      // K-sums [G][tpn][128] + weight sums [G][tpn]
   const bool fused = Gd <= NAMP_FUSED_TAIL_MAX_RESIDUES;
   float* Pfw[NAMP_MAX_LAYERS];
   for (int l = 0; l < w->n_dec; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
@@ -1678,7 +1693,8 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
         return rc;
       const float* pnx[2] = {last ? nullptr : w->dec[l + 1].W1a_ximg, last ? nullptr : w->dec[l + 1].W1v_ximg};
       if ((rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img,
-                                 D->b_out, D->ln2_g, D->ln2_b, hin, partial, mask, out, pn, np, S, Gd, K, stream)))
+                                 D->b_out, D->ln2_g, D->ln2_b, hin, partial, D->W3_img, D->W3_ximg, D->b3, mask, out, pn, np, S, Gd,
+                                 K, stream)))
         return rc;
     }
     hin = out;

@@ -287,6 +287,15 @@ __device__ __forceinline__ void chain_gemm_global_x3(f4 (&acc)[8], const f4 (&x)
   }
 }
 
+// GELU of layer-2 pre-activations in front of the K-sum, in the form the precision's chain GEMM applies to its operand
+// (PREC: 0 exact fp32, 1 bf16 throughput, 2 split-bf16 — the PREC_* codes of namp_kernels.h)
+template <int PREC>
+__device__ __forceinline__ f4 gelu_prec(const f4 v) {
+  if constexpr (PREC == 1) return gelu4_bf16mode(v);
+  else if constexpr (PREC == 2) return gelu4_scalar(v);
+  else return gelu4(v);
+}
+
 // one 128 x 128 tile GEMM of the edge kernels out of a 64 KiB LDS slot: exact fp32 MFMA or the split-bf16 form
 template <bool X3, bool FLIP, bool ACT>
 __device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {
@@ -297,6 +306,26 @@ __device__ __forceinline__ void gemm128(f4 (&acc)[8], const f4 (&x)[8], const f4
 #endif
   if constexpr (X3) chain_gemm_x3<FLIP, ACT>(acc, x, (const bf8*)w);
   else chain_gemm<8, 8, FLIP, ACT>(acc, x, w, 8);
+}
+
+// One 16-channel output tile (tn) of a 128 x 128 product out of an LDS slot (T orientation: lane (m, g) gets channels
+// 16tn + 4g + r of row m): the per-residue layer 3 behind the K-sum in the fused edge kernels.  w = slot base + lane.
+template <bool X3>
+__device__ __forceinline__ f4 tile_gemm1(f4 o, const f4 (&x)[8], const f4* w, const int tn) {
+  if constexpr (X3) {
+    const bf8* wb = (const bf8*)w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf8 hi, mid;
+      split_x3(x[2 * s], x[2 * s + 1], hi, mid);
+      o = mfma_x3(wb[(s * 8 + tn) * 64], wb[NAMP_BIMG_BYTES / 16 + (s * 8 + tn) * 64], hi, mid, o);
+    }
+    return o;
+  } else {
+    f4 oo[1] = {o};
+    chain_gemm<8, 1, false, false>(oo, x, w + tn * 64, 8);
+    return oo[0];
+  }
 }
 
 // The training kernels' tile GEMM by precision code (the `x3` argument of the namp_train_* entry points): 0 exact fp32 MFMA,

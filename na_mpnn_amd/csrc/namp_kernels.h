@@ -170,6 +170,12 @@ struct NodeTail {
   const float* ln2_g; const float* ln2_b;
   float* hV_out;          // [G][128]
   const int32_t* S;       // [G] tokens for tok tables (or null)
+  // Layer 3 of the message MLP, hoisted behind the K-sum (it is linear: sum_k w_k (W3 a_k + b3) = W3 (sum_k w_k a_k) + b3 sum_k w_k):
+  // when m3_img is set, the rows handed to the tail are the K-sums of the layer-2 activations (with their weight sums) and the
+  // tail starts with x = h_V + W3 . rows + b3 * wsum — one 128 x 128 product per RESIDUE instead of one per edge.
+  // null: the rows already are h_V + message (sampler, dec_layer operator).
+  const float* m3_img;    // fp32 fragment image of W3 (node_update_multi_kernel<T, true>: its x3 image)
+  const float* m3_b;      // b3 [128]
   // optional output head on h_V' (last decoder layer): log_softmax(W_out . h_V' + b), model_utils.py:420-421
   const float* head_w;    // [vocab][128] plain layout, or null
   const float* head_b;    // [vocab]
@@ -214,12 +220,26 @@ __device__ __forceinline__ void tail_head_row(const NodeTail& a, const float* yb
 // row0: first residue of the tile, nrows: rows of the tile that are real residues, G: total residues.
 // lds: NODE_TAIL_LDS bytes.  DEEP: request every weight fragment of a phase up front (256-VGPR budget).
 template <bool DEEP>
-__device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const int row0, const int nrows, const int G,
+__device__ __forceinline__ void node_tail(const NodeTail& a, f4 (&x)[8], const float wsum_m, const int row0, const int nrows, const int G,
                                           float* lds, const int tid, const int wave, const int nwaves, const int lane) {
   float* xs = lds;                          // [16][FFN_LD]    x = LN1(...)
   float* ys = xs + 16 * FFN_LD;             // [16][FFN_LD]    h_V' tile for the projections
   float* ps = ys + 16 * FFN_LD;             // [8][16][FFN_LD] per-wave partial FFN outputs
   const int m = lane & 15, g = lane >> 4;
+
+  if (a.m3_img) {
+    // hoisted message layer 3: x holds the K-sums (every wave the whole tile); wave w evaluates channel tile w
+    if (wave < 8) {
+      f4 o[1] = {*(const f4*)(a.m3_b + 16 * wave + 4 * g) * wsum_m};
+      chain_gemm_global<8, 1, false>(o, x, (const f4*)a.m3_img + wave * 64 + lane, 8);
+      *(f4*)(ys + m * FFN_LD + 16 * wave + 4 * g) = o[0];
+    }
+    __syncthreads();
+    const int hr = (m < nrows && row0 + m < G) ? row0 + m : row0;
+    const float* hsrc = a.hV + (long)hr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(hsrc + 16 * t) + *(const f4*)(ys + m * FFN_LD + 16 * t + 4 * g);
+  }
 
   f4 win[DEEP ? 8 : 1][4];
   if (DEEP && wave < 8) {
@@ -385,8 +405,9 @@ __device__ __forceinline__ void st_out(float* p, const float v) {
   else *p = v;
 }
 
-template <int R, typename RowFn, bool SC1 = false>
-__device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const RowFn orow, float* lds,
+// M3 = false: the caller has already applied the hoisted message layer 3 (x = h_V + message), whatever a.m3_img says
+template <int R, typename RowFn, bool SC1 = false, bool M3 = true>
+__device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const float wsum_m, const RowFn orow, float* lds,
                                                const int tid, const int wave, const int nwaves, const int lane) {
   float* xT = lds;                    // [128][R]    x = LN1(...)          (k-major, residue-minor)
   float* hT = xT + 128 * R;           // [512][R]    gelu(W_in x + b_in)
@@ -394,6 +415,46 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
   float* yT = oP + 4 * 128 * R;       // [128][R]    h_V'
   float* red = yT + 128 * R;          // [2][32]     LayerNorm2 cross-wave sums
   const int m = lane & 15, g = lane >> 4;
+
+  if (M3 && a.m3_img) {
+    // hoisted message layer 3 (see NodeTail): x = K-sums of the layer-2 activations -> x = h_V + W3 . x + b3 * wsum
+    if (wave == 0 && m < R) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        xT[(16 * t + 4 * g + 0) * R + m] = x[t].x; xT[(16 * t + 4 * g + 1) * R + m] = x[t].y;
+        xT[(16 * t + 4 * g + 2) * R + m] = x[t].z; xT[(16 * t + 4 * g + 3) * R + m] = x[t].w;
+      }
+      if (g == 0) red[m] = wsum_m;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tn = wave; tn < 8; tn += nwaves) {
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.m3_img)[(tk * 8 + tn) * 64 + lane];
+      float acc[R];
+#pragma unroll
+      for (int n = 0; n < R; ++n) acc[n] = 0.f;
+      rows_fma<R>(acc, wf, xT, g);
+#pragma unroll
+      for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
+      if (g == 0) {
+        const float b = a.m3_b[16 * tn + m];
+#pragma unroll
+        for (int n = 0; n < R; ++n) yT[(16 * tn + m) * R + n] = acc[n] + b * red[n];
+      }
+    }
+    __syncthreads();
+    const int mr = m < R ? m : 0;
+    int hr = orow(mr);
+    if (hr < 0) hr = orow(0) < 0 ? 0 : orow(0);
+    const float* hsrc = a.hV + (long)hr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float* yp = yT + (16 * t + 4 * g) * R + mr;
+      x[t] = *(const f4*)(hsrc + 16 * t) + (f4){yp[0], yp[R], yp[2 * R], yp[3 * R]};
+    }
+  }
 
   layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
   if (wave == 0 && m < R) {
@@ -582,7 +643,7 @@ struct EdgeArgs {
 // TAIL (message modes only): the workgroup goes on to update its own residues (node_tail) instead of
 // writing partial sums — one launch per layer half instead of two, worth it while the whole batch is
 // a single wave of workgroups (every workgroup re-streams the 768 KiB of FFN / projection weights).
-#define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4)
+#define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)      // ring + per-wave K-sums + their weight sums
 
 // TAIL: 0 = write partial sums; 4 / 8 = node_tail_rows<4/8> (the workgroup owns <= 4 / <= 6 residues);
 // 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
@@ -608,6 +669,11 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   constexpr bool X3 = (PREC == PREC_X3);
   static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32-class message + tail only");
   constexpr bool FUSE = (PRE == PRE_EDGE);
+  constexpr bool MSG = (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG);    // layer 3 is hoisted behind the K-sum (NodeTail.m3_img)
+  // fused tail of <= 8 residues, fp32-class GEMMs: W3 still streams through the ring (under layer 2) and the per-residue
+  // product runs as ONE MFMA tile out of LDS, channel tiles dealt over the waves — fetching the fragments from L2 after the K-sum
+  // instead put a full L2 round trip on the launch's critical path
+  constexpr bool M3_LDS = MSG && !BF16 && (TAIL == 4 || TAIL == 8);
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
   const int tid = threadIdx.x;
@@ -691,18 +757,22 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   if (BF16) {
     const bf8* bw = (const bf8*)smem + lane;               // image l at smem + l * 32 KiB
     dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
-    if (MODE != MODE_EMBED) {
-      dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
-      dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
-    }
+    if (MODE != MODE_EMBED) dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
+    if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
     wait_dma_and_sync();                                   // the only barrier of the MLP
     chain_gemm_bf16<false, false>(acc, x, bw);
     if (MODE != MODE_EMBED) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
+      if (MSG) {                                           // layer 2 in the F orientation: rows 4g+r of channel 16t + m
 #pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-      chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
+        for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+        chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+        chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
+      }
     }
   } else {
   if (FUSE) {
@@ -800,6 +870,15 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   if (MODE != MODE_EMBED) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] += pjv[t];           // acc = layer-1 pre-activations
+  if (MSG) {
+    // ---- layer 2 (F): lane (m, g) gets rows 4g..4g+3 of channel 16*tn + m — what the K-sum needs; there is no per-edge layer 3
+    if (PRE != PRE_NONE) wait_dma_and_sync();             // W2 (issued one GEMM ago) landed; buf0 (W1) is free
+    else if (M3_LDS) __syncthreads();                     // every wave is done with buf0 (W1)
+    if (M3_LDS) dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);   // for the per-residue layer 3 behind the K-sum
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+    gemm128<X3, true, true>(y, acc, w1);
+  } else {
   if (PRE != PRE_NONE) wait_dma_and_sync();               // W2 (issued one GEMM ago) landed; buf0 (W1) is free
   else __syncthreads();                                   // every wave is done with buf0 (W1)
   dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);     // lands while layer 2 runs out of buf1
@@ -809,6 +888,7 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
   gemm128<X3, false, true>(y, acc, w1);           // y = layer-2 pre-activations
   wait_dma_and_sync();                                    // W3 has landed in buf0
+  }
   }
   }
   if (MODE == MODE_EMBED) {
@@ -851,48 +931,51 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
       for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
     }
   } else {
-    // ---- layer 3 (F): lane (n_local=m, g) gets rows 4g..4g+3 of channel 16*tn + m
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const float b = a.b3[16 * t + m];
-      acc[t] = (f4){b, b, b, b};
-    }
-    if (BF16) chain_gemm_bf16<true, true>(acc, y, (const bf8*)smem + lane + 2 * (NAMP_BIMG_BYTES / 16));
-    else      gemm128<X3, true, true>(acc, y, w0);
+    // ---- K-sum of the layer-2 activations (layer 3 follows per residue: NodeTail.m3_img).  y: rows 4g+r of channel 16t + m;
     // weights of rows 4g+r live in lanes with (lane&15) == 4g+r
     float wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
+    float wsum = w_row;                                         // sum of the tile's 16 row weights (lanes m = 0..15 of any g)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
     if (!TAIL) {
       float* dst = a.partial + ((long)node * a.TPN + kt) * NAMP_H + m;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        const f4 v = gelu_prec<PREC>(y[t]);
+        float s = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
         s = xg_sum(s);
         if (wave_active && g == 0) dst[16 * t] = s;
       }
+      if (wave_active && lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)node * a.TPN + kt] = wsum;
     } else {
       // per-tile sums -> LDS (beyond the weight ring, which slower waves may still be reading)
-      float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);       // [nwaves][128]
+      float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);       // [nwaves][128], then [nwaves] weight sums
+      float* dws = dpart + 12 * NAMP_H;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        float s = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        const f4 v = gelu_prec<PREC>(y[t]);
+        float s = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
         s = xg_sum(s);
         if (g == 0) dpart[wave * NAMP_H + 16 * t + m] = s;
       }
-      __syncthreads();                                          // all tiles summed; weight ring is free
+      if (lane == 0) dws[wave] = wsum;
+      if (M3_LDS) wait_dma_and_sync();                          // all tiles summed; W3 landed in buf0
+      else __syncthreads();                                     // all tiles summed; weight ring is free
       // tile rows = this workgroup's residues: row m -> residue row0 + m
       const int row0 = blockIdx.x * npw;
       const int trow = row0 + m;
       const bool tvalid = (m < npw) && (trow < a.G);
       const int mm = tvalid ? m : 0;
-      const float* hsrc = a.tail.hV + (long)(row0 + mm) * NAMP_H + 4 * g;
+      float wsum_m = 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(hsrc + 16 * t);
+      for (int t = 0; t < 8; ++t) y[t] = (f4){0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < a.TPN; ++q) {
         const float* dp = dpart + (mm * a.TPN + q) * NAMP_H + 4 * g;
 #pragma unroll
         for (int t = 0; t < 8; ++t) y[t] += *(const f4*)(dp + 16 * t);
+        wsum_m += dws[mm * a.TPN + q];
       }
 #ifdef NAMP_ABL_NOTAIL
       if (tvalid) {
@@ -905,9 +988,25 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
       if (TAIL == 4 || TAIL == 8) {
         constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
         const ConsecutiveRows orow = {row0, npw, a.G};
-        node_tail_rows<R, ConsecutiveRows, (PERSIST != 0)>(a.tail, y, orow, (float*)smem, tid, wave, nwaves, lane);
+        if (M3_LDS) {
+          // x = h_V + W3 . (K-sums) + b3 * wsum: wave w < 8 evaluates channel tile w of the (<= 8-row) tile, exchanged through
+          // the K-sum area (8 rows x 128 floats <= 12 x 128)
+          __syncthreads();                                      // every wave has read dpart / dws
+          for (int tn = wave; tn < 8; tn += nwaves) {          // (a workgroup may have fewer than 8 waves: K > 96)
+            const f4 o = tile_gemm1<X3>(*(const f4*)(a.tail.m3_b + 16 * tn + 4 * g) * wsum_m, y, w0, tn);
+            if (m < 8) *(f4*)(dpart + m * NAMP_H + 16 * tn + 4 * g) = o;
+          }
+          __syncthreads();
+          const float* hsrc = a.tail.hV + (long)(row0 + mm) * NAMP_H + 4 * g;
+          const float* dsrc = dpart + (mm & 7) * NAMP_H + 4 * g;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(hsrc + 16 * t) + *(const f4*)(dsrc + 16 * t);
+          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0), false>(a.tail, y, 0.f, orow, (float*)smem, tid, wave, nwaves, lane);
+        } else {
+          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0)>(a.tail, y, wsum_m, orow, (float*)smem, tid, wave, nwaves, lane);
+        }
       } else {
-        node_tail<false>(a.tail, y, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
+        node_tail<false>(a.tail, y, wsum_m, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
       }
     }
   }
@@ -1117,7 +1216,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
   }
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
-  dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+  if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
   wait_dma_and_sync();
   const bf8* bw = (const bf8*)smem + lane;
   for (; tile < ntiles; tile += stride) {
@@ -1144,10 +1243,10 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
     f4 (&y)[8] = pjv;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-    chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
     if (MODE == MODE_ENC_EDGE) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
@@ -1169,22 +1268,26 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
         for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
       }
     } else {
+      // layer 2 in the F orientation: rows 4g+r of channel 16t + m
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float b = a.b3[16 * t + m];
-        acc[t] = (f4){b, b, b, b};
-      }
-      chain_gemm_bf16<true, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
+      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
+      // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
       float wr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
+      float wsum = me.w_row;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
       float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        const f4 v = gelu_prec<PREC_BF16>(y[t]);
+        float s_ = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
         s_ = xg_sum(s_);
         if (g == 0) dst[16 * t] = s_;
       }
+      if (lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)me.node * a.TPN + me.kt] = wsum;
     }
   }
 }
@@ -1243,8 +1346,33 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
     wait_dma_and_sync();                                   // W2 landed; everyone is done with slotA (W1)
-    dma_to_lds(slotA, a.W3_img, 64, wave, nwaves, lane);
     f4 (&y)[8] = pjv;
+    if (MODE != MODE_ENC_EDGE) {
+      // message modes: two images per round (layer 3 is hoisted behind the K-sum) — W1 of the next round streams into slotA
+      // under GEMM 2, the slots keep their roles
+      if (more) dma_to_lds(slotA, a.W1_img, 64, wave, nwaves, lane);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      gemm128<true, true, true>(y, acc, (const f4*)slotB + lane);       // F orientation: rows 4g+r of channel 16t + m
+      // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
+      float wr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
+      float wsum = me.w_row;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
+      float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const f4 v = gelu_prec<PREC_X3>(y[t]);
+        float s_ = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
+        s_ = xg_sum(s_);
+        if (active && g == 0) dst[16 * t] = s_;
+      }
+      if (active && lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)me.node * a.TPN + me.kt] = wsum;
+      continue;
+    }
+    dma_to_lds(slotA, a.W3_img, 64, wave, nwaves, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
     gemm128<true, false, true>(y, acc, (const f4*)slotB + lane);
@@ -1271,23 +1399,6 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
         float* dst = a.hE_out + me.erow * NAMP_H + 4 * g;
 #pragma unroll
         for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float b = a.b3[16 * t + m];
-        acc[t] = (f4){b, b, b, b};
-      }
-      gemm128<true, true, true>(acc, y, (const f4*)slotA + lane);
-      float wr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
-      float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
-        s_ = xg_sum(s_);
-        if (active && g == 0) dst[16 * t] = s_;
       }
     }
     char* tmp = slotA; slotA = slotB; slotB = tmp;         // next round's W1 sits in this round's slotB
@@ -1403,7 +1514,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
   }
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
-  dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+  if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
   wait_dma_and_sync();
   const bf8* bw = (const bf8*)smem + lane;
   for (; tile < ntiles; tile += stride) {
@@ -1449,10 +1560,10 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
     f4 (&y)[8] = pjv;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
-    chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
     if (MODE == MODE_ENC_EDGE) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
@@ -1469,21 +1580,24 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float b = a.b3[16 * t + m];
-        acc[t] = (f4){b, b, b, b};
-      }
-      chain_gemm_bf16<true, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
+      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));       // F orientation: rows 4g+r of channel 16t + m
+      // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
       float wr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
+      float wsum = me.w_row;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
       float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        float s_ = (acc[t].x * wr[0] + acc[t].y * wr[1]) + (acc[t].z * wr[2] + acc[t].w * wr[3]);
+        const f4 v = gelu_prec<PREC_BF16>(y[t]);
+        float s_ = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
         s_ = xg_sum(s_);
         if (g == 0) dst[16 * t] = s_;
       }
+      if (lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)me.node * a.TPN + me.kt] = wsum;
     }
   }
 }
@@ -1646,7 +1760,7 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
 #pragma unroll
           for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * q);
         }
-        node_tail_rows<NAMP_SAMPLE_SLOTS>(L.tail, x, rows, (float*)smem, tid, wave, nwaves, lane);
+        node_tail_rows<NAMP_SAMPLE_SLOTS>(L.tail, x, 0.f, rows, (float*)smem, tid, wave, nwaves, lane);
       }
       __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
     }
@@ -1825,7 +1939,7 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
 // ------------------------------------------------------------------------------------------
 struct NodeUpdateArgs {
   NodeTail t;
-  const float* partial;   // [G][TPN][128] or null (no message term)
+  const float* partial;   // [G][TPN][128] (+ [G][TPN] weight sums behind it when t.m3_img is set) or null (no message term)
   int G, TPN;
 };
 
@@ -1837,9 +1951,16 @@ static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdat
   const int row0 = blockIdx.x * 16;
   const int rr = (row0 + m < a.G) ? row0 + m : row0;
   f4 x[8];
-  const float* src = a.t.hV + (long)rr * NAMP_H + 4 * g;
+  float wsum_m = 0.f;
+  if (a.t.m3_img) {                                       // partial = K-sums of layer-2 activations + their weight sums (see NodeTail)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+    for (int t = 0; t < 8; ++t) x[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < a.TPN; ++p) wsum_m += a.partial[(long)a.G * a.TPN * NAMP_H + (long)rr * a.TPN + p];
+  } else {
+    const float* src = a.t.hV + (long)rr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
+  }
   if (a.partial) {
     for (int p = 0; p < a.TPN; ++p) {
       const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
@@ -1847,7 +1968,7 @@ static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdat
       for (int t = 0; t < 8; ++t) x[t] += *(const f4*)(ps_ + 16 * t);
     }
   }
-  node_tail<true>(a.t, x, row0, 16, a.G, (float*)smem, tid, wave, 8, lane);
+  node_tail<true>(a.t, x, wsum_m, row0, 16, a.G, (float*)smem, tid, wave, 8, lane);
 }
 
 // node_update_multi_kernel<T> — the same residue update for T 16-row tiles per workgroup (large batches).  With one tile
@@ -1870,6 +1991,62 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
   const int m = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * 16 * T;
   const NodeTail& t = a.t;
+  // ---- hoisted message layer 3 (see NodeTail): K-sums -> xs, W3 . sums + b3 * wsum -> ys (wave w: channel tile w of every tile)
+  if (t.m3_img) {
+    for (int q = wave; q < T; q += 8) {
+      const int row = row0 + 16 * q + m;
+      const int rr = row < a.G ? row : (a.G - 1);
+      f4 x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = (f4){0.f, 0.f, 0.f, 0.f};
+      float ws = 0.f;
+      for (int p = 0; p < a.TPN; ++p) {
+        const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] += *(const f4*)(ps_ + 16 * c);
+        ws += a.partial[(long)a.G * a.TPN * NAMP_H + (long)rr * a.TPN + p];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+      if (g == 0) ps[q * 16 + m] = ws;
+    }
+    __syncthreads();
+    const f4 b3v = *(const f4*)(t.m3_b + 16 * wave + 4 * g);
+    if constexpr (X3) {
+      bf8 wh[4], wm[4];
+      const bf8* w3 = (const bf8*)t.m3_img + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { wh[s] = w3[(s * 8 + wave) * 64]; wm[s] = w3[NAMP_BIMG_BYTES / 16 + (s * 8 + wave) * 64]; }
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        f4 o = b3v * ps[q * 16 + m];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float* xr = xs + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
+          bf8 hi, mid;
+          split_x3(*(const f4*)xr, *(const f4*)(xr + 16), hi, mid);
+          o = mfma_x3(wh[s], wm[s], hi, mid, o);
+        }
+        *(f4*)(ys + (q * 16 + m) * FFN_LD + 16 * wave + 4 * g) = o;
+      }
+    } else {
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)t.m3_img)[(tk * 8 + wave) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        f4 o = b3v * ps[q * 16 + m];
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) {
+          const f4 xv = *(const f4*)(xs + (q * 16 + m) * FFN_LD + 16 * tk + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o = mfma4(wf[tk][r], xv[r], o);
+        }
+        *(f4*)(ys + (q * 16 + m) * FFN_LD + 16 * wave + 4 * g) = o;
+      }
+    }
+    __syncthreads();
+  }
   // ---- phase 0: pre-activation + LayerNorm1, one wave per tile
   for (int q = wave; q < T; q += 8) {
     const int row = row0 + 16 * q + m;
@@ -1878,7 +2055,10 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
     const float* src = t.hV + (long)rr * NAMP_H + 4 * g;
 #pragma unroll
     for (int c = 0; c < 8; ++c) x[c] = *(const f4*)(src + 16 * c);
-    if (a.partial) {
+    if (t.m3_img) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] += *(const f4*)(ys + (q * 16 + m) * FFN_LD + 16 * c + 4 * g);
+    } else if (a.partial) {
       for (int p = 0; p < a.TPN; ++p) {
         const float* ps_ = a.partial + ((long)rr * a.TPN + p) * NAMP_H + 4 * g;
 #pragma unroll

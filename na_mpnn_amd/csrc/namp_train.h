@@ -73,13 +73,10 @@ struct EdgeBwdArgs {
   const float* W1t_img;
   const float* b2;
   const float* g_rows;         // BWD_ROWS: dL/dz3 per edge row [E][128]
-  const float* g_node;         // MSG modes: dL/d(dh) per residue [G][128]; g3[e] = w_e * g_node[i]
+  const float* g_node;         // MSG modes: dL/d(K-sum of a2) per residue [G][128]; dL/da2[e] = w_e * g_node[i]
   float* A1; float* A2;        // [E][128] activations gelu(z1), gelu(z2) (for wgrad)
   float* G1; float* G2; float* G3;   // [E][128] (G3 only written in MSG modes)
-  // MSG modes with tiles aligned to residues (K % 16 == 0), optional: in a message MODE the upstream gradient of row (i,k)
-  // is w_ik * g_node[i], so dW3 = sum_e G3[e]^T A2[e] = g_node^T . (sum_k w_ik A2[i,k]): the kernel then writes the
-  // weighted row sum of each 16-row tile (S3 [E/16][128], w3 [E/16] = sum of the tile's w) INSTEAD of the A2 and G3 rows —
-  // 2 x 590 MB of stores and the same again of weight-gradient reads less per launch at cfg5.
+  // (unused since layer 3 moved behind the K-sum: kept so that the argument block keeps its layout)
   float* S3; float* w3;
   float* g_hE;                 // [E][128]
   float* g_Pa;                 // optional [G][128], ZEROED by the caller: += sum_k G1[i,k]   (fp32 atomics)
@@ -99,13 +96,14 @@ struct EdgeBwdArgs {
 // per-row operand is gathered per lane anyway).  8 waves per workgroup share the 2 x 64 KiB LDS weight ring;
 // the five images W1, W2, W3^T, W2^T, W1^T stream through it by LDS-DMA one GEMM ahead of their use.
 // X3: the six / five GEMMs as split-bf16 products (chain_gemm_x3; the images are then x3 images), like the forward kernels
-// TSUM (message modes): write the per-tile weighted sums S3 / w3 instead of the A2 and G3 rows (see EdgeBwdArgs)
 // PREC: 0 exact fp32 MFMA, 1 split-bf16 products (X3), 2 plain bf16 products (mixed-precision mode; 32 KiB images)
-template <int MODE, int PREC, bool TSUM = false>
+template <int MODE, int PREC>
 __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a) {
   constexpr int IMG_KB = (PREC == 2) ? 32 : 64;
   constexpr bool RB = (PREC == 2);            // bf16 row tensors (A1, A2, G1, G2, G3)
-  static_assert(!TSUM || MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG, "tile sums: message modes only");
+  // Message modes: layer 3 sits BEHIND the K-sum (forward: NodeTail.m3_img), so the upstream gradient g_node is dL/d(sum_k w_k a2_k)
+  // and dL/da2 of row k is just w_k * g_node — no W3^T product, no A2 / G3 rows, four GEMMs (W1, W2, W2^T, W1^T + dh_E).
+  constexpr bool MSG = (MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
   if (MODE == BWD_EDGE_LN) { if (threadIdx.x < 2 * NAMP_H) colsum[threadIdx.x] = 0.f; }
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
   for (int t = 0; t < 8; ++t) z1[t] += pjv[t];
   __syncthreads();                                            // everyone is done with W1
-  dma_to_lds(buf0, MODE == BWD_EDGE_LN ? a.W3_img : a.W3t_img, IMG_KB, wave, nwaves, lane);
+  dma_to_lds(buf0, MODE == BWD_EDGE_LN ? a.W3_img : (MSG ? a.W2t_img : a.W3t_img), IMG_KB, wave, nwaves, lane);
   // activations and their derivatives from ONE evaluation each: x <- a1 = gelu(z1), z1 <- gelu'(z1)
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z1[t]);
@@ -255,36 +253,23 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     for (int t = 0; t < 8; ++t) gr[t] = *(const f4*)(src + 16 * t) * w_row;
   }
   // images from here on: W3^T, W2^T, W1b^T in slots (A, B, A) with A = buf0 — or buf1 in BWD_EDGE_LN, whose extra z3 GEMM
-  // shifted the ring by one
-  const f4* wA = (MODE == BWD_EDGE_LN) ? w1 : w0;
-  const f4* wB = (MODE == BWD_EDGE_LN) ? w0 : w1;
-  char* bufA = (MODE == BWD_EDGE_LN) ? buf1 : buf0;
-  char* bufB = (MODE == BWD_EDGE_LN) ? buf0 : buf1;
+  // shifted the ring by one.  Message modes: W2^T (already requested into buf0), W1b^T in slots (B, A) with A = buf1.
+  const f4* wA = (MODE == BWD_EDGE_LN || MSG) ? w1 : w0;
+  const f4* wB = (MODE == BWD_EDGE_LN || MSG) ? w0 : w1;
+  char* bufA = (MODE == BWD_EDGE_LN || MSG) ? buf1 : buf0;
+  char* bufB = (MODE == BWD_EDGE_LN || MSG) ? buf0 : buf1;
+  f4 acc[8];
+  if (MSG) {
+    wait_dma_and_sync();                                      // W2^T landed in buf0; buf1 (W2) is free
+    dma_to_lds(bufA, a.W1t_img, IMG_KB, wave, nwaves, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gr[t] = gr[t] * z2[t];        // g2 = w_k * g_node * gelu'(z2)
+  } else {
   wait_dma_and_sync();                                        // W3^T landed in slot A; slot B is free
   dma_to_lds(bufB, a.W2t_img, IMG_KB, wave, nwaves, lane);
-  if (TSUM) {
-    // weighted row sum of the tile's a2 over its 16 rows (lanes of equal g): 4 exchange steps per value
-    const long tile = ((long)blockIdx.x * nwaves + wave);
-    float ws = w_row;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) ws += __shfl_xor(ws, o);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      f4 v = x[t] * w_row;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
-      }
-      if (m == 0 && tile * 16 < a.E) *(f4*)(a.S3 + tile * NAMP_H + 16 * t + 4 * g) = v;
-    }
-    if (lane == 0 && tile * 16 < a.E) a.w3[tile] = ws;
-  }
-  if (!TSUM) {
-    if (MODE != BWD_EDGE_LN) store_rows(a.A2, x);
-    if (MODE != BWD_ROWS) store_rows(a.G3, gr);
-  }
+  if (MODE != BWD_EDGE_LN) store_rows(a.A2, x);
+  if (MODE != BWD_ROWS) store_rows(a.G3, gr);
   // ---- g2 = (W3^T g3) * gelu'(z2)
-  f4 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
   gemm128p<PREC, false>(acc, gr, wA);
@@ -292,6 +277,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   for (int t = 0; t < 8; ++t) gr[t] = acc[t] * z2[t];
   wait_dma_and_sync();                                        // W2^T landed in slot B; slot A is free
   dma_to_lds(bufA, a.W1t_img, IMG_KB, wave, nwaves, lane);
+  }
   store_rows(a.G2, gr);
   // ---- g1 = (W2^T g2) * gelu'(z1)
 #pragma unroll

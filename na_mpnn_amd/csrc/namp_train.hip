@@ -48,8 +48,6 @@ int ensure_attributes() {
 #define NAMP_SET3(M, ...) set((const void*)(edge_chain_bwd_kernel<M, 0 __VA_ARGS__>)); set((const void*)(edge_chain_bwd_kernel<M, 1 __VA_ARGS__>)); \
                           set((const void*)(edge_chain_bwd_kernel<M, 2 __VA_ARGS__>))
     NAMP_SET3(BWD_ENC_MSG); NAMP_SET3(BWD_DEC_MSG); NAMP_SET3(BWD_ROWS); NAMP_SET3(BWD_EDGE_LN);
-#define NAMP_COMMA ,
-    NAMP_SET3(BWD_ENC_MSG, NAMP_COMMA true); NAMP_SET3(BWD_DEC_MSG, NAMP_COMMA true);
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -67,19 +65,12 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N, int K,
                         void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
-  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3t_img);
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
   REQUIRE_PTR(A1); REQUIRE_PTR(G1); REQUIRE_PTR(G2); REQUIRE_PTR(g_hE);
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_bwd: null E_idx");
-  REQUIRE((S3 == nullptr) == (w3 == nullptr), "namp_train_edge_bwd: S3 and w3 go together");
-  if (S3) {
-    REQUIRE(mode != 2 && (K % 16) == 0, "namp_train_edge_bwd: tile sums (S3) need a message mode and K %% 16 == 0 (mode=%d, K=%d)", mode, K);
-    REQUIRE_PTR(S3);
-    if (((uintptr_t)w3 & 3) != 0) return fail(NAMP_EINVAL, "namp_train_edge_bwd: w3 must be 4-byte aligned");
-  } else {
-    REQUIRE_PTR(A2);
-    if (mode != 2) REQUIRE_PTR(G3);
-  }
+  (void)S3; (void)w3;                                        // message modes: layer 3 is a residue-level product (see namp.h)
+  if (mode == 2) { REQUIRE_PTR(W3t_img); REQUIRE_PTR(A2); }
   if (mode == 1) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_bwd: decoder message needs rank"); }
   REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_bwd: bad dims B=%d N=%d K=%d", B, N, K);
   int rc = ensure_attributes();
@@ -105,14 +96,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
     else if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 1>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);      \
     else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 0>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);              \
   } while (0)
-#define NAMP_LAUNCH_BWD_TSUM(M)                                                                                         \
-  do {                                                                                                                    \
-    if (x3 == 2) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 2, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a); \
-    else if (x3) hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 1, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a); \
-    else hipLaunchKernelGGL((edge_chain_bwd_kernel<M, 0, true>), dim3(grid), dim3(512), 2 * NAMP_IMG_BYTES, s, a);        \
-  } while (0)
-  if (mode == 0) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_ENC_MSG); else NAMP_LAUNCH_BWD(BWD_ENC_MSG); }
-  else if (mode == 1) { if (S3) NAMP_LAUNCH_BWD_TSUM(BWD_DEC_MSG); else NAMP_LAUNCH_BWD(BWD_DEC_MSG); }
+  if (mode == 0) NAMP_LAUNCH_BWD(BWD_ENC_MSG);
+  else if (mode == 1) NAMP_LAUNCH_BWD(BWD_DEC_MSG);
   else NAMP_LAUNCH_BWD(BWD_ROWS);
   CHECK_LAUNCH();
   return NAMP_OK;

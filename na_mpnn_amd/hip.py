@@ -78,7 +78,7 @@ _PROTOTYPES = {
     "namp_edge_embed": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
     "namp_enc_message": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
     "namp_enc_edge_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
-    "namp_node_update": (i32, [c_fp] * 8 + [c_fp, c_fp, c_ip, c_fp, C.POINTER(NampProj), i32, c_ip, i32, i32, vp]),
+    "namp_node_update": (i32, [c_fp] * 8 + [c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, C.POINTER(NampProj), i32, c_ip, i32, i32, vp]),
     "namp_dec_message": (i32, [C.POINTER(NampDecLayerW), c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,
                                i32, i32, i32, i32, vp]),
     "namp_enc_message_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp,

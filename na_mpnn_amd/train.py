@@ -171,28 +171,38 @@ class _EdgeMLP(torch.autograd.Function):
         Pj1 = Pj1.contiguous() if Pj1 is not None else None
         imgs = [_image(W1b.detach()), _image(W2.detach()), _image(W3.detach())]
         b2c, b3c = b2.detach().contiguous(), b3.detach().contiguous()
+        G, tpn = B * N, (K + 15) // 16
         if mode == ENC_EDGE:
             out = torch.empty(B, N, K, H, device=h_E.device)
         else:
-            out = torch.empty(B * N, (K + 15) // 16, H, device=h_E.device)
+            # message modes: K-sums of the layer-2 activations per 16-neighbour tile + the tiles' weight sums (include/namp.h);
+            # layer 3 is linear and is applied to the summed rows below — once per residue instead of once per edge
+            out = torch.empty(G * tpn * (H + 1) + 3, device=h_E.device)
         hip.check(L.namp_train_edge_fwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), imgs[0].data_ptr(),
                                         imgs[1].data_ptr(), imgs[2].data_ptr(), b2c.data_ptr(), b3c.data_ptr(),
                                         None, None, 0.0, 0, out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "train_edge_fwd")
         ctx.mode, ctx.rev, ctx.x3, ctx.step = mode, rev, X3, _STEP     # backward runs at the precision of ITS forward
-        ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
         ctx.set_materialize_grads(False)
         if mode == ENC_EDGE:
+            ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
             return out
-        # second output: h_E itself, for the NEXT consumer of the same edge rows (EncLayer's edge update, the next DecLayer).
+        msum = out[:G * tpn * H].view(G, tpn, H).sum(1)
+        wsum = out[G * tpn * H:G * tpn * (H + 1)].view(G, tpn).sum(1, keepdim=True)
+        ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32, msum, wsum)
+        dh = torch.addmm(wsum * b3.detach(), msum, W3.detach().t())
+        return dh.view(B, N, H), h_E.view_as(h_E)
+        # (second output: h_E itself, for the NEXT consumer of the same edge rows (EncLayer's edge update, the next DecLayer).
         # Its gradient then arrives HERE, and the backward launch adds its own dL/dh_E onto those rows in place — autograd
-        # would otherwise sum the consumers' [E,128] gradients with a separate 1.8 GB pass each.
-        return out.sum(1).view(B, N, H), h_E.view_as(h_E)
+        # would otherwise sum the consumers' [E,128] gradients with a separate 1.8 GB pass each.)
 
     @staticmethod
     def backward(ctx, g, g_pass=None):
         mode = ctx.mode
-        h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32 = ctx.saved_tensors
+        if mode == ENC_EDGE:
+            h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32 = ctx.saved_tensors
+        else:
+            h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32, msum, wsum = ctx.saved_tensors
         B, N, K = E_idx32.shape
         E = B * N * K
         dev = h_E.device
@@ -201,7 +211,14 @@ class _EdgeMLP(torch.autograd.Function):
             g = torch.zeros(B, N, H, device=dev) if mode != ENC_EDGE else torch.zeros(B, N, K, H, device=dev)
         g = g.contiguous()
         img1, img2 = _image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step)
-        img3t, img2t, img1t = _image_t(W3, ctx.x3, ctx.step), _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
+        img2t, img1t = _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
+        img3t = _image_t(W3, ctx.x3, ctx.step) if mode == ENC_EDGE else None
+        if mode != ENC_EDGE:
+            # layer 3 behind the K-sum: its gradients are residue-level products, and the edge kernel gets dL/d(K-sum)
+            g2d = g.view(B * N, H)
+            dW3 = g2d.t() @ msum
+            db3 = (g2d * wsum).sum(0)
+            g = (g2d @ W3.detach()).contiguous()
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         A1, G1, G2 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(3))
         acc = g_pass is not None and g_pass.is_contiguous() and g_pass.dtype == torch.float32 and g_pass.numel() == E * H
@@ -209,18 +226,14 @@ class _EdgeMLP(torch.autograd.Function):
             g_pass = g_pass.contiguous().float()
             acc = True
         g_hE = g_pass.view(E, H) if acc else torch.empty(E, H, device=dev)     # accumulate in place onto the later consumer's gradient
-        # message modes with tiles aligned to residues: dW3 = g^T . (sum_k w_ik a2[i,k]) from per-tile sums, no A2 / G3 rows
-        tile_sums = mode != ENC_EDGE and K % 16 == 0
-        A2 = None if tile_sums else torch.empty(E, H, device=dev, dtype=rdt)
-        G3 = torch.empty(E, H, device=dev, dtype=rdt) if (mode != ENC_EDGE and not tile_sums) else None
-        S3 = torch.empty(E // 16, H, device=dev) if tile_sums else None
-        w3 = torch.empty(E // 16, device=dev) if tile_sums else None
+        A2 = torch.empty(E, H, device=dev, dtype=rdt) if mode == ENC_EDGE else None
+        G3 = S3 = w3 = None
         b2c = b2.detach().contiguous()
         gpa_tiles = K % 16 == 0                                # deterministic per-tile sums instead of fp32 atomics
         g_Pa = torch.empty(E // 16, H, device=dev) if gpa_tiles else torch.zeros(B * N, H, device=dev)
         hip.check(L.namp_train_edge_bwd(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
-                                        img2.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
+                                        img2.data_ptr(), hip.ptr(img3t), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
                                         g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3) | (4 if acc else 0) | (8 if gpa_tiles else 0),
                                         B, N, K, hip.current_stream()), "train_edge_bwd")
@@ -233,13 +246,9 @@ class _EdgeMLP(torch.autograd.Function):
             g_Pj0, g_Pj1 = rev.scatter(G1)
         if mode == ENC_EDGE:
             G3 = g.view(E, H).to(rdt)
-        if tile_sums:
-            g2d = g.view(B * N, H)
-            dW3 = g2d.t() @ S3.view(B * N, K // 16, H).sum(1)
-            db3 = (g2d * w3.view(B * N, K // 16).sum(1, keepdim=True)).sum(0)
-            (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
-        else:
             (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
+        else:
+            (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         if gpa_tiles:
             g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)

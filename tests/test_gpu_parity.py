@@ -350,7 +350,7 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     Pa, Pc = torch.randn(G, 128, device=dev), torch.randn(G, 128, device=dev)
     outs = [[torch.empty(G, 128, device=dev) for _ in range(3)] for _ in range(2)]
     hv = [torch.empty(G, 128, device=dev) for _ in range(2)]
-    partial = torch.empty(G, tpn, 128, device=dev)
+    partial = torch.empty(G * tpn * 129 + 3, device=dev)      # K-sums [G][tpn][128] + weight sums [G][tpn] (include/namp.h)
     def projs(o):
         return (hip.NampProj * 3)(hip.NampProj(a("W11a_img"), a("b11"), None, o[0].data_ptr()),
                                   hip.NampProj(a("W11c_img"), None, None, o[1].data_ptr()),
@@ -362,8 +362,8 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_enc_message(packed.enc_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(), None,
                                  Pa.data_ptr(), Pc.data_ptr(), partial.data_ptr(), 1, n, K, s))
     hip.check(L.namp_node_update(a("ln1_g"), a("ln1_b"), a("Win_img"), a("b_in"), a("Wout_img"), a("b_out"), a("ln2_g"),
-                                 a("ln2_b"), d["V"].data_ptr(), partial.data_ptr(), d["mask"].data_ptr(), hv[1].data_ptr(),
-                                 projs(outs[1]), 3, None, G, K, s))
+                                 a("ln2_b"), d["V"].data_ptr(), partial.data_ptr(), a("W3_img"), a("b3"), d["mask"].data_ptr(),
+                                 hv[1].data_ptr(), projs(outs[1]), 3, None, G, K, s))
     # K <= 16: both forms run the same 16-row MFMA tail (bit-identical); K > 16: the fused form's tile has
     # <= 8 residues and uses the VALU tail (same math, different fp32 summation order)
     tol = 0.0 if K <= 16 else 2e-5
@@ -381,7 +381,7 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     Pa, Pbw, Pfw = torch.randn(Gd, 128, device=dev), torch.randn(Gd, 128, device=dev), torch.randn(G, 128, device=dev)
     outs = [[torch.empty(Gd, 128, device=dev) for _ in range(2)] for _ in range(2)]
     hv = [torch.empty(Gd, 128, device=dev) for _ in range(2)]
-    partial = torch.empty(Gd, tpn, 128, device=dev)
+    partial = torch.empty(Gd * tpn * 129 + 3, device=dev)
     lp = [torch.empty(Gd, 33, device=dev) for _ in range(2)]
     def dprojs(o):
         return (hip.NampProj * 2)(hip.NampProj(b("W1a_img"), b("b1"), None, o[0].data_ptr()),
@@ -394,8 +394,8 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     hip.check(L.namp_dec_message(packed.dec_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), rank.data_ptr(),
                                  Pa.data_ptr(), Pbw.data_ptr(), Pfw.data_ptr(), partial.data_ptr(), bdec, 1, n, K, s))
     hip.check(L.namp_node_update(b("ln1_g"), b("ln1_b"), b("Win_img"), b("b_in"), b("Wout_img"), b("b_out"), b("ln2_g"),
-                                 b("ln2_b"), hVd.data_ptr(), partial.data_ptr(), maskd.data_ptr(), hv[1].data_ptr(),
-                                 dprojs(outs[1]), 2, S.data_ptr(), Gd, K, s))
+                                 b("ln2_b"), hVd.data_ptr(), partial.data_ptr(), b("W3_img"), b("b3"), maskd.data_ptr(),
+                                 hv[1].data_ptr(), dprojs(outs[1]), 2, S.data_ptr(), Gd, K, s))
     assert maxdiff(hv[0], hv[1]) <= tol
     for x, y in zip(outs[0], outs[1]):
         assert maxdiff(x, y) <= tol
@@ -532,7 +532,12 @@ def test_cfg3_sized_batch(L, dev, wt, packed):
         ref = cpu_ref.score_from_encoded(wt, rV, rE, t["E_idx"][sl].long(), t["S"][sl], t["mask"][sl],
                                          t["chain_mask"][sl], t["randn"][sl])
         assert maxdiff(logp[sl], ref["log_probs"]) < TOL_LOGP
-        assert torch.equal(logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1))
+        # arg-max identical, except where the oracle's own top two log-probs are closer than the tolerance (a tie at fp32 level)
+        am, ar = logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1)
+        for i in torch.nonzero(am != ar).flatten().tolist():
+            r = ref["log_probs"][0][i]
+            assert abs(float(r[am[i]] - r[ar[i]])) < 2 * TOL_LOGP, (b, i, float(r[am[i]]), float(r[ar[i]]))
+        assert int((am != ar).sum()) <= 1
     d1 = {k_: v[31:32].contiguous() for k_, v in d.items()}
     _, _, logp1, _ = run_encdec(L, dev, packed, d1, 1, N, K)          # fused small-batch path on the same complex
     assert maxdiff(logp1, logp[31:32]) < 5e-5

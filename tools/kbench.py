@@ -49,7 +49,7 @@ def main():
     hV2 = torch.empty_like(hV)
     Pa, Pc, Pf = (torch.randn(G, 128, device=dev) for _ in range(3))
     T = [torch.empty(G, 128, device=dev) for _ in range(4)]
-    partial = torch.randn(G, tpn, 128, device=dev)
+    partial = torch.randn(G * tpn * 129 + 3, device=dev)       # K-sums + weight sums (include/namp.h)
     idx = torch.randint(0, N, (B, N, K), device=dev, dtype=torch.int32)
     mask = torch.ones(G, dtype=torch.int32, device=dev)
     rank = torch.randperm(N, device=dev).to(torch.int32).repeat(B)
@@ -71,7 +71,7 @@ def main():
                                     for i, nm in enumerate(["W11a_img", "W11c_img", "W1a_img", "W1c_img"])])
         res[f"node_update_p{npj}"] = timeit(lambda: L.namp_node_update(
             a("ln1_g"), a("ln1_b"), a("Win_img"), a("b_in"), a("Wout_img"), a("b_out"), a("ln2_g"), a("ln2_b"),
-            hV.data_ptr(), partial.data_ptr(), mask.data_ptr(), hV2.data_ptr(), proj, npj, None, G, K, s), args.reps)
+            hV.data_ptr(), partial.data_ptr(), a("W3_img"), a("b3"), mask.data_ptr(), hV2.data_ptr(), proj, npj, None, G, K, s), args.reps)
     for npj in (0, 2, 4):
         proj = (hip.NampProj * 4)(*[hip.NampProj(a(nm), None, None, T[i].data_ptr())
                                     for i, nm in enumerate(["W11a_img", "W11c_img", "W1a_img", "W1c_img"])])
