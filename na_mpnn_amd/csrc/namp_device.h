@@ -133,8 +133,9 @@ __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
 #ifdef NAMP_ABL_NOGELU
   return x;
 #endif
-  const f4 lim = (f4){4.f, 4.f, 4.f, 4.f};
-  const f4 xc = __builtin_elementwise_min(__builtin_elementwise_max(x, -lim), lim);
+  // v_med3_f32 directly: min(max(x, -4), 4) made the compiler canonicalise x first (one v_max_f32 x, x per value fresh out of an MFMA)
+  const f4 xc = (f4){__builtin_amdgcn_fmed3f(x.x, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f),
+                     __builtin_amdgcn_fmed3f(x.z, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.w, -4.f, 4.f)};
   const f4 t = xc * xc;
   f4 q = (f4){-1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f};
   q = q * t + 1.0826653014e-07f;
