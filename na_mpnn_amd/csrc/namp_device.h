@@ -39,24 +39,32 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// GELU in its exact-erf form (torch.nn.GELU default; reference model_utils.py:600,633,678), with
-// erf evaluated by the Abramowitz-Stegun 7.1.26 rational form
-//     erf(u) = sign(u) * (1 - (a1 t + ... + a5 t^5) exp(-u^2)),  t = 1 / (1 + p |u|),   |err| <= 1.5e-7,
-// i.e. below fp32 resolution of the unit-scale activations; measured |gelu - fp64 gelu| <= 4.7e-7 over
-// [-12, 12] (tests/test_layout_sim.py), the same size as torch's own fp32 erf-GELU rounding error.
-// 13 VALU ops (2 transcendental) and branch-free, vs ~45 with branches for ocml erff.
-// With c1 = sqrt(log2 e) / sqrt(2): exp(-u^2) = exp2(-(c1 x)^2), and p is rescaled to match.
+// GELU in its exact-erf form (torch.nn.GELU default; reference model_utils.py:600,633,678):  gelu(x) = x Phi(x)  with
+//     Phi(-|x|) = erfc(|x| / sqrt 2) / 2 = 2^(-Q(|x|)),   Q(a) = 1 + a (c1 + a (c2 + ... + a c6)),
+// Q a degree-6 weighted fit of -log2(erfc(a / sqrt 2) / 2) on [0, 5.6] with Q(0) = 1 exactly (beyond 5.6 Phi(-|x|) < 1.1e-8: clamped),
+// so that  gelu(x) = x/2 + |x/2| (1 - 2 Phi(-|x|)).  All coefficients but two small ones are positive: Horner in fp32 is stable.
+// Measured |gelu - fp64 gelu| <= 7.0e-7 over [-12, 12] — the fp32 rounding of the result at |x| ~ 4 — and 4e-7 relative near 0,
+// the same as the Abramowitz-Stegun 7.1.26 form it replaces (7.2e-7; that one needs v_rcp_f32 besides v_exp_f32: 13 full-rate
+// + 2 quarter-rate operations per value against 10 + 1 here, and GELU is more than half of the issue time of a split-bf16
+// message launch).  The training kernels' gelu_val_grad (namp_train.h) keeps the A-S form, which shares exp(-x^2/2) with the derivative.
+#define NAMP_GELU_LIM 5.6f
+#define NAMP_GELU_C1 1.151147093e+00f
+#define NAMP_GELU_C2 4.589156358e-01f
+#define NAMP_GELU_C3 5.323827185e-02f
+#define NAMP_GELU_C4 -7.977526064e-03f
+#define NAMP_GELU_C5 7.398953830e-04f
+#define NAMP_GELU_C6 -2.992676888e-05f
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float v = x * 0.84932180028801904f;                     // c1 * x
-  const float e = __builtin_amdgcn_exp2f(-(v * v));
-  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(v), 0.27273943f, 1.0f));   // p / sqrt(log2 e)
-  float q = fmaf(1.061405429f, t, -1.453152027f);
-  q = fmaf(q, t, 1.421413741f);
-  q = fmaf(q, t, -0.284496736f);
-  q = fmaf(q, t, 0.254829592f);
-  const float y = fmaf(-(q * t), e, 1.0f);                      // |erf|
+  const float a = fabsf(__builtin_amdgcn_fmed3f(x, -NAMP_GELU_LIM, NAMP_GELU_LIM));
+  float q = fmaf(NAMP_GELU_C6, a, NAMP_GELU_C5);
+  q = fmaf(q, a, NAMP_GELU_C4);
+  q = fmaf(q, a, NAMP_GELU_C3);
+  q = fmaf(q, a, NAMP_GELU_C2);
+  q = fmaf(q, a, NAMP_GELU_C1);
+  q = fmaf(q, a, 1.0f);
+  const float e = __builtin_amdgcn_exp2f(-q);                   // Phi(-|x|)
   const float h = 0.5f * x;
-  return fmaf(fabsf(h), y, h);                                  // h + h * sign(x) * |erf|
+  return fmaf(fabsf(h), fmaf(-2.0f, e, 1.0f), h);               // h + |h| (1 - 2 Phi(-|x|))
 }
 
 // Ablation switches for tools/kbench.py (never defined in the shipped build).
@@ -71,23 +79,22 @@ __device__ __forceinline__ f4 gelu4(f4 v) {
 #ifdef NAMP_ABL_NOGELU
   return v;
 #endif
-  // gelu_erf() on four values, written on vectors so that the full-rate part (9 of the 13 operations) can be selected as
-  // packed fp32 (v_pk_mul_f32 / v_pk_fma_f32); the two transcendentals stay per element.  Same operation order per
-  // element as gelu_erf(): bit-identical results.
-  const f4 u = v * 0.84932180028801904f;
-  const f4 au = __builtin_elementwise_abs(u);
-  const f4 nu2 = -(u * u);
-  const f4 d = au * 0.27273943f + 1.0f;
-  f4 e, t;
-  e.x = __builtin_amdgcn_exp2f(nu2.x); e.y = __builtin_amdgcn_exp2f(nu2.y); e.z = __builtin_amdgcn_exp2f(nu2.z); e.w = __builtin_amdgcn_exp2f(nu2.w);
-  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y); t.z = __builtin_amdgcn_rcpf(d.z); t.w = __builtin_amdgcn_rcpf(d.w);
-  f4 q = t * 1.061405429f + -1.453152027f;
-  q = q * t + 1.421413741f;
-  q = q * t + -0.284496736f;
-  q = q * t + 0.254829592f;
-  const f4 y = -(q * t) * e + 1.0f;
+  // gelu_erf() on four values, written on vectors so that the Horner steps can be selected as packed fp32 (v_pk_fma_f32);
+  // the transcendental stays per element.  Same operation order per element as gelu_erf(): bit-identical results.
+  const f4 a = __builtin_elementwise_abs((f4){__builtin_amdgcn_fmed3f(v.x, -NAMP_GELU_LIM, NAMP_GELU_LIM),
+                                              __builtin_amdgcn_fmed3f(v.y, -NAMP_GELU_LIM, NAMP_GELU_LIM),
+                                              __builtin_amdgcn_fmed3f(v.z, -NAMP_GELU_LIM, NAMP_GELU_LIM),
+                                              __builtin_amdgcn_fmed3f(v.w, -NAMP_GELU_LIM, NAMP_GELU_LIM)});
+  f4 q = a * NAMP_GELU_C6 + NAMP_GELU_C5;
+  q = q * a + NAMP_GELU_C4;
+  q = q * a + NAMP_GELU_C3;
+  q = q * a + NAMP_GELU_C2;
+  q = q * a + NAMP_GELU_C1;
+  q = q * a + 1.0f;
+  f4 e;
+  e.x = __builtin_amdgcn_exp2f(-q.x); e.y = __builtin_amdgcn_exp2f(-q.y); e.z = __builtin_amdgcn_exp2f(-q.z); e.w = __builtin_amdgcn_exp2f(-q.w);
   const f4 h = v * 0.5f;
-  return __builtin_elementwise_abs(h) * y + h;
+  return __builtin_elementwise_abs(h) * (e * -2.0f + 1.0f) + h;
 }
 
 // acc[tn] (+)= W . x  over TK k-tiles.  `w` points at img[tk0][0][lane]; consecutive
