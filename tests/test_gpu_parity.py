@@ -405,6 +405,39 @@ def test_fused_tail_matches_unfused(L, dev, packed, n, k, bdec):
     assert maxdiff(lp[0], lp[1]) <= 2e-6
 
 
+@pytest.mark.parametrize("n,k", [(200, 48), (90, 30)])
+def test_message_phase_writes_ksums_of_layer2_activations(L, dev, wt, packed, n, k):
+    """namp_enc_message's `partial` (include/namp.h): per 16-neighbour tile the weighted K-sum of the layer-2 activations
+    a_k = gelu(W2 gelu(W1 [h_V_i | h_E_ik | h_V_j] + b1) + b2), w_k = mask_i mask_j / 30, followed by the tiles' weight sums — and
+    W3 . sum + b3 . wsum is the reference's message sum (model_utils.py:684-690), checked in fp64 from the raw weights."""
+    t, d = graph(dev, seed=77 + n, batch=1, n=n, k=k, masked_frac=0.15)
+    K = t["E_idx"].shape[-1]
+    tpn, G = (K + 15) // 16, n
+    W = {nm: wt["encoder_layers.1." + nm].to(dev).double() for nm in ("W1.weight", "W1.bias", "W2.weight", "W2.bias", "W3.weight", "W3.bias")}
+    hV, hE = d["V"][0].double(), d["E"][0].double()                       # [n,128], [n,K,128] stand in for h_V, h_E
+    idx, mask = d["E_idx"][0].long(), d["mask"][0].double()
+    W1a, W1b, W1c = W["W1.weight"][:, :128], W["W1.weight"][:, 128:256], W["W1.weight"][:, 256:]
+    Pa = (hV @ W1a.t() + W["W1.bias"]).float().contiguous()
+    Pc = (hV @ W1c.t()).float().contiguous()
+    partial = torch.zeros(G * tpn * 129 + 3, device=dev)
+    hip.check(L.namp_enc_message(packed.enc_layer(1), d["E"].data_ptr(), d["E_idx"].data_ptr(), d["mask"].data_ptr(), None,
+                                 Pa.data_ptr(), Pc.data_ptr(), partial.data_ptr(), 1, n, K, stream()))
+    gelu = torch.nn.functional.gelu
+    z1 = hE @ W1b.t() + Pa.double()[:, None, :] + Pc.double()[idx]
+    a2 = gelu(gelu(z1) @ W["W2.weight"].t() + W["W2.bias"])
+    w = mask[:, None] * mask[idx] / 30.0                                   # [n,K]
+    pad = tpn * 16 - K
+    a2p = torch.nn.functional.pad(a2 * w[..., None], (0, 0, 0, pad)).view(n, tpn, 16, 128).sum(2)
+    wp = torch.nn.functional.pad(w, (0, pad)).view(n, tpn, 16).sum(2)
+    S = partial[:G * tpn * 128].view(n, tpn, 128).double()
+    ws = partial[G * tpn * 128:G * tpn * 129].view(n, tpn).double()
+    assert float((ws - wp).abs().max()) < 1e-6
+    assert float((S - a2p).abs().max()) < 2e-4 * max(1.0, float(a2p.abs().max()))        # split-bf16 products: ~2^-16 per product
+    dh_ref = ((a2 @ W["W3.weight"].t() + W["W3.bias"]) * w[..., None]).sum(1)
+    dh = S.sum(1) @ W["W3.weight"].t() + W["W3.bias"] * ws.sum(1, keepdim=True)
+    assert float((dh - dh_ref).abs().max()) < 2e-4 * max(1.0, float(dh_ref.abs().max()))
+
+
 @pytest.mark.parametrize("n,k,b", [(300, 48, 1), (130, 30, 2), (75, 16, 1), (23, 48, 1)])
 def test_fused_edge_message_matches_separate_launches(L, dev, packed, n, k, b):
     """namp_enc_edge_message_update (layer l-1's edge update + layer l's message + tail, one launch) ==

@@ -203,3 +203,35 @@ def test_bench_respawns_one_rank_per_gpu(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit, match="contradicts"):
         bench.main()
+
+
+def test_device_gelu_formula_accuracy():
+    """The kernels' GELU (csrc/namp_device.h: x/2 + |x/2| (1 - 2 * 2^-Q(|x|)), Q a degree-6 polynomial, Q(0) = 1) restated in
+    float32 numpy with the constants parsed from the header, against the exact erf form in float64: <= 8e-7 absolute over
+    [-12, 12] (fp32 rounding of the result at |x| ~ 4) and <= 1e-6 relative near zero; and the linearity the kernels use to move
+    the message MLP's last layer behind the K-sum: sum_k w_k (W3 a_k + b3) = W3 (sum_k w_k a_k) + b3 sum_k w_k."""
+    from math import erf, sqrt
+    src = open(os.path.join(ROOT, "na_mpnn_amd", "csrc", "namp_device.h")).read()
+    c = {m.group(1): np.float32(m.group(2)) for m in re.finditer(r"#define NAMP_GELU_(LIM|C[1-6]) (-?[0-9.e+-]+)f", src)}
+    assert set(c) == {"LIM", "C1", "C2", "C3", "C4", "C5", "C6"}
+    xs = np.linspace(-12.0, 12.0, 480001)
+    x = xs.astype(np.float32)
+    a = np.abs(np.clip(x, -c["LIM"], c["LIM"]))
+    q = c["C6"] * a + c["C5"]
+    for k in ("C4", "C3", "C2", "C1"):
+        q = q * a + c[k]
+    q = q * a + np.float32(1.0)
+    e = np.exp2(-q).astype(np.float32)
+    h = np.float32(0.5) * x
+    y = (h + np.abs(h) * (np.float32(1.0) - np.float32(2.0) * e)).astype(np.float64)
+    ref = np.array([0.5 * v * (1.0 + erf(v / sqrt(2.0))) for v in xs])
+    assert np.abs(y - ref).max() <= 8e-7
+    near0 = (np.abs(xs) < 1e-2) & (xs != 0)
+    assert (np.abs(y - ref)[near0] / np.abs(ref[near0])).max() <= 1e-6
+    # linearity behind the K-sum
+    rng = np.random.default_rng(3)
+    W3, b3 = rng.standard_normal((128, 128)), rng.standard_normal(128)
+    a2, w = rng.standard_normal((48, 128)), rng.integers(0, 2, 48) / 30.0
+    per_edge = ((a2 @ W3.T + b3) * w[:, None]).sum(0)
+    hoisted = W3 @ (a2 * w[:, None]).sum(0) + b3 * w.sum()
+    assert np.abs(per_edge - hoisted).max() < 1e-12

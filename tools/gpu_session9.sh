@@ -3,18 +3,13 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02n
 mkdir -p $O
 cd $R
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "ksums or cfg3" 2>&1 | tail -4
+for v in shipped prefetch shipped prefetch; do
+if [ $v = shipped ]; then unset NAMP_LIB_PATH; else export NAMP_LIB_PATH=$R/tools/_variants/$v.so; fi
+timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/nu_$v.json 2> $O/nu_$v.err
 python - <<PY
 import json
-d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], 'x3', d['x3']['value'], d['x3']['ms_per_step'], d['roofline']['frac'], d.get('parity_vs_cpu') or d.get('parity'))
-print({k:v['avg_ms'] for k,v in d['per_kernel'].items()})
-for s in d['secondary']:
-    print(s['config']['workload'][:50], s['value'], s['ms_per_step'], s.get('hip_kernel_share'))
-    if 'mixed_precision_bf16' in s: print('   mixed', s['mixed_precision_bf16']['ms_per_step'])
+d=json.loads(open('$O/nu_$v.json').read().strip().splitlines()[-1])
+print('$v', d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})
 PY
-timeout 900 python bench.py --workload cfg4 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
-python -c "
-import json
-d=json.loads(open('$O/bench_cfg4.json').read().strip().splitlines()[-1]); print('cfg4', d['value'], d['ms_per_step'])"
+done
