@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAMP_ABI_VERSION 1
+#define NAMP_ABI_VERSION 2   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3 */
 #define NAMP_HIDDEN 128
 #define NAMP_MAX_LAYERS 8
 #define NAMP_MAX_K 192

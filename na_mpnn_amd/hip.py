@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnamp_hip.so")   # env: tools/kbench.py ablations
 
-NAMP_ABI_VERSION = 1
+NAMP_ABI_VERSION = 2
 NAMP_MAX_LAYERS = 8
 NAMP_FLAG_BF16 = 1
 NAMP_FLAG_X3 = 2
