@@ -35,12 +35,14 @@ def main():
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--N", type=int, default=1000)
     ap.add_argument("--K", type=int, default=48)
+    ap.add_argument("--precision", default="x3", choices=["x3", "fp32", "bf16"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = hip.lib()
     B, N, K = args.B, args.N, args.K
     w = synth.make_weights(0)
     P = PackedWeights({k: torch.from_numpy(v).to(dev) for k, v in w.items()}, 3, 3, spec.VOCAB, dev)
+    P.set_precision(args.precision)
     G = B * N
     tpn = (K + 15) // 16
     hE = torch.randn(G, K, 128, device=dev)
@@ -91,7 +93,7 @@ def main():
     res["logits"] = timeit(lambda: L.namp_logits_log_softmax(P.addr("Wout_w"), P.addr("Wout_b"), hV.data_ptr(),
                                                              logp.data_ptr(), None, G, 33, s), args.reps)
     tag = os.path.basename(os.environ.get("NAMP_LIB_PATH", "default"))
-    print(tag, " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
+    print(tag, args.precision, " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
 
 
 if __name__ == "__main__":
