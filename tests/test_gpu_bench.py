@@ -50,7 +50,9 @@ def test_default_line_contract():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
     assert out["dtype"] == "f32" and out["roofline"]["peak"] == 157.3 and out["roofline"]["bound"] == "mfma"
-    assert 0 < out["roofline"]["frac"] <= 1.0
+    # `frac` prices the ALGORITHMIC flops (the reference's dense formulation) against the peak: the launch executes half of
+    # them (hoisted first layer, layer 3 behind the K-sum), so it may come close to — on a fast box pass — 1; `executed_frac` may not
+    assert 0 < out["roofline"]["frac"] <= 1.5 and 0 < out["roofline"]["executed_frac"] <= 1.0
     assert out["x3"]["roofline"]["peak"] == 2500.0 and out["x3"]["parity"]["argmax_equal"] is True
     par = out["parity"]
     assert par["argmax_equal"] is True and par["max_abs_dlogp_vs_cpu"] < 1e-3 and par["seq_recovery"]["gpu_vs_cpu_argmax"] == 1.0
