@@ -2700,11 +2700,19 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
             const int bb = b0 + h;
             if ((mj_s >> bb) & 1u) {
               const float dx = xi0 - xj[(3 * bb) * 16], dy = xi1 - xj[(3 * bb + 1) * 16], dz = xi2 - xj[(3 * bb + 2) * 16];
-              const float D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);
+              // this lane's four RBFs have equidistant centres mu0 + r * 4/3: with v_r = (D - mu_r) * 0.8 * sqrt(log2 e) = v_0 - r d,
+              //   G_r = exp(-((D - mu_r)/1.25)^2) = 2^(-v_r^2),   G_{r+1} / G_r = 2^(2 d v_r - d^2) =: q_r,   q_{r+1} = q_r * 2^(-2 d^2)
+              // — two v_exp_f32 and six multiplications instead of four exponentials with their argument arithmetic (the RBF generation
+              // is more than half of this kernel's issue time beside bf16 MFMAs).  D is capped at 40 A (every RBF is exactly 0 in fp32
+              // beyond 34 A) so that q_0 stays finite; relative error of G_3 ~1e-6, far below the split-bf16 products that consume it.
+              const float D = fminf(sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
               const float mk = mia * (float)((mj >> bb) & 1u);
-              const float t0 = (D - mu0) * 0.8f, t1 = (D - mu1) * 0.8f, t2 = (D - mu2) * 0.8f, t3 = (D - mu3) * 0.8f;
-              xk[h].x = __expf(-(t0 * t0)) * mk; xk[h].y = __expf(-(t1 * t1)) * mk;
-              xk[h].z = __expf(-(t2 * t2)) * mk; xk[h].w = __expf(-(t3 * t3)) * mk;
+              const float v0 = (D - mu0) * 0.9608979270291599f;
+              const float G0 = __builtin_amdgcn_exp2f(-(v0 * v0)) * mk;
+              const float q0 = __builtin_amdgcn_exp2f(fmaf(v0, 2.5623944720777594f, -1.6414663576336648f));
+              const float G1 = G0 * q0, q1 = q0 * 0.10273981490249438f;
+              const float G2 = G1 * q1, q2 = q1 * 0.10273981490249438f;
+              xk[h].x = G0; xk[h].y = G1; xk[h].z = G2; xk[h].w = G2 * q2;
             } else {
               xk[h] = (f4){0.f, 0.f, 0.f, 0.f};
             }

@@ -2,11 +2,12 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02o
 mkdir -p $O
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof4 -o cfg4 -- python $R/bench.py --workload cfg4 --no-cpu-baseline > $O/prof4.log 2>&1
 cd $R
-db=$(ls $O/prof4/*/*.db $O/prof4/*.db 2>/dev/null | head -1)
-python tools/rocpd_summary.py $db > $O/cfg4_kernel_stats.md
-rm -rf $O/prof4
-head -30 $O/cfg4_kernel_stats.md
-tail -2 $O/prof4.log | cut -c1-300
+timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -5
+for v in head new head new; do
+if [ $v = new ]; then unset NAMP_LIB_PATH; else export NAMP_LIB_PATH=$R/tools/_variants/$v.so; fi
+timeout 600 python bench.py --workload cfg4 --no-cpu-baseline > $O/rbf_$v.json 2> $O/rbf_$v.err
+python -c "
+import json
+d=json.loads(open('$O/rbf_$v.json').read().strip().splitlines()[-1]); print('$v cfg4', d['value'], d['ms_per_step'])"
+done
