@@ -134,8 +134,8 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 // GELU of the bf16 throughput mode: its output is rounded to bf16 (ulp 2^-8 relative) right away, so the exact-erf form
 // with its two quarter-rate transcendentals per value is wasted there.  x * Phi(x) with Phi(x) - 1/2 = x * Q(x^2), Q a
-// degree-7 least-squares fit on |x| <= 4 (clamped beyond: Phi(4) = 0.99997): max |error| 4.9e-4 over the real line, 12
-// full-rate VALU ops, written on 4-vectors so that the packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32) can be selected.
+// degree-6 weighted minimax-style fit on |x| <= 4 (clamped beyond: Phi(4) = 0.99997): max |error| 1.9e-4 over the real line (round 1's
+// degree-7 least-squares fit: 4.9e-4), 11 full-rate VALU ops, written on 4-vectors so that the packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32) can be selected.
 __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
 #ifdef NAMP_ABL_NOGELU
   return x;
@@ -144,14 +144,13 @@ __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
   const f4 xc = (f4){__builtin_amdgcn_fmed3f(x.x, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f),
                      __builtin_amdgcn_fmed3f(x.z, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.w, -4.f, 4.f)};
   const f4 t = xc * xc;
-  f4 q = (f4){-1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f, -1.3716095494e-09f};
-  q = q * t + 1.0826653014e-07f;
-  q = q * t + -3.7514161992e-06f;
-  q = q * t + 7.5968897781e-05f;
-  q = q * t + -1.0135644180e-03f;
-  q = q * t + 9.5286519412e-03f;
-  q = q * t + -6.5922144089e-02f;
-  q = q * t + 3.9868862006e-01f;
+  f4 q = (f4){2.2787273029e-08f, 2.2787273029e-08f, 2.2787273029e-08f, 2.2787273029e-08f};
+  q = q * t + -1.5988982626e-06f;
+  q = q * t + 4.7961328822e-05f;
+  q = q * t + -8.1407082443e-04f;
+  q = q * t + 8.7726502299e-03f;
+  q = q * t + -6.4573666617e-02f;
+  q = q * t + 3.9788372746e-01f;
   return x * (xc * q + 0.5f);
 }
 

@@ -3,11 +3,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02o
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -5
-for v in head new head new; do
-if [ $v = new ]; then unset NAMP_LIB_PATH; else export NAMP_LIB_PATH=$R/tools/_variants/$v.so; fi
-timeout 600 python bench.py --workload cfg4 --no-cpu-baseline > $O/rbf_$v.json 2> $O/rbf_$v.err
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_train.py -m gpu -q -x 2>&1 | tail -4
+for i in 1 2; do
+timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/g6_$i.json 2> $O/g6_$i.err
 python -c "
 import json
-d=json.loads(open('$O/rbf_$v.json').read().strip().splitlines()[-1]); print('$v cfg4', d['value'], d['ms_per_step'])"
+d=json.loads(open('$O/g6_$i.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})"
 done
