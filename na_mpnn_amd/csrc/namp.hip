@@ -319,6 +319,12 @@ int check_proj(const char* fn, const NampProj* proj, int nproj, const int32_t* S
   return NAMP_OK;
 }
 
+// bf16-storage path (encdec_bf16_storage): the residue kernels write the tables the edge launches gather directly as bf16 rows in
+// fragment order (and skip the fp32 copy) instead of a conversion launch per stage.  Set around the producer call; `honoured`
+// tells the caller whether the launch that ran supports it (the one-tile fp32 residue kernel does not).
+struct Out16Req { __bf16* p[8]; int n; bool honoured; };
+thread_local Out16Req* g_out16 = nullptr;
+
 int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
                        const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s, bool x3 = false, unsigned* zero = nullptr) {
   NodeLinearArgs a;
@@ -328,7 +334,10 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
   for (int i = 0; i < 8; ++i) {
     const NampProj& p = proj[i < nproj ? i : 0];
     a.p[i].img = p.img; a.p[i].bias = p.bias; a.p[i].tok = p.tok; a.p[i].out = p.out;
+    a.out16[i] = (g_out16 && i < nproj && i < g_out16->n) ? g_out16->p[i] : nullptr;
+    if (a.out16[i]) a.p[i].out = nullptr;
   }
+  if (g_out16) g_out16->honoured = true;
   const int units = ((G_out + 15) / 16) * nproj;
   if (x3) hipLaunchKernelGGL(node_linear_kernel<true>, dim3((units + 3) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(node_linear_kernel<false>, dim3((units + 3) / 4), dim3(256), 0, s, a);
@@ -346,6 +355,12 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   fill_tail(a.t, ln1_g, ln1_b, Win_img, b_in, Wout_img, b_out, ln2_g, ln2_b, hV, mask, hV_out, proj, nproj, S);
   a.t.m3_img = partial ? m3_img : nullptr; a.t.m3_b = m3_b;      // (x3: the x3 image of W3)
   a.partial = partial; a.G = G; a.TPN = TPN;
+  const bool multi = x3 || G >= 32 * 2 * device_cus();
+  for (int i = 0; i < 8; ++i) {
+    a.out16[i] = (multi && g_out16 && i < nproj && i < g_out16->n) ? g_out16->p[i] : nullptr;
+    if (a.out16[i]) a.t.p[i].out = nullptr;
+  }
+  if (multi && g_out16) g_out16->honoured = true;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
   if (x3)                      // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
@@ -1273,8 +1288,12 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   const NampEncLayerW* L0 = &w->enc[0];
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
-  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
-  cvt({P[0], P[1]}, {T16[0], T16[1]});
+  {
+    Out16Req rq = {{T16[0], T16[1]}, 2, false};
+    g_out16 = &rq; rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream); g_out16 = nullptr;
+    if (rc) return rc;
+    if (!rq.honoured) cvt({P[0], P[1]}, {T16[0], T16[1]});
+  }
   {
     EdgeArgs a = {};
     a.hE = E; a.hE16_out = h16; a.W1_img = w->We_bimg ? w->We_bimg : w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
@@ -1306,12 +1325,18 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
       np = 4;
     }
     const float* pex[4] = {L->W11a_ximg, L->W11c_ximg, last ? nullptr : w->enc[l + 1].W1a_ximg, last ? nullptr : w->enc[l + 1].W1c_ximg};
-    if ((rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out,
-                               L->ln2_g, L->ln2_b, hv[cur], partial, L->W3_img, L->W3_ximg, L->b3, mask, out, pe, np, nullptr, G, K,
-                               stream)))
-      return rc;
-    if (last) cvt({P[2], P[3]}, {T16[2], T16[3]});
-    else cvt({P[2], P[3], P[0], P[1]}, {T16[2], T16[3], T16[0], T16[1]});
+    {
+      Out16Req rq = {{T16[2], T16[3], T16[0], T16[1]}, np, false};
+      g_out16 = &rq;
+      rc = node_update_auto(L->flags, L->Win_ximg, L->Wout_ximg, pex, L->ln1_g, L->ln1_b, L->Win_img, L->b_in, L->Wout_img, L->b_out,
+                            L->ln2_g, L->ln2_b, hv[cur], partial, L->W3_img, L->W3_ximg, L->b3, mask, out, pe, np, nullptr, G, K, stream);
+      g_out16 = nullptr;
+      if (rc) return rc;
+      if (!rq.honoured) {
+        if (last) cvt({P[2], P[3]}, {T16[2], T16[3]});
+        else cvt({P[2], P[3], P[0], P[1]}, {T16[2], T16[3], T16[0], T16[1]});
+      }
+    }
     {
       EdgeArgs a = {};
       a.hE16 = h16; a.hE16_out = h16; a.E_idx = E_idx; a.Pa16 = T16[2]; a.Pj016 = T16[3];
@@ -1329,12 +1354,20 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   for (int l = 0; l < w->n_dec; ++l) pf[nf++] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
   pf[nf++] = {D0->W1a_img, D0->b1, nullptr, P[0]};
   pf[nf++] = {D0->W1v_img, nullptr, D0->tok, P[1]};
-  if ((rc = namp_node_linear(h_V, S, B, B, N, pf, nf, nullptr, stream))) return rc;
-  cvt({P[0], P[1]}, {T16[0], T16[1]});
-  for (int l = 0; l < w->n_dec; l += 4) {
-    const float* sp[4]; __bf16* dp[4]; int n = 0;
-    for (int q = l; q < w->n_dec && q < l + 4; ++q) { sp[n] = Pfw[q]; dp[n] = T16[4 + q]; ++n; }
-    launch_cvt_tables(sp, dp, n, G, s);
+  {
+    Out16Req rq = {{}, nf <= 8 ? nf : 0, false};
+    for (int l = 0; l < w->n_dec && l < 8; ++l) rq.p[l] = T16[4 + l];
+    if (nf <= 8) { rq.p[nf - 2] = T16[0]; rq.p[nf - 1] = T16[1]; }
+    g_out16 = rq.n ? &rq : nullptr; rc = namp_node_linear(h_V, S, B, B, N, pf, nf, nullptr, stream); g_out16 = nullptr;
+    if (rc) return rc;
+    if (!rq.honoured) {
+      cvt({P[0], P[1]}, {T16[0], T16[1]});
+      for (int l = 0; l < w->n_dec; l += 4) {
+        const float* sp[4]; __bf16* dp[4]; int n = 0;
+        for (int q = l; q < w->n_dec && q < l + 4; ++q) { sp[n] = Pfw[q]; dp[n] = T16[4 + q]; ++n; }
+        launch_cvt_tables(sp, dp, n, G, s);
+      }
+    }
   }
   const float* hin = h_V;
   for (int l = 0; l < w->n_dec; ++l) {
@@ -1359,10 +1392,15 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
       np = 2;
     }
     const float* pnx[2] = {last ? nullptr : w->dec[l + 1].W1a_ximg, last ? nullptr : w->dec[l + 1].W1v_ximg};
-    if ((rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out,
-                               D->ln2_g, D->ln2_b, hin, partial, D->W3_img, D->W3_ximg, D->b3, mask, out, pn, np, S, G, K, stream)))
-      return rc;
-    if (!last) cvt({P[0], P[1]}, {T16[0], T16[1]});
+    {
+      Out16Req rq = {{T16[0], T16[1]}, np, false};
+      g_out16 = np ? &rq : nullptr;
+      rc = node_update_auto(D->flags, D->Win_ximg, D->Wout_ximg, pnx, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out,
+                            D->ln2_g, D->ln2_b, hin, partial, D->W3_img, D->W3_ximg, D->b3, mask, out, pn, np, S, G, K, stream);
+      g_out16 = nullptr;
+      if (rc) return rc;
+      if (!last && !rq.honoured) cvt({P[0], P[1]}, {T16[0], T16[1]});
+    }
     hin = out;
   }
   CHECK_LAUNCH();

@@ -1878,6 +1878,8 @@ struct NodeLinearArgs {
                        // projections then apply to h (h_V = W_v.V + b feeding enc0's tables in one launch)
   ProjDesc p[8];
   unsigned* zero;      // optional: 64 words cleared by this launch (the grid-barrier state of the persistent launch that follows)
+  __bf16* out16[8];    // optional per block: the projection ALSO (out == null: only) goes out as bf16 rows in fragment order — the tables
+                       // the bf16-storage edge launches gather (edge_mlp_bf16s_kernel); replaces a separate conversion launch
 };
 
 template <bool X3>       // X3: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products
@@ -1897,8 +1899,9 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   const int src_row = (b % (a.G_src / a.N)) * a.N + (rr - b * a.N);
   // select the descriptor without dynamic indexing of the kernarg struct
   ProjDesc d = a.p[0];
+  __bf16* o16 = a.out16[0];
 #pragma unroll
-  for (int q = 1; q < 8; ++q) if (pi == q) d = a.p[q];
+  for (int q = 1; q < 8; ++q) if (pi == q) { d = a.p[q]; o16 = a.out16[q]; }
 
   f4 x[8], acc[8];
   const float* src = a.X + (long)src_row * NAMP_H + 4 * g;
@@ -1926,10 +1929,15 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(tk + 16 * t);
   }
-  if (valid) {
+  if (valid && d.out) {
     float* dst = d.out + (long)row * NAMP_H + 4 * g;
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+  }
+  if (valid && o16) {                                  // piece (s, g) of the row = this lane's channel tiles 2s, 2s+1
+    bf8* dst = (bf8*)(o16 + (long)row * NAMP_H) + g;
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
   }
 }
 
@@ -1943,6 +1951,7 @@ struct NodeUpdateArgs {
   NodeTail t;
   const float* partial;   // [G][TPN][128] (+ [G][TPN] weight sums behind it when t.m3_img is set) or null (no message term)
   int G, TPN;
+  __bf16* out16[8];       // node_update_multi_kernel only, optional per projection: bf16 fragment-order copy (out == null: only that)
 };
 
 static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdateArgs a) {
@@ -2233,7 +2242,12 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
           for (int r = 0; r < 4; ++r) acc = mfma4(wf[X3 ? 0 : tk][r], xv[r], acc);
         }
         }
-        if (valid) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
+        if (valid && d.out) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
+        if (valid && a.out16[pi]) {                            // half a 16-byte piece: (s = tn / 2, g), values 4 (tn & 1) .. + 3
+          typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+          *(bf4*)(a.out16[pi] + (long)row * NAMP_H + 8 * (4 * (tn >> 1) + g) + 4 * (tn & 1)) =
+              (bf4){(__bf16)acc.x, (__bf16)acc.y, (__bf16)acc.z, (__bf16)acc.w};
+        }
       }
     }
   }
