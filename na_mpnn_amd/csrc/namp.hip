@@ -141,6 +141,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)(edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
@@ -239,6 +240,12 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   a.TPN = e.tpn;
   if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
   // 12 waves per CU; 16 (1,024 threads, 128 VGPRs) measured the same: the launch is instruction-issue bound, not latency bound
+  if constexpr (MODE == MODE_ENC_MSG) {
+    if (a.eW1_img) {                     // fused edge embedding: a.hE = fp32 E, a.hE16_out = the bf16 rows
+      hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
+      return NAMP_OK;
+    }
+  }
   hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
   return NAMP_OK;
 }
@@ -1294,7 +1301,9 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     if (rc) return rc;
     if (!rq.honoured) cvt({P[0], P[1]}, {T16[0], T16[1]});
   }
-  {
+  static const bool fuse_embed = [] { const char* e = getenv("NAMP_BF16S_SEPARATE_EMBED"); return !(e && atoi(e) != 0); }();   // A/B switch
+  const bool emb_fused = fuse_embed && w->We_bimg != nullptr;
+  if (!emb_fused) {
     EdgeArgs a = {};
     a.hE = E; a.hE16_out = h16; a.W1_img = w->We_bimg ? w->We_bimg : w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
     ProfScope prof_(NAMP_KIND_EDGE_EMBED, s);
@@ -1313,6 +1322,7 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
       a.hE16 = h16; a.E_idx = E_idx; a.mask = mask; a.Pa16 = T16[0]; a.Pj016 = T16[1];
       a.W1_img = L->W1b_bimg; a.W2_img = L->W2_bimg; a.W3_img = L->W3_bimg; a.b2 = L->b2; a.b3 = L->b3;
       a.partial = partial; a.G = a.G_enc = G; a.N = N; a.K = K;
+      if (l == 0 && emb_fused) { a.hE = E; a.hE16_out = h16; a.eW1_img = w->We_bimg; a.eb2 = w->We_b; }   // h_E = W_e.E + b_e in this launch
       ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
       if ((rc = launch_edge_bf16s<MODE_ENC_MSG>(a, s))) return rc;
     }

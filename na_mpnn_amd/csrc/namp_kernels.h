@@ -1497,8 +1497,13 @@ static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
 
 // (Tried: fp32 tables — no bf16 -> fp32 conversions, no conversion launches — 6.93 -> 7.13 ms per cfg3 step: the gathers'
 // L2 bytes count.)
-template <int MODE>
+// EMB (encoder message of layer 0): the rows arrive as the fp32 edge features E (a.hE); h_E = W_e . E + b_e (model_utils.py:89, image
+// a.eW1_img in the slot layer 3 left free, bias a.eb2) is evaluated here, stored as bf16 rows (a.hE16_out) for the later launches
+// and fed straight into the message MLP — the separate embedding launch wrote those rows and this one read them back (0.8 GB each way
+// at B = 64).  Same arithmetic, same rounding points as edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16> followed by this kernel.
+template <int MODE, bool EMB = false>
 __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
+  static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1508,8 +1513,13 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
   const long stride = (long)gridDim.x * nwaves;
   long tile = (long)blockIdx.x * nwaves + wave;
   TileMeta cur = tile_meta<MODE>(a, tile < ntiles ? tile : 0, m, g);
-  bf8 xn[4];
-  {
+  bf8 xn[EMB ? 1 : 4];
+  f4 xe[EMB ? 8 : 1];
+  if constexpr (EMB) {
+    const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xe[t] = *(const f4*)(src + 16 * t);
+  } else {
     const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
 #pragma unroll
     for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
@@ -1517,14 +1527,29 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
   if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+  if (EMB) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.eW1_img, 32, wave, nwaves, lane);
   wait_dma_and_sync();
   const bf8* bw = (const bf8*)smem + lane;
   for (; tile < ntiles; tile += stride) {
     asm volatile("" ::: "memory");        // keep the (loop-invariant) LDS weight fragments out of registers
     bf8 xb[4];
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) xb[sq] = xn[sq];
     const TileMeta me = cur;
+    if constexpr (EMB) {
+      f4 he[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) he[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
+      chain_gemm_bf16<false, false>(he, xe, bw + 2 * (NAMP_BIMG_BYTES / 16));
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) xb[sq] = pack_bf16<false>(he[2 * sq], he[2 * sq + 1]);
+      if (me.valid) {
+        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + g;
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = xb[sq];
+      }
+    } else {
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) xb[sq] = xn[sq];
+    }
     f4 acc[8], pjv[8];
 #ifdef NAMP_ABL_NOPROLOG
 #pragma unroll
@@ -1536,7 +1561,11 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
     bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H, g);
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
-    {
+    if constexpr (EMB) {
+      const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xe[t] = *(const f4*)(src + 16 * t);
+    } else {
       const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
