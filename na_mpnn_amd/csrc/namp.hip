@@ -1297,8 +1297,20 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
   {
     Out16Req rq = {{T16[0], T16[1]}, 2, false};
-    g_out16 = &rq; rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream); g_out16 = nullptr;
+    g_out16 = &rq;
+    if (w->Wv_ximg && L0->W1a_ximg && L0->W1c_ximg && aligned16(w->Wv_ximg) && aligned16(L0->W1a_ximg) && aligned16(L0->W1c_ximg)) {
+      // split-bf16 products instead of two chained fp32 MFMA GEMMs per unit (the fp32 form is MFMA-bound at this size)
+      const NampProj prex = {w->Wv_ximg, w->Wv_b, nullptr, hv[0]};
+      const NampProj px[2] = {{L0->W1a_ximg, L0->b1, nullptr, P[0]}, {L0->W1c_ximg, nullptr, nullptr, P[1]}};
+      ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
+      rc = (w->Wv_b && L0->b1) ? launch_node_linear(V, nullptr, G, G, N, px, 2, &prex, s, true)
+                               : fail(NAMP_EINVAL, "namp_encdec_fwd: null W_v / W1 bias");
+    } else {
+      rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream);
+    }
+    g_out16 = nullptr;
     if (rc) return rc;
+    CHECK_LAUNCH();
     if (!rq.honoured) cvt({P[0], P[1]}, {T16[0], T16[1]});
   }
   static const bool fuse_embed = [] { const char* e = getenv("NAMP_BF16S_SEPARATE_EMBED"); return !(e && atoi(e) != 0); }();   // A/B switch
@@ -1368,8 +1380,23 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     Out16Req rq = {{}, nf <= 8 ? nf : 0, false};
     for (int l = 0; l < w->n_dec && l < 8; ++l) rq.p[l] = T16[4 + l];
     if (nf <= 8) { rq.p[nf - 2] = T16[0]; rq.p[nf - 1] = T16[1]; }
-    g_out16 = rq.n ? &rq : nullptr; rc = namp_node_linear(h_V, S, B, B, N, pf, nf, nullptr, stream); g_out16 = nullptr;
+    g_out16 = rq.n ? &rq : nullptr;
+    bool xok = nf <= 8 && D0->W1a_ximg && D0->W1v_ximg && aligned16(D0->W1a_ximg) && aligned16(D0->W1v_ximg);
+    for (int l = 0; l < w->n_dec && xok; ++l) xok = w->dec[l].W1v_ximg && aligned16(w->dec[l].W1v_ximg);
+    if (xok) {
+      NampProj pfx[8];
+      for (int i = 0; i < nf; ++i) pfx[i] = pf[i];
+      for (int l = 0; l < w->n_dec; ++l) pfx[l].img = w->dec[l].W1v_ximg;
+      pfx[nf - 2].img = D0->W1a_ximg; pfx[nf - 1].img = D0->W1v_ximg;
+      ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
+      rc = check_proj(__func__, pf, nf, S);
+      if (!rc) rc = launch_node_linear(h_V, S, G, G, N, pfx, nf, nullptr, s, true);
+    } else {
+      rc = namp_node_linear(h_V, S, B, B, N, pf, nf, nullptr, stream);
+    }
+    g_out16 = nullptr;
     if (rc) return rc;
+    CHECK_LAUNCH();
     if (!rq.honoured) {
       cvt({P[0], P[1]}, {T16[0], T16[1]});
       for (int l = 0; l < w->n_dec; l += 4) {

@@ -4,9 +4,9 @@ O=$R/gpurun_out/r02o
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "cfg3 or bf16 or wide" 2>&1 | tail -4
-for v in 1 0 1 0; do
-NAMP_BF16S_SEPARATE_EMBED=$v timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/emb_$v.json 2> $O/emb_$v.err
+for v in 1 2; do
+timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/nl_$v.json 2> $O/nl_$v.err
 python -c "
 import json
-d=json.loads(open('$O/emb_$v.json').read().strip().splitlines()[-1]); print('separate=$v', d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})"
+d=json.loads(open('$O/nl_$v.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})"
 done
