@@ -866,7 +866,7 @@ int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const floa
   REQUIRE(G >= 1 && vocab >= 1 && vocab <= 64, "namp_logits_log_softmax: vocab=%d must be in [1,64]", vocab);
   ProfScope prof_(NAMP_KIND_LOGITS, (hipStream_t)stream);
   int per_wg = (G + 2 * device_cus() - 1) / (2 * device_cus());            // ~2 workgroups per CU; W_out is staged once per workgroup
-  per_wg = (per_wg + 3) / 4 * 4;
+  per_wg = (per_wg + 15) / 16 * 16;                                         // 4 waves x 4 residues per pass
   hipLaunchKernelGGL(logits_kernel, dim3((G + per_wg - 1) / per_wg), dim3(256), (size_t)32 * vocab * 16, (hipStream_t)stream, h_V,
                      Wout_w, Wout_b, log_probs, logits, G, vocab, per_wg);
   CHECK_LAUNCH();

@@ -2367,26 +2367,38 @@ static __global__ __launch_bounds__(256) void logits_kernel(const float* __restr
   const int first = blockIdx.x * per_wg, last = min(G, first + per_wg);
   const float b = lane < V ? bias[lane] : 0.f;
   const f4* wt = wl + (lane < V ? lane : 0);
-  for (int node = first + (threadIdx.x >> 6); node < last; node += 4) {
-    const float* h = hV + (long)node * NAMP_H;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
+  // four residues per wave and pass: one W_out fragment read serves four dot products (per-residue summation order unchanged)
+  for (int n0 = first + 4 * (threadIdx.x >> 6); n0 < last; n0 += 16) {
+    const float* h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = hV + (long)min(n0 + r, last - 1) * NAMP_H;
+    f4 s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int c4 = 0; c4 < NAMP_H / 4; ++c4) {
       const f4 wv = wt[c4 * V];
-      const f4 hv = *(const f4*)(h + 4 * c4);
-      s0 = fmaf(wv.x, hv.x, s0); s1 = fmaf(wv.y, hv.y, s1);
-      s2 = fmaf(wv.z, hv.z, s2); s3 = fmaf(wv.w, hv.w, s3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f4 hv = *(const f4*)(h[r] + 4 * c4);
+        s[r].x = fmaf(wv.x, hv.x, s[r].x); s[r].y = fmaf(wv.y, hv.y, s[r].y);
+        s[r].z = fmaf(wv.z, hv.z, s[r].z); s[r].w = fmaf(wv.w, hv.w, s[r].w);
+      }
     }
-    const float z = lane < V ? (s0 + s1) + (s2 + s3) + b : -INFINITY;
-    float mx = z;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float e = (lane < V) ? expf(z - mx) : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const int node = n0 + r;
+      const float z = lane < V ? (s[r].x + s[r].y) + (s[r].z + s[r].w) + b : -INFINITY;
+      float mx = z;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
-    if (lane < V) {
-      log_probs[(long)node * V + lane] = (z - mx) - logf(e);
-      if (logits_out) logits_out[(long)node * V + lane] = z;
+      for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = (lane < V) ? expf(z - mx) : 0.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+      if (lane < V && node < last) {
+        log_probs[(long)node * V + lane] = (z - mx) - logf(e);
+        if (logits_out) logits_out[(long)node * V + lane] = z;
+      }
     }
   }
 }
