@@ -146,6 +146,7 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
+  set((const void*)(node_update_multi_kernel<2, true>), NODE_MULTI_LDS_X3(2));
   set((const void*)dec_sample_kernel<false, false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<true, false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<false, true>, SAMPLE_LDS);
@@ -371,7 +372,7 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
   if (x3)                      // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
-    hipLaunchKernelGGL((node_update_multi_kernel<2, true>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
+    hipLaunchKernelGGL((node_update_multi_kernel<2, true>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
   else if (G >= 32 * 2 * device_cus())
     hipLaunchKernelGGL((node_update_multi_kernel<2, false>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
   else

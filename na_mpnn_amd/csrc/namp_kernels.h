@@ -2017,6 +2017,10 @@ static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdat
 // applied to all T tiles: W_in (its 64 hidden units) against the T LayerNorm-1 tiles kept in LDS, then W_out, then each
 // projection fragment against the T output tiles.  Arithmetic per row is that of node_tail<true>.
 #define NODE_MULTI_LDS(T) (((2 * (T) * 16) + 8 * 16) * FFN_LD * 4)
+// X3 form: two more [T][16] row sets hold the LayerNorm-1 / h_V' rows already SPLIT into bf16 hi | mid fragment pieces (256 + 256 B
+// per row, the row pitch of the fp32 tiles) — every wave used to re-split the same fp32 rows for each of its GEMM phases (and for
+// each projection block): 576 of ~1,000 VALU instructions per tile and wave in a kernel that is instruction-issue bound.
+#define NODE_MULTI_LDS_X3(T) (((4 * (T) * 16) + 8 * 16) * FFN_LD * 4)
 
 // X3: Win_img / Wout_img / every projection image are x3 images (pack_image_x3_general_kernel / pack_image_x3_kernel) and
 // the three GEMM phases run as split-bf16 products: 144 bf16 MFMAs per tile instead of 384 fp32 MFMAs (5.3x fewer cycles).
@@ -2026,6 +2030,18 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
   float* xs = (float*)smem;                       // [T][16][FFN_LD]  LN1 outputs
   float* ys = xs + T * 16 * FFN_LD;               // [T][16][FFN_LD]  h_V' tiles
   float* ps = ys + T * 16 * FFN_LD;               // [8][16][FFN_LD]  per-wave partial FFN outputs of the tile in flight
+  // X3: split copies of the xs / ys rows: piece (s, g) of a row = the 8 bf16 lane (m, g) feeds into MFMA step s; hi at byte 0, mid at 256
+  char* xsp = (char*)(ps + 8 * 16 * FFN_LD);      // [T][16][FFN_LD * 4 bytes]
+  char* ysp = xsp + T * 16 * FFN_LD * 4;
+  auto put_split = [&](char* base, const int row, const f4 (&v)[8], const int g_) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      bf8 hi, mid;
+      split_x3(v[2 * s_], v[2 * s_ + 1], hi, mid);
+      *(bf8*)(base + row * (FFN_LD * 4) + 16 * (4 * s_ + g_)) = hi;
+      *(bf8*)(base + row * (FFN_LD * 4) + 256 + 16 * (4 * s_ + g_)) = mid;
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
@@ -2046,8 +2062,11 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         for (int c = 0; c < 8; ++c) x[c] += *(const f4*)(ps_ + 16 * c);
         ws += a.partial[(long)a.G * a.TPN * NAMP_H + (long)rr * a.TPN + p];
       }
+      if constexpr (X3) put_split(xsp, q * 16 + m, x, g);
+      else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+        for (int c = 0; c < 8; ++c) *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+      }
       if (g == 0) ps[q * 16 + m] = ws;
     }
     __syncthreads();
@@ -2062,10 +2081,8 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         f4 o = b3v * ps[q * 16 + m];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const float* xr = xs + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
-          bf8 hi, mid;
-          split_x3(*(const f4*)xr, *(const f4*)(xr + 16), hi, mid);
-          o = mfma_x3(wh[s], wm[s], hi, mid, o);
+          const char* xr = xsp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
+          o = mfma_x3(wh[s], wm[s], *(const bf8*)xr, *(const bf8*)(xr + 256), o);
         }
         *(f4*)(ys + (q * 16 + m) * FFN_LD + 16 * wave + 4 * g) = o;
       }
@@ -2108,6 +2125,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
     layernorm_row_T(x, t.ln1_g, t.ln1_b, g);
 #pragma unroll
     for (int c = 0; c < 8; ++c) *(f4*)(xs + (q * 16 + m) * FFN_LD + 16 * c + 4 * g) = x[c];
+    if constexpr (X3) put_split(xsp, q * 16 + m, x, g);
   }
   __syncthreads();
   // ---- phase A: hidden = gelu(W_in x + b_in); wave w owns hidden units 64w .. 64w+63
@@ -2125,9 +2143,8 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
       for (int c = 0; c < 4; ++c) hacc[q][c] = *(const f4*)(t.b_in + 64 * wave + 16 * c + 4 * g);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float* xr = xs + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
-        bf8 hi, mid;
-        split_x3(*(const f4*)xr, *(const f4*)(xr + 16), hi, mid);
+        const char* xr = xsp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
+        const bf8 hi = *(const bf8*)xr, mid = *(const bf8*)(xr + 256);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma_x3(wh[s][tn], wm[s][tn], hi, mid, hacc[q][tn]);
       }
@@ -2218,6 +2235,17 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         const float mk = (t.mask && ok) ? (float)t.mask[orow] : 1.0f;
         const f4 y = (v * rstd * *(const f4*)(t.ln2_g + c) + *(const f4*)(t.ln2_b + c)) * mk;
         *(f4*)(ys + (q * 16 + r) * FFN_LD + c) = y;
+        if constexpr (X3) {
+          // channels c..c+3 = elements 4 (tile & 1) .. + 3 of piece (s = tile / 2, g = (c % 16) / 4): half a piece per thread
+          typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+          const int tile_ = c >> 4, g_ = (c & 15) >> 2;
+          const bf4 hi = (bf4){(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+          const bf4 mid = (bf4){(__bf16)(y.x - (float)hi[0]), (__bf16)(y.y - (float)hi[1]), (__bf16)(y.z - (float)hi[2]),
+                                (__bf16)(y.w - (float)hi[3])};
+          char* yp = ysp + (q * 16 + r) * (FFN_LD * 4) + 16 * (4 * (tile_ >> 1) + g_) + 8 * (tile_ & 1);
+          *(bf4*)yp = hi;
+          *(bf4*)(yp + 256) = mid;
+        }
         if (ok) *(f4*)(t.hV_out + (long)orow * NAMP_H + c) = y;
       }
       __syncthreads();                                        // ps is free for the next tile; ys[q] is complete
@@ -2258,10 +2286,8 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         if constexpr (X3) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float* yr = ys + (q * 16 + m) * FFN_LD + 32 * s + 4 * g;
-            bf8 hi, mid;
-            split_x3(*(const f4*)yr, *(const f4*)(yr + 16), hi, mid);
-            acc = mfma_x3(wfh[s], wfm[s], hi, mid, acc);
+            const char* yr = ysp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
+            acc = mfma_x3(wfh[s], wfm[s], *(const bf8*)yr, *(const bf8*)(yr + 256), acc);
           }
         } else {
 #pragma unroll

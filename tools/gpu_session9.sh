@@ -4,9 +4,10 @@ O=$R/gpurun_out/r02o
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_model.py -m gpu -q -x 2>&1 | tail -4
-for v in 1 2; do
-timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/lg_$v.json 2> $O/lg_$v.err
+for v in head new head new; do
+if [ $v = new ]; then unset NAMP_LIB_PATH; else export NAMP_LIB_PATH=$R/tools/_variants/$v.so; fi
+timeout 600 python bench.py --workload cfg3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > $O/sp_$v.json 2> $O/sp_$v.err
 python -c "
 import json
-d=json.loads(open('$O/lg_$v.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})"
+d=json.loads(open('$O/sp_$v.json').read().strip().splitlines()[-1]); print('$v', d['ms_per_step'], d['value'], {k:v['avg_ms'] for k,v in d['per_kernel'].items()})"
 done
