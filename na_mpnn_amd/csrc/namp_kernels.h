@@ -1528,6 +1528,13 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
   if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
   if (EMB) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.eW1_img, 32, wave, nwaves, lane);
+  // edge update: b2 | b3 | LayerNorm-3 weight | bias (4 x 128 floats) staged behind the images — read per tile as 32 16-byte
+  // loads, they were 32 KiB per tile through the vector-memory path (1 KiB per wave-instruction at 64 B/clk), next to 12 KiB of rows
+  float* cst = (float*)(smem + 3 * NAMP_BIMG_BYTES);
+  if (MODE == MODE_ENC_EDGE && tid < 512) {
+    const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
+    cst[tid] = srcv[tid & 127];
+  }
   wait_dma_and_sync();
   const bf8* bw = (const bf8*)smem + lane;
   for (; tile < ntiles; tile += stride) {
@@ -1593,17 +1600,17 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
     f4 (&y)[8] = pjv;
     if (MODE == MODE_ENC_EDGE) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(cst + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(cst + 128 + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
 #pragma unroll
       for (int sq = 0; sq < 4; ++sq) {                                  // residual: the row is still in registers
         acc[2 * sq] += (f4){(float)xb[sq][0], (float)xb[sq][1], (float)xb[sq][2], (float)xb[sq][3]};
         acc[2 * sq + 1] += (f4){(float)xb[sq][4], (float)xb[sq][5], (float)xb[sq][6], (float)xb[sq][7]};
       }
-      layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+      layernorm_row_T(acc, cst + 256, cst + 384, g);
       if (me.valid) {
         bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + g;
 #pragma unroll
