@@ -1318,6 +1318,13 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 #pragma unroll
     for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
   }
+  // edge update: b2 | b3 | LayerNorm-3 weight | bias staged behind the ring (see edge_mlp_bf16s_kernel): 32 of the 64 16-byte
+  // loads per tile were these four constant vectors
+  float* cst = (float*)(smem + 2 * NAMP_IMG_BYTES);
+  if (MODE == MODE_ENC_EDGE && tid < 512) {
+    const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
+    cst[tid] = srcv ? srcv[tid & 127] : 0.f;              // (ln_g / ln_b are null when the bare message is requested)
+  }
   dma_to_lds(slotA, a.W1_img, 64, wave, nwaves, lane);
   for (; base < ntiles; base += stride) {
     const bool active = base + wave < ntiles;
@@ -1374,13 +1381,13 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
     }
     dma_to_lds(slotA, a.W3_img, 64, wave, nwaves, lane);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+    for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(cst + 16 * t + 4 * g);
     gemm128<true, false, true>(y, acc, (const f4*)slotB + lane);
     wait_dma_and_sync();                                   // W3 landed; everyone is done with slotB (W2)
     if (more) dma_to_lds(slotB, a.W1_img, 64, wave, nwaves, lane);   // next round's W1, under GEMM 3
     if (MODE == MODE_ENC_EDGE) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(cst + 128 + 16 * t + 4 * g);
       gemm128<true, false, true>(acc, y, (const f4*)slotA + lane);
       if (a.drop_thresh) {
         const uint32_t key = drop_row_key(a.drop_seed, me.erow);
@@ -1393,7 +1400,7 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
         const float* src = a.hE + me.erow * NAMP_H + 4 * g;           // residual: re-read (L2), 32 registers less than keeping x
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] += *(const f4*)(src + 16 * t);
-        layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+        layernorm_row_T(acc, cst + 256, cst + 384, g);
       }
       if (active && me.valid) {
         float* dst = a.hE_out + me.erow * NAMP_H + 4 * g;
