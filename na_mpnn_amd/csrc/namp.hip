@@ -138,10 +138,10 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048);
-  set((const void*)(edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), 3 * NAMP_BIMG_BYTES + 2048);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
+  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
+  set((const void*)(edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
@@ -243,11 +243,11 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   // 12 waves per CU; 16 (1,024 threads, 128 VGPRs) measured the same: the launch is instruction-issue bound, not latency bound
   if constexpr (MODE == MODE_ENC_MSG) {
     if (a.eW1_img) {                     // fused edge embedding: a.hE = fp32 E, a.hE16_out = the bf16 rows
-      hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048, s, a);
+      hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256, s, a);
       return NAMP_OK;
     }
   }
-  hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048, s, a);
+  hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256, s, a);
   return NAMP_OK;
 }
 

@@ -1531,6 +1531,16 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
 #pragma unroll
     for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
   }
+  // Pa[i] is ONE row per tile (all 16 rows of a tile belong to residue i): as four per-lane 16-byte loads it went through the vector-
+  // memory path sixteen times over (4 KiB per tile for 256 B).  The row of the NEXT tile is DMA'd (16 lanes x 16 B, global_load_lds)
+  // into a 256-byte slot per wave and read back as LDS broadcasts.
+  char* pa_slot = smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 256;
+  auto pa_fetch = [&](const long row) {
+    if (lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa16 + row * NAMP_H + 8 * lane),
+                                       (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
+  };
+  pa_fetch(cur.pa_row);
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
   if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
@@ -1542,6 +1552,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
     const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
     cst[tid] = srcv[tid & 127];
   }
+  if (MODE != MODE_ENC_EDGE && tid < 128) cst[tid] = a.b2[tid];        // message modes: b2 (read per lane as b2[16 t + m])
   wait_dma_and_sync();
   const bf8* bw = (const bf8*)smem + lane;
   for (; tile < ntiles; tile += stride) {
@@ -1571,10 +1582,13 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
 #else
-    bf16_row_to_f32(acc, a.Pa16 + me.pa_row * NAMP_H, g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's Pa row (DMA'd one tile ahead) and h_E row have landed
+    bf16_row_to_f32(acc, (const __bf16*)pa_slot, g);
     bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H, g);
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot has been read before the next row overwrites it
+    pa_fetch(cur.pa_row);
     if constexpr (EMB) {
       const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1625,7 +1639,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      for (int t = 0; t < 8; ++t) { const float b = cst[16 * t + m]; y[t] = (f4){b, b, b, b}; }
       chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));       // F orientation: rows 4g+r of channel 16t + m
       // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
       float wr[4];
