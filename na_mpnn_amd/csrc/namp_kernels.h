@@ -643,7 +643,8 @@ struct EdgeArgs {
 // TAIL (message modes only): the workgroup goes on to update its own residues (node_tail) instead of
 // writing partial sums — one launch per layer half instead of two, worth it while the whole batch is
 // a single wave of workgroups (every workgroup re-streams the 768 KiB of FFN / projection weights).
-#define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)      // ring + per-wave K-sums + their weight sums
+#define EDGE_TAIL_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64 + 2048)   // ring + per-wave K-sums + their weight sums + the fused
+                                                                          // edge update's constant vectors (eb2 | eb3 | LN3 weight | bias)
 
 // TAIL: 0 = write partial sums; 4 / 8 = node_tail_rows<4/8> (the workgroup owns <= 4 / <= 6 residues);
 // 16 = node_tail (16-row MFMA tile).  Chosen by the host from 12/TPN so that only one variant is inlined.
@@ -775,11 +776,18 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
       }
     }
   } else {
+  float* cstf = (float*)(smem + 2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64);
   if (FUSE) {
     // ---- fused edge update of the previous layer: images eW1 -> buf1, eW2 -> buf0, eW3 -> buf1, so that the
     // message images land in their usual slots (W1 buf0, W2 buf1, W3 buf0) one GEMM ahead of their use
     dma_to_lds(buf1, a.eW1_img, 64, wave, nwaves, lane);
     dma_to_lds(buf0, a.eW2_img, 64, wave, nwaves, lane);
+    // eb2 | eb3 | LayerNorm-3 weight | bias -> LDS: as 32 16-byte loads per wave they were 32 KiB x 12 waves through the CU's
+    // 64 B/clk vector-memory path per launch (profiles/r02k_bf16s_ablation.md, last table)
+    for (int i = tid; i < 512; i += (int)blockDim.x) {      // (a workgroup has 7 .. 12 waves)
+      const float* srcv = i < 128 ? a.eb2 : i < 256 ? a.eb3 : i < 384 ? a.ln_g : a.ln_b;
+      cstf[i] = srcv[i & 127];
+    }
     wait_dma_and_sync();
     gemm128<X3, false, false>(acc, x, w1);
 #pragma unroll
@@ -787,16 +795,16 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
     __syncthreads();                                      // every wave is done with buf1 (eW1)
     dma_to_lds(buf1, a.eW3_img, 64, wave, nwaves, lane);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) pjv[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
+    for (int t = 0; t < 8; ++t) pjv[t] = *(const f4*)(cstf + 16 * t + 4 * g);
     gemm128<X3, false, true>(pjv, acc, w0);       // pjv = edge-MLP layer-2 pre-activations
     wait_dma_and_sync();                                  // eW3 landed; buf0 (eW2) is free
     dma_to_lds(buf0, a.W1_img, 64, wave, nwaves, lane);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.eb3 + 16 * t + 4 * g);
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(cstf + 128 + 16 * t + 4 * g);
     gemm128<X3, false, true>(acc, pjv, w1);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] += acc[t];           // residual
-    layernorm_row_T(x, a.ln_g, a.ln_b, g);                // x = updated h_E row: stored, and the message input
+    layernorm_row_T(x, cstf + 256, cstf + 384, g);        // x = updated h_E row: stored, and the message input
 #ifdef NAMP_ABL_NOSTORE
     if (valid && a.G < 0) {
 #else
