@@ -151,9 +151,9 @@ void set_lds_attributes() {
   set((const void*)dec_sample_kernel<true, false>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<false, true>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<true, true>, SAMPLE_LDS);
-  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES + 2048);
-  set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES + 2048);
-  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES + 2048);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
+  set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_features_kernel<0>, FEAT_LDS);
   set((const void*)edge_features_kernel<1>, FEAT_LDS);
   set((const void*)edge_features_kernel<2>, FEAT_LDS);
@@ -228,7 +228,7 @@ int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
-  hipLaunchKernelGGL((edge_mlp_x3_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 2 * NAMP_IMG_BYTES + 2048, s, a);
+  hipLaunchKernelGGL((edge_mlp_x3_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 2 * NAMP_IMG_BYTES + 2048 + 12 * 512, s, a);
   return NAMP_OK;
 }
 

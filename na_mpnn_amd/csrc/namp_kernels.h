@@ -1333,6 +1333,15 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
     const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
     cst[tid] = srcv ? srcv[tid & 127] : 0.f;              // (ln_g / ln_b are null when the bare message is requested)
   }
+  if (MODE != MODE_ENC_EDGE && tid < 128) cst[tid] = a.b2[tid];
+  // the tile's single Pa row through a 512-byte LDS slot per wave, DMA'd one round ahead (see edge_mlp_bf16s_kernel)
+  const float* pa_slot = (const float*)(smem + 2 * NAMP_IMG_BYTES + 2048 + wave * 512);
+  auto pa_fetch = [&](const long row) {
+    if (lane < 32)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa + row * NAMP_H + 4 * lane),
+                                       (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
+  };
+  pa_fetch(cur.pa_row);
   dma_to_lds(slotA, a.W1_img, 64, wave, nwaves, lane);
   for (; base < ntiles; base += stride) {
     const bool active = base + wave < ntiles;
@@ -1343,15 +1352,17 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xn[t];
     {
-      const float* pa = a.Pa + me.pa_row * NAMP_H + 4 * g;
+      // (the wait at the top of the round drained the vector-memory counter: this round's Pa row has landed in the slot)
       const float* pj = (me.pj_from1 ? a.Pj1 : a.Pj0) + me.pj_row * NAMP_H + 4 * g;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa_slot + 16 * t + 4 * g); pjv[t] = *(const f4*)(pj + 16 * t); }
     }
     // next round: metadata chain + h_E row, in flight under this round's GEMMs
     const long nb = base + stride;
     const bool more = nb < ntiles;                         // workgroup-uniform
     cur = tile_meta<MODE>(a, nb + wave < ntiles ? nb + wave : (active ? base + wave : 0), m, g);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot has been read before the next row overwrites it
+    pa_fetch(cur.pa_row);
     {
       const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1367,7 +1378,7 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
       // under GEMM 2, the slots keep their roles
       if (more) dma_to_lds(slotA, a.W1_img, 64, wave, nwaves, lane);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      for (int t = 0; t < 8; ++t) { const float b = cst[16 * t + m]; y[t] = (f4){b, b, b, b}; }
       gemm128<true, true, true>(y, acc, (const f4*)slotB + lane);       // F orientation: rows 4g+r of channel 16t + m
       // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
       float wr[4];
