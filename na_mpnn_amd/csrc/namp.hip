@@ -135,9 +135,9 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 4, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 8, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
   set((const void*)(edge_mlp_kernel<MODE_ENC_MSG, 16, PREC_X3, PRE_EMBED>), EDGE_TAIL_LDS);
-  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES);
-  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES);
-  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
+  set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
   set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
   set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
@@ -216,7 +216,7 @@ int launch_edge_bf16_persistent(EdgeArgs a, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
-  hipLaunchKernelGGL((edge_mlp_bf16_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES, s, a);
+  hipLaunchKernelGGL((edge_mlp_bf16_persistent_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512, s, a);
   return NAMP_OK;
 }
 

@@ -1222,6 +1222,20 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
     for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
   }
+  // constant vectors and the tile's single Pa row through LDS instead of the vector-memory path (see edge_mlp_bf16s_kernel)
+  float* cst = (float*)(smem + 3 * NAMP_BIMG_BYTES);
+  if (MODE == MODE_ENC_EDGE && tid < 512) {
+    const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
+    cst[tid] = srcv ? srcv[tid & 127] : 0.f;
+  }
+  if (MODE != MODE_ENC_EDGE && tid < 128) cst[tid] = a.b2[tid];
+  const float* pa_slot = (const float*)(smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 512);
+  auto pa_fetch = [&](const long row) {
+    if (lane < 32)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa + row * NAMP_H + 4 * lane),
+                                       (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
+  };
+  pa_fetch(cur.pa_row);
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
   if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
@@ -1233,15 +1247,17 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xn[t];
     const TileMeta me = cur;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's Pa row (DMA'd one tile ahead) and h_E row have landed
     {
-      const float* pa = a.Pa + me.pa_row * NAMP_H + 4 * g;
       const float* pj = (me.pj_from1 ? a.Pj1 : a.Pj0) + me.pj_row * NAMP_H + 4 * g;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa + 16 * t); pjv[t] = *(const f4*)(pj + 16 * t); }
+      for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(pa_slot + 16 * t + 4 * g); pjv[t] = *(const f4*)(pj + 16 * t); }
     }
     // next tile: metadata chain + h_E row, in flight under this tile's GEMMs
     const long nt = tile + stride;
     cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot has been read before the next row overwrites it
+    pa_fetch(cur.pa_row);
     {
       const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1253,10 +1269,10 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
     f4 (&y)[8] = pjv;
     if (MODE == MODE_ENC_EDGE) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(cst + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(cst + 128 + 16 * t + 4 * g);
       chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
       if (a.drop_thresh) {                                        // training forward: dropout3 on the message
         const uint32_t key = drop_row_key(a.drop_seed, me.erow);
@@ -1268,7 +1284,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
       if (a.ln_g) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] += x[t];               // residual: the row is still in registers
-        layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+        layernorm_row_T(acc, cst + 256, cst + 384, g);
       }
       if (me.valid) {
         float* dst = a.hE_out + me.erow * NAMP_H + 4 * g;
@@ -1278,7 +1294,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
     } else {
       // layer 2 in the F orientation: rows 4g+r of channel 16t + m
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
+      for (int t = 0; t < 8; ++t) { const float b = cst[16 * t + m]; y[t] = (f4){b, b, b, b}; }
       chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
       // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
       float wr[4];
