@@ -107,6 +107,11 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
   if (MODE == BWD_EDGE_LN) { if (threadIdx.x < 2 * NAMP_H) colsum[threadIdx.x] = 0.f; }
+  // b2 (| b3 | LayerNorm-3 weight) staged once per workgroup: as 16-byte loads per lane they are 8 KiB per wave and vector through the
+  // CU's 64 B/clk vector-memory path (profiles/r02k_bf16s_ablation.md, last table)
+  __shared__ __attribute__((aligned(16))) float cstb[3 * NAMP_H];
+  if (threadIdx.x < NAMP_H) cstb[threadIdx.x] = a.b2[threadIdx.x];
+  else if (MODE == BWD_EDGE_LN && threadIdx.x < 3 * NAMP_H) cstb[threadIdx.x] = (threadIdx.x < 2 * NAMP_H ? a.b3 : a.ln_g)[threadIdx.x & (NAMP_H - 1)];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     }
   }
 #pragma unroll
-  for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(a.b2 + 16 * t + 4 * g);
+  for (int t = 0; t < 8; ++t) z2[t] = *(const f4*)(cstb + 16 * t + 4 * g);
   gemm128p<PREC, false>(z2, x, w1);
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = gelu_split4(z2[t]);      // x <- a2 (only stored, for dW3), z2 <- gelu'(z2)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     store_rows(a.A2, x);
     f4 z3[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(a.b3 + 16 * t + 4 * g);
+    for (int t = 0; t < 8; ++t) z3[t] = *(const f4*)(cstb + NAMP_H + 16 * t + 4 * g);
     gemm128p<PREC, false>(z3, x, w0);
     asm volatile("" ::: "memory");       // the row loads below have kernel-constant addresses: do not hoist them (96 VGPRs) over the GEMMs
     const uint32_t key = drop_row_key(a.drop_seed, e);
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
     for (int t = 0; t < 8; ++t) {
       z3[t] *= rstd;                                           // xhat
       const f4 gy = valid ? *(const f4*)(gsrc + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
-      const f4 gg = gy * *(const f4*)(a.ln_g + 16 * t + 4 * g);
+      const f4 gg = gy * *(const f4*)(cstb + 2 * NAMP_H + 16 * t + 4 * g);
       gr[t] = gg;
       m1 += (gg.x + gg.y) + (gg.z + gg.w);
       m2 += (gg.x * z3[t].x + gg.y * z3[t].y) + (gg.z * z3[t].z + gg.w * z3[t].w);
