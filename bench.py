@@ -19,14 +19,17 @@ the launcher's ranks and refuses a WORLD_SIZE that contradicts --gpus.
 The default cfg2 run times the path TWICE with the same K / W: the headline (`value`, `dtype` "f32")
 is the EXACT fp32 evaluation (v_mfma_f32_16x16x4_f32, what BASELINE configs[1] states); the `x3`
 object beside it is the split-bf16 evaluation (three bf16 products per fp32 product, fp32-equivalent
-to ~2^-16), the model's default.  Rank 0 prints ONE JSON line with the driver's contract keys plus
-  roofline      – dominant kernel, algorithmic FLOPs / HIP-event-measured duration vs the MFMA peak of its dtype
-  x3            – {value, ms_per_step, roofline, parity} of the split-bf16 evaluation (cfg2 only)
+to ~2^-16), the model's default.  Rank 0 prints ONE COMPACT JSON line (< 6 KB) with the driver's contract keys plus
+  roofline      – dominant kernel: EXECUTED FLOPs / HIP-event-measured duration vs the MFMA peak of its dtype (`frac`); the
+                  rate of the reference's dense formulation (the launch executes about half of it) beside it as
+                  `algorithmic_*`; `traffic` = HBM bytes per launch from two live rocprofv3 PMC passes of this very workload
+  cpu_baseline  – the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores
   parity        – max |dlogp|, arg-max equality and sequence recovery vs the CPU oracle on the same inputs
   gather        – the standalone neighbour-gather (cat_neighbors_nodes) HBM figure, cfg3-shaped
-  cpu_baseline  – the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores:
-                  best thread count, 1 thread, and the full forward from coordinates
-  secondary     – short runs of cfg3 (bf16, B=64), cfg5 (training step) and cfg1 (design call), N = 1 only
+  x3            – the split-bf16 evaluation of the same pass (cfg2 only)
+  secondary     – short runs of cfg3 (bf16, B=64), cfg5 (training step), cfg1 (design call) and cfg4 (the split), N = 1 only
+Everything longer (per-kernel tables, sample descriptions, the full line of every secondary workload) goes to
+`--detail-out` (default gpurun_out/bench_detail.json when that directory exists) or to stdout's line with --verbose.
 """
 from __future__ import annotations
 
@@ -62,6 +65,10 @@ ALGO_FLOP = {"enc_message": 7_864_320, "enc_edge_update": 7_864_320, "dec_messag
 EXEC_GEMMS = {"enc_message": 2, "enc_edge_update": 3, "dec_message": 2, "enc_edge_message": 5, "enc_edge_dec_message": 5,
               "encdec_persistent": 22}           # 1 (W_e) + 9 edge-update + 12 message GEMMs per edge
 ALGO_FLOP_TOTAL = 78_684_416
+# algorithmic HBM bytes per launch at cfg2 (N = 1000): h_E rows 48 x 128 x 4 B per residue and pass (message: one read;
+# edge update: read + write), E_idx 192 B, residue rows 512 B each
+TRAFFIC_ALGO = {"enc_message": 1000 * (24_576 + 192 + 4 * 512), "dec_message": 1000 * (24_576 + 192 + 8 + 4 * 512),
+                "enc_edge_message": 1000 * (2 * 24_576 + 192 + 5 * 512), "enc_edge_dec_message": 1000 * (2 * 24_576 + 192 + 8 + 6 * 512)}
 KERNEL_OF = {"encdec_persistent": "encdec_persistent_kernel"}      # launch kind -> kernel name when it is not edge_mlp_kernel
 # executed FLOP / residue of the hoisted formulation (three 128x128 GEMMs per edge)
 EXEC_FLOP_EDGE = 48 * 3 * 2 * 128 * 128
@@ -136,16 +143,84 @@ def gather_microbench(dev, reps=10):
     copy_gbs = 2 * src.numel() * 4 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
     del hE, hV, idx, out, src, dst
     torch.cuda.empty_cache()
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get("gather_cfg3")
-    except OSError:
-        pass
     return {"kernel": "gather_cat_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4),
-            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": traffic,
+            "shape": "B=64 N=1000 K=48 C=128|128 fp32", "traffic": None,
             "d2d_copy_GBps": round(copy_gbs, 1), "frac_of_d2d_copy": round(gbs / copy_gbs, 3)}
+
+
+def pmc_child():
+    """`bench.py --pmc-child`: the launches whose HBM traffic the parent reads from rocprofv3's PMC passes — three cfg2 passes in
+    exact fp32, three in split-bf16, two gather launches at the cfg3 shape.  Prints nothing."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)
+    for prec in ("fp32", "x3"):
+        r = Runner(dev, 1, 1000, 48, seed=3, precision=prec)
+        for _ in range(3):
+            r.step()
+        torch.cuda.synchronize()
+        del r
+    gather_microbench(dev, reps=1)
+    torch.cuda.synchronize()
+
+
+# edge_mlp_kernel<MODE, TAIL, PREC, PRE> -> launch kind (PREC 0 = exact fp32, 2 = split-bf16)
+PMC_KIND = {(0, 1): "enc_message", (0, 3): "enc_edge_message", (1, 3): "enc_edge_dec_message", (1, 0): "dec_message"}
+
+
+def live_pmc_traffic(timeout_s=150):
+    """HBM-side bytes per launch, measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE need separate passes,
+    MI355X_MICROARCH.md) over `bench.py --pmc-child`; bytes = 2 x FETCH_SIZE KB (gfx950 counts a wide read's 128-B request as
+    64 B) + WRITE_SIZE KB, averaged over the dispatches of a kernel.  Returns ({"fp32": {kind: bytes}, "x3": {...},
+    "gather": bytes}, source-description) or (None, reason)."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if os.environ.get("NAMP_BENCH_NO_PMC") == "1" or any(k.startswith("ROCPROFILER_") or k.startswith("ROCP_") for k in os.environ):
+        return None, "skipped (NAMP_BENCH_NO_PMC=1 or already under a profiler)"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="namp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", NAMP_BENCH_NO_PMC="1")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if p.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-200:]}"
+            rows = sqlite3.connect(dbs[0]).execute("select kernel_name, dispatch_id, counter_name, value from counters_collection").fetchall()
+            acc = defaultdict(float)
+            for k, disp, c, v in rows:
+                if c == counter:
+                    acc[(re.sub(r"\(.*", "", k), disp)] += v
+            agg = defaultdict(list)
+            for (k, _), v in acc.items():
+                agg[k].append(v)
+            per[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+    except Exception as e:                                       # noqa: BLE001 — a failed profile must not take the line down
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"fp32": {}, "x3": {}, "gather": None}
+    for k in set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]):
+        nbytes = round((2 * per["FETCH_SIZE"].get(k, 0.0) + per["WRITE_SIZE"].get(k, 0.0)) * 1024)
+        m = re.search(r"edge_mlp_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
+        if m:
+            mode, tail, prec, pre = map(int, m.groups())
+            kind = PMC_KIND.get((mode, pre))
+            if kind and tail:
+                out["x3" if prec == 2 else "fp32"][kind] = nbytes
+        if "gather_cat_kernel" in k:
+            out["gather"] = nbytes
+    return out, "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over `bench.py --pmc-child` in this run; bytes = 2 x FETCH_SIZE KB + WRITE_SIZE KB"
 
 
 def seq_recovery(S_true, S_pred, mask):
@@ -299,11 +374,11 @@ def train_bench(args, dev, rank, world, dist):
     x3 = mp != "fp32"                                       # bf16 pipe; "x3": 3 bf16 MFMAs per algorithmic product, "bf16": 1
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
     algo_tf = BWD_FLOP_EDGE_ALGO * edges / avg_s / 1e12
+    exec_tf = BWD_FLOP_EDGE_EXEC * (3 if mp == "x3" else 1) * edges / avg_s / 1e12
     roofline = {"kernel": "edge_chain_bwd_kernel", "bound": "mfma",
-                "achieved": round(algo_tf, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(algo_tf / peak, 4), "traffic": None,
-                "executed_frac": round(BWD_FLOP_EDGE_EXEC * (3 if mp == "x3" else 1) * edges / avg_s / 1e12 / peak, 4),
-                "frac_vs_fp32_mfma_peak": round(algo_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "achieved": round(exec_tf, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(exec_tf / peak, 4), "basis": "executed FLOPs", "executed_frac": round(exec_tf / peak, 4),
+                "algorithmic_achieved": round(algo_tf, 3), "algorithmic_frac": round(algo_tf / peak, 4), "traffic": None,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": bwd_n,
                 "note": "algorithmic = 3 data-gradient GEMMs per edge; executed adds the 2 recomputed forward GEMMs "
                         "(the reference's checkpoint-recompute policy); durations from the device trace of one step"}
@@ -368,26 +443,47 @@ def split_bench(args, dev, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         step()
+    # Strong scaling divides one pass by the rank count (~40 ms per pass at N = 8): a timed region of a few passes would be
+    # decided by launch latency and the slowest rank's jitter.  The pass count is therefore scaled so that the timed region
+    # lasts >= --min-seconds on the SLOWEST rank (every rank uses the same count: MAX all-reduce of one calibration pass).
+    barrier()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_pass = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([t_pass], device=coll_device(dev, dist), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_pass = float(t.item())
+    steps_requested = args.steps
+    args.steps = max(args.steps, int(np.ceil(args.min_seconds / max(t_pass, 1e-6))))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0                     # this rank's own passes, before waiting for the others
     barrier()
     elapsed = time.perf_counter() - t0
+    my_res = int(sum(lengths[i] for i in mine))
+    per_rank = [[float(my_res), my_elapsed]]
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine_t = torch.tensor([float(my_res), my_elapsed], device=coll_device(dev, dist), dtype=torch.float64)
+        allr = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
+        per_rank = [[float(a[0]), float(a[1])] for a in allr]
     total_res = int(lengths.sum())
     t1 = time.perf_counter()
     collated = shard.all_gather_ragged(result, len(lengths), device=coll_device(dev, dist))
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t1) * 1e3
     n_coll = sum(int(x.numel()) for x in collated if x is not None)
-    my_res = int(sum(lengths[i] for i in mine))
+    rr, rs = [a[0] for a in per_rank], [a[1] for a in per_rank]
     out = {"metric": "residues/sec (featurise + enc + dec forward from coordinates), design_test-sized split", "unit": "residues/s",
            "value": round(total_res * args.steps / elapsed, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -395,9 +491,14 @@ def split_bench(args, dev, rank, world, dist):
            "config": {"workload": f"cfg4: {len(lengths)} complexes, {total_res} residues (N_i log-uniform 50..3000), K=48, one "
                                   "score() from coordinates per token-bucket batch, LPT shards, no data-path collective",
                       "global_batch": len(lengths), "seq_len": int(np.median(lengths)), "parallelism": f"independent complexes x{world}"},
-           "shard": {"rank0_complexes": len(mine), "rank0_batches": len(batches), "batch_tokens": args.batch_tokens, "rank0_residues": my_res, "ideal_residues_per_rank": total_res // world},
+           "shard": {"rank0_complexes": len(mine), "rank0_batches": len(batches), "batch_tokens": args.batch_tokens, "rank0_residues": my_res,
+                     "ideal_residues_per_rank": total_res // world, "steps_requested": steps_requested, "calibration_pass_s": round(t_pass, 4),
+                     "per_rank_residues": {"min": int(min(rr)), "mean": round(sum(rr) / len(rr), 1), "max": int(max(rr))},
+                     "per_rank_seconds": {"min": round(min(rs), 4), "mean": round(sum(rs) / len(rs), 4), "max": round(max(rs), 4)},
+                     "lpt_imbalance": round(max(rr) / (sum(rr) / len(rr)), 4)},
            "collation": {"collective": "all_reduce(lengths) + all_gather(padded int32 sequences)", "ms": round(gather_ms, 3),
-                         "residues_collated": n_coll}}
+                         "backend": (dist.get_backend() if dist is not None else None),
+                         "ranks": (dist.get_world_size() if dist is not None else 1), "residues_collated": n_coll}}
     assert n_coll == total_res, (n_coll, total_res)
     return out
 
@@ -491,19 +592,6 @@ def coll_device(dev, dist):
     return torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else dev
 
 
-def traffic_entry(workload, kind):
-    """HBM-side bytes per launch of `kind` from the committed PMC passes (tools/profile_round.sh regenerates
-    profiles/pmc_traffic.json every round and stamps the commit it profiled); bench.py cannot run rocprofv3 on itself."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-    except OSError:
-        return None, None
-    src = {"file": "profiles/pmc_traffic.json", "commit": t.get("_commit"), "round": t.get("_round"),
-           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (MI355X_MICROARCH.md)"}
-    return (t.get(workload, {}) or {}).get(kind), src
-
-
 def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmup, profile_steps=None):
     """Time `steps` passes of the encoder+decoder forward (one namp_encdec_fwd call each) at `precision`."""
     cfg = WORKLOADS[workload]
@@ -562,19 +650,19 @@ def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmu
     dom = max((k for k in per_kernel if k in ALGO_FLOP), key=lambda k: per_kernel[k]["ms_per_step"])
     avg_s = per_kernel[dom]["avg_ms"] * 1e-3
     algo = ALGO_FLOP[dom] * B * N
-    traffic, traffic_source = traffic_entry(workload + ("" if precision == "x3" else "_" + precision), dom)
     # fp32: exact fp32 MFMA (peak 157.3).  x3 / bf16: the products run on the bf16 pipe (dense peak 2500); x3 executes three
-    # bf16 products per fp32 product.  `achieved` stays the ALGORITHMIC rate (dense fp32 formulation of SURVEY 8(d)).
+    # bf16 products per fp32 product.  `achieved` / `frac` price the FLOPs the launch EXECUTES (hoisted first layer, layer 3
+    # behind the K-sum: about half of the reference's dense formulation) — the matrix-pipe utilisation; the rate of the dense
+    # formulation of SURVEY 8(d) is reported beside it as algorithmic_*.
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     mult = 3 if precision == "x3" else 1
     exec_flop = EXEC_FLOP_EDGE * B * N * EXEC_GEMMS[dom] // 3 * mult
-    roofline = {"kernel": f"{KERNEL_OF.get(dom, 'edge_mlp_kernel')}<{dom}>", "bound": "mfma", "achieved": round(algo / avg_s / 1e12, 3),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(algo / avg_s / 1e12 / peak, 4),
-                "traffic": traffic, "traffic_source": traffic_source, "flop_per_launch_algorithmic": algo,
-                "flop_per_launch_executed": exec_flop,
-                "executed_frac": round(exec_flop / avg_s / 1e12 / peak, 4),
-                "frac_vs_fp32_mfma_peak": round(algo / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+    roofline = {"kernel": f"{KERNEL_OF.get(dom, 'edge_mlp_kernel')}<{dom}>", "bound": "mfma", "achieved": round(exec_flop / avg_s / 1e12, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(exec_flop / avg_s / 1e12 / peak, 4),
+                "basis": "executed FLOPs", "executed_frac": round(exec_flop / avg_s / 1e12 / peak, 4),
+                "algorithmic_achieved": round(algo / avg_s / 1e12, 3), "algorithmic_frac": round(algo / avg_s / 1e12 / peak, 4),
+                "traffic": None, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": exec_flop,
+                "avg_launch_ms": per_kernel[dom]["avg_ms"], "launch_kind": dom}
     dtype = {"fp32": "f32", "x3": "bf16x3 (per-edge GEMMs as three bf16 products of split fp32 operands, fp32 accumulate: "
                                    "fp32-equivalent to 2^-16; fp32 everywhere else)",
              "bf16": "bf16 (per-edge GEMMs; fp32 accumulate, fp32 elsewhere)"}[precision]
@@ -601,7 +689,7 @@ def secondary_runs(args, dev):
     Each entry is a full bench line of that workload (its own metric / roofline / cpu_baseline) or {"error": ...}."""
     import copy
     res = []
-    for wl, steps, warm in (("cfg3", 6, 2), ("cfg5", 4, 2), ("cfg1", 10, 3)):
+    for wl, steps, warm in (("cfg3", 6, 2), ("cfg5", 4, 2), ("cfg1", 10, 3), ("cfg4", 1, 1)):
         a = copy.copy(args)
         a.steps, a.warmup, a.workload = steps, warm, wl
         t0 = time.perf_counter()
@@ -620,6 +708,9 @@ def secondary_runs(args, dev):
                 o2 = train_bench(a2, dev, 0, 1, None)            # the mixed-precision mode of the same step
                 o["mixed_precision_bf16"] = {k: o2[k] for k in ("value", "ms_per_step", "dtype", "hip_kernel_share", "roofline")}
                 o["mixed_precision_bf16"]["final_loss"] = o2["whole_step"]["final_loss"]
+            elif wl == "cfg4":
+                a.min_seconds = 0.0                              # one pass over the split (BASELINE configs[3] at N = 1)
+                o = split_bench(a, dev, 0, 1, None)
             else:
                 o = design_bench(a, dev, 0, 1, None)
         except Exception as e:          # a failing secondary must not take the headline down with it
@@ -628,6 +719,97 @@ def secondary_runs(args, dev):
         res.append(o)
         torch.cuda.empty_cache()
     return res
+
+
+def short_dtype(d):
+    return str(d).split(" (")[0]
+
+
+def compact_roofline(r):
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "basis", "algorithmic_achieved", "algorithmic_frac", "traffic",
+            "traffic_algorithmic", "avg_launch_ms")
+    return {k: r[k] for k in keep if k in r}
+
+
+def compact_secondary(o):
+    """What the driver's record needs of a secondary workload; the full line goes to the detail file."""
+    if "error" in o:
+        return o
+    wl = o.get("config", {}).get("workload", "")
+    c = {"workload": wl.split(":")[0], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+         "dtype": short_dtype(o["dtype"])}
+    if "roofline" in o:
+        r = o["roofline"]
+        c["roofline"] = {"kernel": r["kernel"], "frac": r["frac"], "algorithmic_frac": r.get("algorithmic_frac"),
+                         "avg_launch_ms": r.get("avg_launch_ms")}
+    if "cpu_baseline" in o:
+        c["cpu_baseline"] = o["cpu_baseline"]["value"]
+    for k in ("hip_kernel_share", "checks", "levels"):
+        if k in o:
+            c[k] = o[k]
+    if "whole_step" in o:
+        c["peak_mem_gib"] = o["whole_step"]["peak_mem_gib"]
+        c["final_loss"] = o["whole_step"]["final_loss"]
+    if "mixed_precision_bf16" in o:
+        m = o["mixed_precision_bf16"]
+        c["mixed_precision_bf16"] = {"value": m["value"], "ms_per_step": m["ms_per_step"], "hip_kernel_share": m.get("hip_kernel_share")}
+    if "shard" in o:
+        c["batches"] = o["shard"]["rank0_batches"]
+        c["residues"] = o["collation"]["residues_collated"]
+    c["wall_s"] = o.get("wall_s")
+    return c
+
+
+def compact_line(out):
+    """The one JSON line rank 0 prints: contract keys first, then roofline / cpu_baseline / parity / gather / x3, then the
+    secondaries — all short; per-kernel tables and sample descriptions stay in the detail file."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data", "config") if k in out}
+    c["dtype"] = short_dtype(c["dtype"])
+    if "roofline" in out:
+        c["roofline"] = compact_roofline(out["roofline"])
+        if "traffic_source" in out["roofline"]:
+            c["roofline"]["traffic_source"] = out["roofline"]["traffic_source"][:60]
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample"][:110]}
+        if "one_thread" in cb:
+            c["cpu_baseline"]["one_thread"] = cb["one_thread"]["value"]
+            c["cpu_baseline"]["full_forward_from_X"] = cb["full_forward_from_X"]["value"]
+    if "parity" in out:
+        pr = out["parity"]
+        c["parity"] = {"max_abs_dlogp_vs_cpu": pr["max_abs_dlogp_vs_cpu"], "argmax_equal": pr["argmax_equal"],
+                       "seq_recovery_gpu_vs_cpu_argmax": pr["seq_recovery"]["gpu_vs_cpu_argmax"]}
+    if "gather" in out:
+        g = out["gather"]
+        c["gather"] = {k: g[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "ms_per_launch",
+                                         "traffic", "d2d_copy_GBps")}
+    if "x3" in out:
+        x = out["x3"]
+        c["x3"] = {"value": x["value"], "ms_per_step": x["ms_per_step"], "dtype": "bf16x3", "kernel": x["roofline"]["kernel"],
+                   "executed_frac": x["roofline"]["frac"], "algorithmic_frac": x["roofline"]["algorithmic_frac"],
+                   "avg_launch_ms": x["roofline"]["avg_launch_ms"], "traffic": x["roofline"].get("traffic")}
+        if "parity" in x:
+            c["x3"]["max_abs_dlogp_vs_cpu"] = x["parity"]["max_abs_dlogp_vs_cpu"]
+            c["x3"]["argmax_equal"] = x["parity"]["argmax_equal"]
+    if "x3_persistent_launch" in out:
+        c["x3_persistent_launch_ms"] = out["x3_persistent_launch"]["ms_per_step"]
+    for k in ("hip_kernel_share", "levels"):
+        if k in out:
+            c[k] = out[k]
+    if "whole_step" in out:
+        c["whole_step"] = out["whole_step"]
+    if "mixed_precision_bf16" in out:
+        c["mixed_precision_bf16"] = out["mixed_precision_bf16"]
+    if "shard" in out:
+        c["shard"] = out["shard"]
+    if "collation" in out:
+        co = out["collation"]
+        c["collation"] = {k: co[k] for k in ("backend", "ranks", "collated_residues", "expected_residues", "residues_collated", "ms") if k in co}
+    if "secondary" in out:
+        c["secondary"] = [compact_secondary(o) for o in out["secondary"]]
+    return c
 
 
 def respawn(args):
@@ -659,12 +841,20 @@ def main():
     ap.add_argument("--batch-tokens", type=int, default=32000,
                     help="cfg4: padded-token budget per batch inside a shard (32,000 tokens = 0.8 GB of h_E: sized for 288 GB of HBM; "
                          "measured 2.66 / 2.76 / 2.91 / 2.85 M residues/s at 8,000 / 16,000 / 32,000 / 64,000)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="cfg4: the pass count is raised until the timed region lasts at least this long on the slowest rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two live rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--verbose", action="store_true", help="print the full detail (per-kernel tables, every secondary line) instead of the compact line")
+    ap.add_argument("--detail-out", default=None, help="file for the full detail (default: gpurun_out/bench_detail.json when gpurun_out/ exists)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg5 / cfg1 runs appended to the default line")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.pmc_child:
+        return pmc_child()
 
     launched = "WORLD_SIZE" in os.environ
     if not launched and args.gpus > 1:
@@ -695,9 +885,24 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
 
+    if dist is not None:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+
     def finish(out):
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            assert out["n_gpus"] == world == args.gpus
+            detail = args.detail_out or (os.path.join(ROOT, "gpurun_out", f"bench_detail_{args.workload}.json")
+                                         if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+            if detail:
+                try:
+                    with open(detail, "w") as f:
+                        json.dump(out, f, indent=1)
+                except OSError:
+                    detail = None
+            line = out if args.verbose else compact_line(out)
+            if detail and not args.verbose:
+                line["detail_file"] = os.path.relpath(detail, ROOT)
+            print(json.dumps(line), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -719,9 +924,19 @@ def main():
     precision = args.precision or ("bf16" if args.workload == "cfg3" else "fp32")
     out, runner = encdec_bench(args, dev, rank, world, dist, args.workload, precision, args.steps, args.warmup)
     ref_out = None
+    traffic = None
     if rank == 0 and world == 1:
         if not args.no_gather:
             out["gather"] = gather_microbench(dev)
+        if args.workload == "cfg2" and not args.no_pmc:
+            # HBM bytes per launch of the dominant kernel (and of the gather), measured in this run by two rocprofv3 PMC passes
+            traffic, tsrc = live_pmc_traffic()
+            out["roofline"]["traffic_source"] = tsrc
+            if traffic:
+                out["roofline"]["traffic"] = traffic.get(precision if precision in traffic else "fp32", {}).get(out["roofline"]["launch_kind"])
+                out["roofline"]["traffic_algorithmic"] = TRAFFIC_ALGO.get(out["roofline"]["launch_kind"])
+                if "gather" in out:
+                    out["gather"]["traffic"] = traffic.get("gather")
         if not args.no_cpu_baseline:
             ref_out, cb = cpu_baseline(runner)
             out["cpu_baseline"] = cb
@@ -732,16 +947,12 @@ def main():
         del runner
         x3, rx = encdec_bench(args, dev, rank, world, dist, "cfg2", "x3", args.steps, args.warmup)
         xo = {k: x3[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "per_kernel", "whole_path")}
+        if traffic:
+            xo["roofline"]["traffic"] = traffic.get("x3", {}).get(xo["roofline"]["launch_kind"])
         if ref_out is not None:
             g = rx.g_np
             xo["parity"] = parity_vs_cpu(rx.logp[:1], ref_out, torch.from_numpy(g["S"][:1]).long(), torch.from_numpy(g["mask"][:1]))
         out["x3"] = xo
-        # compact copy inside `roofline`, which the driver's record keeps verbatim
-        out["roofline"]["also_measured_x3"] = {"value": xo["value"], "ms_per_step": xo["ms_per_step"],
-                                               "frac_vs_bf16_peak": xo["roofline"]["frac"],
-                                               "executed_frac": xo["roofline"]["executed_frac"],
-                                               "max_abs_dlogp_vs_cpu": xo.get("parity", {}).get("max_abs_dlogp_vs_cpu"),
-                                               "argmax_equal": xo.get("parity", {}).get("argmax_equal")}
         del rx
         torch.cuda.empty_cache()
         if world == 1 and not args.no_secondary:

@@ -230,7 +230,10 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
  * stages are separated by in-kernel grid barriers.  Results are bit-identical to the launch chain.  OFF by default — on
  * MI355X the barriers cost more than the launch boundaries they replace —; namp_set_persistent(1) or the
  * environment variable NAMP_PERSISTENT=1 selects it; returns the previous setting.  Two persistent launches are never in
- * flight on different streams (the second caller gets the chain).
+ * flight on different streams (the second caller gets the chain).  Co-residency is NOT guarded against OTHER kernels holding
+ * CUs on other streams: a workgroup that cannot become resident makes a bounded grid-barrier spin give up; the launch then
+ * overwrites the log-probabilities of the affected workgroups' residues with NaN (the call itself has already returned
+ * NAMP_OK), so a timeout cannot pass for a valid result.  Keep the device to this stream while the mode is on.
  * namp_persistent_status: synchronous read-back of the barrier state of the last persistent launch that used `ws`
  * (0 = every grid barrier completed; otherwise the code of the barrier that gave up — the outputs are then invalid). */
 int namp_set_persistent(int on);

@@ -140,6 +140,18 @@ __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
 #ifdef NAMP_ABL_NOGELU
   return x;
 #endif
+#ifdef NAMP_ABL_GELU16_SCALAR
+  f4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float c = __builtin_amdgcn_fmed3f(x[i], -4.f, 4.f), t = c * c;
+    float q = fmaf(2.2787273029e-08f, t, -1.5988982626e-06f);
+    q = fmaf(q, t, 4.7961328822e-05f); q = fmaf(q, t, -8.1407082443e-04f); q = fmaf(q, t, 8.7726502299e-03f);
+    q = fmaf(q, t, -6.4573666617e-02f); q = fmaf(q, t, 3.9788372746e-01f);
+    o[i] = x[i] * fmaf(c, q, 0.5f);
+  }
+  return o;
+#endif
   // v_med3_f32 directly: min(max(x, -4), 4) made the compiler canonicalise x first (one v_max_f32 x, x per value fresh out of an MFMA)
   const f4 xc = (f4){__builtin_amdgcn_fmed3f(x.x, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f),
                      __builtin_amdgcn_fmed3f(x.z, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.w, -4.f, 4.f)};

@@ -1153,6 +1153,21 @@ __global__ __launch_bounds__(768) void encdec_persistent_kernel(const PersistArg
   edge_stage<MODE_DEC_MSG, TAIL, PREC, PRE_NONE, 2>(P->st[4], x, smem);
   grid_barrier(P->sync, 5, tid);
   edge_stage<MODE_DEC_MSG, TAIL, PREC, PRE_NONE, 2>(P->st[5], x, smem);
+  // A bounded spin that gave up (another kernel occupying CUs on a different stream can starve a non-resident workgroup: co-residency is
+  // only guarded against other persistent launches) let its workgroup run past the barrier on stale tables.  The call has long
+  // returned NAMP_OK by then, so the failure must travel with the data: every workgroup that sees the timeout word set when it
+  // finishes — the one that timed out always does — overwrites the log-probabilities of its residues with NaN
+  // (namp_persistent_status still reports which barrier gave up).
+  __syncthreads();
+  if (__hip_atomic_load((gu32*)P->sync + NAMP_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    const StageArgs& L = P->st[5];
+    const int npw = (int)(blockDim.x >> 6) / L.TPN;
+    const int vocab = L.tail.vocab;
+    for (int e = tid; e < npw * vocab; e += blockDim.x) {
+      const int node = blockIdx.x * npw + e / vocab;
+      if (node < L.G && L.tail.log_probs) L.tail.log_probs[(long)node * vocab + e % vocab] = __builtin_nanf("");
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------

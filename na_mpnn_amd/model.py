@@ -16,6 +16,8 @@ from __future__ import annotations
 import ctypes as C
 import sys
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -140,7 +142,7 @@ class ProteinMPNN(nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws = None
-        self._tokens_ok = None
+        self._tokens_ok = {}          # argument name -> (weakref to the validated tensor, its version)
         # per-edge message / edge-update GEMMs: "x3" (default, parity mode) = three bf16 products of split operands with fp32
         # accumulation, fp32-equivalent to ~2^-16 (3e-5 on log-probs, arg-max unchanged) at 3/16 of the fp32 MFMA cost;
         # "fp32" = exact fp32 MFMA; "bf16" = plain bf16 inputs, BASELINE configs[2]'s throughput mode (~1e-2 on log-probs).
@@ -184,14 +186,16 @@ class ProteinMPNN(nn.Module):
     def _check_tokens(self, S, what="S"):
         """Token ids index the per-token tables inside the kernels: anything outside [0, vocab) would read out of bounds
         where the reference's nn.Embedding raises (model_utils.py:402).  One device reduction + host read per NEW tensor
-        (same storage and version: already checked), so steady-state calls on a resident feature_dict stay asynchronous."""
-        key = (S.data_ptr(), S._version, tuple(S.shape), what)
-        if self._tokens_ok == key:
+        OBJECT (identity through a weak reference + its version counter, one slot per argument name — never the address: the
+        caching allocator hands a fresh `S.to(device)` the block of the previous batch), so steady-state calls on a resident
+        feature_dict stay asynchronous."""
+        slot = self._tokens_ok.get(what)
+        if slot is not None and slot[0]() is S and slot[1] == S._version:
             return
         lo, hi = torch.aminmax(S)
         if int(lo) < 0 or int(hi) >= self.vocab:
             raise IndexError(f"na_mpnn_amd: token ids in '{what}' must lie in [0, {self.vocab}); got [{int(lo)}, {int(hi)}]")
-        self._tokens_ok = key
+        self._tokens_ok[what] = (weakref.ref(S), S._version)
 
     def _workspace(self, B_enc, B_dec, N, K, device):
         need = hip.lib().namp_workspace_bytes(B_enc, B_dec, N, K)
@@ -200,9 +204,10 @@ class ProteinMPNN(nn.Module):
         return self._ws
 
     # ---------------------------------------------------------------------------------------
-    # a11: featurisation (ProteinFeaturesNA.forward, model_utils.py:528-593).  First build: stock
-    # PyTorch-ROCm tensor ops, chunked over residues so the [.,K,18,18,16] RBF block stays small
-    # (the fused HIP featuriser is the next widening step).
+    # a11: featurisation (ProteinFeaturesNA.forward, model_utils.py:528-593).  The product path is the fused HIP
+    # featuriser (`_featurize_hip`: prep_atoms / knn_select / edge_features kernels); `featurize_torch` below —
+    # stock PyTorch-ROCm tensor ops chunked over residues — is only reached for a non-standard atom order and serves
+    # as an on-device cross-check in the tests.
     # ---------------------------------------------------------------------------------------
     def _virtual(self, p0, p1, p2, wa, wb, wc):
         b, c = p1 - p0, p2 - p1

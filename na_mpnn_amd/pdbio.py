@@ -293,6 +293,11 @@ def write_backbone_pdb(path, parsed, resnames3, bfactors):
     by_res = {}
     for i, (c, r) in enumerate(zip(parsed["chain_letters"], parsed["R_idx"].tolist())):
         by_res.setdefault((c, int(r)), i)             # the reference selects "chain c and resnum r": insertion codes share it
+    # PDB has ONE column for the chain id: mmCIF auth_asym_id values longer than that would collide once truncated
+    long_ids = sorted({at.chain for at in list(parsed["backbone_atoms"]) + list(parsed["other_atoms"]) if at.chain and len(at.chain) > 1})
+    if long_ids:
+        raise ValueError(f"write_backbone_pdb: chain ids {long_ids} do not fit the PDB format's one-character chain column "
+                         "(mmCIF input with multi-character auth_asym_id): rename the chains before asking for --output_pdbs")
     lines, serial = [], 1
     for at in parsed["backbone_atoms"]:
         i = by_res.get((at.chain, at.resnum))
@@ -301,7 +306,8 @@ def write_backbone_pdb(path, parsed, resnames3, bfactors):
         lines.append(_pdb_line(at.het, serial, at.name, rn, at.chain, at.resnum, at.icode, at.xyz, at.occ, bf, at.element))
         serial += 1
     for at in parsed["other_atoms"]:
-        lines.append(_pdb_line(at.het, serial, at.name, at.resname, at.chain, at.resnum, at.icode, at.xyz, at.occ, at.bfac, at.element))
+        # run.py:336-338: other_atoms.setBetas(other_bfactors * 0.0) — the non-polymer atoms are written with B-factor 0.00
+        lines.append(_pdb_line(at.het, serial, at.name, at.resname, at.chain, at.resnum, at.icode, at.xyz, at.occ, 0.0, at.element))
         serial += 1
     lines.append("END")
     with open(path, "w") as fh:

@@ -621,11 +621,9 @@ def _tail(h_V, dh, mask32, maskf, p, drop, drop_p):
 
 
 def _ffn(x, dense):
-    """PositionWiseFeedForward (na_model_utils.py:286-296).  Mixed-precision mode: under bf16 autocast like the reference's
-    training loop (na_run.py:217) — the two [B*N,128] x [128,512] library GEMMs run on the bf16 matrix pipe."""
-    if X3 == 2 and x.is_cuda:
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-            return dense.W_out(F.gelu(dense.W_in(x))).float()
+    """PositionWiseFeedForward (na_model_utils.py:286-296) on stock ops: only the exact-fp32 mode comes here — in the
+    split-bf16 AND the mixed-precision (bf16) modes `_tail` takes the fused `_NodeTail` launches, whose GEMMs are split-bf16
+    products in both (the residue-level math stays fp32-equivalent under mixed precision; only the per-edge GEMMs are plain bf16)."""
     return dense.W_out(F.gelu(dense.W_in(x)))
 
 

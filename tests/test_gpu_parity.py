@@ -549,28 +549,45 @@ def test_small_and_wide_neighbourhoods(L, dev, wt, packed, n, k):
 
 
 def test_cfg3_sized_batch(L, dev, wt, packed):
-    """BASELINE configs[2] shape in fp32: B=64 x N=1000, K=48 (3.07 M edges, unfused large-batch path).  Spot-check
-    three complexes against the oracle and the whole batch for normalisation / batch independence."""
+    """BASELINE configs[2] shape at the parity precisions: B=64 x N=1000, K=48 (3.07 M edges, unfused large-batch path).
+    EXACT fp32 (the headline dtype): log-probs within 1e-3 of the oracle and arg-max sequences STRICTLY identical on the
+    spot-checked complexes (north_star: "argmax sequences bit-exact").  Split-bf16 (the product's default): the same bar,
+    except that a residue whose top two ORACLE log-probs are closer than 2e-3 may flip — the number of residues that used
+    the exception is printed.  Whole batch: normalisation / finiteness / batch independence."""
     B, N, K = 64, 1000, 48
     parts = [synth.make_graph(seed=7000 + b, batch=1, n=N, k=K) for b in range(B)]
     g = {k_: np.concatenate([p[k_] for p in parts], 0) for k_ in parts[0]}
     t = {k_: torch.from_numpy(v) for k_, v in g.items()}
     d = {k_: v.to(dev) for k_, v in t.items()}
-    _, _, logp, _ = run_encdec(L, dev, packed, d, B, N, K)
-    assert torch.isfinite(logp).all()
-    assert maxdiff(torch.logsumexp(logp, -1), torch.zeros(B, N)) < 1e-5
-    for b in (0, 31, 63):
+    _, _, logp, _ = run_encdec(L, dev, packed, d, B, N, K)                  # split-bf16 (the fixture's default precision)
+    packed.set_precision("fp32")
+    try:
+        _, _, logp32, _ = run_encdec(L, dev, packed, d, B, N, K)            # exact fp32 MFMA
+    finally:
+        packed.set_precision("x3")
+    for lp in (logp, logp32):
+        assert torch.isfinite(lp).all()
+        assert maxdiff(torch.logsumexp(lp, -1), torch.zeros(B, N)) < 1e-5
+    near_ties_used = 0
+    for b in (0, 13, 31, 47, 63):
         sl = slice(b, b + 1)
         rV, rE = cpu_ref.encode_from_graph(wt, t["V"][sl], t["E"][sl], t["E_idx"][sl].long(), t["mask"][sl])
         ref = cpu_ref.score_from_encoded(wt, rV, rE, t["E_idx"][sl].long(), t["S"][sl], t["mask"][sl],
                                          t["chain_mask"][sl], t["randn"][sl])
+        ar = ref["log_probs"][0].argmax(-1)
+        # exact fp32: strict
+        assert maxdiff(logp32[sl], ref["log_probs"]) < TOL_LOGP
+        assert torch.equal(logp32[b].argmax(-1).cpu(), ar), f"exact fp32: arg-max sequence of complex {b} differs from the oracle's"
+        # split-bf16: arg-max identical, except where the oracle's own top two log-probs are closer than 2 x the tolerance
         assert maxdiff(logp[sl], ref["log_probs"]) < TOL_LOGP
-        # arg-max identical, except where the oracle's own top two log-probs are closer than the tolerance (a tie at fp32 level)
-        am, ar = logp[b].argmax(-1).cpu(), ref["log_probs"][0].argmax(-1)
+        am = logp[b].argmax(-1).cpu()
         for i in torch.nonzero(am != ar).flatten().tolist():
             r = ref["log_probs"][0][i]
             assert abs(float(r[am[i]] - r[ar[i]])) < 2 * TOL_LOGP, (b, i, float(r[am[i]]), float(r[ar[i]]))
         assert int((am != ar).sum()) <= 1
+        near_ties_used += int((am != ar).sum())
+    print(f"cfg3-sized parity: exact fp32 arg-max identical on 5 x {N} residues; split-bf16 used the near-tie exception on "
+          f"{near_ties_used} of {5 * N} residues")
     d1 = {k_: v[31:32].contiguous() for k_, v in d.items()}
     _, _, logp1, _ = run_encdec(L, dev, packed, d1, 1, N, K)          # fused small-batch path on the same complex
     assert maxdiff(logp1, logp[31:32]) < 5e-5

