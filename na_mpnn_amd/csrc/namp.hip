@@ -147,10 +147,14 @@ void set_lds_attributes() {
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)(node_update_multi_kernel<2, true>), NODE_MULTI_LDS_X3(2));
-  set((const void*)dec_sample_kernel<false, false>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, false>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<false, true>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, true>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, false, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, false, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, true, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, true, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, false, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, false, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<false, true, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<true, true, 12>, SAMPLE_LDS);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
@@ -1007,7 +1011,9 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   a.sym_w = sym_weights; a.pair_bias = pair_bias; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
   a.probs_out = probs_out; a.logp_out = logp_out; a.special = special_tokens; a.inv_T = 1.0f / temperature;
   a.B_dec = B_dec; a.B_enc = B_enc; a.N = N; a.K = K; a.TPN = (K + 15) / 16; a.n_layers = w->n_dec; a.vocab = w->vocab;
-  int slots = 12 / a.TPN; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;
+  // 8 waves per workgroup (256 VGPRs per lane: no scratch) serve 8 / TPN streams; K > 128 falls back to the 12-wave form
+  const int maxw = a.TPN <= 8 ? 8 : 12;
+  int slots = maxw / a.TPN; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;
   a.slots = slots;
   int nwaves = slots * a.TPN; if (nwaves < 8) nwaves = 8;
   REQUIRE(nwaves <= 12, "namp_decoder_sample: K=%d needs %d waves per workgroup (max 12)", K, nwaves);
@@ -1037,6 +1043,20 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   return NAMP_OK;
 }
 
+// the sampler kernel by (level mode, precision, waves per workgroup <= 8 or <= 12)
+static void launch_sample(bool level, bool x3, int nwaves, int grid, hipStream_t s, const SampleArgs& a, const int32_t* work, int nwork) {
+  const dim3 g(grid), b(nwaves * 64);
+#define NAMP_LS(LV, X3, W) hipLaunchKernelGGL((dec_sample_kernel<LV, X3, W>), g, b, SAMPLE_LDS, s, a, work, nwork)
+  if (nwaves <= 8) {
+    if (level) { if (x3) NAMP_LS(true, true, 8); else NAMP_LS(true, false, 8); }
+    else       { if (x3) NAMP_LS(false, true, 8); else NAMP_LS(false, false, 8); }
+  } else {
+    if (level) { if (x3) NAMP_LS(true, true, 12); else NAMP_LS(true, false, 12); }
+    else       { if (x3) NAMP_LS(false, true, 12); else NAMP_LS(false, false, 12); }
+  }
+#undef NAMP_LS
+}
+
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                         const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
@@ -1050,12 +1070,7 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
                           ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  if (prec_of(w->dec[0].flags) == PREC_X3)
-    hipLaunchKernelGGL((dec_sample_kernel<false, true>), dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
-                       (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
-  else
-    hipLaunchKernelGGL((dec_sample_kernel<false, false>), dim3((B_dec + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS,
-                       (hipStream_t)stream, a, (const int32_t*)nullptr, 0);
+  launch_sample(false, prec_of(w->dec[0].flags) == PREC_X3, nwaves, (B_dec + a.slots - 1) / a.slots, (hipStream_t)stream, a, nullptr, 0);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -1095,10 +1110,7 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   for (int l = 0; l < n_levels; ++l) {
     const int cnt = level_counts[l];
     if (cnt == 0) continue;
-    if (x3) hipLaunchKernelGGL((dec_sample_kernel<true, true>), dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
-                               work + 2 * off, cnt);
-    else hipLaunchKernelGGL((dec_sample_kernel<true, false>), dim3((cnt + a.slots - 1) / a.slots), dim3(nwaves * 64), SAMPLE_LDS, s, a,
-                            work + 2 * off, cnt);
+    launch_sample(true, x3, nwaves, (cnt + a.slots - 1) / a.slots, s, a, work + 2 * off, cnt);
     off += cnt;
   }
   CHECK_LAUNCH();

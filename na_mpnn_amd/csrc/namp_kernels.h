@@ -405,8 +405,51 @@ __device__ __forceinline__ void st_out(float* p, const float v) {
   else *p = v;
 }
 
+// The units of one phase (a 16-channel output tile = 8 weight fragments of 1 KiB per wave) dealt over the waves: unit u, u + nwaves, ...
+// PF = false: load the unit's fragments, then compute (the fused edge launches: 250 workgroups stream the same weights, the phase
+// is bound by L2 bandwidth chip-wide and a deeper queue measured nothing, profiles/r02k).  PF = true (the sampler: ONE workgroup per
+// <= 4 residues with the chip idle around it — the phase is bound by the latency of each unit's 8 KiB): the next unit's fragments
+// are requested before the current unit's FMAs, so two units are in flight per wave.  frag(u, tk) -> address of fragment tk.
+template <bool PF, class FragFn, class BodyFn>
+__device__ __forceinline__ void tail_units(const int u0, const int total, const int step, const int lane, FragFn frag, BodyFn body) {
+  if constexpr (!PF) {
+#pragma unroll 1
+    for (int u = u0; u < total; u += step) {
+      f4 wf[8];
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wf[tk] = frag(u, tk)[lane];
+      body(u, wf);
+    }
+  } else {
+    f4 wa[8], wb[8];
+    int u = u0;
+    if (u < total) {
+#pragma unroll
+      for (int tk = 0; tk < 8; ++tk) wa[tk] = frag(u, tk)[lane];
+    }
+#pragma unroll 1
+    while (u < total) {
+      int un = u + step;
+      if (un < total) {
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) wb[tk] = frag(un, tk)[lane];
+      }
+      body(u, wa);
+      u = un;
+      if (u >= total) break;
+      un = u + step;
+      if (un < total) {
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) wa[tk] = frag(un, tk)[lane];
+      }
+      body(u, wb);
+      u = un;
+    }
+  }
+}
+
 // M3 = false: the caller has already applied the hoisted message layer 3 (x = h_V + message), whatever a.m3_img says
-template <int R, typename RowFn, bool SC1 = false, bool M3 = true>
+template <int R, typename RowFn, bool SC1 = false, bool M3 = true, bool PF = false>
 __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const float wsum_m, const RowFn orow, float* lds,
                                                const int tid, const int wave, const int nwaves, const int lane) {
   float* xT = lds;                    // [128][R]    x = LN1(...)          (k-major, residue-minor)
@@ -466,42 +509,38 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
   }
   __syncthreads();
   // ---- hidden = gelu(W_in x + b_in): 32 channel tiles dealt over the waves
-#pragma unroll 1
-  for (int tn = wave; tn < 32; tn += nwaves) {
-    f4 wf[8];
+  tail_units<PF>(wave, 32, nwaves, lane,
+                 [&](const int tn, const int tk) { return (const f4*)a.Win_img + (tk * 32 + tn) * 64; },
+                 [&](const int tn, const f4 (&wf)[8]) {
+                   float acc[R];
 #pragma unroll
-    for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Win_img)[(tk * 32 + tn) * 64 + lane];
-    float acc[R];
+                   for (int n = 0; n < R; ++n) acc[n] = 0.f;
+                   rows_fma<R>(acc, wf, xT, g);
 #pragma unroll
-    for (int n = 0; n < R; ++n) acc[n] = 0.f;
-    rows_fma<R>(acc, wf, xT, g);
+                   for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
+                   if (g == 0) {
+                     const float b = a.b_in[16 * tn + m];
 #pragma unroll
-    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
-    if (g == 0) {
-      const float b = a.b_in[16 * tn + m];
-#pragma unroll
-      for (int n = 0; n < R; ++n) hT[(16 * tn + m) * R + n] = gelu_erf(acc[n] + b);
-    }
-  }
+                     for (int n = 0; n < R; ++n) hT[(16 * tn + m) * R + n] = gelu_erf(acc[n] + b);
+                   }
+                 });
   __syncthreads();
   // ---- W_out: units (channel tile tn, k-quarter kq); partials reduced in the LayerNorm2 pass
-#pragma unroll 1
-  for (int u = wave; u < 32; u += nwaves) {
-    const int tn = u & 7, kq = u >> 3;
-    f4 wf[8];
+  tail_units<PF>(wave, 32, nwaves, lane,
+                 [&](const int u, const int tk) { return (const f4*)a.Wout_img + ((8 * (u >> 3) + tk) * 8 + (u & 7)) * 64; },
+                 [&](const int u, const f4 (&wf)[8]) {
+                   const int tn = u & 7, kq = u >> 3;
+                   float acc[R];
 #pragma unroll
-    for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)a.Wout_img)[((8 * kq + tk) * 8 + tn) * 64 + lane];
-    float acc[R];
+                   for (int n = 0; n < R; ++n) acc[n] = 0.f;
+                   rows_fma<R>(acc, wf, hT + 128 * kq * R, g);
 #pragma unroll
-    for (int n = 0; n < R; ++n) acc[n] = 0.f;
-    rows_fma<R>(acc, wf, hT + 128 * kq * R, g);
+                   for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
+                   if (g == 0) {
 #pragma unroll
-    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
-    if (g == 0) {
-#pragma unroll
-      for (int n = 0; n < R; ++n) oP[(kq * 128 + 16 * tn + m) * R + n] = acc[n];
-    }
-  }
+                     for (int n = 0; n < R; ++n) oP[(kq * 128 + 16 * tn + m) * R + n] = acc[n];
+                   }
+                 });
   __syncthreads();
   // ---- LayerNorm2 over channels: thread -> (residue n = tid / 128, channel c = tid % 128), 128*R threads
   const int n_ = tid >> 7, c_ = tid & 127;
@@ -543,7 +582,39 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
       if (orw >= 0) tail_head_row(a, yT + n, R, orw, lane);
     }
   }
-  // ---- projections of h_V': unit (block pi, channel tile tn) -> wave (8 pi + tn) % nwaves
+  // ---- projections of h_V': unit v = 8 pi + tn (block pi, channel tile tn) -> wave v % nwaves
+  if constexpr (PF) {
+    // (the sampler's tails have at most two blocks: a runtime index into a.p[] would copy the descriptors to scratch)
+    tail_units<true>(wave, 8 * (a.nproj < 2 ? a.nproj : 2), nwaves, lane,
+                     [&](const int v, const int tk) { return (const f4*)((v >> 3) ? a.p[1].img : a.p[0].img) + (tk * 8 + (v & 7)) * 64; },
+                     [&](const int v, const f4 (&wf)[8]) {
+                       const bool second = (v >> 3) != 0;
+                       const int tn = v & 7;
+                       float acc[R];
+#pragma unroll
+                       for (int n = 0; n < R; ++n) acc[n] = 0.f;
+                       rows_fma<R>(acc, wf, yT, g);
+#pragma unroll
+                       for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
+                       if (g == 0) {
+                         const int c = 16 * tn + m;
+                         const float* bias = second ? a.p[1].bias : a.p[0].bias;
+                         const float* tok = second ? a.p[1].tok : a.p[0].tok;
+                         float* out = second ? a.p[1].out : a.p[0].out;
+                         const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+                         for (int n = 0; n < R; ++n) {
+                           const int orw = orow(n);
+                           if (orw >= 0) {
+                             float o = acc[n] + b;
+                             if (tok) o += tok[(long)a.S[orw] * NAMP_H + c];
+                             st_out<SC1>(out + (long)orw * NAMP_H + c, o);
+                           }
+                         }
+                       }
+                     });
+    return;
+  }
 #pragma unroll
   for (int pi = 0; pi < 8; ++pi) {
     if (pi >= a.nproj) break;
@@ -1477,7 +1548,10 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 // that share cache lines with not-yet-written neighbours (S) are read with L1-bypassing loads.
 // ------------------------------------------------------------------------------------------
 #define NAMP_SAMPLE_SLOTS 4
-#define SAMPLE_LDS (2 * NAMP_IMG_BYTES + 12 * NAMP_H * 4 + 64)     // ring + per-wave partial sums + node / visit ids
+// LDS of the sampler: the 2 x 64 KiB weight ring | the residue tail's scratch (its own region: the next layer's images stream into the ring
+// while the tail runs) | per-wave partial K-sums | node / visit ids
+#define SAMPLE_TAIL_BYTES (((128 + 512 + 4 * 128 + 128) * NAMP_SAMPLE_SLOTS + 64) * 4)
+#define SAMPLE_LDS (2 * NAMP_IMG_BYTES + SAMPLE_TAIL_BYTES + 12 * NAMP_H * 4 + 64)
 
 struct SampleLayer {
   const float* W1e_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
@@ -1742,12 +1816,16 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
 // dependency levels (sample_levels_kernel: level = 1 + max level of the earlier neighbours) and launches one grid per level:
 // ~64 launches instead of 1000 sequential steps at N = 1000, K = 48, with every workgroup of the chip busy.  Same arithmetic
 // per residue, same uniform per visit, hence the same draws.
-template <bool LEVEL, bool X3 = false>
-__global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork) {
+// MAXW = 8 waves per workgroup (K <= 128: 8 / TPN streams per workgroup) leaves 256 VGPRs per lane — the three row operands, the
+// residue tail's two fragment sets in flight and the head fit without scratch (the 12-wave form spilled 165 registers per lane); MAXW = 12
+// only serves K > 128.
+template <bool LEVEL, bool X3 = false, int MAXW = 8>
+__global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
-  float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES);            // [12 waves][128]
+  float* tail_lds = (float*)(smem + 2 * NAMP_IMG_BYTES);
+  float* dpart = (float*)(smem + 2 * NAMP_IMG_BYTES + SAMPLE_TAIL_BYTES);            // [12 waves][128]
   int* node_lds = (int*)(dpart + 12 * NAMP_H);                   // [4] residue (dec-global) per slot, -1 idle
   int* t_lds = node_lds + NAMP_SAMPLE_SLOTS;                     // [4] visit index per slot (LEVEL)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1775,7 +1853,11 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
     __syncthreads();
   }
 
+  dma_to_lds(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);      // the first layer's images: in flight under the index chain below
+  dma_to_lds(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
+#pragma unroll 1
   for (int t_seq = 0; t_seq < (LEVEL ? 1 : a.N); ++t_seq) {
+    asm volatile("" ::: "memory");      // sequential walk: keep the step's (loop-invariant) vector loads inside the step, not in registers across it
     const int t = LEVEL ? t_level : t_seq;
     const int i_loc = a.order[(long)bb * a.N + t];
     const int node = bb * a.N + i_loc;                   // stream-global residue
@@ -1825,8 +1907,8 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
           pjv[q] *= ctx;
         }
       }
-      dma_to_lds(buf0, L.W1e_img, 64, wave, nwaves, lane);
-      dma_to_lds(buf1, L.W2_img, 64, wave, nwaves, lane);
+      // W1e / W2 of this layer were requested ahead (before the walk / under the previous layer's residue tail); the
+      // rows above were requested after them, so one vmcnt(0) covers both
       wait_dma_and_sync();
       gemm128<X3, false, false>(acc, x, w0);
 #pragma unroll
@@ -1853,6 +1935,15 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
         if (g == 0) dpart[wave * NAMP_H + 16 * q + m] = sres;
       }
       __syncthreads();
+      // both ring slots are free: the next layer's W1e / W2 (the next step's first layer in the sequential walk) stream in
+      // under the residue tail, whose scratch lives behind the ring
+      if (l + 1 < a.n_layers) {
+        dma_to_lds(buf0, a.l[l + 1 < 3 ? l + 1 : 2].W1e_img, 64, wave, nwaves, lane);
+        dma_to_lds(buf1, a.l[l + 1 < 3 ? l + 1 : 2].W2_img, 64, wave, nwaves, lane);
+      } else if (!LEVEL && t_seq + 1 < a.N) {
+        dma_to_lds(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);
+        dma_to_lds(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
+      }
       // residue tail over the workgroup's <= 4 streams: tile row m -> stream slot m
       {
         const int nd = (m < NAMP_SAMPLE_SLOTS) ? node_lds[m] : -1;
@@ -1869,7 +1960,9 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
 #pragma unroll
           for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * q);
         }
-        node_tail_rows<NAMP_SAMPLE_SLOTS>(L.tail, x, 0.f, rows, (float*)smem, tid, wave, nwaves, lane);
+#ifndef NAMP_ABL_SAMPLE_NOTAIL
+        node_tail_rows<NAMP_SAMPLE_SLOTS, SampleRows, false, true, true>(L.tail, x, 0.f, rows, tail_lds, tid, wave, nwaves, lane);
+#endif
       }
       __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
     }
@@ -1877,7 +1970,7 @@ __global__ __launch_bounds__(768) void dec_sample_kernel(const SampleArgs a, con
     // ---- output head + draw, one wave per stream slot (wave n owns slot n for the whole walk, so the running
     // logit sum of a symmetry group lives in its registers).  h^(n_layers) row of slot n is yT[c * R + n].
     {
-      const float* yT = (const float*)smem + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
+      const float* yT = tail_lds + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
       for (int n = wave; n < NAMP_SAMPLE_SLOTS; n += nwaves) {
         const int nd = node_lds[n];
         if (nd < 0) continue;

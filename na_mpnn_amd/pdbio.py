@@ -26,7 +26,7 @@ from . import spec
 # documented for ProDy 2.x — standard + non-standard amino acids; nucleobases, nucleotides, nucleosides).  prody is not
 # installable here, so these tables are a restatement from its documentation, not a pinned import.
 PROTEIN_NAMES = set(spec.RESTYPES[:20]) | {"ASX", "GLX", "CSO", "HIP", "HSD", "HSE", "HSP", "MSE", "SEC", "SEP", "TPO", "PTR",
-                                           "XLE", "XAA", "UNK"}
+                                           "XLE", "XAA"}      # (UNK is in neither of prody's amino-acid tables: "other atoms")
 NUCLEIC_NAMES = {"GUN", "ADE", "CYT", "THY", "URA",                                    # nucleobase
                  "DA", "DC", "DG", "DT", "DU", "A", "C", "G", "T", "U",                # nucleotide
                  "AMP", "ADP", "ATP", "CDP", "CTP", "GMP", "GDP", "GTP", "TMP", "TTP", "UMP", "UDP", "UTP",   # nucleoside
@@ -146,16 +146,25 @@ def _mmcif_atoms(path):
                    resnum, nul(get(row, "pdbx_PDB_ins_code")), xyz, occ, bfac, nul(get(row, "type_symbol")))
 
 
-def read_atoms(path, chains=None, normalize_legacy_names=False):
+def read_atoms(path, chains=None, normalize_legacy_names=False, chain_order=None, ca_residues=None):
     """Coordinate records the reference's parse_PDB keeps before any polymer logic (data_utils.py:232-238): first model,
     altloc blank or 'A' (prody's default), occupancy > 0, optionally only the given chains.  `.cif` / `.mmcif` files go
     through the mmCIF reader.  normalize_legacy_names maps pre-remediation nucleic atom names (O1P, O2P, C1*, ...) to the
-    current ones; the reference (prody) does not, so it is off by default."""
+    current ones; the reference (prody) does not, so it is off by default.  chain_order (a list) receives the chain ids in
+    order of first appearance over EVERY parsed record — before the occupancy / chain filters, hetero atoms and waters
+    included: that is the numbering prody's getChindices() reports (data_utils.py:303).  ca_residues (a set) receives the
+    (chain, number, insertion code) keys of the residues that have an atom named CA, likewise over every parsed record."""
     low = str(path).lower()
     src = _mmcif_atoms(path) if low.endswith((".cif", ".mmcif")) else _pdb_atoms(path)
     chains = set(chains) if chains else None
-    for a in src:
-        if a.altloc not in ("", "A") or a.occ <= 0 or (chains and a.chain not in chains):
+    records = [a for a in src if a.altloc in ("", "A")]
+    for a in records:                                   # properties of the WHOLE parsed structure, like prody's flags / hierarchy
+        if chain_order is not None and a.chain not in chain_order:
+            chain_order.append(a.chain)
+        if ca_residues is not None and a.name == "CA":
+            ca_residues.add((a.chain, a.resnum, a.icode))
+    for a in records:
+        if a.occ <= 0 or (chains and a.chain not in chains):
             continue
         if normalize_legacy_names:
             a.name = LEGACY_ATOM_NAMES.get(a.name.replace("*", "'"), a.name.replace("*", "'"))
@@ -173,9 +182,12 @@ def parse_pdb(path, chains=None, parse_na_only=False, na_shared_tokens=True, loa
     chain_order = []
     backbone_atoms, other_atoms = [], []
     bb_names = {"protein": set(PROTEIN_BB), "nucleic": set(RNA_BB)}
-    for at in read_atoms(path, chains, normalize_legacy_names):
+    ca_residues = set()
+    for at in read_atoms(path, chains, normalize_legacy_names, chain_order, ca_residues):
         name, resname, chain = at.name, at.resname, at.chain
-        kind = "protein" if resname in PROTEIN_NAMES else ("nucleic" if resname in NUCLEIC_NAMES else None)
+        # prody's `protein` flag: a qualifying residue name AND an atom named CA in the residue (manual, Atom Flags)
+        kind = "protein" if (resname in PROTEIN_NAMES and (chain, at.resnum, at.icode) in ca_residues) else \
+            ("nucleic" if resname in NUCLEIC_NAMES else None)
         if parse_na_only and kind != "nucleic":
             continue
         if kind is None:
@@ -192,8 +204,6 @@ def parse_pdb(path, chains=None, parse_na_only=False, na_shared_tokens=True, loa
         if name == ("CA" if kind == "protein" else "C1'") and not r["ref"]:
             r["ref"] = True
             order.append(key)                       # residue order = order of reference atoms
-            if chain not in chain_order:
-                chain_order.append(chain)
     n = len(order)
     X = np.zeros((n, spec.N_ATOMS, 3), np.float32)
     X_m = np.zeros((n, spec.N_ATOMS), np.int32)

@@ -108,7 +108,8 @@ def n_layers(w, kind):
 # ----------------------------------------------------------------------------------------
 # a11: graph construction / featurisation (model_utils.py:426-593, :606-617)
 # ----------------------------------------------------------------------------------------
-ATOM = {"N": 0, "CA": 1, "C": 2, "O4'": 10, "C2'": 13, "C1'": 15}
+# atom order of inference/run.py:15-19
+ATOM = {a: i for i, a in enumerate(["N", "CA", "C", "O", "OP1", "OP2", "P", "O5'", "C5'", "C4'", "O4'", "C3'", "O3'", "C2'", "O2'", "C1'"])}
 
 
 def _virtual_atom(p0, p1, p2, wa, wb, wc):
@@ -149,12 +150,13 @@ def positional(w, offset, same_chain, max_rel=32):
     return _lin(w, "features.embeddings.linear", F.one_hot(d, 2 * max_rel + 2).float())
 
 
-def features(w, fd, top_k):
-    """ProteinFeaturesNA.forward in eval mode (model_utils.py:528-593)."""
+def features(w, fd, top_k, na_ref_atom="C1'"):
+    """ProteinFeaturesNA.forward in eval mode (model_utils.py:528-593).  na_ref_atom: the nucleic reference atom of the kNN
+    point CA + X[na_ref_atom] (ctor argument, model_utils.py:438,457,554,573; na_model_utils.py:361,381,478,497)."""
     X, mask = fd["X"], fd["mask"]
     Ca, N, C = X[:, :, ATOM["CA"], :], X[:, :, ATOM["N"], :], X[:, :, ATOM["C"], :]
     Cb = _virtual_atom(N, Ca, C, -0.58273431, 0.56802827, -0.54067466)
-    ref_na = X[:, :, ATOM["C1'"], :]
+    ref_na = X[:, :, ATOM[na_ref_atom], :]
     N_na = _virtual_atom(X[:, :, ATOM["O4'"], :], X[:, :, ATOM["C1'"], :], X[:, :, ATOM["C2'"], :],
                          -0.56967352, 0.51055973, -0.53122153)
     X18 = torch.cat((X, Cb[:, :, None, :], N_na[:, :, None, :]), -2)
@@ -189,8 +191,8 @@ def encode_from_graph(w, V, E, E_idx, mask):
     return h_V, h_E
 
 
-def encode(w, fd, top_k):
-    V, E, E_idx = features(w, fd, top_k)
+def encode(w, fd, top_k, na_ref_atom="C1'"):
+    V, E, E_idx = features(w, fd, top_k, na_ref_atom)
     h_V, h_E = encode_from_graph(w, V, E, E_idx, fd["mask"])
     return h_V, h_E, E_idx
 
@@ -275,10 +277,10 @@ def unconditional_probs(w, fd, top_k):
     return {"log_probs": F.log_softmax(_lin(w, "W_out", h_V), dim=-1)}
 
 
-def forward_train(w, fd, top_k, randn, decode_protein_first=False):
+def forward_train(w, fd, top_k, randn, decode_protein_first=False, na_ref_atom="C1'"):
     """Training-copy ProteinMPNN.forward in eval mode with the decoding-order
     noise passed in (na_model_utils.py:589-646; its internal torch.randn is :623)."""
-    h_V, h_E, E_idx = encode(w, fd, top_k)
+    h_V, h_E, E_idx = encode(w, fd, top_k, na_ref_atom)
     chain_M = fd["mask"]
     if decode_protein_first:
         chain_M = chain_M.masked_fill(fd["protein_mask"].to(torch.bool), 0.0)

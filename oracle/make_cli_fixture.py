@@ -2,7 +2,8 @@
 """TEST INFRASTRUCTURE — expected output FILES of the design CLI, made with the CPU oracle.
 
 The reference's inference/run.py cannot run in the build container (prody is absent), so its file formats are pinned this
-way: a small mixed protein / DNA / RNA complex with a ligand and waters is written as PDB and as mmCIF
+way, with ORACLE-side code only (oracle/pdb_ref.py: parse_PDB, featurize, run.py's token tables / residue codes / sequence
+strings; oracle/cpu_ref.py: the model) — the product's reader and CLI are what the fixture tests, so they take no part in it: a small mixed protein / DNA / RNA complex with a ligand and waters is written as PDB and as mmCIF
 (tests/golden/cli/input.{pdb,cif}); the oracle's `sample()` (proven bit-identical to the reference's, make_goldens.py G5)
 draws sequences under a fixed torch seed; and the output files are written with the reference's own format strings
 (run.py:445-455 native header, :501-511 per-sample header, :426-443 specificity keys, np.format_float_positional with 4
@@ -19,8 +20,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from na_mpnn_amd import cli, pdbio, spec, synth   # noqa: E402   (host-side parsing / formatting helpers only)
-from oracle import cpu_ref                        # noqa: E402
+from na_mpnn_amd import pdbio, synth   # noqa: E402   (only to WRITE the synthetic input files: pdbio.write_pdb / write_mmcif)
+from oracle import cpu_ref, pdb_ref    # noqa: E402   (everything the expected files are computed with is oracle-side)
 
 OUT = os.path.join(ROOT, "tests", "golden", "cli")
 SEED, T, BS, K = 7, 1.0, 2, 32
@@ -28,7 +29,7 @@ SEED, T, BS, K = 7, 1.0, 2, 32
 
 def build_input():
     cx = synth.make_complex(seed=77, n=48, n_chains=3)
-    int_to_res = {v: k for k, v in spec.restype_to_int().items()}
+    int_to_res = dict(enumerate(pdb_ref.RESTYPES))
     letters = ["ABC"[c] for c in cx["chain_labels"]]
     names = [int_to_res[int(s)] for s in cx["S"]]
     pdb = os.path.join(OUT, "input.pdb")
@@ -47,17 +48,23 @@ def main():
     torch.set_grad_enabled(False)
     torch.set_num_threads(8)
     pdb = build_input()
-    P = pdbio.parse_pdb(pdb, na_shared_tokens=True)
+    # the oracle's restatement of parse_PDB / featurize / run.py's bookkeeping — NOT the product's reader
+    P = pdb_ref.parse_PDB(pdb, na_shared_tokens=True)
     L = len(P["S"])
     fixed = [f"A{P['R_idx'][0]}", f"A{P['R_idx'][1]}"]
-    encoded = [f"{c}{r}{ic}" for c, r, ic in zip(P["chain_letters"], P["R_idx"].tolist(), P["icodes"])]
-    chain_mask = np.array([int(e not in fixed) for e in encoded], np.int32)
-    fd = pdbio.to_feature_dict(P, chain_mask, "cpu")
-    rti = spec.restype_to_int(True)
-    alphabet = [spec.RESTYPE_3TO1[r] for r in spec.RESTYPES]
-    omit = torch.tensor([float(c in "X" + "bdhuy") for c in alphabet])
+    encoded = pdb_ref.encoded_residues(P)
+    chain_mask = np.array([int(e not in fixed) for e in encoded], np.int32)                       # run.py:259 (all chains designed)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt)[None]
+    fd = {"X": t(P["X"], torch.float32), "X_m": t(P["X_m"], torch.int32), "mask": t(P["mask"], torch.int32),
+          "S": t(P["S"], torch.int64), "R_idx": t(pdb_ref.featurize_R_idx(P["R_idx"]), torch.int64),
+          "chain_labels": t(P["chain_labels"], torch.int32), "chain_mask": t(chain_mask, torch.int32),
+          "R_polymer_type": t(P["R_polymer_type"], torch.int64)}
+    for k_ in ("protein_mask", "dna_mask", "rna_mask", "rna_mask_for_token_conversion"):
+        fd[k_] = t(P[k_], torch.int32)
+    rti, alphabet, int_to_str, dna_to_rna = pdb_ref.token_tables(True)
+    omit = torch.tensor([float(c in "X" + "bdhuy") for c in alphabet])                            # run.py:135-139
     fd.update({"batch_size": BS, "temperature": T, "bias": (-1e8 * omit[None, None, :]).repeat(1, L, 1),
-               "symmetry_residues": [[]], "symmetry_weights": [[]], "S": fd["S"].long()})
+               "symmetry_residues": [[]], "symmetry_weights": [[]]})
     torch.manual_seed(SEED)
     fd["randn"] = torch.randn(BS, L)
     w = {k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()}
@@ -74,21 +81,15 @@ def main():
     for v in list(np.exp(-loss.numpy())) + list(rec.numpy()):
         frac = (float(v) * 1e4) % 1.0
         assert abs(frac - 0.5) > 0.02, f"value {v} too close to a 4-digit rounding boundary: change SEED"
-    str_to_int = {spec.RESTYPE_3TO1[k]: v for k, v in rti.items()}
-    int_to_str = {}
-    for k, v in str_to_int.items():
-        int_to_str.setdefault(v, k)
-    dna_to_rna = {spec.RESTYPE_3TO1[d]: spec.RESTYPE_3TO1[r] for d, r in (("DA", "A"), ("DC", "C"), ("DG", "G"), ("DT", "U"), ("DX", "RX"))}
-    rna_flag = P["rna_mask_for_token_conversion"]
     name, ckpt = "input", "random_init_seed_0"
     entries = ['>{}, T={}, seed={}, num_res={}, batch_size={}, number_of_batches={}, model_path={}\n{}'.format(
         name, T, SEED, (fd["mask"] * fd["chain_mask"]).sum().numpy(), BS, 1, ckpt,
-        cli.seq_string(P["S"], rna_flag, int_to_str, dna_to_rna, P["chain_letters"]))]
+        pdb_ref.sequence_string(P["S"], P, int_to_str, dna_to_rna))]
     for ix in range(BS):
         conf = np.format_float_positional(np.exp(-loss[ix].numpy()), unique=False, precision=4)
         srec = np.format_float_positional(rec[ix].numpy(), unique=False, precision=4)
         entries.append('>{}, id={}, T={}, seed={}, overall_confidence={} seq_rec={}\n{}'.format(
-            name, ix + 1, T, SEED, conf, srec, cli.seq_string(S[ix].numpy(), rna_flag, int_to_str, dna_to_rna, P["chain_letters"])))
+            name, ix + 1, T, SEED, conf, srec, pdb_ref.sequence_string(S[ix].numpy(), P, int_to_str, dna_to_rna)))
     open(os.path.join(OUT, "expected.fa"), "w").write("\n".join(entries))
     np.savez(os.path.join(OUT, "expected_specificity.npz"),
              predicted_ppm=np.mean(sp.numpy().astype(np.float64), axis=0), true_sequence=P["S"].astype(np.int64),

@@ -147,6 +147,55 @@ def g4b_no_pred_na_N():
          E_rows=E[0, ::max(1, n // 8)].numpy()[:8], randn=randn.numpy(), log_probs=lp[0].numpy())
 
 
+def g4c_ctor_variants(weights):
+    """Two constructor variants of the TRAINING copy that change the path's results and had no golden:
+    decode_protein_first=1 (na_model_utils.py:536,547,620-621: protein residues decode before the nucleic ones) and
+    na_ref_atom="P" (na_model_utils.py:361,381,478,497 — the inference copy has the same argument on ProteinFeaturesNA,
+    model_utils.py:438,457,554,573: the kNN point becomes CA + P instead of CA + C1')."""
+    n, k = 90, 24
+    cx = synth.make_complex(seed=470, n=n, n_chains=4, masked_frac=0.03, missing_atom_frac=0.03)
+    fd = batchify(cx)
+    fd["S"] = fd["S"].long()
+    w = tw(weights)
+    kw = dict(atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int(), k_neighbors=k,
+              dropout=0.0, protein_augment_eps=0.0, dna_augment_eps=0.0, rna_augment_eps=0.0)
+    out = {}
+    torch.manual_seed(2468)
+    randn = torch.randn(fd["mask"].shape)
+    for tag, extra, okw in (("dpf", dict(decode_protein_first=1), dict(decode_protein_first=True)),
+                            ("refP", dict(na_ref_atom="P"), dict(na_ref_atom="P"))):
+        m = ref_train.ProteinMPNN(**kw, **extra)
+        m.load_state_dict(w)
+        m.eval()
+        torch.manual_seed(2468)
+        lp, p = m(fd)
+        o_lp, o_p = cpu_ref.forward_train(w, fd, k, randn, **okw)
+        same(o_lp, lp, f"g4c {tag} forward"); same(o_p, p, f"g4c {tag} probs")
+        out[f"{tag}_log_probs"] = lp[0].numpy()
+        if tag == "refP":
+            V, E, E_idx = m.features(fd)
+            oV, oE, oI = cpu_ref.features(w, fd, k, na_ref_atom="P")
+            same(oE, E, "g4c refP E"); assert torch.equal(oI, E_idx)
+            # the inference copy's featuriser takes the same argument
+            fi = ref_inf.ProteinFeaturesNA(128, 128, top_k=k, atom_dict=spec.atom_dict(), polytype_to_int=spec.polytype_to_int(), na_ref_atom="P")
+            fi.load_state_dict({k_[len("features."):]: v for k_, v in w.items() if k_.startswith("features.")})
+            fi.eval()
+            Vi, Ei, Ii = fi(fd)
+            same(Ei, E, "g4c refP inference featuriser"); assert torch.equal(Ii, E_idx)
+            out["refP_E_idx"] = E_idx[0].numpy().astype(np.int16)
+            out["refP_E_rows"] = E[0, ::max(1, n // 8)].numpy()[:8]
+            V0, E0, I0 = cpu_ref.features(w, fd, k)
+            assert not torch.equal(I0, E_idx), "na_ref_atom=P must change some neighbour lists on this complex"
+    chain_M = fd["mask"].masked_fill(fd["protein_mask"].to(torch.bool), 0.0)
+    order = cpu_ref.decoding_order_of(chain_M, randn)
+    npro = int((fd["protein_mask"][0].bool() | ~fd["mask"][0].bool()).sum())
+    # every protein (and masked) residue is visited before every unmasked nucleic residue
+    first = set(order[0, :npro].tolist())
+    assert first == set(torch.nonzero(fd["protein_mask"][0].bool() | ~fd["mask"][0].bool()).flatten().tolist())
+    save("g4c_ctor_variants_n90_k24", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), randn=randn.numpy(),
+         dpf_decoding_order=order[0].numpy().astype(np.int32), **out)
+
+
 def g3_encdec(weights, n, tag, masked_frac=0.0, batch=1):
     """encode-from-graph + score (the BASELINE metric scope), K=48."""
     g = synth.make_graph(seed=300 + n + batch, batch=batch, n=n, k=48, masked_frac=masked_frac)
@@ -379,7 +428,7 @@ def main():
     if len(sys.argv) > 1:                       # e.g. `python oracle/make_goldens.py g7_training`: regenerate one fixture
         for name in sys.argv[1:]:
             print(name)
-            globals()[name]() if name == "g4b_no_pred_na_N" else globals()[name](weights)
+            globals()[name]() if name in ("g4b_no_pred_na_N", "g1_gather") else globals()[name](weights)
         return
     print("G1 gather"); g1_gather()
     print("G2 layers"); g2_layers(weights)
@@ -395,6 +444,7 @@ def main():
     print("G5 sample"); g5_sample(weights)
     print("G6 sample variants (symmetry-tied, pair_bias)"); g6_sample_variants(weights)
     print("G4b include_pred_na_N=0"); g4b_no_pred_na_N()
+    print("G4c decode_protein_first=1 / na_ref_atom=P"); g4c_ctor_variants(weights)
     print("G7 training step"); g7_training(weights)
     print("G7b training step with a PPM target"); g7b_training(weights)
     print("all reference == oracle checks passed")

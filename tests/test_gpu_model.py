@@ -103,6 +103,65 @@ def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw, prec):
 
 
 @pytest.mark.parametrize("prec", ["x3", "fp32"])
+def test_ctor_variants_decode_protein_first_and_ref_atom(golden_dir, weights_np, prec):
+    """Golden G4c (reference training copy built with decode_protein_first=1, na_model_utils.py:620-621, and with
+    na_ref_atom="P", na_model_utils.py:497 / model_utils.py:573): the no-grad forward (inference kernels) and the
+    differentiable forward (training kernels) of models built with the same constructor arguments."""
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "g4c_ctor_variants_n90_k24.npz"))
+    n, k = 90, 24
+    cx = synth.make_complex(seed=470, n=n, n_chains=4, masked_frac=0.03, missing_atom_frac=0.03)
+    fd = fd_of(cx, dev)
+    fd["S"] = fd["S"].long()
+    valid = cx["mask"].astype(bool)
+    randn = torch.from_numpy(g["randn"]).to(dev)
+
+    def build(**kw):
+        m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=k, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                        polytype_to_int=spec.polytype_to_int(), dropout=0.0, **kw)
+        m.load_state_dict({k_: torch.from_numpy(v) for k_, v in weights_np.items()})
+        m = m.to(dev).eval()
+        m.message_precision = prec
+        return m
+
+    for tag, kw in (("dpf", dict(decode_protein_first=1)), ("refP", dict(na_ref_atom="P"))):
+        m = build(**kw)
+        ref = g[f"{tag}_log_probs"]
+        with torch.no_grad():
+            lp, p = m.forward(fd, decoding_randn=randn)
+        assert maxdiff(lp[0], ref) < 1e-3, tag
+        assert np.array_equal(lp[0].argmax(-1).cpu().numpy()[valid], ref.argmax(-1)[valid]), tag
+        assert maxdiff(p[0].log()[valid], torch.from_numpy(ref)[valid]) < 1e-3
+        with torch.enable_grad():                                   # the training path (na_mpnn_amd/train.py) on the same model
+            lp_t, _ = m.forward(fd, decoding_randn=randn)
+        assert lp_t.requires_grad
+        assert maxdiff(lp_t[0].detach(), ref) < 1e-3, tag
+        assert np.array_equal(lp_t[0].argmax(-1).cpu().numpy()[valid], ref.argmax(-1)[valid]), tag
+        if tag == "dpf":
+            chain_M = fd["mask"].masked_fill(fd["protein_mask"].to(torch.bool), 0)
+            order = m.decoding_order(chain_M, randn)
+            assert np.array_equal(order[0].cpu().numpy(), g["dpf_decoding_order"])
+        else:
+            V, E, E_idx = m.featurize(fd)
+            ours_idx, ref_idx = E_idx[0].cpu().numpy(), g["refP_E_idx"].astype(np.int64)
+            assert np.array_equal(np.sort(ours_idx, -1)[valid], np.sort(ref_idx, -1)[valid])
+            compared = 0
+            for q, i in enumerate(np.arange(n)[::max(1, n // 8)][:8]):
+                if not valid[i]:
+                    continue
+                pos = {int(j): c for c, j in enumerate(ours_idx[i])}
+                perm = torch.tensor([pos[int(j)] for j in ref_idx[i]], device=dev)
+                assert maxdiff(E[0, i][perm], g["refP_E_rows"][q]) < 2e-4
+                compared += 1
+            assert compared >= 4
+    # the default model on the same inputs differs from both variants (the arguments are not silently ignored)
+    m0 = build()
+    with torch.no_grad():
+        lp0, _ = m0.forward(fd, decoding_randn=randn)
+    assert maxdiff(lp0[0], g["dpf_log_probs"]) > 1e-3 and maxdiff(lp0[0], g["refP_log_probs"]) > 1e-3
+
+
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
 def test_include_pred_na_N_0(golden_dir, prec):
     """A model built with include_pred_na_N=0 (na_model_utils.py:404-407,479-491: no virtual N_na atom, edge embedding
     [128 x 4640]) against the reference golden G4b: neighbour sets, edge-feature rows, and the training copy's forward."""

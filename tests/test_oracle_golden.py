@@ -237,3 +237,27 @@ def test_g4b_no_pred_na_N(golden_dir):
     exact(E[0, ::max(1, 60 // 8)][:8], g["E_rows"])
     lp, _ = cpu_ref.forward_train(w, fd, 24, torch.from_numpy(g["randn"]))
     exact(lp[0], g["log_probs"])
+
+
+def test_g4c_ctor_variants(golden_dir, weights_np):
+    """decode_protein_first=1 (na_model_utils.py:620-621) and na_ref_atom="P" (na_model_utils.py:497; model_utils.py:573): the
+    oracle against the outputs of the reference's training copy built with those constructor arguments."""
+    from na_mpnn_amd import synth
+    g = load(golden_dir, "g4c_ctor_variants_n90_k24")
+    w = tw(weights_np)
+    cx = synth.make_complex(seed=470, n=90, n_chains=4, masked_frac=0.03, missing_atom_frac=0.03)
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+    fd["S"] = fd["S"].long()
+    randn = torch.from_numpy(g["randn"])
+    lp, _ = cpu_ref.forward_train(w, fd, 24, randn, decode_protein_first=True)
+    exact(lp[0], g["dpf_log_probs"])
+    chain_M = fd["mask"].masked_fill(fd["protein_mask"].to(torch.bool), 0.0)
+    assert np.array_equal(cpu_ref.decoding_order_of(chain_M, randn)[0].numpy(), g["dpf_decoding_order"])
+    lp0, _ = cpu_ref.forward_train(w, fd, 24, randn)
+    assert float((lp0[0] - torch.from_numpy(g["dpf_log_probs"])).abs().max()) > 1e-3          # the flag really changes the result
+    V, E, E_idx = cpu_ref.features(w, fd, 24, na_ref_atom="P")
+    assert np.array_equal(E_idx[0].numpy(), g["refP_E_idx"].astype(np.int64))
+    exact(E[0, ::max(1, 90 // 8)][:8], g["refP_E_rows"])
+    lp, _ = cpu_ref.forward_train(w, fd, 24, randn, na_ref_atom="P")
+    exact(lp[0], g["refP_log_probs"])
+

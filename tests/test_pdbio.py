@@ -152,3 +152,64 @@ def test_backbone_pdb_writer_round_trip(tmp_path, golden_dir):
     with pytest.raises(ValueError, match="one-character chain column"):
         pdbio.write_backbone_pdb(out, P2, new_names, conf)
 
+
+
+ARRAY_KEYS = ("X_m", "mask", "R_idx", "chain_labels", "protein_mask", "dna_mask", "rna_mask", "rna_mask_for_token_conversion",
+              "R_polymer_type", "S")
+
+
+def _check_against(g, P, with_X=True):
+    for k in ARRAY_KEYS + (("X",) if with_X else ()):
+        assert g[k].shape == P[k].shape and np.array_equal(g[k], P[k]), k
+    assert g["chain_letters"].tolist() == list(P["chain_letters"])
+    assert g["icodes"].tolist() == list(P["icodes"])
+    assert g["na_chain_letters"].tolist() == list(P["na_chain_letters"])
+    assert np.array_equal(g["R_idx_renumbered"], pdbio.renumber(P["R_idx"]))
+    enc = [f"{c}{r}{ic}" for c, r, ic in zip(P["chain_letters"], P["R_idx"].tolist(), P["icodes"])]
+    assert g["encoded_residues"].tolist() == enc
+    other = sorted(f"{a.resname}:{a.chain}:{a.resnum}:{a.name}" for a in P["other_atoms"])
+    assert other == sorted(g["other_atom_names"].tolist())
+    assert int(g["n_backbone_atoms"]) == len(P["backbone_atoms"])
+
+
+@pytest.mark.parametrize("tag,kw", [("shared", dict(na_shared_tokens=True)), ("legacy", dict(na_shared_tokens=False)),
+                                    ("missing", dict(na_shared_tokens=True, load_residues_with_missing_atoms=True)),
+                                    ("naonly", dict(na_shared_tokens=True, parse_na_only=True)),
+                                    ("chainsBC", dict(na_shared_tokens=True, chains=["B", "C"]))])
+def test_edge_cases_match_the_oracle_arrays(golden_dir, tag, kw):
+    """The product's reader against per-residue arrays written by the ORACLE's independent restatement of parse_PDB
+    (oracle/pdb_ref.py via oracle/make_pdb_fixture.py) on a file built to exercise the selection rules of data_utils.py:232-345:
+    chain numbering over every chain of the file, altlocs, zero occupancy, MSE as HETATM, an amino acid without CA, UNK / PSU
+    (outside prody's tables), insertion codes, a nucleotide without phosphate, waters, a second MODEL."""
+    g = np.load(os.path.join(golden_dir, "pdb", f"edge_cases_expected_{tag}.npz"))
+    P = pdbio.parse_pdb(os.path.join(golden_dir, "pdb", "edge_cases.pdb"), **kw)
+    _check_against(g, P)
+    if tag == "shared":
+        assert P["chain_labels"].min() == 1                     # the ligand chain 'L' came first in the file
+        assert list(P["icodes"]).count("A") == 1 and len(P["S"]) == 13
+
+
+def test_oracle_restatement_reproduces_its_fixture(golden_dir):
+    """The committed arrays are what oracle/pdb_ref.py computes today (the fixture is not stale)."""
+    from oracle import pdb_ref
+    g = np.load(os.path.join(golden_dir, "pdb", "edge_cases_expected_shared.npz"))
+    O = pdb_ref.parse_PDB(os.path.join(golden_dir, "pdb", "edge_cases.pdb"), na_shared_tokens=True)
+    for k in ARRAY_KEYS + ("X",):
+        assert np.array_equal(g[k], O[k]), k
+
+
+@pytest.mark.parametrize("name,facts", [("4oqu", dict(L=97, protein=0, dna=0, rna=97, masked=0, chains=1)),
+                                        ("1am9", dict(L=389, protein=313, dna=72, rna=0, masked=4, chains=8))])
+def test_reference_examples_match_the_oracle_arrays(golden_dir, name, facts):
+    """The reference's two example inputs (inference/examples, build container only: the files are not copied into the repo):
+    the product's reader against the oracle-made arrays of tests/golden/pdb, and those against SURVEY App. B's facts."""
+    g = np.load(os.path.join(golden_dir, "pdb", f"{name}_expected.npz"))
+    assert len(g["S"]) == facts["L"] and int(g["protein_mask"].sum()) == facts["protein"] and int(g["dna_mask"].sum()) == facts["dna"]
+    assert int(g["rna_mask"].sum()) == facts["rna"] and int((g["mask"] == 0).sum()) == facts["masked"]
+    assert len(set(g["chain_letters"].tolist())) == facts["chains"]
+    path = f"/root/reference/inference/examples/{name}.pdb"
+    if not os.path.exists(path):
+        pytest.skip("the reference's example files exist in the build container only")
+    P = pdbio.parse_pdb(path, na_shared_tokens=True)
+    _check_against(g, P, with_X=False)
+    assert abs(float(P["X"].astype(np.float64).sum()) - float(g["X_checksum"])) < 1e-6
