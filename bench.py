@@ -39,11 +39,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import na_mpnn_amd  # noqa: E402,F401   (first: sets HIP_FORCE_DEV_KERNARG before the HIP runtime initialises)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from na_mpnn_amd import hip, shard, spec, synth   # noqa: E402
 from na_mpnn_amd.pack import PackedWeights        # noqa: E402
@@ -546,7 +547,7 @@ def design_bench(args, dev, rank, world, dist):
            "config": {"workload": f"cfg1: model.sample() on one {n}-residue RNA chain, K={K}, batch_size={bs}, T=0.1, from "
                                   "coordinates; level-parallel decoding", "global_batch": bs * world, "seq_len": n,
                       "parallelism": f"replicas x{world}"},
-           "levels": out.get("levels")}
+           "levels": (int(out["levels"]) if out.get("levels") is not None else None)}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         if True:
             from oracle import cpu_ref

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAMP_ABI_VERSION 2   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3 */
+#define NAMP_ABI_VERSION 3   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3; 3: namp_train_edge_bwd takes g_hE_in */
 #define NAMP_HIDDEN 128
 #define NAMP_MAX_LAYERS 8
 #define NAMP_MAX_K 192
@@ -332,7 +332,8 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   buffers are given (each optional; NULL: the caller reduces G1 — namp_train_scatter_rows does dL/dPj without atomics).
  *   The `x3` argument of the namp_train_* entry points is a precision code: 0 exact fp32 MFMA, 1 split-bf16 products, 2 plain
  *   bf16 products (mixed-precision training).  For namp_train_edge_bwd, adding 4 makes the launch ADD its dL/dh_E to the rows
- *   already in g_hE (another consumer's gradient of the same h_E) instead of overwriting them; adding 8 (both backward
+ *   of g_hE_in (another consumer's gradient of the same h_E, [B*N*K][128]; read only) and write the sum to g_hE — g_hE_in may
+ *   equal g_hE (in place) when the caller owns that buffer exclusively; without the flag g_hE_in is ignored; adding 8 (both backward
  *   entry points, K % 16 == 0) makes g_Pa a [B*N*K/16][128] buffer of per-tile sums written with plain stores — the caller adds
  *   a residue's K/16 tiles — instead of a zeroed [B*N][128] buffer accumulated with fp32 atomics (deterministic).
  * namp_train_wgrad: dW_part[c] = sum over row chunk c of G[row]^T (gelu_A ? gelu(A[row]) : A[row]), db_part[c] = sum G[row];
@@ -364,7 +365,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N, int K, void* stream);
+                        float* g_hE, const float* g_hE_in, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N,
+                        int K, void* stream);
 /* dL/dPj = transpose of the neighbour gather, as a gather over the reverse adjacency: rev_edge [B*N*K] = edge ids sorted by
  * the table row they gathered (global row b*N + E_idx), rev_off [B*N+1] their offsets per row; out0[j] = sum of G1[e] over the
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */
@@ -415,7 +417,13 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
  * residue and the same uniform per visit as namp_decoder_sample, hence identical draws.
  *   namp_sample_levels: level[b][t] (int32, indexed by VISIT t of stream b) = 1 + max level of the earlier neighbours.
  *   namp_decoder_sample_levels: work = int32 pairs (stream, visit) sorted by level [B_dec*N][2] (device);
- *     level_counts = HOST array of n_levels counts (the caller reads the histogram back; this library never synchronises). */
+ *     level_counts = HOST array of n_levels counts (the caller reads the histogram back; this library never synchronises).
+ *   namp_decoder_sample_walk (round 3): the same levels in ONE persistent launch — no kernel boundary per level (whose cold L2 made
+ *     the level's workgroups re-fetch the decoder weights at ~45 GB/s) and no host read-back: level_off = DEVICE int32 array,
+ *     level_off[l] = index of the first pair of level l in `work`, every entry behind the last level = B_dec*N (at least N + 2
+ *     entries).  namp_decoder_sample_walk_grid workgroups (<= 128, one per CU: the device must not be shared with other
+ *     streams meanwhile) walk the levels with a grid barrier in between; a barrier that gives up (bounded spin) makes the launch
+ *     overwrite log_probs with NaN.  K <= 128 (returns 0 workgroups otherwise: use the per-level launches).  Identical draws. */
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream);
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
@@ -424,6 +432,14 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
                                const int32_t* work, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                                void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
+
+int namp_decoder_sample_walk_grid(int B_dec, int N, int K);
+int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                             const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* work, const int32_t* level_off,
+                             float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                             void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 
 /* ---- measurement hook (bench.py) ------------------------------------------------------------
  * When enabled (thread-local), every kernel launch made through this ABI is bracketed by HIP

@@ -147,14 +147,16 @@ void set_lds_attributes() {
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
   set((const void*)(node_update_multi_kernel<2, true>), NODE_MULTI_LDS_X3(2));
-  set((const void*)dec_sample_kernel<false, false, 8>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, false, 8>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<false, true, 8>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, true, 8>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<false, false, 12>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, false, 12>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<false, true, 12>, SAMPLE_LDS);
-  set((const void*)dec_sample_kernel<true, true, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<0, false, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<1, false, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<2, false, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<0, true, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<1, true, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<2, true, 8>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<0, false, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<1, false, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<0, true, 12>, SAMPLE_LDS);
+  set((const void*)dec_sample_kernel<1, true, 12>, SAMPLE_LDS);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_DEC_MSG>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_x3_persistent_kernel<MODE_ENC_EDGE>, 2 * NAMP_IMG_BYTES + 2048 + 12 * 512);
@@ -967,7 +969,7 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N;
   // Pfw[3] + Pa0 on the encoder side; Pa[2] + Pv[2] + h[3] on the sample-stream side
-  return (3 + 1) * tbl(Ge) + (2 + 2 + 3) * tbl(Gd) + 4096;
+  return (3 + 1) * tbl(Ge) + (2 + 2 + 3) * tbl(Gd) + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
 }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
@@ -1027,32 +1029,42 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
     L.Pfw = Pfw[l];
     L.Pa = (l == 0) ? Pa0 : Pa[l - 1];
     L.Pv = (l == 0) ? Pfw[0] : Pv[l - 1];
+    // split-bf16 mode with <= 8 waves per workgroup: the residue tail runs as an MFMA tile on the x3 images (node_tail_x3_rows)
+    const bool tail_x3 = prec == PREC_X3 && maxw == 8;
+    if (tail_x3) {
+      REQUIRE(D->Win_ximg && D->Wout_ximg && aligned16(D->Win_ximg) && aligned16(D->Wout_ximg),
+              "namp_decoder_sample: split-bf16 mode needs dec[%d].Win_ximg / Wout_ximg", l);
+      REQUIRE(l + 1 >= w->n_dec || (w->dec[l + 1].W1a_ximg && w->dec[l + 1].W1v_ximg),
+              "namp_decoder_sample: split-bf16 mode needs dec[%d].W1a_ximg / W1v_ximg", l + 1);
+    }
     NampProj pn[2] = {{}, {}};
     int np = 0;
     if (l + 1 < w->n_dec) {
       const NampDecLayerW* Dn = &w->dec[l + 1];
-      pn[0] = {Dn->W1a_img, Dn->b1, nullptr, Pa[l]};
-      pn[1] = {Dn->W1v_img, nullptr, nullptr, Pv[l]};
+      pn[0] = {tail_x3 ? Dn->W1a_ximg : Dn->W1a_img, Dn->b1, nullptr, Pa[l]};
+      pn[1] = {tail_x3 ? Dn->W1v_ximg : Dn->W1v_img, nullptr, nullptr, Pv[l]};
       np = 2;
     }
-    fill_tail(L.tail, D->ln1_g, D->ln1_b, D->Win_img, D->b_in, D->Wout_img, D->b_out, D->ln2_g, D->ln2_b,
-              (l == 0) ? h_V_enc : hs[l - 1], mask_dec, hs[l], pn, np, nullptr);
+    fill_tail(L.tail, D->ln1_g, D->ln1_b, tail_x3 ? D->Win_ximg : D->Win_img, D->b_in, tail_x3 ? D->Wout_ximg : D->Wout_img, D->b_out,
+              D->ln2_g, D->ln2_b, (l == 0) ? h_V_enc : hs[l - 1], mask_dec, hs[l], pn, np, nullptr);
   }
   *a_out = a;
   *nwaves_out = nwaves;
   return NAMP_OK;
 }
 
-// the sampler kernel by (level mode, precision, waves per workgroup <= 8 or <= 12)
-static void launch_sample(bool level, bool x3, int nwaves, int grid, hipStream_t s, const SampleArgs& a, const int32_t* work, int nwork) {
+// the sampler kernel by (mode: 0 sequential walk / 1 one level per launch / 2 persistent level walk, precision, waves per workgroup)
+static void launch_sample(int mode, bool x3, int nwaves, int grid, hipStream_t s, const SampleArgs& a, const int32_t* work, int nwork,
+                          const int32_t* level_off = nullptr, unsigned* sync = nullptr) {
   const dim3 g(grid), b(nwaves * 64);
-#define NAMP_LS(LV, X3, W) hipLaunchKernelGGL((dec_sample_kernel<LV, X3, W>), g, b, SAMPLE_LDS, s, a, work, nwork)
+#define NAMP_LS(MD, X3, W) hipLaunchKernelGGL((dec_sample_kernel<MD, X3, W>), g, b, SAMPLE_LDS, s, a, work, nwork, level_off, sync)
   if (nwaves <= 8) {
-    if (level) { if (x3) NAMP_LS(true, true, 8); else NAMP_LS(true, false, 8); }
-    else       { if (x3) NAMP_LS(false, true, 8); else NAMP_LS(false, false, 8); }
+    if (mode == 2)      { if (x3) NAMP_LS(2, true, 8); else NAMP_LS(2, false, 8); }
+    else if (mode == 1) { if (x3) NAMP_LS(1, true, 8); else NAMP_LS(1, false, 8); }
+    else                { if (x3) NAMP_LS(0, true, 8); else NAMP_LS(0, false, 8); }
   } else {
-    if (level) { if (x3) NAMP_LS(true, true, 12); else NAMP_LS(true, false, 12); }
-    else       { if (x3) NAMP_LS(false, true, 12); else NAMP_LS(false, false, 12); }
+    if (mode == 1) { if (x3) NAMP_LS(1, true, 12); else NAMP_LS(1, false, 12); }
+    else           { if (x3) NAMP_LS(0, true, 12); else NAMP_LS(0, false, 12); }
   }
 #undef NAMP_LS
 }
@@ -1070,7 +1082,7 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
                           ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  launch_sample(false, prec_of(w->dec[0].flags) == PREC_X3, nwaves, (B_dec + a.slots - 1) / a.slots, (hipStream_t)stream, a, nullptr, 0);
+  launch_sample(0, prec_of(w->dec[0].flags) == PREC_X3, nwaves, (B_dec + a.slots - 1) / a.slots, (hipStream_t)stream, a, nullptr, 0);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -1110,7 +1122,7 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   for (int l = 0; l < n_levels; ++l) {
     const int cnt = level_counts[l];
     if (cnt == 0) continue;
-    launch_sample(true, x3, nwaves, (cnt + a.slots - 1) / a.slots, s, a, work + 2 * off, cnt);
+    launch_sample(1, x3, nwaves, (cnt + a.slots - 1) / a.slots, s, a, work + 2 * off, cnt);
     off += cnt;
   }
   CHECK_LAUNCH();
@@ -1118,6 +1130,51 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
 }
 
 
+
+int namp_decoder_sample_walk_grid(int B_dec, int N, int K) {
+  if (B_dec < 1 || N < 1 || K < 1 || K > 128) return 0;                     // K > 128 (12-wave workgroups): no persistent form
+  const int tpn = (K + 15) / 16;
+  int slots = 8 / tpn; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;
+  long g = ((long)B_dec * N + slots - 1) / slots;
+  return (int)(g < NAMP_WALK_MAX_GRID ? g : NAMP_WALK_MAX_GRID);
+}
+
+int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
+                             const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* work, const int32_t* level_off,
+                             float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
+                             void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
+  REQUIRE(work != nullptr && level_off != nullptr, "namp_decoder_sample_walk: work list / level offsets missing");
+  const int grid = namp_decoder_sample_walk_grid(B_dec, N, K);
+  REQUIRE(grid >= 1, "namp_decoder_sample_walk: no persistent form for B_dec=%d N=%d K=%d (K <= 128)", B_dec, N, K);
+  SampleArgs a; int nwaves = 0;
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
+                          nullptr, nullptr, nullptr, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+                          B_dec, B_enc, N, K, stream, &a, &nwaves);
+  if (rc) return rc;
+  REQUIRE(nwaves <= 8, "namp_decoder_sample_walk: needs the 8-wave workgroup form (K <= 128)");
+  // grid-barrier words: the last 4 KiB of the workspace (namp_sample_workspace_bytes reserves them behind the tables)
+  REQUIRE(ws_bytes >= namp_sample_workspace_bytes(B_enc, B_dec, N, K), "namp_decoder_sample_walk: workspace too small");
+  unsigned* sync = (unsigned*)((char*)ws + namp_sample_workspace_bytes(B_enc, B_dec, N, K) - 4096);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(S_out, 0xFF, (size_t)B_dec * N * sizeof(int32_t), s);          // every token "not drawn" (-1)
+  if (e == hipSuccess) e = hipMemsetAsync(sync, 0, NAMP_SYNC_WORDS * sizeof(unsigned), s);
+  if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_walk: hipMemsetAsync: %s", hipGetErrorString(e));
+  ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
+  launch_sample(2, prec_of(w->dec[0].flags) == PREC_X3, nwaves, grid, s, a, work, B_dec * N, level_off, sync);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+#ifdef NAMP_ABL_STAMPS
+extern "C" int namp_debug_stamps(long long* out16, int reset) {
+  long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(namp_stamp_acc), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(namp_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 int namp_set_persistent(int on) {
   std::lock_guard<std::mutex> lk(g_persist_mutex);

@@ -404,6 +404,27 @@ __device__ __forceinline__ void dma_to_lds(char* lds_dst, const float* gsrc, int
   }
 }
 
+// The same copy through registers (global_load_dwordx4 -> ds_write_b128), NPER chunks per wave at a time.  LDS-DMA lands at
+// ~20-25 GB/s per CU whatever is in flight (measured in the sampler, profiles/r03c; the guide's ldsdma-fill row) — fine when 250
+// workgroups stream the same images and the chip-wide rate is what counts, but a one-workgroup launch (the sampler: one dependency
+// level = one or two workgroups) waited 3.2 us per 64 KiB image; plain loads pull 150-230 GB/s into one CU (tools/clock_probe.hip).
+// Synchronous: returns with the wave's chunks written; the caller still needs a barrier before other waves read them.
+template <int NPER>
+__device__ __forceinline__ void copy_to_lds(char* lds_dst, const float* gsrc, int nchunks, int wave, int nwaves, int lane) {
+#ifdef NAMP_ABL_NODMA
+  return;
+#endif
+  for (int c0 = wave * NPER; c0 < nchunks; c0 += nwaves * NPER) {
+    f4 v[NPER];
+#pragma unroll
+    for (int u = 0; u < NPER; ++u)
+      if (c0 + u < nchunks) v[u] = *(const f4*)((const char*)gsrc + (size_t)(c0 + u) * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < NPER; ++u)
+      if (c0 + u < nchunks) *(f4*)(lds_dst + (c0 + u) * 1024 + lane * 16) = v[u];
+  }
+}
+
 __device__ __forceinline__ void wait_dma_and_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

@@ -152,6 +152,23 @@ static __global__ void gather_cat_scalar_kernel(const float* __restrict__ nodes,
 // channel tile tn) units over all waves.  Used by node_update_kernel (16 residues per workgroup) and
 // as the fused tail of the message kernels (the workgroup's own <= 12 residues).
 // ------------------------------------------------------------------------------------------
+#ifdef NAMP_ABL_STAMPS
+// phase attribution of the sampler step (tools/build_variants.sh stamps:-DNAMP_ABL_STAMPS): wall-clock ticks (100 MHz) of workgroup 0,
+// summed per phase over the whole launch; read back by namp_debug_stamps()
+__device__ long long namp_stamp_acc[16];
+__device__ long long namp_stamp_prev;
+#define NAMP_STAMP(slot)                                                                          \
+  do {                                                                                            \
+    __syncthreads();                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                                    \
+      const long long now_ = wall_clock64();                                                      \
+      namp_stamp_acc[slot] += now_ - namp_stamp_prev;                                             \
+      namp_stamp_prev = now_;                                                                     \
+    }                                                                                             \
+  } while (0)
+#else
+#define NAMP_STAMP(slot) do {} while (0)
+#endif
 struct ProjDesc {
   const float* img;    // 64 KiB image of the [128x128] block
   const float* bias;   // [128] or null
@@ -365,8 +382,29 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // acc[n] += sum_k w[k] * x[k][n] for the R residues of the tile: two residues per v_pk_fma_f32 (the weight broadcast to
 // both halves) — this loop is instruction-issue bound, and the packed form halves its instruction count.
-template <int R>
+// BULK: request the unit's LDS operands in two halves of 16 reads instead of k-tile by k-tile (one wait per half instead of per k-tile;
+// 64 more live registers: the sampler's 256-register workgroups only)
+template <int R, bool BULK = false>
 __device__ __forceinline__ void rows_fma(float (&acc)[R], const f4 (&wf)[8], const float* xT, const int g) {
+  if constexpr (BULK && R == 4) {
+    f2 a0 = (f2){acc[0], acc[1]}, a1 = (f2){acc[2], acc[3]};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f4 xv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xv[q] = *(const f4*)(xT + (16 * (4 * half + (q >> 2)) + 4 * g + (q & 3)) * 4);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float w = wf[4 * half + (q >> 2)][q & 3];
+        const f2 w2 = (f2){w, w};
+        a0 = __builtin_elementwise_fma(w2, (f2){xv[q].x, xv[q].y}, a0);
+        a1 = __builtin_elementwise_fma(w2, (f2){xv[q].z, xv[q].w}, a1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
+    return;
+  }
   f2 a2[R / 2];
 #pragma unroll
   for (int q = 0; q < R / 2; ++q) a2[q] = (f2){acc[2 * q], acc[2 * q + 1]};
@@ -515,7 +553,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
                    float acc[R];
 #pragma unroll
                    for (int n = 0; n < R; ++n) acc[n] = 0.f;
-                   rows_fma<R>(acc, wf, xT, g);
+                   rows_fma<R, PF>(acc, wf, xT, g);
 #pragma unroll
                    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
                    if (g == 0) {
@@ -533,7 +571,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
                    float acc[R];
 #pragma unroll
                    for (int n = 0; n < R; ++n) acc[n] = 0.f;
-                   rows_fma<R>(acc, wf, hT + 128 * kq * R, g);
+                   rows_fma<R, PF>(acc, wf, hT + 128 * kq * R, g);
 #pragma unroll
                    for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
                    if (g == 0) {
@@ -593,7 +631,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
                        float acc[R];
 #pragma unroll
                        for (int n = 0; n < R; ++n) acc[n] = 0.f;
-                       rows_fma<R>(acc, wf, yT, g);
+                       rows_fma<R, true>(acc, wf, yT, g);
 #pragma unroll
                        for (int n = 0; n < R; ++n) acc[n] = xg_sum(acc[n]);
                        if (g == 0) {
@@ -642,6 +680,145 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
             st_out<SC1>(pd.out + (long)orw * NAMP_H + c, o);
           }
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// node_tail_x3_rows<R> — the residue tail of <= R (<= 16) scattered rows as ONE 16-row MFMA tile of split-bf16 products, for
+// the sampler's 8-wave workgroups (round 3).  The VALU form above is right where 250 workgroups stream the same weights (bound by
+// L2 bandwidth chip-wide); in the sampler ONE workgroup serves a whole dependency level with the chip idle around it, and the
+// VALU form's 640 dependent-LDS-read + packed-FMA groups per wave were 15 us of a 29 us layer (profiles/r03c).  Here (the schedule
+// of node_update_multi_kernel): every wave holds the LayerNorm-1 rows in the register-chain layout (lane (m, g): channels
+// 16t + 4g + r of row m), wave w owns hidden units 64w .. 64w+63 through BOTH FFN products — W_in slice (4 channel tiles x 4
+// K-steps), exact-erf GELU in registers, W_out slice (8 channel tiles x its 2 K-steps) — the eight [R x 128] partial outputs are
+// summed through LDS, every wave normalises the rows again (LayerNorm-2 in the chain layout) and takes its share of the projection
+// tiles.  120 x 16x16x32 bf16 MFMAs and 80 KiB of x3 fragments (straight from L2, one tile ahead) per wave; padding rows (m >= R)
+// ride along for free.  a.Win_img / a.Wout_img / a.p[].img are x3 images here (namp_pack_image_x3_general / namp_pack_image_x3).
+// nwaves must be 8.  lds: >= (2048 + 8 * R * 128 + 128 * R + 64) floats; leaves yT[c * R + n] = h_V' where node_tail_rows does.
+// ------------------------------------------------------------------------------------------
+// SC1: the rows other workgroups of the SAME launch gather later (persistent level walk) are stored write-through
+template <bool SC1>
+__device__ __forceinline__ void st_f4(float* p, const f4 v) {
+  if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+  else *(f4*)p = v;
+}
+
+template <int R, typename RowFn, bool SC1 = false>
+__device__ __forceinline__ void node_tail_x3_rows(const NodeTail& a, f4 (&x)[8], const RowFn orow, float* lds,
+                                                  const int tid, const int wave, const int lane) {
+  float* part = lds + 128 * R;                       // [8 waves][R][128] partial W_out products (hT | oP of the VALU form)
+  float* yT = lds + (128 + 512 + 4 * 128) * R;       // [128][R] h_V' for the caller's output head
+  const int m = lane & 15, g = lane >> 4;
+  const int mr = m < R ? m : 0;
+  const float* win_p = a.Win_img; const float* wout_p = a.Wout_img; const float* p0_p = a.p[0].img; const float* p1_p = a.p[1].img;
+  const float* bin_p = a.b_in; const float* bout_p = a.b_out; const float* l1g = a.ln1_g; const float* l1b = a.ln1_b;
+  const float* l2g = a.ln2_g; const float* l2b = a.ln2_b;
+  NAMP_STAMP(7);                       // (entry: images for the next layer copied, K-sums read)
+  layernorm_row_T(x, l1g, l1b, g);
+  NAMP_STAMP(8);                       // LayerNorm 1
+  bf8 xh[4], xm[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) split_x3(x[2 * s], x[2 * s + 1], xh[s], xm[s]);
+  // ---- hidden = gelu(W_in x + b_in), this wave's four channel tiles 4w .. 4w+3
+  const bf8* wi = (const bf8*)win_p + lane;
+  constexpr int WI_MID = 512 * 128 / 8;              // bf8 units between the hi and the mid image
+  f4 h[4];
+  bf8 fa[8], fb[8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { fa[2 * s] = wi[(s * 32 + 4 * wave) * 64]; fa[2 * s + 1] = wi[WI_MID + (s * 32 + 4 * wave) * 64]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tn = 4 * wave + q;
+    bf8 (&cur)[8] = (q & 1) ? fb : fa;
+    bf8 (&nxt)[8] = (q & 1) ? fa : fb;
+    if (q + 1 < 4) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { nxt[2 * s] = wi[(s * 32 + tn + 1) * 64]; nxt[2 * s + 1] = wi[WI_MID + (s * 32 + tn + 1) * 64]; }
+    }
+    f4 acc = *(const f4*)(bin_p + 16 * tn + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma_x3(cur[2 * s], cur[2 * s + 1], xh[s], xm[s], acc);
+    h[q] = gelu4_scalar(acc);
+  }
+  NAMP_STAMP(9);                       // W_in + GELU
+  // ---- W_out restricted to this wave's 64 hidden units: K-steps 2w, 2w+1 of the [128 x 512] image; partial rows to LDS
+  const bf8* wo = (const bf8*)wout_p + lane;
+  constexpr int WO_MID = 128 * 512 / 8;
+  bf8 hh[2], hm[2];
+  split_x3(h[0], h[1], hh[0], hm[0]);
+  split_x3(h[2], h[3], hh[1], hm[1]);
+  {
+    // four channel tiles per group: 16 fragments in flight (hi | mid of 2 K-steps x 4 tiles), the next group requested first
+    bf8 ga[16], gb[16];
+    auto fetch = [&](bf8 (&dst)[16], const int t0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          dst[4 * q + 2 * s2] = wo[((2 * wave + s2) * 8 + t0 + q) * 64];
+          dst[4 * q + 2 * s2 + 1] = wo[WO_MID + ((2 * wave + s2) * 8 + t0 + q) * 64];
+        }
+    };
+    fetch(ga, 0);
+    fetch(gb, 4);
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      bf8 (&cur)[16] = grp ? gb : ga;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f4 po = (f4){0.f, 0.f, 0.f, 0.f};
+        po = mfma_x3(cur[4 * q], cur[4 * q + 1], hh[0], hm[0], po);
+        po = mfma_x3(cur[4 * q + 2], cur[4 * q + 3], hh[1], hm[1], po);
+        if (m < R) *(f4*)(part + ((wave * R + m) * 128 + 16 * (4 * grp + q) + 4 * g)) = po;
+      }
+    }
+  }
+  __syncthreads();
+  NAMP_STAMP(10);                      // W_out partials
+  // ---- y = LayerNorm2(x + W_out h + b_out) * mask, in the chain layout, by every wave
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    f4 v = x[t] + *(const f4*)(bout_p + 16 * t + 4 * g);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += *(const f4*)(part + ((w * R + mr) * 128 + 16 * t + 4 * g));
+    x[t] = v;
+  }
+  layernorm_row_T(x, l2g, l2b, g);
+  const int orw = (m < R) ? orow(m) : -1;
+  {
+    const float mk = (a.mask && orw >= 0) ? (float)a.mask[orw] : 1.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] *= mk;
+  }
+  if (wave == 0 && m < R) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      yT[(16 * t + 4 * g + 0) * R + m] = x[t].x; yT[(16 * t + 4 * g + 1) * R + m] = x[t].y;
+      yT[(16 * t + 4 * g + 2) * R + m] = x[t].z; yT[(16 * t + 4 * g + 3) * R + m] = x[t].w;
+      if (orw >= 0) st_f4<SC1>(a.hV_out + (long)orw * NAMP_H + 16 * t + 4 * g, x[t]);
+    }
+  }
+  NAMP_STAMP(11);                      // partial sums + LayerNorm 2 + h_V' out
+  // ---- projections of h_V' (<= 2 blocks: the next layer's Pa / Pv): unit v = 8 pi + tn -> wave v % 8
+  if (a.nproj > 0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_x3(x[2 * s], x[2 * s + 1], xh[s], xm[s]);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      if (pi >= a.nproj) break;
+      const bf8* wp = (const bf8*)(pi ? p1_p : p0_p) + lane;
+      const int tn = wave;
+      bf8 f[8];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { f[2 * s] = wp[(s * 8 + tn) * 64]; f[2 * s + 1] = wp[NAMP_BIMG_BYTES / 16 + (s * 8 + tn) * 64]; }
+      f4 acc = a.p[pi].bias ? *(const f4*)(a.p[pi].bias + 16 * tn + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_x3(f[2 * s], f[2 * s + 1], xh[s], xm[s], acc);
+      if (orw >= 0) {
+        if (a.p[pi].tok) acc += *(const f4*)(a.p[pi].tok + (long)a.S[orw] * NAMP_H + 16 * tn + 4 * g);
+        st_f4<SC1>(a.p[pi].out + (long)orw * NAMP_H + 16 * tn + 4 * g, acc);
       }
     }
   }
@@ -1548,10 +1725,15 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 // that share cache lines with not-yet-written neighbours (S) are read with L1-bypassing loads.
 // ------------------------------------------------------------------------------------------
 #define NAMP_SAMPLE_SLOTS 4
+#define NAMP_WALK_MAX_GRID 128      // workgroups of the persistent level walk (all must be resident: one 155 KiB-LDS workgroup per CU)
 // LDS of the sampler: the 2 x 64 KiB weight ring | the residue tail's scratch (its own region: the next layer's images stream into the ring
 // while the tail runs) | per-wave partial K-sums | node / visit ids
 #define SAMPLE_TAIL_BYTES (((128 + 512 + 4 * 128 + 128) * NAMP_SAMPLE_SLOTS + 64) * 4)
 #define SAMPLE_LDS (2 * NAMP_IMG_BYTES + SAMPLE_TAIL_BYTES + 12 * NAMP_H * 4 + 64)
+
+// generic -> global: a pointer loaded from memory has no address space; every pointer of this ABI is device global memory
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
 
 struct SampleLayer {
   const float* W1e_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
@@ -1819,8 +2001,17 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
 // MAXW = 8 waves per workgroup (K <= 128: 8 / TPN streams per workgroup) leaves 256 VGPRs per lane — the three row operands, the
 // residue tail's two fragment sets in flight and the head fit without scratch (the 12-wave form spilled 165 registers per lane); MAXW = 12
 // only serves K > 128.
-template <bool LEVEL, bool X3 = false, int MAXW = 8>
-__global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork) {
+// MODE 0: the sequential walk.  MODE 1: one dependency level per launch (work = the level's (stream, visit) pairs).  MODE 2 (round 3):
+// ALL levels in one persistent launch — work = every (stream, visit) pair sorted by level, level_off[l] = first pair of level l
+// (level_off[l] >= nwork ends the walk), a grid barrier between levels.  A kernel boundary per level costs more than its ~2 us here:
+// the level's one or two workgroups re-fetch the 2.5 MB of decoder weights through a cold L2 (they came at ~45 GB/s, half of a level's
+// 90 us at B = 1), and the host has to read the level histogram back before it can launch.  What later levels gather from other
+// workgroups — the next layer's Pv rows — is stored write-through (sc1); tokens travel through agent-scope atomics as before; no
+// workgroup ever reads a row before the level that wrote it (rank order), so no reader holds a stale line.
+template <int MODE, bool X3 = false, int MAXW = 8>
+__global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork,
+                                                               const int32_t* __restrict__ level_off, unsigned* sync) {
+  constexpr bool LEVEL = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* buf0 = smem;
   char* buf1 = smem + NAMP_IMG_BYTES;
@@ -1833,11 +2024,6 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
   const int nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int slot = wave / a.TPN, kt = wave - slot * a.TPN;
-  const int item = blockIdx.x * a.slots + slot;                  // LEVEL: index into the work list; else: the stream
-  const bool wave_active = (slot < a.slots) && (LEVEL ? item < nwork : item < a.B_dec);
-  const int bb = wave_active ? (LEVEL ? work[2 * item] : item) : (LEVEL ? work[0] : 0);
-  const int t_level = LEVEL ? work[2 * (wave_active ? item : 0) + 1] : 0;
-  const int b_enc = bb % a.B_enc;
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
   const SampleRows rows = {node_lds};
@@ -1853,19 +2039,29 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     __syncthreads();
   }
 
-  dma_to_lds(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);      // the first layer's images: in flight under the index chain below
-  dma_to_lds(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
-#pragma unroll 1
-  for (int t_seq = 0; t_seq < (LEVEL ? 1 : a.N); ++t_seq) {
-    asm volatile("" ::: "memory");      // sequential walk: keep the step's (loop-invariant) vector loads inside the step, not in registers across it
+  copy_to_lds<8>(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);   // the first layer's images (through registers: see copy_to_lds)
+  copy_to_lds<8>(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
+  // One step: the workgroup's <= a.slots items starting at item0 (MODE 0: streams item0 .. at visit t_seq; else work-list entries
+  // item0 .. < nitems).  `more`: another step follows in this launch (its first layer's images are requested under this step's last tail).
+#ifdef NAMP_ABL_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) namp_stamp_prev = wall_clock64();
+#endif
+  auto step = [&](const int item0, const int nitems, const int t_seq, const bool more) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");      // keep the step's (loop-invariant) vector loads inside the step, not in registers across steps
+    NAMP_STAMP(0);                      // (time since the previous stamp: barrier / launch-side)
+    const int item = item0 + slot;                                // LEVEL: index into the work list; else: the stream
+    const bool wave_active = (slot < a.slots) && (item < nitems);
+    const int bb = LEVEL ? work[2 * (wave_active ? item : item0)] : (wave_active ? item : 0);
+    const int t_level = LEVEL ? work[2 * (wave_active ? item : item0) + 1] : 0;
+    const int b_enc = bb % a.B_enc;
     const int t = LEVEL ? t_level : t_seq;
     const int i_loc = a.order[(long)bb * a.N + t];
     const int node = bb * a.N + i_loc;                   // stream-global residue
     const int node_enc = b_enc * a.N + i_loc;
     if (tid < NAMP_SAMPLE_SLOTS) {
-      const int it = blockIdx.x * a.slots + tid;
+      const int it = item0 + tid;
       if (LEVEL) {
-        const bool ok = tid < a.slots && it < nwork;
+        const bool ok = tid < a.slots && it < nitems;
         const int bs = ok ? work[2 * it] : 0, ts = ok ? work[2 * it + 1] : 0;
         node_lds[tid] = ok ? bs * a.N + a.order[(long)bs * a.N + ts] : -1;
         t_lds[tid] = ts;
@@ -1888,61 +2084,96 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     // parallel decoder never notices — its output mask is the same mask_i — but here the output mask may be stream 0's.)
     const float ctx = a.mask_true[node_enc] ? 1.0f : 0.0f;
 
+    // The layer loop is NOT unrolled (round 3).  A step executes every instruction once, so an unrolled step streams ~100 KB of
+    // code through the 64 KiB instruction cache per level and runs at the speed of its instruction fetches — ~7 ns per
+    // instruction, 90 us per level whatever the instructions do (profiles/r03c: neither an MFMA tail, nor faster weight staging,
+    // nor one persistent launch moved it).  Rolled, the ~30 KB layer body is fetched once and re-used by the other layers — and,
+    // in the persistent level walk, by every later level.  The per-layer arguments are read from the kernel-argument segment
+    // with a run-time index (a by-value struct indexed at run time would be copied to scratch).
+    const SampleArgs* A = (const SampleArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+      // pointers read through the segment pointer are generic: tell the compiler they are global (flat loads otherwise)
+      SampleLayer L = A->l[l];
+      L.W1e_img = as_global(L.W1e_img); L.W2_img = as_global(L.W2_img); L.W3_img = as_global(L.W3_img); L.b2 = as_global(L.b2);
+      L.b3 = as_global(L.b3); L.tok = as_global(L.tok); L.Pfw = as_global(L.Pfw); L.Pa = as_global(L.Pa); L.Pv = as_global(L.Pv);
+      {
+        NodeTail& T = L.tail;
+        T.hV = as_global(T.hV); T.mask = as_global(T.mask); T.ln1_g = as_global(T.ln1_g); T.ln1_b = as_global(T.ln1_b);
+        T.Win_img = as_global(T.Win_img); T.b_in = as_global(T.b_in); T.Wout_img = as_global(T.Wout_img); T.b_out = as_global(T.b_out);
+        T.ln2_g = as_global(T.ln2_g); T.ln2_b = as_global(T.ln2_b); T.hV_out = as_global(T.hV_out); T.S = as_global(T.S);
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {          // unrolled: a.l[l] must be a static index into the kernarg struct
-      if (l >= a.n_layers) break;
-      const SampleLayer& L = a.l[l];
+        for (int pi = 0; pi < 2; ++pi) {
+          T.p[pi].img = as_global(T.p[pi].img); T.p[pi].bias = as_global(T.p[pi].bias); T.p[pi].tok = as_global(T.p[pi].tok);
+          T.p[pi].out = as_global(T.p[pi].out);
+        }
+      }
+      const float* b2p = L.b2; const float* b3p = L.b3;
       f4 x[8], acc[8], pjv[8];
       {
         const float* src = a.hE + erow * NAMP_H + 4 * g;
         const float* pa = L.Pa + (long)(l == 0 ? node_enc : node) * NAMP_H + 4 * g;
         const float* pj = (bw ? L.Pv + (long)(l == 0 ? j_enc : j_dec) * NAMP_H : L.Pfw + (long)j_enc * NAMP_H) + 4 * g;
         const float* tk = L.tok + (long)(has_tok ? S_j : 0) * NAMP_H + 4 * g;
+        const float tokf = has_tok ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           x[q] = *(const f4*)(src + 16 * q) * ctx;
           acc[q] = *(const f4*)(pa + 16 * q);
           pjv[q] = *(const f4*)(pj + 16 * q);
-          if (has_tok) pjv[q] += *(const f4*)(tk + 16 * q);
-          pjv[q] *= ctx;
+          pjv[q] = (pjv[q] + *(const f4*)(tk + 16 * q) * tokf) * ctx;      // (no branch: a conditional load here cost one memory round trip per q)
         }
       }
       // W1e / W2 of this layer were requested ahead (before the walk / under the previous layer's residue tail); the
       // rows above were requested after them, so one vmcnt(0) covers both
       wait_dma_and_sync();
-      gemm128<X3, false, false>(acc, x, w0);
+      NAMP_STAMP(1);                    // index chain + row gather + W1e / W2 landed
+      // A wave whose slot holds no residue (a level of B = 1 has ~2.5 of 4) skips the three tile GEMMs — it would only take matrix-pipe
+      // and issue time from the wave it shares a SIMD with — but keeps every barrier and its share of the image copies.
+      if (wave_active) {
+        gemm128<X3, false, false>(acc, x, w0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
+        for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
+      }
       __syncthreads();
-      dma_to_lds(buf0, L.W3_img, 64, wave, nwaves, lane);
+      NAMP_STAMP(2);                    // GEMM 1
+      copy_to_lds<8>(buf0, L.W3_img, 64, wave, nwaves, lane);
+      if (wave_active) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(L.b2 + 16 * q + 4 * g);
-      gemm128<X3, false, true>(x, acc, w1);
+        for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(b2p + 16 * q + 4 * g);
+        gemm128<X3, false, true>(x, acc, w1);
+      }
       wait_dma_and_sync();
+      NAMP_STAMP(3);                    // GEMM 2 (+ W3 landed)
+      if (wave_active) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float bq = L.b3[16 * q + m];
-        acc[q] = (f4){bq, bq, bq, bq};
-      }
-      gemm128<X3, true, true>(acc, x, w0);
-      float wr[4];
+        for (int q = 0; q < 8; ++q) {
+          const float bq = b3p[16 * q + m];
+          acc[q] = (f4){bq, bq, bq, bq};
+        }
+        gemm128<X3, true, true>(acc, x, w0);
+        float wr[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
+        for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float sres = (acc[q].x * wr[0] + acc[q].y * wr[1]) + (acc[q].z * wr[2] + acc[q].w * wr[3]);
-        sres = xg_sum(sres);
-        if (g == 0) dpart[wave * NAMP_H + 16 * q + m] = sres;
+        for (int q = 0; q < 8; ++q) {
+          float sres = (acc[q].x * wr[0] + acc[q].y * wr[1]) + (acc[q].z * wr[2] + acc[q].w * wr[3]);
+          sres = xg_sum(sres);
+          if (g == 0) dpart[wave * NAMP_H + 16 * q + m] = sres;
+        }
+      } else if (lane < 32) {
+        *(f4*)(dpart + wave * NAMP_H + 4 * lane) = (f4){0.f, 0.f, 0.f, 0.f};      // (read by the tail's padding rows: keep it finite)
       }
       __syncthreads();
+      NAMP_STAMP(4);                    // GEMM 3 + K-sum
       // both ring slots are free: the next layer's W1e / W2 (the next step's first layer in the sequential walk) stream in
       // under the residue tail, whose scratch lives behind the ring
       if (l + 1 < a.n_layers) {
-        dma_to_lds(buf0, a.l[l + 1 < 3 ? l + 1 : 2].W1e_img, 64, wave, nwaves, lane);
-        dma_to_lds(buf1, a.l[l + 1 < 3 ? l + 1 : 2].W2_img, 64, wave, nwaves, lane);
-      } else if (!LEVEL && t_seq + 1 < a.N) {
-        dma_to_lds(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);
-        dma_to_lds(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
+        copy_to_lds<8>(buf0, as_global(A->l[l + 1].W1e_img), 64, wave, nwaves, lane);
+        copy_to_lds<8>(buf1, as_global(A->l[l + 1].W2_img), 64, wave, nwaves, lane);
+      } else if (more) {
+        copy_to_lds<8>(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);
+        copy_to_lds<8>(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
       }
       // residue tail over the workgroup's <= 4 streams: tile row m -> stream slot m
       {
@@ -1961,16 +2192,21 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
           for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * q);
         }
 #ifndef NAMP_ABL_SAMPLE_NOTAIL
-        node_tail_rows<NAMP_SAMPLE_SLOTS, SampleRows, false, true, true>(L.tail, x, 0.f, rows, tail_lds, tid, wave, nwaves, lane);
+        // split-bf16 mode, 8-wave workgroups: the tail as one MFMA tile on x3 images (both walks: level == sequential bit for bit);
+        // otherwise the VALU form on fp32 images (prefetching in the level kernel, whose 256 registers hold two units in flight)
+        if constexpr (X3 && MAXW == 8) node_tail_x3_rows<NAMP_SAMPLE_SLOTS, SampleRows, MODE == 2>(L.tail, x, rows, tail_lds, tid, wave, lane);
+        else node_tail_rows<NAMP_SAMPLE_SLOTS, SampleRows, MODE == 2, true, LEVEL && MAXW == 8>(L.tail, x, 0.f, rows, tail_lds, tid, wave, nwaves, lane);
 #endif
       }
       __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
+      NAMP_STAMP(5);                    // next images requested + residue tail
     }
 
     // ---- output head + draw, one wave per stream slot (wave n owns slot n for the whole walk, so the running
     // logit sum of a symmetry group lives in its registers).  h^(n_layers) row of slot n is yT[c * R + n].
     {
       const float* yT = tail_lds + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
+      const float* head_w = a.head_w; const float* head_b = a.head_b;
       for (int n = wave; n < NAMP_SAMPLE_SLOTS; n += nwaves) {
         const int nd = node_lds[n];
         if (nd < 0) continue;
@@ -1978,7 +2214,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         const int ne = (bq % a.B_enc) * a.N + iq;
         float z = -INFINITY;
         if (lane < a.vocab) {
-          const float* w = a.head_w + (long)lane * NAMP_H;
+          const float* w = head_w + (long)lane * NAMP_H;
           float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
           for (int c = 0; c < NAMP_H; c += 4) {
@@ -1986,7 +2222,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
             s0 = fmaf(wv.x, yT[(c + 0) * NAMP_SAMPLE_SLOTS + n], s0); s1 = fmaf(wv.y, yT[(c + 1) * NAMP_SAMPLE_SLOTS + n], s1);
             s2 = fmaf(wv.z, yT[(c + 2) * NAMP_SAMPLE_SLOTS + n], s2); s3 = fmaf(wv.w, yT[(c + 3) * NAMP_SAMPLE_SLOTS + n], s3);
           }
-          z = (s0 + s1) + (s2 + s3) + a.head_b[lane];
+          z = (s0 + s1) + (s2 + s3) + head_b[lane];
         }
         // log_softmax(logits) of this residue                          (model_utils.py:190 / :296-297)
         float mx = z;
@@ -2059,7 +2295,31 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
       }
     }
     __syncthreads();              // S of this step is published before the next step's neighbours read it
+    NAMP_STAMP(6);                      // output head + draw
+  };
+
+  if constexpr (MODE == 0) {
+#pragma unroll 1
+    for (int t_seq = 0; t_seq < a.N; ++t_seq) step(blockIdx.x * a.slots, a.B_dec, t_seq, t_seq + 1 < a.N);
+  } else if constexpr (MODE == 1) {
+    step(blockIdx.x * a.slots, nwork, 0, false);
+  } else {
+#pragma unroll 1
+    for (int lvl = 0;; ++lvl) {
+      const int off = level_off[lvl];
+      if (off >= nwork) break;
+      const int end = level_off[lvl + 1];
+#pragma unroll 1
+      for (int base = off + blockIdx.x * a.slots; base < end; base += gridDim.x * a.slots) step(base, end, 0, true);
+      grid_barrier(sync, (unsigned)lvl + 1u, tid);
+    }
+    // a barrier that gave up let its workgroup run ahead of data it needed: the failure travels with the outputs (cf. encdec_persistent_kernel)
+    if (__hip_atomic_load((gu32*)sync + NAMP_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      for (long e = (long)blockIdx.x * blockDim.x + tid; e < (long)a.B_dec * a.N * a.vocab; e += (long)gridDim.x * blockDim.x)
+        a.logp_out[e] = __builtin_nanf("");
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA of a prefetched image is in flight when the workgroup's LDS is released
 }
 
 // ------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ struct EdgeBwdArgs {
   // (unused since layer 3 moved behind the K-sum: kept so that the argument block keeps its layout)
   float* S3; float* w3;
   float* g_hE;                 // [E][128]
+  const float* g_hE_in;        // message modes with acc_hE: the other consumer's dL/dh_E rows (may alias g_hE)
   float* g_Pa;                 // optional [G][128], ZEROED by the caller: += sum_k G1[i,k]   (fp32 atomics)
   float* g_Pj0; float* g_Pj1;  // optional [G][128], zeroed: += G1[e] at the row's gathered table (Pj0 / Pj1 like the forward)
   // BWD_EDGE_LN: the whole edge update h_E' = LN3(h_E + dropout(z3)) is differentiated here; g_rows = dL/dh_E'
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   // ---- dL/dh_E = W1b^T g1 (+ the residual path of the edge update)
 #pragma unroll
   for (int t = 0; t < 8; ++t)
-    acc[t] = ((MODE == BWD_EDGE_LN || a.acc_hE) && valid) ? *(const f4*)(a.g_hE + e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+    acc[t] = ((MODE == BWD_EDGE_LN || a.acc_hE) && valid) ? *(const f4*)((MODE == BWD_EDGE_LN ? a.g_hE : a.g_hE_in) + e * NAMP_H + 4 * g + 16 * t)
+                                                            : (f4){0.f, 0.f, 0.f, 0.f};
   gemm128p<PREC, false>(acc, gr, wA);
   if (valid) {
     float* d = a.g_hE + e * NAMP_H + 4 * g;

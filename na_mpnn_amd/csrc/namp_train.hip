@@ -62,8 +62,8 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3t_img, const float* W2t_img, const float* W1t_img,
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
-                        float* g_hE, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N, int K,
-                        void* stream) {
+                        float* g_hE, const float* g_hE_in, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B,
+                        int N, int K, void* stream) {
   REQUIRE(mode >= 0 && mode <= 2, "namp_train_edge_bwd: mode=%d must be 0 (enc message), 1 (dec message) or 2 (enc edge)", mode);
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img);
   REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
@@ -83,7 +83,9 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   a.g_Pa = g_Pa; a.g_Pj0 = g_Pj0; a.g_Pj1 = g_Pj1;
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.S3 = S3; a.w3 = w3;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
-  a.acc_hE = (x3 & 4) ? 1 : 0;                               // bit 2 of the precision argument: accumulate into g_hE
+  a.acc_hE = (x3 & 4) ? 1 : 0;                               // bit 2 of the precision argument: g_hE = g_hE_in + this launch's dL/dh_E
+  a.g_hE_in = g_hE_in;
+  REQUIRE(!a.acc_hE || g_hE_in != nullptr, "namp_train_edge_bwd: the accumulate flag needs g_hE_in");
   a.gpa_tiles = (x3 & 8) ? 1 : 0;                            // bit 3: g_Pa holds per-tile sums [E/16][128] (needs K % 16 == 0)
   REQUIRE(!a.gpa_tiles || (K % 16) == 0, "namp_train_edge_bwd: per-tile g_Pa sums need K %% 16 == 0 (K=%d)", K);
   x3 &= 3;

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnamp_hip.so")   # env: tools/kbench.py ablations
 
-NAMP_ABI_VERSION = 2
+NAMP_ABI_VERSION = 3
 NAMP_MAX_LAYERS = 8
 NAMP_FLAG_BF16 = 1
 NAMP_FLAG_X3 = 2
@@ -101,7 +101,7 @@ _PROTOTYPES = {
     "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, i32, vp]),
     "namp_train_edge_update_bwd_groups": (i32, [i32, i32, i32]),
     "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 10 + [i32, i32, i32, i32, vp]),
-    "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 21 + [i32, i32, i32, i32, vp]),
+    "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 22 + [i32, i32, i32, i32, vp]),
     "namp_train_scatter_rows": (i32, [c_fp, c_ip, c_ip, vp, c_fp, c_fp, i32, vp]),
     "namp_train_scatter_rows_bf16": (i32, [c_fp, c_ip, c_ip, vp, c_fp, c_fp, i32, vp]),
     "namp_train_tail_groups": (i32, [i32]),
@@ -121,6 +121,10 @@ _PROTOTYPES = {
     "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                          c_ip, C.POINTER(C.c_int32), i32,
                                          C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
+    "namp_decoder_sample_walk_grid": (i32, [i32, i32, i32]),
+    "namp_decoder_sample_walk": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+                                       c_ip, c_ip,
+                                       C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),
     "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,

@@ -455,6 +455,8 @@ class ProteinMPNN(nn.Module):
     reference_sample_mask_quirk = True
     # decode the plain sampling branch by dependency level (False: the one-launch sequential walk; same results)
     sample_level_parallel = True
+    # ... as ONE persistent launch walking the levels (no host read-back, warm L2); False: one launch per level
+    sample_level_walk = True
 
     @torch.no_grad()
     def sample(self, feature_dict):
@@ -538,8 +540,20 @@ class ProteinMPNN(nn.Module):
                                             hip.current_stream()), "sample_levels")
             flat = level.view(-1).long()
             perm = torch.argsort(flat, stable=True)
-            counts = torch.bincount(flat).cpu().tolist()                       # the one host sync of the sampler
             work = torch.stack((perm // L, perm % L), 1).to(torch.int32).contiguous()
+            common = (W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),
+                      St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), work.data_ptr())
+            tail = (float(fd["temperature"]), special, S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
+                    B_dec, B, L, K, hip.current_stream())
+            if self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0:
+                # one persistent launch: the level histogram stays on the device (levels < L, so L + 2 offsets; everything behind
+                # the last level equals B_dec * L) — nothing is read back, the call returns with the whole design enqueued
+                hist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
+                level_off = torch.cat((hist.new_zeros(1), hist.cumsum(0))).to(torch.int32).contiguous()
+                hip.check(Lb.namp_decoder_sample_walk(*common, level_off.data_ptr(), *tail), "decoder_sample_walk")
+                return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
+                        "uniform": uniform, "levels": (hist > 0).sum()}
+            counts = torch.bincount(flat).cpu().tolist()                       # per-level launches: the one host sync of the sampler
             counts_c = (C.c_int32 * len(counts))(*counts)
             hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),
                                                     cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(),

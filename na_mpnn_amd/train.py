@@ -193,7 +193,7 @@ class _EdgeMLP(torch.autograd.Function):
         dh = torch.addmm(wsum * b3.detach(), msum, W3.detach().t())
         return dh.view(B, N, H), h_E.view_as(h_E)
         # (second output: h_E itself, for the NEXT consumer of the same edge rows (EncLayer's edge update, the next DecLayer).
-        # Its gradient then arrives HERE, and the backward launch adds its own dL/dh_E onto those rows in place — autograd
+        # Its gradient then arrives HERE, and the backward launch writes (that gradient + its own dL/dh_E) in one pass — autograd
         # would otherwise sum the consumers' [E,128] gradients with a separate 1.8 GB pass each.)
 
     @staticmethod
@@ -221,11 +221,13 @@ class _EdgeMLP(torch.autograd.Function):
             g = (g2d @ W3.detach()).contiguous()
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         A1, G1, G2 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(3))
-        acc = g_pass is not None and g_pass.is_contiguous() and g_pass.dtype == torch.float32 and g_pass.numel() == E * H
-        if g_pass is not None and not acc:
+        # the later consumer's dL/dh_E arrives as g_pass: the launch reads it and writes the SUM to a fresh buffer (same HBM
+        # traffic as adding in place — one read and one write of [E,128] — without mutating a gradient autograd handed in,
+        # which a hook / retain_grad / a second consumer of the pass-through output could still be looking at)
+        acc = g_pass is not None
+        if acc and not (g_pass.is_contiguous() and g_pass.dtype == torch.float32):
             g_pass = g_pass.contiguous().float()
-            acc = True
-        g_hE = g_pass.view(E, H) if acc else torch.empty(E, H, device=dev)     # accumulate in place onto the later consumer's gradient
+        g_hE = torch.empty(E, H, device=dev)
         A2 = torch.empty(E, H, device=dev, dtype=rdt) if mode == ENC_EDGE else None
         G3 = S3 = w3 = None
         b2c = b2.detach().contiguous()
@@ -235,7 +237,8 @@ class _EdgeMLP(torch.autograd.Function):
                                         hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                         img2.data_ptr(), hip.ptr(img3t), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(),
                                         g.data_ptr(), A1.data_ptr(), hip.ptr(A2), G1.data_ptr(), G2.data_ptr(), hip.ptr(G3),
-                                        g_hE.data_ptr(), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3), int(ctx.x3) | (4 if acc else 0) | (8 if gpa_tiles else 0),
+                                        g_hE.data_ptr(), (g_pass.data_ptr() if acc else None), g_Pa.data_ptr(), None, None, hip.ptr(S3), hip.ptr(w3),
+                                        int(ctx.x3) | (4 if acc else 0) | (8 if gpa_tiles else 0),
                                         B, N, K, hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:

@@ -360,27 +360,38 @@ def test_sample_free_running(weights_np, n, k, bs, T, mf):
     assert maxdiff(out["sampling_probs"][:, valid], ref["sampling_probs"][:, valid]) < 1e-3
 
 
-@pytest.mark.parametrize("n,k,bs,mf", [(120, 24, 3, 0.05), (300, 48, 1, 0.0), (40, 48, 2, 0.0)])
-def test_level_parallel_sampling_equals_the_sequential_walk(weights_np, n, k, bs, mf):
-    """sample() decoded by dependency level (one launch per level over all streams) gives bit-identical tokens,
-    probabilities and log-probabilities to the one-launch sequential walk under the same uniforms."""
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
+@pytest.mark.parametrize("n,k,bs,mf", [(120, 24, 3, 0.05), (300, 48, 1, 0.0), (40, 48, 2, 0.0), (97, 32, 1, 0.0), (700, 30, 4, 0.02)])
+def test_level_parallel_sampling_equals_the_sequential_walk(weights_np, n, k, bs, mf, prec):
+    """sample() decoded by dependency level — as ONE persistent launch walking the levels (round 3: device-side level offsets, grid
+    barriers, no host read-back) and as one launch per level — gives bit-identical tokens, probabilities and log-probabilities to
+    the one-launch sequential walk under the same uniforms, in both fp32-class precisions.  (700 x 4 visits = more work per level
+    than the walk's grid holds in one pass.)"""
     dev = torch.device("cuda:0")
     cx = synth.make_complex(seed=900 + n, n=n, masked_frac=mf)
     cx["chain_mask"][::7] = 0
     rng = np.random.default_rng(n)
     fd = _sample_fd(cx, dev, bs, 0.4, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
     m = make_model(weights_np, k, dev)
+    m.message_precision = prec
     outs = []
-    for lvl in (True, False):
-        m.sample_level_parallel = lvl
+    for lvl, walk in ((True, True), (True, False), (False, False)):
+        m.sample_level_parallel, m.sample_level_walk = lvl, walk
         torch.manual_seed(21)
         outs.append(m.sample(fd))
-    a, b = outs
+        if lvl and walk:                                   # twice: the barrier words and the workspace are reused
+            torch.manual_seed(21)
+            again = m.sample(fd)
+            assert torch.equal(again["S"], outs[-1]["S"]) and torch.equal(again["log_probs"], outs[-1]["log_probs"])
+    w_, a, b = outs
+    assert int(w_["levels"]) == a["levels"]
     assert "levels" in a and a["levels"] <= n and (a["levels"] < n or k >= n) and "levels" not in b   # complete graph: no parallelism
-    assert torch.equal(a["uniform"], b["uniform"]) and torch.equal(a["decoding_order"], b["decoding_order"])
-    assert torch.equal(a["S"], b["S"])
-    assert torch.equal(a["sampling_probs"], b["sampling_probs"])
-    assert torch.equal(a["log_probs"], b["log_probs"])
+    for o in (w_, a):
+        assert torch.equal(o["uniform"], b["uniform"]) and torch.equal(o["decoding_order"], b["decoding_order"])
+        assert torch.isfinite(o["log_probs"]).all()
+        assert torch.equal(o["S"], b["S"])
+        assert torch.equal(o["sampling_probs"], b["sampling_probs"])
+        assert torch.equal(o["log_probs"], b["log_probs"])
 
 
 def test_cpu_tensors_are_rejected(weights_np):
