@@ -411,6 +411,26 @@ long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
                           float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream);
 
+/* ---- training: loss and optimiser step (round 3) ----------------------------------------------
+ * namp_train_loss_smoothed: the per-residue label-smoothed loss of na_model_utils.py:111-146 in fp64 (backward = 0: loss[G]) and its
+ *   gradient with respect to log_probs (backward = 1: g_log_probs[G][V] = -target * g_loss[G]); masks float32 [G], restype tables
+ *   float32 [V] (0 / 1), eps_scale3 = HOST array {weight/21, weight/5, weight/5} as float32, ppm_mask int32 [G] + aligned_ppm fp64
+ *   [G][V] optional (the specificity model's targets, :134).  The reduction sum(loss * mask) / tokens stays with the caller.
+ * namp_train_adam_step: gradient clip (max_norm > 0: torch.nn.utils.clip_grad_norm_, scaled gradients written back) + one
+ *   torch.optim.Adam step over ALL parameter tensors in one launch (three with clipping).  Plan arrays (device): blk_tensor /
+ *   blk_off [nblocks] = the tensor and first element of each block of namp_train_adam_chunk() elements, numel [ntensors], ptrs
+ *   [4][ntensors] = param / grad / exp_avg / exp_avg_sq addresses (fp32).  step_size = lr / (1 - beta1^t), bias_correction2_sqrt =
+ *   sqrt(1 - beta2^t) (host doubles rounded to float, like torch).  ws: nblocks + 2 floats (ws[0] = gradient norm, ws[1] = clip
+ *   coefficient afterwards); may be NULL without clipping. */
+int namp_train_loss_smoothed(int backward, const int32_t* S, const float* log_probs, const float* protein_mask, const float* dna_mask,
+                             const float* rna_mask, const float* protein_restypes, const float* dna_restypes, const float* rna_restypes,
+                             const float* eps_scale3, double weight, const int32_t* ppm_mask, const double* aligned_ppm,
+                             double* loss, const double* g_loss, float* g_log_probs, long G, int V, void* stream);
+int namp_train_adam_chunk(void);
+int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, const long long* numel, const unsigned long long* ptrs,
+                         int ntensors, int nblocks, float max_norm, double beta1, double beta2, float step_size, float bias_correction2_sqrt,
+                         float eps, float* ws, void* stream);
+
 /* Level-parallel form of the plain sampling branch (no symmetry groups, no pair_bias).  The step for residue i depends
  * only on the neighbours visited before it, so visits can be grouped into dependency levels and every level decoded in
  * one launch over all streams: ~64 launches instead of 1000 sequential steps at N = 1000, K = 48.  Same arithmetic per

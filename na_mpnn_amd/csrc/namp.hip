@@ -968,8 +968,10 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
 size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N;
-  // Pfw[3] + Pa0 on the encoder side; Pa[2] + Pv[2] + h[3] on the sample-stream side
-  return (3 + 1) * tbl(Ge) + (2 + 2 + 3) * tbl(Gd) + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
+  // sized for NAMP_MAX_LAYERS decoder layers (the entry point has no layer count): Pfw[L] + Pa0 on the encoder side; Pa[L-1] + Pv[L-1] +
+  // h[L] on the sample-stream side
+  const size_t L = NAMP_MAX_LAYERS;
+  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
 }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
@@ -982,7 +984,7 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
                           SampleArgs* a_out, int* nwaves_out) {
   REQUIRE(w != nullptr, "namp_decoder_sample: null weights");
   REQUIRE((group_first == nullptr) == (group_last == nullptr), "namp_decoder_sample: group_first and group_last go together");
-  REQUIRE(w->n_dec >= 1 && w->n_dec <= 3, "namp_decoder_sample: supports 1..3 decoder layers (got %d)", w->n_dec);
+  REQUIRE(w->n_dec >= 1 && w->n_dec <= NAMP_MAX_LAYERS, "namp_decoder_sample: supports 1..%d decoder layers (got %d)", NAMP_MAX_LAYERS, w->n_dec);
   REQUIRE(w->vocab >= 1 && w->vocab <= 64, "namp_decoder_sample: vocab=%d must be in [1,64]", w->vocab);
   REQUIRE_PTR(h_V_enc); REQUIRE_PTR(h_E); REQUIRE_PTR(ws);
   if (!E_idx || !mask || !chain_mask || !S_true || !bias || !order || !rank || !uniform || !S_out || !probs_out || !logp_out)
@@ -994,18 +996,20 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   if ((rc = ensure_attributes())) return rc;
   const int Gd = B_dec * N, Ge = B_enc * N;
   Carver c(ws, ws_bytes);
-  float* Pfw[3]; for (int l = 0; l < 3; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
+  const int nd = w->n_dec;
+  float* Pfw[NAMP_MAX_LAYERS]; for (int l = 0; l < nd; ++l) Pfw[l] = c.take((size_t)Ge * NAMP_HIDDEN);
   float* Pa0 = c.take((size_t)Ge * NAMP_HIDDEN);
-  float* Pa[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
-  float* Pv[2] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
-  float* hs[3] = {c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN), c.take((size_t)Gd * NAMP_HIDDEN)};
-  if (!hs[2]) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
+  float *Pa[NAMP_MAX_LAYERS] = {}, *Pv[NAMP_MAX_LAYERS] = {}, *hs[NAMP_MAX_LAYERS] = {};
+  for (int l = 0; l + 1 < nd; ++l) { Pa[l] = c.take((size_t)Gd * NAMP_HIDDEN); Pv[l] = c.take((size_t)Gd * NAMP_HIDDEN); }
+  for (int l = 0; l < nd; ++l) hs[l] = c.take((size_t)Gd * NAMP_HIDDEN);
+  if (!hs[nd - 1]) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
   // static tables from the encoder output: Pfw_l = W1v_l . h_V^enc, Pa_0 = W1a_0 . h_V^enc + b1
-  NampProj pf[4];
+  NampProj pf[NAMP_MAX_LAYERS + 1];
   int nf = 0;
   for (int l = 0; l < w->n_dec; ++l) pf[nf++] = {w->dec[l].W1v_img, nullptr, nullptr, Pfw[l]};
   pf[nf++] = {w->dec[0].W1a_img, w->dec[0].b1, nullptr, Pa0};
-  if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, nf, nullptr, stream))) return rc;
+  for (int q0 = 0; q0 < nf; q0 += 8)                         // (a node_linear launch takes up to 8 blocks)
+    if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf + q0, nf - q0 < 8 ? nf - q0 : 8, nullptr, stream))) return rc;
 
   SampleArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask_true = mask; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;

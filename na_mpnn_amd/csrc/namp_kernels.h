@@ -2,6 +2,9 @@
 // layout conventions and DESIGN.md for the per-kernel roofline accounting.
 #pragma once
 #include "namp_device.h"
+#ifndef NAMP_MAX_LAYERS
+#define NAMP_MAX_LAYERS 8           // == include/namp.h (this header is also compiled without it: namp_persist.hip)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // pack_image_kernel: nn.Linear weight block -> MFMA fragment image (see namp_device.h).
@@ -1767,8 +1770,9 @@ struct SampleArgs {
   unsigned long long special;  // bit t set -> token t can never be drawn
   float inv_T;
   int B_dec, B_enc, N, K, TPN, n_layers, vocab, slots;
-  SampleLayer l[3];
+  SampleLayer l[NAMP_MAX_LAYERS];      // 8 x 480 B: with the scalars and the launch's own arguments 4,072 of the 4,096 kernel-argument bytes
 };
+static_assert(sizeof(SampleArgs) + 32 <= 4096, "SampleArgs + the sampler launch's scalar arguments must fit the kernel-argument segment");
 
 struct SampleRows {             // tile row n -> residue of stream (b0 + n) at this step, or -1
   const int* node_lds;

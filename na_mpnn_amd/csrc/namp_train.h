@@ -1330,3 +1330,105 @@ __global__ __launch_bounds__(512) void tail_train_bwd_kernel(const TailTrainArgs
     a.part[(long)blockIdx.x * 4 * NAMP_H + tid] = s_;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Round 3: the loss and the optimiser step as launches of this library.
+//
+// loss_smoothed_kernel — label-smoothed negative log-likelihood per residue in fp64 (na_model_utils.py:111-146): target =
+// one-hot(S) (or the aligned position-probability row where ppm_mask is set, :134), scaled by (1 - weight) on every token that
+// belongs to some polymer's residue-type list (:140), plus the per-polymer smoothing mass eps = polymer_mask * restype_mask *
+// weight / |list| (:136-139, float32 like the reference's tensors); loss_i = -sum_v target_v * log_probs[i][v].  BWD: the same
+// target, d log_probs[i][v] = -target_v * g_i with g_i = dL/d loss_i (the caller's sum(loss * mask) / tokens stays a torch op, so
+// autograd supplies g_i = mask_i / tokens * dL).  One thread per residue; V <= 64.
+// ------------------------------------------------------------------------------------------
+struct LossArgs {
+  const int32_t* S; const float* log_probs; const float* pm[3]; const float* rm[3]; float eps_scale[3];   // weight / |list| as float32
+  double one_minus_w; const int32_t* ppm_mask; const double* aligned_ppm; long G; int V;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void loss_smoothed_kernel(const LossArgs a, double* __restrict__ loss, const double* __restrict__ g_loss,
+                                                            float* __restrict__ g_lp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.G) return;
+  const int s_i = a.S[i];
+  const bool ppm = a.ppm_mask && a.ppm_mask[i] != 0;
+  const float p0 = a.pm[0][i], p1 = a.pm[1][i], p2 = a.pm[2][i];
+  const double gi = BWD ? g_loss[i] : 0.0;
+  double acc = 0.0;
+  for (int v = 0; v < a.V; ++v) {
+    const float r0 = a.rm[0][v], r1 = a.rm[1][v], r2 = a.rm[2][v];
+    double t = ppm ? a.aligned_ppm[i * a.V + v] : (v == s_i ? 1.0 : 0.0);
+    if ((r0 + r1 + r2) != 0.f) t *= a.one_minus_w;
+    const float eps = ((p0 * r0) * a.eps_scale[0] + (p1 * r1) * a.eps_scale[1]) + (p2 * r2) * a.eps_scale[2];
+    t += (double)eps;
+    if (BWD) g_lp[i * a.V + v] = (float)(-t * gi);
+    else acc += t * (double)a.log_probs[i * a.V + v];
+  }
+  if (!BWD) loss[i] = -acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-tensor gradient clip + Adam (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step, na_run.py:233-238 / na_model_utils.py:
+// 648-686): every parameter tensor in ONE launch.  The plan (static per model): block b works on elements [off[b], off[b] + 2048) of
+// tensor t[b]; per step a table of the tensors' param / grad / exp_avg / exp_avg_sq pointers.  adam_sqnorm_kernel: per-block sums of
+// grad^2; adam_coef_kernel: total norm and the clip coefficient min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1);
+// adam_step_kernel: grad *= coef (written back, like clip_grad_norm_), exp_avg += (grad - exp_avg)(1 - beta1), exp_avg_sq =
+// exp_avg_sq beta2 + (1 - beta2) grad^2, param -= step_size * exp_avg / (sqrt(exp_avg_sq) / sqrt(bias_correction2) + eps) — torch's
+// operation order in fp32.
+// ------------------------------------------------------------------------------------------
+#define NAMP_ADAM_CHUNK 2048
+struct AdamPlan {
+  const int32_t* blk_tensor; const long long* blk_off; const long long* numel;      // [nblocks], [nblocks], [ntensors]
+  const unsigned long long* ptrs;                                                      // [4][ntensors]: param, grad, exp_avg, exp_avg_sq
+  int ntensors, nblocks;
+};
+static __global__ __launch_bounds__(256) void adam_sqnorm_kernel(const AdamPlan p, float* __restrict__ partial) {
+  const int b = blockIdx.x;
+  const int t = p.blk_tensor[b];
+  const long long off = p.blk_off[b], n = p.numel[t];
+  const float* g = (const float*)p.ptrs[1 * p.ntensors + t];
+  float s = 0.f;
+  for (int e = threadIdx.x; e < NAMP_ADAM_CHUNK && off + e < n; e += 256) { const float v = g[off + e]; s = fmaf(v, v, s); }
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+static __global__ __launch_bounds__(256) void adam_coef_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float* __restrict__ out2) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partial[b];
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    float coef = 1.0f;
+    if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.0f) coef = 1.0f; }
+    out2[0] = norm; out2[1] = coef;
+  }
+}
+static __global__ __launch_bounds__(256) void adam_step_kernel(const AdamPlan p, const float* __restrict__ coef2, float one_m_beta1, float beta2,
+                                                               float one_m_beta2, float step_size, float bc2_sqrt, float eps) {
+  const int b = blockIdx.x;
+  const int t = p.blk_tensor[b];
+  const long long off = p.blk_off[b], n = p.numel[t];
+  float* w = (float*)p.ptrs[0 * p.ntensors + t];
+  float* g = (float*)p.ptrs[1 * p.ntensors + t];
+  float* m = (float*)p.ptrs[2 * p.ntensors + t];
+  float* v = (float*)p.ptrs[3 * p.ntensors + t];
+  const float coef = coef2 ? coef2[1] : 1.0f;
+  for (int e = threadIdx.x; e < NAMP_ADAM_CHUNK && off + e < n; e += 256) {
+    const long long i = off + e;
+    float gi = g[i];
+    if (coef != 1.0f) { gi *= coef; g[i] = gi; }
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * one_m_beta1;                             // lerp_ (weight = float(1 - beta1), the host's double rounded)
+    vi = vi * beta2 + (one_m_beta2 * gi) * gi;                     // mul_ + addcmul_
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    m[i] = mi; v[i] = vi;
+    w[i] = w[i] + (-step_size) * (mi / denom);                     // addcdiv_
+  }
+}
+

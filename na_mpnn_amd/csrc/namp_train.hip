@@ -333,4 +333,52 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   return NAMP_OK;
 }
 
+int namp_train_loss_smoothed(int backward, const int32_t* S, const float* log_probs, const float* protein_mask, const float* dna_mask,
+                             const float* rna_mask, const float* protein_restypes, const float* dna_restypes, const float* rna_restypes,
+                             const float* eps_scale3, double weight, const int32_t* ppm_mask, const double* aligned_ppm,
+                             double* loss, const double* g_loss, float* g_log_probs, long G, int V, void* stream) {
+  if (!S) return fail(NAMP_EINVAL, "namp_train_loss_smoothed: null S");
+  REQUIRE_PTR(protein_mask); REQUIRE_PTR(dna_mask); REQUIRE_PTR(rna_mask);
+  if (!protein_restypes || !dna_restypes || !rna_restypes || !eps_scale3) return fail(NAMP_EINVAL, "namp_train_loss_smoothed: null restype tables");
+  REQUIRE(G >= 1 && V >= 1 && V <= 64, "namp_train_loss_smoothed: bad dims G=%ld V=%d", G, V);
+  REQUIRE((ppm_mask == nullptr) == (aligned_ppm == nullptr), "namp_train_loss_smoothed: ppm_mask and aligned_ppm go together");
+  LossArgs a = {};
+  a.S = S; a.log_probs = log_probs; a.pm[0] = protein_mask; a.pm[1] = dna_mask; a.pm[2] = rna_mask;
+  a.rm[0] = protein_restypes; a.rm[1] = dna_restypes; a.rm[2] = rna_restypes;
+  for (int k = 0; k < 3; ++k) a.eps_scale[k] = eps_scale3[k];
+  a.one_minus_w = 1.0 - weight; a.ppm_mask = ppm_mask; a.aligned_ppm = aligned_ppm; a.G = G; a.V = V;
+  const unsigned grid = (unsigned)((G + 255) / 256);
+  if (backward) {
+    if (!g_loss || !g_log_probs) return fail(NAMP_EINVAL, "namp_train_loss_smoothed: backward needs g_loss and g_log_probs");
+    hipLaunchKernelGGL(loss_smoothed_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (double*)nullptr, g_loss, g_log_probs);
+  } else {
+    if (!log_probs || !loss) return fail(NAMP_EINVAL, "namp_train_loss_smoothed: forward needs log_probs and loss");
+    hipLaunchKernelGGL(loss_smoothed_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, loss, (const double*)nullptr, (float*)nullptr);
+  }
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_adam_chunk(void) { return NAMP_ADAM_CHUNK; }
+
+int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, const long long* numel, const unsigned long long* ptrs,
+                         int ntensors, int nblocks, float max_norm, double beta1, double beta2, float step_size, float bias_correction2_sqrt,
+                         float eps, float* ws, void* stream) {
+  if (!blk_tensor || !blk_off || !numel || !ptrs) return fail(NAMP_EINVAL, "namp_train_adam_step: null plan");
+  REQUIRE(ntensors >= 1 && nblocks >= 1, "namp_train_adam_step: ntensors=%d nblocks=%d", ntensors, nblocks);
+  REQUIRE(max_norm <= 0.f || ws != nullptr, "namp_train_adam_step: clipping needs a workspace of nblocks + 2 floats");
+  AdamPlan p = {blk_tensor, blk_off, numel, ptrs, ntensors, nblocks};
+  hipStream_t s = (hipStream_t)stream;
+  const float* coef2 = nullptr;
+  if (max_norm > 0.f) {
+    hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(nblocks), dim3(256), 0, s, p, ws + 2);
+    hipLaunchKernelGGL(adam_coef_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + 2), nblocks, max_norm, ws);
+    coef2 = ws;
+  }
+  hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks), dim3(256), 0, s, p, coef2, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size,
+                     bias_correction2_sqrt, eps);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 }  // extern "C"

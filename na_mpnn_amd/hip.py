@@ -117,6 +117,10 @@ _PROTOTYPES = {
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
     "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, i32, vp]),
+    "namp_train_loss_smoothed": (i32, [i32, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(C.c_float), C.c_double, c_ip, vp,
+                                       vp, vp, c_fp, C.c_long, i32, vp]),
+    "namp_train_adam_chunk": (i32, []),
+    "namp_train_adam_step": (i32, [vp, vp, vp, vp, i32, i32, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float, c_fp, vp]),
     "namp_sample_levels": (i32, [c_ip, c_ip, c_ip, c_ip, i32, i32, i32, i32, vp]),
     "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                          c_ip, C.POINTER(C.c_int32), i32,

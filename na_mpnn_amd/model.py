@@ -471,9 +471,6 @@ class ProteinMPNN(nn.Module):
         symmetric = not (len(sym) == 1 and len(sym[0]) == 0)
         B, L = S_true.shape
         dev = S_true.device
-        if len(self.decoder_layers) > 3:
-            raise NotImplementedError("sample(): the sampler kernels hold at most 3 decoder layers (score / training take up to "
-                                      f"{hip.NAMP_MAX_LAYERS}); this model has {len(self.decoder_layers)}")
         self._check_tokens(S_true)
         if fd.get("S_forced") is not None:
             self._check_tokens(fd["S_forced"], "S_forced")

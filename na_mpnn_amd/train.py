@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -697,9 +699,47 @@ def loss_nll(S, log_probs, mask):
     return loss, torch.sum(loss * mask) / torch.sum(mask), true_false
 
 
+class _LossSmoothed(torch.autograd.Function):
+    """Per-residue label-smoothed loss (fp64) on the HIP kernel loss_smoothed_kernel, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, log_probs, S32, pm, rm, eps3, weight, ppm_mask32, aligned_ppm64):
+        G, V = log_probs.numel() // log_probs.shape[-1], log_probs.shape[-1]
+        lp = log_probs.contiguous().float()
+        loss = torch.empty(log_probs.shape[:-1], dtype=torch.float64, device=lp.device)
+        ctx.args = (S32, pm, rm, eps3, float(weight), ppm_mask32, aligned_ppm64, G, V)
+        ctx.lp_shape = log_probs.shape
+        hip.check(hip.lib().namp_train_loss_smoothed(0, S32.data_ptr(), lp.data_ptr(), *[t.data_ptr() for t in pm], *[t.data_ptr() for t in rm],
+                                                     eps3, float(weight), hip.ptr(ppm_mask32), hip.ptr(aligned_ppm64), loss.data_ptr(), None, None,
+                                                     G, V, hip.current_stream()), "train_loss_smoothed")
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        S32, pm, rm, eps3, weight, ppm_mask32, aligned_ppm64, G, V = ctx.args
+        g = g_loss.contiguous().double()
+        g_lp = torch.empty(ctx.lp_shape, dtype=torch.float32, device=g.device)
+        hip.check(hip.lib().namp_train_loss_smoothed(1, S32.data_ptr(), None, *[t.data_ptr() for t in pm], *[t.data_ptr() for t in rm],
+                                                     eps3, weight, hip.ptr(ppm_mask32), hip.ptr(aligned_ppm64), None, g.data_ptr(), g_lp.data_ptr(),
+                                                     G, V, hip.current_stream()), "train_loss_smoothed_bwd")
+        return g_lp, None, None, None, None, None, None, None
+
+
 def loss_smoothed(S, log_probs, mask, polymer_masks, polymer_restype_masks, polymer_restype_nums, weight=0.1, tokens=2000.0,
                   num_letters=33, ppm_mask=None, aligned_ppm=None):
-    """Label-smoothed negative log-likelihood in fp64 with per-polymer smoothing mass (na_model_utils.py:111-146)."""
+    """Label-smoothed negative log-likelihood in fp64 with per-polymer smoothing mass (na_model_utils.py:111-146).  On a HIP device
+    the per-residue loss and its gradient are one launch each (`_LossSmoothed`); host tensors take the stock-op restatement below."""
+    if log_probs.is_cuda:
+        keys = ("protein", "dna", "rna")
+        f32 = lambda t: t.contiguous().to(torch.float32)
+        pm = [f32(polymer_masks[k]) for k in keys]
+        rm = [f32(polymer_restype_masks[k]) for k in keys]
+        eps3 = (C.c_float * 3)(*[float(np.float32(weight / polymer_restype_nums[k])) for k in keys])
+        S32 = S.contiguous().to(torch.int32)
+        pm32 = ppm_mask.contiguous().to(torch.int32) if ppm_mask is not None else None
+        ppm64 = aligned_ppm.contiguous().to(torch.float64) if ppm_mask is not None else None
+        loss = _LossSmoothed.apply(log_probs, S32, pm, rm, eps3, weight, pm32, ppm64)
+        return loss, torch.sum(loss * mask) / tokens
     pr, dr, rr = (polymer_restype_masks[k] for k in ("protein", "dna", "rna"))
     onehot = F.one_hot(S, num_letters).to(torch.float64)
     if ppm_mask is not None:
@@ -738,9 +778,70 @@ class NoamOpt:
         self.optimizer.zero_grad()
 
 
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step — optionally preceded by torch.nn.utils.clip_grad_norm_ (`clip_norm`, na_run.py:233-236) — runs as
+    ONE multi-tensor HIP launch over all parameter tensors (namp_train_adam_step; three launches with clipping) instead of the
+    foreach kernel chain.  The state is torch's own (`step` / `exp_avg` / `exp_avg_sq` per parameter), so `state_dict()` is the
+    reference's checkpoint format (na_run.py:342) and loads into a plain torch.optim.Adam.  Plain Adam only (no amsgrad / weight decay
+    / maximize), fp32 parameters on one HIP device; anything else falls back to torch's step."""
+
+    clip_norm = 0.0            # > 0: clip the global gradient norm to this value inside the step
+    last_grad_norm = None      # device tensor [2]: (gradient norm, clip coefficient) of the last clipped step
+
+    def _fused_ok(self, params):
+        g0 = self.param_groups[0]
+        return (len(self.param_groups) == 1 and not g0.get("amsgrad") and g0.get("weight_decay", 0) == 0 and not g0.get("maximize")
+                and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad is not None and p.grad.is_contiguous()
+                        and p.grad.dtype == torch.float32 and not p.grad.is_sparse for p in params))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        params = [p for p in self.param_groups[0]["params"] if p.grad is not None] if len(self.param_groups) == 1 else []
+        if closure is not None or not params or not self._fused_ok(params):
+            if self.clip_norm > 0:
+                torch.nn.utils.clip_grad_norm_([p for g in self.param_groups for p in g["params"]], self.clip_norm)
+            return super().step(closure)
+        grp = self.param_groups[0]
+        dev = params[0].device
+        for p in params:                                      # torch's lazy state initialisation (_init_group)
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        steps = [self.state[p]["step"] for p in params]
+        torch._foreach_add_(steps, 1)
+        t = int(steps[0].item())
+        if any(int(s_.item()) != t for s_ in steps[1:]):
+            raise RuntimeError("FusedAdam: parameters with different step counts (load a consistent optimizer_state_dict)")
+        key = tuple((p.data_ptr(), p.numel()) for p in params)
+        if getattr(self, "_plan_key", None) != key:
+            chunk = hip.lib().namp_train_adam_chunk()
+            bt, bo = [], []
+            for i, p in enumerate(params):
+                for off in range(0, p.numel(), chunk):
+                    bt.append(i); bo.append(off)
+            self._plan = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bo, dtype=torch.int64, device=dev),
+                          torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev), len(bt))
+            self._ws = torch.empty(len(bt) + 2, dtype=torch.float32, device=dev)
+            self._plan_key = key
+        bt, bo, numel, nb = self._plan
+        ptrs = torch.tensor([[p.data_ptr() for p in params], [p.grad.data_ptr() for p in params],
+                             [self.state[p]["exp_avg"].data_ptr() for p in params], [self.state[p]["exp_avg_sq"].data_ptr() for p in params]],
+                            dtype=torch.int64).to(dev, non_blocking=False)
+        b1, b2 = grp["betas"]
+        lr = float(grp["lr"])
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        hip.check(hip.lib().namp_train_adam_step(bt.data_ptr(), bo.data_ptr(), numel.data_ptr(), ptrs.data_ptr(), len(params), nb,
+                                                 float(self.clip_norm), float(b1), float(b2), lr / bc1, bc2 ** 0.5, float(grp["eps"]),
+                                                 self._ws.data_ptr(), hip.current_stream()), "train_adam_step")
+        self.last_grad_norm = self._ws[:2] if self.clip_norm > 0 else None
+        return None
+
+
 def get_std_opt(parameters, d_model, step):
-    """na_model_utils.py:682-686."""
-    return NoamOpt(d_model, 2, 4000, torch.optim.Adam(parameters, lr=0, betas=(0.9, 0.98), eps=1e-9), step)
+    """na_model_utils.py:682-686 (Adam lr 0, betas (0.9, 0.98), eps 1e-9 under the Noam schedule) on the multi-tensor HIP step."""
+    return NoamOpt(d_model, 2, 4000, FusedAdam(parameters, lr=0, betas=(0.9, 0.98), eps=1e-9), step)
 
 
 def save_checkpoint(path, model, optimizer, epoch, step, save_step=None):
@@ -793,9 +894,14 @@ def train_step(model, optimizer, fd, polymer_restype_masks, polymer_restype_nums
     if data_parallel:
         from . import shard
         shard.allreduce_gradients(model.parameters())          # one RCCL all-reduce of the 9.2 MB gradient bucket
-    if gradient_norm > 0.0:
+    fused = isinstance(getattr(optimizer, "optimizer", None), FusedAdam) and scaler is None
+    if fused:
+        optimizer.optimizer.clip_norm = float(gradient_norm)       # clip + Noam rate + Adam: one multi-tensor launch sequence
+    elif gradient_norm > 0.0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_norm)
     if scaler is not None:
+        if isinstance(getattr(optimizer, "optimizer", None), FusedAdam):
+            optimizer.optimizer.clip_norm = 0.0
         scaler.step(optimizer)
         scaler.update()
     else:

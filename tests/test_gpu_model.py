@@ -394,6 +394,37 @@ def test_level_parallel_sampling_equals_the_sequential_walk(weights_np, n, k, bs
         assert torch.equal(o["log_probs"], b["log_probs"])
 
 
+def test_sampler_with_more_than_three_decoder_layers():
+    """The sampler kernels index their per-layer arguments at run time (round 3): a model with 5 decoder layers — more than the
+    reference configuration's 3, up to NAMP_MAX_LAYERS = 8 — samples through all three forms (persistent level walk, one launch
+    per level, sequential walk) with identical draws, and its teacher-forced log-probs match the oracle's step-by-step decoder."""
+    dev = torch.device("cuda:0")
+    n, k, bs = 60, 24, 2
+    w_np = synth.make_weights(5, num_encoder_layers=2, num_decoder_layers=5)
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=k, num_encoder_layers=2, num_decoder_layers=5, atom_dict=spec.atom_dict(),
+                    restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
+    m.load_state_dict({k_: torch.from_numpy(v) for k_, v in w_np.items()})
+    m = m.to(dev).eval()
+    cx = synth.make_complex(seed=555, n=n, masked_frac=0.05)
+    rng = np.random.default_rng(5)
+    fd = _sample_fd(cx, dev, bs, 0.5, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
+    outs = []
+    for lvl, walk in ((True, True), (True, False), (False, False)):
+        m.sample_level_parallel, m.sample_level_walk = lvl, walk
+        torch.manual_seed(3)
+        outs.append(m.sample(fd))
+    for o in outs[:2]:
+        assert torch.equal(o["S"], outs[2]["S"]) and torch.equal(o["log_probs"], outs[2]["log_probs"])
+    S = outs[0]["S"].cpu()
+    w = {k_: torch.from_numpy(v) for k_, v in w_np.items()}
+    fdc = {k_: (v.cpu() if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    ref = cpu_ref.sample(w, fdc, k, S_forced=S)
+    valid = torch.from_numpy(cx["mask"].astype(bool))
+    assert torch.equal(ref["S"], S)
+    assert maxdiff(outs[0]["log_probs"][:, valid], ref["log_probs"][:, valid]) < 1e-3
+    assert maxdiff(outs[0]["sampling_probs"][:, valid], ref["sampling_probs"][:, valid]) < 1e-3
+
+
 def test_cpu_tensors_are_rejected(weights_np):
     m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=8, atom_dict=spec.atom_dict(),
                     restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
