@@ -446,9 +446,15 @@ int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, co
  *     overwrite log_probs with NaN.  K <= 128 (returns 0 workgroups otherwise: use the per-level launches).  Identical draws. */
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream);
+/* ... with extra dependencies per residue, dep_idx int32 [B_enc][N][D] (-1 = none): `pair_bias` (optional argument of the two level
+ * decoders below, [B_enc][N][vocab][N][vocab] as in namp_decoder_sample) makes the step of residue i read the token of every j whose
+ * block pair_bias[i, :, j, :] is not all zero; with those j listed here the levels respect that, and the level decoders — which
+ * treat every residue later in the decoding order as undecoded (PAD), like the sequential walk sees it — give identical draws. */
+int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D, int32_t* level,
+                           int B_dec, int B_enc, int N, int K, void* stream);
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                                const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
                                const int32_t* work, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                                void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
@@ -456,7 +462,7 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
 int namp_decoder_sample_walk_grid(int B_dec, int N, int K);
 int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                              const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
                              const int32_t* work, const int32_t* level_off,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);

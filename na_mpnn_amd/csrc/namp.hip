@@ -1091,20 +1091,26 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
   return NAMP_OK;
 }
 
-int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
-                       int N, int K, void* stream) {
+int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D, int32_t* level,
+                           int B_dec, int B_enc, int N, int K, void* stream) {
   if (!E_idx || !order || !rank || !level) return fail(NAMP_EINVAL, "namp_sample_levels: null pointer argument");
   REQUIRE(B_dec >= 1 && B_enc >= 1 && B_dec % B_enc == 0 && N >= 1 && K >= 1 && N <= 16384,
           "namp_sample_levels: bad dims B_dec=%d B_enc=%d N=%d K=%d", B_dec, B_enc, N, K);
-  hipLaunchKernelGGL(sample_levels_kernel, dim3(B_dec), dim3(64), (size_t)N * 4, (hipStream_t)stream, E_idx, order, rank, level,
+  REQUIRE(dep_idx == nullptr || D >= 1, "namp_sample_levels_dep: D=%d", D);
+  hipLaunchKernelGGL(sample_levels_kernel, dim3(B_dec), dim3(64), (size_t)N * 4, (hipStream_t)stream, E_idx, order, rank, dep_idx, D, level,
                      B_enc, N, K);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
 
+int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
+                       int N, int K, void* stream) {
+  return namp_sample_levels_dep(E_idx, order, rank, nullptr, 0, level, B_dec, B_enc, N, K, stream);
+}
+
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                                const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
                                const int32_t* work, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                                void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
@@ -1114,7 +1120,7 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   REQUIRE(total == (long)B_dec * N, "namp_decoder_sample_levels: level counts sum to %ld, expected B_dec*N = %ld", total, (long)B_dec * N);
   SampleArgs a; int nwaves = 0;
   int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
-                          nullptr, nullptr, nullptr, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+                          nullptr, nullptr, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
                           B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1145,7 +1151,7 @@ int namp_decoder_sample_walk_grid(int B_dec, int N, int K) {
 
 int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                              const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
                              const int32_t* work, const int32_t* level_off,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
@@ -1154,7 +1160,7 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
   REQUIRE(grid >= 1, "namp_decoder_sample_walk: no persistent form for B_dec=%d N=%d K=%d (K <= 128)", B_dec, N, K);
   SampleArgs a; int nwaves = 0;
   int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
-                          nullptr, nullptr, nullptr, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+                          nullptr, nullptr, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
                           B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   REQUIRE(nwaves <= 8, "namp_decoder_sample_walk: needs the 8-wave workgroup form (K <= 128)");

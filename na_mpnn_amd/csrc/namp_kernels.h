@@ -1974,9 +1974,11 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
 // sample_levels_kernel: dependency level of every visit of the plain sampling branch.  One wave per stream walks its
 // decoding order once: level(i) = 1 + max level of the neighbours visited before i (0 if none) — lanes cover the K
 // neighbours, levels live in LDS.  level_out[b][t] is indexed by VISIT t.
+// dep_idx (optional, [B_enc][N][D], -1 = none): further residues a step depends on besides the graph neighbours — with `pair_bias` the
+// bias of residue i reads the token of every residue j whose block pair_bias[i, :, j, :] is not all zero (model_utils.py:169-172).
 static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __restrict__ E_idx, const int32_t* __restrict__ order,
-                                                          const int32_t* __restrict__ rank, int32_t* __restrict__ level_out,
-                                                          int B_enc, int N, int K) {
+                                                          const int32_t* __restrict__ rank, const int32_t* __restrict__ dep_idx, int D,
+                                                          int32_t* __restrict__ level_out, int B_enc, int N, int K) {
   extern __shared__ int lv[];                                    // [N]
   const int b = blockIdx.x, lane = threadIdx.x;
   const int b_enc = b % B_enc;
@@ -1988,6 +1990,11 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
       const int j = E_idx[((long)b_enc * N + i) * K + k];
       if (rk[j] < t) d = max(d, lv[j]);                          // rank[i] == t; earlier neighbours already have their level
     }
+    if (dep_idx)
+      for (int k = lane; k < D; k += 64) {
+        const int j = dep_idx[((long)b_enc * N + i) * D + k];
+        if (j >= 0 && rk[j] < t) d = max(d, lv[j]);
+      }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) d = max(d, __shfl_xor(d, o));
     if (lane == 0) { lv[i] = d + 1; level_out[(long)b * N + t] = d + 1; }
@@ -2252,8 +2259,12 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         if (a.pair_bias && lane < a.vocab) {
           const float* pb = a.pair_bias + ((long)ne * a.vocab + lane) * a.N * a.vocab;
           float acc_pb = 0.f;
+          const int rk_i = LEVEL ? a.rank[(long)bq * a.N + iq] : 0;
           for (int j2 = 0; j2 < a.N; ++j2) {
             int Sj2 = __hip_atomic_load(a.S_out + (long)bq * a.N + j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // decoded by dependency level, a residue that comes LATER in the decoding order may already hold its token (it sits in
+            // an earlier or in this level when nothing ties it to residue i): the sequential walk sees PAD there
+            if (LEVEL && a.rank[(long)bq * a.N + j2] >= rk_i) Sj2 = -1;
             if (Sj2 < 0) Sj2 = a.vocab - 1;            // not decoded yet: the reference's initial S is PAD (:157)
             acc_pb += pb[(long)j2 * a.vocab + Sj2];
           }

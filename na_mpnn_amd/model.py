@@ -529,17 +529,34 @@ class ProteinMPNN(nn.Module):
         bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
         forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
-        if self.sample_level_parallel and not symmetric and pair_bias is None:
+        dep_idx, n_dep = None, 0
+        pb_levels = pair_bias is None
+        if pair_bias is not None and self.sample_level_parallel and not symmetric:
+            # pair_bias (model_utils.py:116,169-172): the bias of residue i reads the token of every residue j whose block
+            # pair_bias[i, :, j, :] is not all zero — the sequence neighbours for run.py's --pair_bias_AA (data_utils.py:7-16).  Those
+            # j become extra dependencies of the levels; a dense bias (more than 64 partners for some residue) keeps the sequential walk.
+            if tuple(pair_bias.shape) != (B, L, self.num_letters, L, self.num_letters):
+                raise ValueError(f"pair_bias must be [B, L, {self.num_letters}, L, {self.num_letters}]; got {tuple(pair_bias.shape)}")
+            nz = pair_bias.abs().amax(dim=(2, 4)) > 0                          # [B, L, L]
+            n_dep = int(nz.sum(-1).max())
+            if n_dep <= 64:
+                pb_levels = True
+                if n_dep > 0:
+                    cols = torch.where(nz, torch.arange(L, device=dev)[None, None, :], torch.full((), L, device=dev))
+                    cols = cols.sort(dim=-1).values[:, :, :n_dep]
+                    dep_idx = torch.where(cols < L, cols, torch.full((), -1, device=dev)).to(torch.int32).contiguous()
+        if self.sample_level_parallel and not symmetric and pb_levels:
             # plain branch: residue i depends only on the neighbours decoded before it -> decode by dependency level
             # (one launch per level over all streams, ~64 levels at L = 1000 instead of 1000 sequential steps)
             level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
-            hip.check(Lb.namp_sample_levels(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), level.data_ptr(), B_dec, B, L, K,
-                                            hip.current_stream()), "sample_levels")
+            hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep, level.data_ptr(),
+                                                B_dec, B, L, K, hip.current_stream()), "sample_levels")
             flat = level.view(-1).long()
             perm = torch.argsort(flat, stable=True)
             work = torch.stack((perm // L, perm % L), 1).to(torch.int32).contiguous()
             common = (W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),
-                      St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), work.data_ptr())
+                      St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced),
+                      hip.ptr(pair_bias), work.data_ptr())
             tail = (float(fd["temperature"]), special, S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
                     B_dec, B, L, K, hip.current_stream())
             if self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0:
@@ -554,7 +571,7 @@ class ProteinMPNN(nn.Module):
             counts_c = (C.c_int32 * len(counts))(*counts)
             hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),
                                                     cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(),
-                                                    r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), work.data_ptr(), counts_c,
+                                                    r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), hip.ptr(pair_bias), work.data_ptr(), counts_c,
                                                     len(counts), float(fd["temperature"]), special, S_out.data_ptr(),
                                                     probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(), B_dec, B, L, K,
                                                     hip.current_stream()), "decoder_sample_levels")

@@ -394,6 +394,51 @@ def test_level_parallel_sampling_equals_the_sequential_walk(weights_np, n, k, bs
         assert torch.equal(o["log_probs"], b["log_probs"])
 
 
+@pytest.mark.parametrize("kind", ["sequence_neighbours", "asymmetric", "dense"])
+def test_pair_bias_sampling_by_level_equals_the_sequential_walk(weights_np, kind):
+    """`pair_bias` (model_utils.py:116,169-172) decoded by dependency level: the residues whose tokens a step's bias reads become
+    extra dependencies of the levels (namp_sample_levels_dep), and the level decoders treat every residue later in the decoding
+    order as undecoded — tokens, probabilities and log-probabilities are bit-identical to the sequential walk.  "asymmetric": i
+    reads j but j does not read i (j may sit in an earlier level although it comes later in the order); "dense": more than 64
+    partners per residue keeps the sequential walk."""
+    from na_mpnn_amd.cli import make_pair_bias
+    dev = torch.device("cuda:0")
+    n, k, bs = 80, 24, 3
+    cx = synth.make_complex(seed=812, n=n, n_chains=2)
+    cx["chain_mask"][[5, 33]] = 0
+    rng = np.random.default_rng(12)
+    fd = _sample_fd(cx, dev, bs, 0.7, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
+    AA = torch.from_numpy(2.0 * rng.standard_normal((33, 33)).astype(np.float32)).to(dev)
+    if kind == "sequence_neighbours":
+        pb = make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0], AA)
+    elif kind == "asymmetric":
+        pb = torch.zeros(1, n, 33, n, 33, device=dev)
+        for i in range(0, n - 9, 3):
+            pb[0, i, :, i + 9, :] = AA                       # i reads i + 9; i + 9 does not read i
+            pb[0, i + 2, :, (i * 7) % n, :] = AA.t()
+    else:
+        pb = 0.05 * torch.from_numpy(rng.standard_normal((1, n, 33, n, 33)).astype(np.float32)).to(dev)
+    fd["pair_bias"] = pb
+    m = make_model(weights_np, k, dev)
+    outs = []
+    for lvl, walk in ((True, True), (True, False), (False, False)):
+        m.sample_level_parallel, m.sample_level_walk = lvl, walk
+        torch.manual_seed(8)
+        outs.append(m.sample(fd))
+    w_, a, b = outs
+    assert ("levels" in a) == (kind != "dense") and "levels" not in b
+    if kind != "dense":
+        assert int(w_["levels"]) == a["levels"] < n
+    for o in (w_, a):
+        assert torch.equal(o["S"], b["S"]) and torch.equal(o["sampling_probs"], b["sampling_probs"]) and torch.equal(o["log_probs"], b["log_probs"])
+    # and the sequential walk itself is the reference's: teacher-forced oracle
+    w = {k_: torch.from_numpy(v) for k_, v in weights_np.items()}
+    fdc = {k_: (v.cpu() if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    ref = cpu_ref.sample(w, fdc, k, S_forced=b["S"].cpu())
+    valid = torch.from_numpy(cx["mask"].astype(bool))
+    assert maxdiff(w_["log_probs"][:, valid], ref["log_probs"][:, valid]) < 1e-3
+
+
 def test_sampler_with_more_than_three_decoder_layers():
     """The sampler kernels index their per-layer arguments at run time (round 3): a model with 5 decoder layers — more than the
     reference configuration's 3, up to NAMP_MAX_LAYERS = 8 — samples through all three forms (persistent level walk, one launch
