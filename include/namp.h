@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAMP_ABI_VERSION 3   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3; 3: namp_train_edge_bwd takes g_hE_in */
+#define NAMP_ABI_VERSION 4   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3; 3: namp_train_edge_bwd takes g_hE_in; 4: *_simg images in the weight structs */
 #define NAMP_HIDDEN 128
 #define NAMP_MAX_LAYERS 8
 #define NAMP_MAX_K 192
@@ -52,6 +52,16 @@ int namp_pack_image(const float* W, int ld, int col0, int out_f, int in_f, float
  * configs[2]'s throughput mode; ~1e-2 on log-probs, not parity-grade.  Residue-level math stays fp32. */
 #define NAMP_FLAG_BF16 1
 int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stream);   /* [128x128] block -> 32 KiB */
+/* ... for v_mfma_f32_32x32x16_bf16: img[s' 0..7][tn 0..3][lane][j] = bf16(W[32tn + (lane&31)][16s' + 8(j>>2) + 4(lane>>5) + (j&3)]) */
+int namp_pack_image_bf16_32(const float* W, int ld, int col0, void* img, void* stream);
+/* The message launch of the bf16-STORAGE path on its own (namp_encdec_fwd takes that path for large batches of the bf16 mode: h_E and the
+ * gathered first-layer tables are kept as rows of 128 bf16 in "fragment order B", channel c at element 16(c>>4) + 8((c>>2)&1) + 4((c>>3)&1) + (c&3)
+ * — the operand order of v_mfma_f32_32x32x16_bf16; images from namp_pack_image_bf16_32).  mode 0 = EncLayer message (model_utils.py:666-672),
+ * 1 = DecLayer message on the implicit context (model_utils.py:636-646).  Output as namp_enc_message / namp_dec_message:
+ * partial [G][ceil(K/16)][128] K-sums of the layer-2 activations + [G][ceil(K/16)] weight sums. */
+int namp_bf16s_message(int mode, const void* hE16, const int32_t* E_idx, const int32_t* mask, const int32_t* rank,
+                       const void* Pa16, const void* Pj016, const void* Pj116, const void* W1_img, const void* W2_img, const float* b2,
+                       float* partial, int B_dec, int B_enc, int N, int K, void* stream);
 /* NAMP_FLAG_X3: the per-edge GEMMs as THREE bf16 products of split operands (x = x_hi + x_mid, W = W_hi + W_mid;
  * W.x ~= W_hi.x_hi + W_hi.x_mid + W_mid.x_hi, fp32 accumulate): fp32-equivalent to ~2^-16 per product at 3/16 of the fp32
  * MFMA cost — the default PARITY mode of the Python surface (log-probs move by 3e-5 against exact fp32 on the N=1000
@@ -81,6 +91,9 @@ typedef struct NampEncLayerW {
   /* optional: x3 images of the residue-level blocks (namp_pack_image_x3_general for W_in / W_out).  When all that a launch
    * needs are present, large batches (>= 64 residues per CU) run the residue update as split-bf16 products too. */
   const float *Win_ximg, *Wout_ximg, *W1a_ximg, *W1c_ximg, *W11a_ximg, *W11c_ximg;
+  /* optional: bf16 images in the 32x32x16 operand order (namp_pack_image_bf16_32) of the blocks the bf16-STORAGE launches multiply
+   * (large batches of the bf16 mode, namp_encdec_fwd): without them those batches take the fp32-storage launches. */
+  const float *W1b_simg, *W2_simg, *W11b_simg, *W12_simg, *W13_simg;
   int64_t flags;                                     /* NAMP_FLAG_BF16 / NAMP_FLAG_X3: precision of the per-edge GEMMs */
 } NampEncLayerW;
 
@@ -95,6 +108,7 @@ typedef struct NampDecLayerW {
   const float *W1e_bimg, *W2_bimg, *W3_bimg;        /* bf16 images (throughput mode) */
   const float *W1e_ximg, *W2_ximg, *W3_ximg;        /* x3 images */
   const float *Win_ximg, *Wout_ximg, *W1a_ximg, *W1v_ximg;   /* optional residue-level x3 images, as in NampEncLayerW */
+  const float *W1e_simg, *W2_simg;                            /* optional 32x32x16-order bf16 images, as in NampEncLayerW */
   int64_t flags;
 } NampDecLayerW;
 
@@ -119,6 +133,7 @@ typedef struct NampModelW {
   const float* We_ximg;            /* x3 image of W_e (the embedding fused in front of EncLayer 0, namp_encdec_fwd) */
   const float* Wv_ximg;            /* optional x3 image of W_v (with enc[0].W1a_ximg / W1c_ximg: namp_encdec_fwd's first launch as split-bf16 products) */
   const float* We_bimg;            /* optional bf16 image of W_e: the edge embedding of the bf16 throughput mode on bf16 MFMA */
+  const float* We_simg;            /* optional 32x32x16-order bf16 image of W_e: the embedding inside the first bf16-storage launch */
 } NampModelW;
 
 /* ---- a1/a3: neighbour gather ----------------------------------------------------------- */

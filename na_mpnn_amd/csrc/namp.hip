@@ -3,6 +3,7 @@
 // launches on the caller's stream; it owns no device memory and never synchronises.
 #include "../../include/namp.h"
 #include "namp_kernels.h"
+#include "namp_bf16s32.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -138,10 +139,10 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
   set((const void*)edge_mlp_bf16_persistent_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 512);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_DEC_MSG>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
-  set((const void*)edge_mlp_bf16s_kernel<MODE_ENC_EDGE>, 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
-  set((const void*)(edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256);
+  set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_MSG>, BF16S32_LDS);
+  set((const void*)edge_mlp_bf16s32_kernel<MODE_DEC_MSG>, BF16S32_LDS);
+  set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_EDGE>, BF16S32_LDS);
+  set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
@@ -238,7 +239,8 @@ int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
   return NAMP_OK;
 }
 
-// bf16 STORAGE variant (h_E and the gathered tables in bf16 fragment order): large batches of the bf16 throughput mode
+// bf16 STORAGE variant (h_E and the gathered tables as bf16 rows in fragment order B): large batches of the bf16 throughput mode, on
+// v_mfma_f32_32x32x16_bf16 (namp_bf16s32.h; images from namp_pack_image_bf16_32)
 template <int MODE>
 int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   int rc = ensure_attributes();
@@ -246,14 +248,14 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   const EdgeGeom e = edge_geom(a.G, a.K);
   a.TPN = e.tpn;
   if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
-  // 12 waves per CU; 16 (1,024 threads, 128 VGPRs) measured the same: the launch is instruction-issue bound, not latency bound
+  // 8 waves per CU (up to 256 VGPRs each), one 32-row pair of tiles per wave and step
   if constexpr (MODE == MODE_ENC_MSG) {
     if (a.eW1_img) {                     // fused edge embedding: a.hE = fp32 E, a.hE16_out = the bf16 rows
-      hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256, s, a);
+      hipLaunchKernelGGL((edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(512), BF16S32_LDS, s, a);
       return NAMP_OK;
     }
   }
-  hipLaunchKernelGGL((edge_mlp_bf16s_kernel<MODE>), dim3(device_cus()), dim3(768), 3 * NAMP_BIMG_BYTES + 2048 + 12 * 256, s, a);
+  hipLaunchKernelGGL((edge_mlp_bf16s32_kernel<MODE>), dim3(device_cus()), dim3(512), BF16S32_LDS, s, a);
   return NAMP_OK;
 }
 
@@ -510,6 +512,36 @@ int namp_pack_image_bf16(const float* W, int ld, int col0, void* img, void* stre
   if (!W || !img) return fail(NAMP_EINVAL, "namp_pack_image_bf16: null pointer");
   REQUIRE(col0 >= 0 && ld >= col0 + 128, "namp_pack_image_bf16: block [0:128, %d:%d) outside ld=%d", col0, col0 + 128, ld);
   hipLaunchKernelGGL(pack_image_bf16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_pack_image_bf16_32(const float* W, int ld, int col0, void* img, void* stream) {
+  if (!W || !img) return fail(NAMP_EINVAL, "namp_pack_image_bf16_32: null pointer");
+  REQUIRE(col0 >= 0 && ld >= col0 + 128, "namp_pack_image_bf16_32: block [0:128, %d:%d) outside ld=%d", col0, col0 + 128, ld);
+  hipLaunchKernelGGL(pack_image_bf16_32_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W, ld, col0, (__bf16*)img);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+// The bf16-storage message launch on its own (per-kernel timing and parity): rows and tables in fragment order B, images from
+// namp_pack_image_bf16_32.  mode 0 = encoder message, 1 = decoder message.  partial: [G][TPN][128] K-sums + [G][TPN] weight sums.
+int namp_bf16s_message(int mode, const void* hE16, const int32_t* E_idx, const int32_t* mask, const int32_t* rank,
+                       const void* Pa16, const void* Pj016, const void* Pj116, const void* W1_img, const void* W2_img, const float* b2,
+                       float* partial, int B_dec, int B_enc, int N, int K, void* stream) {
+  REQUIRE(mode == 0 || mode == 1, "namp_bf16s_message: mode=%d", mode);
+  if (!hE16 || !E_idx || !Pa16 || !Pj016 || !W1_img || !W2_img || !b2 || !partial) return fail(NAMP_EINVAL, "namp_bf16s_message: null pointer");
+  REQUIRE(mode == 0 || (rank && Pj116), "namp_bf16s_message: decoder message needs rank and Pj116");
+  int rc = check_dims(__func__, B_dec, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE16 = (const __bf16*)hE16; a.E_idx = E_idx; a.mask = mask; a.rank = rank; a.Pa16 = (const __bf16*)Pa16; a.Pj016 = (const __bf16*)Pj016;
+  a.Pj116 = (const __bf16*)Pj116; a.W1_img = (const float*)W1_img; a.W2_img = (const float*)W2_img; a.b2 = b2; a.partial = partial;
+  a.G = B_dec * N; a.G_enc = B_enc * N; a.N = N; a.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof_(mode ? NAMP_KIND_DEC_MESSAGE : NAMP_KIND_ENC_MESSAGE, s);
+  rc = mode ? launch_edge_bf16s<MODE_DEC_MSG>(a, s) : launch_edge_bf16s<MODE_ENC_MSG>(a, s);
+  if (rc) return rc;
   CHECK_LAUNCH();
   return NAMP_OK;
 }
@@ -1344,7 +1376,7 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
 }
 
 // bf16 throughput mode on a large batch (unfused residue tail), whole path with bf16 STORAGE of h_E and of the gathered
-// tables (fragment order, see edge_mlp_bf16s_kernel).  The caller's h_E buffer is used as the bf16 store (its first half);
+// tables (fragment order B, see namp_bf16s32.h).  The caller's h_E buffer is used as the bf16 store (its first half);
 // it does not hold fp32 h_E afterwards.
 static int encdec_bf16_storage(const NampModelW* w, const float* V, const float* E, const int32_t* E_idx, const int32_t* mask,
                                const int32_t* S, const int32_t* rank, float* h_V, float* h_E, float* log_probs, float* logits,
@@ -1394,7 +1426,7 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     if (!rq.honoured) cvt({P[0], P[1]}, {T16[0], T16[1]});
   }
   static const bool fuse_embed = [] { const char* e = getenv("NAMP_BF16S_SEPARATE_EMBED"); return !(e && atoi(e) != 0); }();   // A/B switch
-  const bool emb_fused = fuse_embed && w->We_bimg != nullptr;
+  const bool emb_fused = fuse_embed && w->We_simg != nullptr;
   if (!emb_fused) {
     EdgeArgs a = {};
     a.hE = E; a.hE16_out = h16; a.W1_img = w->We_bimg ? w->We_bimg : w->We_img; a.b1 = w->We_b; a.G = a.G_enc = G; a.N = N; a.K = K;
@@ -1407,14 +1439,13 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     const NampEncLayerW* L = &w->enc[l];
     const bool last = (l + 1 == w->n_enc);
     float* out = last ? h_V : hv[cur ^ 1];
-    REQUIRE_PTR(L->W1b_bimg); REQUIRE_PTR(L->W2_bimg); REQUIRE_PTR(L->W3_bimg);
-    REQUIRE_PTR(L->W11b_bimg); REQUIRE_PTR(L->W12_bimg); REQUIRE_PTR(L->W13_bimg);
+    REQUIRE_PTR(L->W1b_simg); REQUIRE_PTR(L->W2_simg); REQUIRE_PTR(L->W11b_simg); REQUIRE_PTR(L->W12_simg); REQUIRE_PTR(L->W13_simg);
     {
       EdgeArgs a = {};
       a.hE16 = h16; a.E_idx = E_idx; a.mask = mask; a.Pa16 = T16[0]; a.Pj016 = T16[1];
-      a.W1_img = L->W1b_bimg; a.W2_img = L->W2_bimg; a.W3_img = L->W3_bimg; a.b2 = L->b2; a.b3 = L->b3;
+      a.W1_img = L->W1b_simg; a.W2_img = L->W2_simg; a.b2 = L->b2; a.b3 = L->b3;
       a.partial = partial; a.G = a.G_enc = G; a.N = N; a.K = K;
-      if (l == 0 && emb_fused) { a.hE = E; a.hE16_out = h16; a.eW1_img = w->We_bimg; a.eb2 = w->We_b; }   // h_E = W_e.E + b_e in this launch
+      if (l == 0 && emb_fused) { a.hE = E; a.hE16_out = h16; a.eW1_img = w->We_simg; a.eb2 = w->We_b; }   // h_E = W_e.E + b_e in this launch
       ProfScope prof_(NAMP_KIND_ENC_MESSAGE, s);
       if ((rc = launch_edge_bf16s<MODE_ENC_MSG>(a, s))) return rc;
     }
@@ -1442,7 +1473,7 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     {
       EdgeArgs a = {};
       a.hE16 = h16; a.hE16_out = h16; a.E_idx = E_idx; a.Pa16 = T16[2]; a.Pj016 = T16[3];
-      a.W1_img = L->W11b_bimg; a.W2_img = L->W12_bimg; a.W3_img = L->W13_bimg; a.b2 = L->b12; a.b3 = L->b13;
+      a.W1_img = L->W11b_simg; a.W2_img = L->W12_simg; a.W3_img = L->W13_simg; a.b2 = L->b12; a.b3 = L->b13;
       a.ln_g = L->ln3_g; a.ln_b = L->ln3_b; a.G = a.G_enc = G; a.N = N; a.K = K;
       ProfScope prof_(NAMP_KIND_ENC_EDGE, s);
       if ((rc = launch_edge_bf16s<MODE_ENC_EDGE>(a, s))) return rc;
@@ -1491,11 +1522,11 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
     const NampDecLayerW* D = &w->dec[l];
     const bool last = (l + 1 == w->n_dec);
     float* out = hv[l & 1];
-    REQUIRE_PTR(D->W1e_bimg); REQUIRE_PTR(D->W2_bimg); REQUIRE_PTR(D->W3_bimg);
+    REQUIRE_PTR(D->W1e_simg); REQUIRE_PTR(D->W2_simg);
     {
       EdgeArgs a = {};
       a.hE16 = h16; a.E_idx = E_idx; a.rank = rank; a.Pa16 = T16[0]; a.Pj016 = T16[1]; a.Pj116 = T16[4 + l];
-      a.W1_img = D->W1e_bimg; a.W2_img = D->W2_bimg; a.W3_img = D->W3_bimg; a.b2 = D->b2; a.b3 = D->b3;
+      a.W1_img = D->W1e_simg; a.W2_img = D->W2_simg; a.b2 = D->b2; a.b3 = D->b3;
       a.partial = partial; a.G = a.G_enc = G; a.N = N; a.K = K;
       ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
       if ((rc = launch_edge_bf16s<MODE_DEC_MSG>(a, s))) return rc;
@@ -1544,7 +1575,12 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
   const bool bf = (w->enc[0].flags & NAMP_FLAG_BF16) != 0 || (w->dec[0].flags & NAMP_FLAG_BF16) != 0;
   const int prec = prec_of(w->enc[0].flags);
   REQUIRE(prec == prec_of(w->dec[0].flags), "namp_encdec_fwd: encoder and decoder layers must use the same precision");
-  if (bf && E && G > NAMP_FUSED_TAIL_MAX_RESIDUES && edge_geom(G, K).grid > 2 * device_cus())
+  // bf16 storage needs the 32x32x16-order images of every per-edge block (optional fields of the weight structs)
+  bool simg = true;
+  for (int l = 0; l < w->n_enc; ++l)
+    simg = simg && w->enc[l].W1b_simg && w->enc[l].W2_simg && w->enc[l].W11b_simg && w->enc[l].W12_simg && w->enc[l].W13_simg;
+  for (int l = 0; l < w->n_dec; ++l) simg = simg && w->dec[l].W1e_simg && w->dec[l].W2_simg;
+  if (bf && simg && E && G > NAMP_FUSED_TAIL_MAX_RESIDUES && edge_geom(G, K).grid > 2 * device_cus())
     return encdec_bf16_storage(w, V, E, E_idx, mask, S, rank, h_V, h_E, log_probs, logits, ws, ws_bytes, B, N, K, stream);
   if (G > NAMP_FUSED_TAIL_MAX_RESIDUES || bf || w->n_dec + 4 > 8) {
     if ((rc = namp_encoder_fwd(w, V, E, E_idx, mask, h_V, h_E, ws, half, B, N, K, stream))) return rc;

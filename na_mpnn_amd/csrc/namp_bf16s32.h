@@ -1,0 +1,271 @@
+// edge_mlp_bf16s32_kernel — the bf16-storage message launches on v_mfma_f32_32x32x16_bf16 (round 3 prototype).
+//
+// One wave = 32 rows = two consecutive 16-row tiles of the flat tile list (the halves may belong to different residues).
+//   v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8(l>>5) + j], B[k = 8(l>>5) + j][n = l&31], j = 0..7, and receives
+//   D[i = 8(v>>2) + 4(l>>5) + (v&3)][n = l&31], v = 0..15.
+// T orientation (A = weights, B = activations): lane (row r = l&31, hk = l>>5) ends with channels 32tn + 8(v>>2) + 4hk + (v&3) of ITS row —
+// the operand of the next layer's K-step s' = 2tn + (v>>3) if the reduction index is enumerated k(s', hk, j) = 16s' + 8(j>>2) + 4hk + (j&3).
+// So a row of 128 bf16 is stored in the order [s' 0..7][hk 0..1][j 0..7] (16-byte piece (s', hk) = what lane (r, hk) feeds into step s'), and
+//   img32[s'][tn 0..3][lane][j] = bf16(W[32tn + (lane&31)][k(s', lane>>5, j)])          (32 KiB per 128 x 128 block, like the 16x16x32 image)
+// serves both orientations.  Per 128 x 128 product and 32 rows: 32 MFMAs of 32 cycles — the pipe time of the 64 16x16x32 MFMAs — but HALF the
+// ds_read_b128 of weight fragments, and a VALU instruction issued beside them costs 1.3-1.5 cycles instead of 1.65-2.1 (profiles/r03a).
+// F orientation (A = activations, B = weights) for layer 2: lane (channel 32tn + (l&31), hk) holds rows 8(v>>2) + 4hk + (v&3): v < 8 are rows of
+// the first 16-row tile, v >= 8 of the second, so each half's K-sum is 8 in-lane FMAs and ONE cross-lane step.
+#pragma once
+#include "namp_kernels.h"
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+static __global__ void pack_image_bf16_32_kernel(const float* __restrict__ W, int ld, int col0, __bf16* __restrict__ img) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 128 * 128) return;
+  const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 3, s = e >> 11;
+  const int n = 32 * tn + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+  img[e] = (__bf16)W[(size_t)n * ld + col0 + k];
+}
+
+__device__ __forceinline__ void bf8_to_f32x8(const bf8 v, float* o) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+
+// GELU (bf16-mode polynomial) of eight accumulators -> the bf16 operand of one K-step
+__device__ __forceinline__ bf8 gelu_pack8(const f16v& v, const int u) {
+  const f4 lo = (f4){v[8 * u + 0], v[8 * u + 1], v[8 * u + 2], v[8 * u + 3]};
+  const f4 hi = (f4){v[8 * u + 4], v[8 * u + 5], v[8 * u + 6], v[8 * u + 7]};
+  return pack_bf16<true>(lo, hi);
+}
+
+// LDS: W1 | W2 | W3 or W_e (32 KiB each) | constants (2 KiB) | per wave: two Pa rows (512 B) + 32 row weights (128 B)
+#define BF16S32_LDS (3 * NAMP_BIMG_BYTES + 2048 + 8 * 512 + 8 * 128)
+
+// EMB (first encoder message): the rows arrive as the fp32 edge features E (a.hE); h_E = W_e . E + b_e (a.eW1_img, a.eb2) is evaluated
+// here, stored as bf16 rows (a.hE16_out) and fed straight into the message MLP (as edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>).
+template <int MODE, bool EMB = false>
+__global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a) {
+  static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
+  constexpr bool EDGE = MODE == MODE_ENC_EDGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int r = lane & 31, hk = lane >> 5, m = r & 15, half = r >> 4;
+  const long ntiles = (long)a.G * a.TPN;
+  const long npairs = (ntiles + 1) >> 1;
+  const long stride = (long)gridDim.x * nwaves;
+  long pair = (long)blockIdx.x * nwaves + wave;
+  auto meta_of = [&](const long p) {
+    const long t = 2 * p + half;
+    const bool ok = t < ntiles;
+    TileMeta mt = tile_meta<MODE>(a, ok ? t : (ntiles - 1), m, 0);
+    if (!ok) { mt.valid = false; mt.w_row = 0.f; }
+    return mt;
+  };
+  TileMeta cur = meta_of(pair < npairs ? pair : 0);
+  bf8 xn[8];
+  auto row_fetch = [&](const TileMeta& mt) {
+    if constexpr (EMB) {
+      // fp32 E row: this lane's channels of K-step s are 16s + 4hk + (0..3) and 16s + 8 + 4hk + (0..3); rounded to bf16 on arrival
+      const float* src = a.hE + mt.erow * NAMP_H + 4 * hk;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xn[s] = pack_bf16<false>(*(const f4*)(src + 16 * s), *(const f4*)(src + 16 * s + 8));
+    } else {
+      const bf8* src = (const bf8*)(a.hE16 + mt.erow * NAMP_H) + hk;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xn[s] = src[2 * s];
+    }
+  };
+  row_fetch(cur);
+  char* pa_slot = smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 512;                       // two Pa rows (one per 16-row half)
+  float* w_slot = (float*)(smem + 3 * NAMP_BIMG_BYTES + 2048 + 8 * 512 + wave * 128);   // 32 row weights
+  auto pa_fetch = [&](const TileMeta& mt) {
+    const long rowA = __shfl(mt.pa_row, 0), rowB = __shfl(mt.pa_row, 16);
+    if (lane < 32) {
+      const long row = lane < 16 ? rowA : rowB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa16 + row * NAMP_H + 8 * (lane & 15)),
+                                       (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
+    }
+  };
+  pa_fetch(cur);
+  dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
+  dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
+  if (EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
+  if (EMB) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.eW1_img, 32, wave, nwaves, lane);
+  float* cst = (float*)(smem + 3 * NAMP_BIMG_BYTES);          // b2 | b3 | LayerNorm-3 weight | bias   (EMB: b2 | b_e)
+  if (EDGE && tid < 512) {
+    const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
+    cst[tid] = srcv[tid & 127];
+  }
+  if (!EDGE && tid < 128) cst[tid] = a.b2[tid];
+  if (EMB && tid >= 128 && tid < 256) cst[tid] = a.eb2[tid & 127];
+  wait_dma_and_sync();
+  const bf8* w1 = (const bf8*)smem + lane;
+  const bf8* w2 = (const bf8*)(smem + NAMP_BIMG_BYTES) + lane;
+  const bf8* w3 = (const bf8*)(smem + 2 * NAMP_BIMG_BYTES) + lane;
+  // this lane's 16 channels of a 32-channel tile tn, as four f4 of a [128] vector: 32tn + 8q + 4hk + (0..3)
+  auto vec16 = [&](const float* v, const int tn) {
+    f16v o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 t = *(const f4*)(v + 32 * tn + 8 * q + 4 * hk);
+      o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+    }
+    return o;
+  };
+  for (; pair < npairs; pair += stride) {
+    asm volatile("" ::: "memory");
+    bf8 xb[8];
+    const TileMeta me = cur;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EMB) {
+      // h_E = W_e . E + b_e for these 32 rows, rounded to bf16: stored for the later launches and used as this launch's operand
+      f16v he[4];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) he[tn] = vec16(cst + 128, tn);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) he[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[(s * 4 + tn) * 64], xn[s], he[tn], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int tin = s >> 1, u = s & 1;
+        xb[s] = pack_bf16<false>((f4){he[tin][8 * u], he[tin][8 * u + 1], he[tin][8 * u + 2], he[tin][8 * u + 3]},
+                                 (f4){he[tin][8 * u + 4], he[tin][8 * u + 5], he[tin][8 * u + 6], he[tin][8 * u + 7]});
+      }
+      if (me.valid) {
+        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + hk;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dst[2 * s] = xb[s];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xb[s] = xn[s];
+    }
+    // gathered first-layer term of this row (bf16 fragment order) — consumed after GEMM 1
+    bf8 pj[8];
+    {
+      const bf8* src = (const bf8*)((me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H) + hk;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) pj[s] = src[2 * s];
+    }
+    f16v acc[4];
+    {
+      const bf8* pa = (const bf8*)(pa_slot + half * 256) + hk;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const bf8 lo = pa[2 * (2 * tn)], hi = pa[2 * (2 * tn + 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[tn][j] = (float)lo[j]; acc[tn][8 + j] = (float)hi[j]; }
+      }
+    }
+    if (!EDGE && hk == 0) w_slot[r] = me.w_row;
+    const long np = pair + stride;
+    cur = meta_of(np < npairs ? np : pair);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pa_fetch(cur);
+    row_fetch(cur);
+    // ---- layer 1 (T): the stored row IS the operand
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[(s * 4 + tn) * 64], xb[s], acc[tn], 0, 0, 0);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[tn][j] += (float)pj[2 * tn][j]; acc[tn][8 + j] += (float)pj[2 * tn + 1][j]; }
+    }
+    f16v y[4];
+    if constexpr (EDGE) {
+      // ---- layers 2 and 3 (T), residual, LayerNorm 3, the row back as bf16
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) y[tn] = vec16(cst, tn);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf8 ab = gelu_pack8(acc[s >> 1], s & 1);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) y[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[(s * 4 + tn) * 64], ab, y[tn], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tn] = vec16(cst + 128, tn);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf8 ab = gelu_pack8(y[s >> 1], s & 1);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[(s * 4 + tn) * 64], ab, acc[tn], 0, 0, 0);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[tn][j] += (float)xb[2 * tn][j]; acc[tn][8 + j] += (float)xb[2 * tn + 1][j]; }   // residual
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sum += acc[tn][v];
+      }
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.0f / 128.0f);
+      float sq = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc[tn][v] -= mean; sq += acc[tn][v] * acc[tn][v]; }
+      sq += __shfl_xor(sq, 32);
+      const float rstd = rsqrtf(sq * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const f16v ga = vec16(cst + 256, tn), be = vec16(cst + 384, tn);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[tn][v] = acc[tn][v] * rstd * ga[v] + be[v];
+      }
+      if (me.valid) {
+        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + hk;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int tin = s >> 1, u = s & 1;
+          dst[2 * s] = pack_bf16<false>((f4){acc[tin][8 * u], acc[tin][8 * u + 1], acc[tin][8 * u + 2], acc[tin][8 * u + 3]},
+                                        (f4){acc[tin][8 * u + 4], acc[tin][8 * u + 5], acc[tin][8 * u + 6], acc[tin][8 * u + 7]});
+        }
+      }
+    } else {
+      // ---- layer 2 (F): GELU of layer 1 step by step inside the MFMA loop
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const float b = cst[32 * tn + r];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) y[tn][v] = b;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf8 ab = gelu_pack8(acc[s >> 1], s & 1);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) y[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, w2[(s * 4 + tn) * 64], y[tn], 0, 0, 0);
+      }
+      // ---- K-sums of the layer-2 activations, per 16-row half
+      f4 wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = *(const f4*)(w_slot + 8 * q + 4 * hk);
+      float wsum = me.w_row;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
+      const int nodeA = __shfl(me.node, 0), ktA = __shfl(me.kt, 0), nodeB = __shfl(me.node, 16), ktB = __shfl(me.kt, 16);
+      const bool okB = 2 * pair + 1 < ntiles;
+      const int node_h = hk ? nodeB : nodeA, kt_h = hk ? ktB : ktA;
+      float* dst = a.partial + ((long)node_h * a.TPN + kt_h) * NAMP_H + r;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f4 g0 = gelu_prec<PREC_BF16>((f4){y[tn][4 * q], y[tn][4 * q + 1], y[tn][4 * q + 2], y[tn][4 * q + 3]});
+          const f4 g1 = gelu_prec<PREC_BF16>((f4){y[tn][8 + 4 * q], y[tn][9 + 4 * q], y[tn][10 + 4 * q], y[tn][11 + 4 * q]});
+          s0 += (g0.x * wv[q].x + g0.y * wv[q].y) + (g0.z * wv[q].z + g0.w * wv[q].w);
+          s1 += (g1.x * wv[2 + q].x + g1.y * wv[2 + q].y) + (g1.z * wv[2 + q].z + g1.w * wv[2 + q].w);
+        }
+        const float t = __shfl_xor(hk ? s0 : s1, 32);
+        const float mine = (hk ? s1 : s0) + t;
+        if (hk == 0 || okB) dst[32 * tn] = mine;
+      }
+      if (lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)nodeA * a.TPN + ktA] = wsum;
+      if (lane == 16 && okB) a.partial[(long)a.G * a.TPN * NAMP_H + (long)nodeB * a.TPN + ktB] = wsum;
+    }
+  }
+}

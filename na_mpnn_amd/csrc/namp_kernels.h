@@ -854,6 +854,15 @@ __device__ __forceinline__ void node_tail_x3_rows(const NodeTail& a, f4 (&x)[8],
 // ------------------------------------------------------------------------------------------
 enum { MODE_ENC_MSG = 0, MODE_DEC_MSG = 1, MODE_ENC_EDGE = 2, MODE_EMBED = 3 };
 
+// bf16 row storage ("fragment order B", the operand order of v_mfma_f32_32x32x16_bf16, see namp_bf16s32.h): channel c of a 128-wide row
+// sits at element 16(c>>4) + 8((c>>2)&1) + 4((c>>3)&1) + (c&3).  A T-layout accumulator lane (row m, g) holds channels 16t + 4g .. +3
+// of tile t: those four go to elements frag_off(t, g) .. +3 (8 bytes).
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int frag_off(const int t, const int g) { return 16 * t + 8 * (g & 1) + 4 * (g >> 1); }
+__device__ __forceinline__ void st_frag4(__bf16* row, const int t, const int g, const f4 v) {
+  *(bf4*)(row + frag_off(t, g)) = (bf4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
 struct EdgeArgs {
   const float* hE;             // [G_enc*K][128] input edge rows
   float* hE_out;               // ENC_EDGE / EMBED output rows
@@ -879,7 +888,7 @@ struct EdgeArgs {
   const float* eW1_img; const float* eW2_img; const float* eW3_img;
   const float* eb2; const float* eb3;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // ENC_EDGE, training only: dropout on the message (thresh 0 = off)
-  // bf16 STORAGE (throughput mode on large batches, edge_mlp_bf16s_kernel): rows of 128 bf16 in fragment order
+  // bf16 STORAGE (throughput mode on large batches, edge_mlp_bf16s32_kernel): rows of 128 bf16 in fragment order B
   // [s][g][j] <-> channel 32s + 16(j>>2) + 4g + (j&3): 16-byte piece (s, g) is what lane (m, g) feeds into MFMA step s, and the four
   // lanes of a row cover one contiguous 64-byte segment per load / store instruction
   const __bf16* hE16; __bf16* hE16_out;
@@ -1152,10 +1161,10 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   }
   if (MODE == MODE_EMBED) {
     if (valid) {
-      if (a.hE16_out) {                 // bf16 storage in fragment order: piece (s, g) of the row = this lane's operand of MFMA step s
-        bf8* dst = (bf8*)(a.hE16_out + erow * NAMP_H) + g;
+      if (a.hE16_out) {                 // bf16 storage in fragment order B
+        __bf16* dst = a.hE16_out + erow * NAMP_H;
 #pragma unroll
-        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+        for (int t = 0; t < 8; ++t) st_frag4(dst, t, g, acc[t]);
       } else {
         float* dst = a.hE_out + erow * NAMP_H + 4 * g;
 #pragma unroll
@@ -1488,7 +1497,7 @@ __global__ __launch_bounds__(768) void edge_mlp_bf16_persistent_kernel(const Edg
 #pragma unroll
     for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
   }
-  // constant vectors and the tile's single Pa row through LDS instead of the vector-memory path (see edge_mlp_bf16s_kernel)
+  // constant vectors and the tile's single Pa row through LDS instead of the vector-memory path (see edge_mlp_bf16s32_kernel)
   float* cst = (float*)(smem + 3 * NAMP_BIMG_BYTES);
   if (MODE == MODE_ENC_EDGE && tid < 512) {
     const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
@@ -1608,7 +1617,7 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 #pragma unroll
     for (int t = 0; t < 8; ++t) xn[t] = *(const f4*)(src + 16 * t);
   }
-  // edge update: b2 | b3 | LayerNorm-3 weight | bias staged behind the ring (see edge_mlp_bf16s_kernel): 32 of the 64 16-byte
+  // edge update: b2 | b3 | LayerNorm-3 weight | bias staged behind the ring (see edge_mlp_bf16s32_kernel): 32 of the 64 16-byte
   // loads per tile were these four constant vectors
   float* cst = (float*)(smem + 2 * NAMP_IMG_BYTES);
   if (MODE == MODE_ENC_EDGE && tid < 512) {
@@ -1616,7 +1625,7 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
     cst[tid] = srcv ? srcv[tid & 127] : 0.f;              // (ln_g / ln_b are null when the bare message is requested)
   }
   if (MODE != MODE_ENC_EDGE && tid < 128) cst[tid] = a.b2[tid];
-  // the tile's single Pa row through a 512-byte LDS slot per wave, DMA'd one round ahead (see edge_mlp_bf16s_kernel)
+  // the tile's single Pa row through a 512-byte LDS slot per wave, DMA'd one round ahead (see edge_mlp_bf16s32_kernel)
   const float* pa_slot = (const float*)(smem + 2 * NAMP_IMG_BYTES + 2048 + wave * 512);
   auto pa_fetch = [&](const long row) {
     if (lane < 32)
@@ -1780,194 +1789,23 @@ struct SampleRows {             // tile row n -> residue of stream (b0 + n) at t
 };
 
 // ------------------------------------------------------------------------------------------
-// bf16 STORAGE variant of the persistent throughput kernel.  With bf16 MFMA the large-batch launches are bound by the
-// bytes of h_E and of the gathered table rows, so those are kept in bf16 too — in FRAGMENT ORDER: position [s][g][j] of a
-// row holds channel 32s + 16(j>>2) + 4g + (j&3), which is at once (i) the 8 values lane (m, g) feeds into MFMA step s and
-// (ii) its fp32 accumulators (tile 2s + (j>>2), element j&3).  A row access is four 16-byte loads / stores per lane, and in
-// each of them the four lanes (g = 0..3) of a row cover 64 contiguous bytes (the first layout, [g][s][j], gave every lane its
-// own 64-byte segment: 16 bytes out of every 64 per instruction, four times the memory requests — the updated rows'
-// stores ran at 2.4 TB/s).  GEMM-1 operands need no conversion at all, and the edge update writes rows in the order the next
-// launch reads them.  fp32 accumulation, fp32 LayerNorm / K-sum / residue tail.
+// bf16 STORAGE of the throughput mode's large batches (namp_bf16s32.h): with bf16 MFMA those launches are bound by the bytes of h_E
+// and of the gathered table rows, so those are kept in bf16 too, in fragment order B (frag_off above) — the order in which
+// v_mfma_f32_32x32x16_bf16 takes a row as an operand, so GEMM-1 operands need no conversion and the edge update writes rows in the order
+// the next launch reads them.  fp32 accumulation, fp32 LayerNorm / K-sum / residue tail.
+// (Tried: fp32 tables — no bf16 -> fp32 conversions, no conversion launches — 6.93 -> 7.13 ms per cfg3 step: the gathers' L2 bytes count.)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bf16_row_to_f32(f4 (&out)[8], const __bf16* __restrict__ row, const int g) {
-#pragma unroll
-  for (int sq = 0; sq < 4; ++sq) {
-    const bf8 v = ((const bf8*)row)[4 * sq + g];
-    out[2 * sq] = (f4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    out[2 * sq + 1] = (f4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-  }
-}
-
-// fp32 [rows][128] (plain channel order) -> bf16 fragment order, for up to 4 tables per launch
+// fp32 [rows][128] (plain channel order) -> bf16 fragment order B, for up to 4 tables per launch
 struct CvtTables { const float* src[4]; __bf16* dst[4]; int n; long rows; };
 static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte output piece: (row, g, s)
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte output piece: (row, s', hk)
   if (e >= c.rows * 16) return;
   const long row = e >> 4;
-  const int sq = (int)(e >> 2) & 3, g = (int)e & 3;                  // consecutive threads write consecutive pieces
+  const int sp = (int)(e >> 1) & 7, hk = (int)e & 1;                 // consecutive threads write consecutive pieces
   for (int q = 0; q < c.n; ++q) {
-    const float* s0 = c.src[q] + row * NAMP_H + 32 * sq + 4 * g;
-    const f4 lo = *(const f4*)s0, hi = *(const f4*)(s0 + 16);
-    *(bf8*)(c.dst[q] + row * NAMP_H + 8 * (4 * sq + g)) = pack_bf16<false>(lo, hi);
-  }
-}
-
-// (Tried: fp32 tables — no bf16 -> fp32 conversions, no conversion launches — 6.93 -> 7.13 ms per cfg3 step: the gathers'
-// L2 bytes count.)
-// EMB (encoder message of layer 0): the rows arrive as the fp32 edge features E (a.hE); h_E = W_e . E + b_e (model_utils.py:89, image
-// a.eW1_img in the slot layer 3 left free, bias a.eb2) is evaluated here, stored as bf16 rows (a.hE16_out) for the later launches
-// and fed straight into the message MLP — the separate embedding launch wrote those rows and this one read them back (0.8 GB each way
-// at B = 64).  Same arithmetic, same rounding points as edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16> followed by this kernel.
-template <int MODE, bool EMB = false>
-__global__ __launch_bounds__(768) void edge_mlp_bf16s_kernel(const EdgeArgs a) {
-  static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = blockDim.x >> 6;
-  const int m = lane & 15, g = lane >> 4;
-  const long ntiles = (long)a.G * a.TPN;
-  const long stride = (long)gridDim.x * nwaves;
-  long tile = (long)blockIdx.x * nwaves + wave;
-  TileMeta cur = tile_meta<MODE>(a, tile < ntiles ? tile : 0, m, g);
-  bf8 xn[EMB ? 1 : 4];
-  f4 xe[EMB ? 8 : 1];
-  if constexpr (EMB) {
-    const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) xe[t] = *(const f4*)(src + 16 * t);
-  } else {
-    const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
-  }
-  // Pa[i] is ONE row per tile (all 16 rows of a tile belong to residue i): as four per-lane 16-byte loads it went through the vector-
-  // memory path sixteen times over (4 KiB per tile for 256 B).  The row of the NEXT tile is DMA'd (16 lanes x 16 B, global_load_lds)
-  // into a 256-byte slot per wave and read back as LDS broadcasts.
-  char* pa_slot = smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 256;
-  auto pa_fetch = [&](const long row) {
-    if (lane < 16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa16 + row * NAMP_H + 8 * lane),
-                                       (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
-  };
-  pa_fetch(cur.pa_row);
-  dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
-  dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
-  if (MODE == MODE_ENC_EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
-  if (EMB) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.eW1_img, 32, wave, nwaves, lane);
-  // edge update: b2 | b3 | LayerNorm-3 weight | bias (4 x 128 floats) staged behind the images — read per tile as 32 16-byte
-  // loads, they were 32 KiB per tile through the vector-memory path (1 KiB per wave-instruction at 64 B/clk), next to 12 KiB of rows
-  float* cst = (float*)(smem + 3 * NAMP_BIMG_BYTES);
-  if (MODE == MODE_ENC_EDGE && tid < 512) {
-    const float* srcv = tid < 128 ? a.b2 : tid < 256 ? a.b3 : tid < 384 ? a.ln_g : a.ln_b;
-    cst[tid] = srcv[tid & 127];
-  }
-  if (MODE != MODE_ENC_EDGE && tid < 128) cst[tid] = a.b2[tid];        // message modes: b2 (read per lane as b2[16 t + m])
-  wait_dma_and_sync();
-  const bf8* bw = (const bf8*)smem + lane;
-  for (; tile < ntiles; tile += stride) {
-    asm volatile("" ::: "memory");        // keep the (loop-invariant) LDS weight fragments out of registers
-    bf8 xb[4];
-    const TileMeta me = cur;
-    if constexpr (EMB) {
-      f4 he[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) he[t] = *(const f4*)(a.eb2 + 16 * t + 4 * g);
-      chain_gemm_bf16<false, false>(he, xe, bw + 2 * (NAMP_BIMG_BYTES / 16));
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) xb[sq] = pack_bf16<false>(he[2 * sq], he[2 * sq + 1]);
-      if (me.valid) {
-        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + g;
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = xb[sq];
-      }
-    } else {
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) xb[sq] = xn[sq];
-    }
-    f4 acc[8], pjv[8];
-#ifdef NAMP_ABL_NOPROLOG
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { acc[t] = (f4){0.01f * lane, 0.02f, 0.03f * t, 0.04f}; pjv[t] = (f4){0.1f, 0.01f * lane, 0.3f, 0.2f * t}; }
-    const long nt = tile + stride;
-    cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's Pa row (DMA'd one tile ahead) and h_E row have landed
-    bf16_row_to_f32(acc, (const __bf16*)pa_slot, g);
-    bf16_row_to_f32(pjv, (me.pj_from1 ? a.Pj116 : a.Pj016) + me.pj_row * NAMP_H, g);
-    const long nt = tile + stride;
-    cur = tile_meta<MODE>(a, nt < ntiles ? nt : tile, m, g);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slot has been read before the next row overwrites it
-    pa_fetch(cur.pa_row);
-    if constexpr (EMB) {
-      const float* src = a.hE + cur.erow * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) xe[t] = *(const f4*)(src + 16 * t);
-    } else {
-      const bf8* src = (const bf8*)(a.hE16 + cur.erow * NAMP_H) + g;
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) xn[sq] = src[4 * sq];
-    }
-#endif
-    // layer 1: the stored row IS the MFMA operand
-#ifdef NAMP_ABL_NOGEMM
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) { acc[sq].x += (float)xb[sq][0]; acc[sq + 4].y += (float)xb[sq][7]; }
-#else
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq)
-#pragma unroll
-      for (int tn = 0; tn < 8; ++tn) {
-#ifdef NAMP_ABL_NOLDSW
-        bf8 wf = xb[sq]; wf[0] = (__bf16)(float)(sq * 8 + tn);
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[sq], acc[tn], 0, 0, 0);
-#else
-        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[(sq * 8 + tn) * 64], xb[sq], acc[tn], 0, 0, 0);
-#endif
-      }
-#endif
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] += pjv[t];
-    f4 (&y)[8] = pjv;
-    if (MODE == MODE_ENC_EDGE) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(cst + 16 * t + 4 * g);
-      chain_gemm_bf16<false, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(cst + 128 + 16 * t + 4 * g);
-      chain_gemm_bf16<false, true>(acc, y, bw + 2 * (NAMP_BIMG_BYTES / 16));
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) {                                  // residual: the row is still in registers
-        acc[2 * sq] += (f4){(float)xb[sq][0], (float)xb[sq][1], (float)xb[sq][2], (float)xb[sq][3]};
-        acc[2 * sq + 1] += (f4){(float)xb[sq][4], (float)xb[sq][5], (float)xb[sq][6], (float)xb[sq][7]};
-      }
-      layernorm_row_T(acc, cst + 256, cst + 384, g);
-      if (me.valid) {
-        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + g;
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { const float b = cst[16 * t + m]; y[t] = (f4){b, b, b, b}; }
-      chain_gemm_bf16<true, true>(y, acc, bw + (NAMP_BIMG_BYTES / 16));       // F orientation: rows 4g+r of channel 16t + m
-      // K-sum of the layer-2 activations (layer 3 is applied per residue by the residue kernel: NodeTail.m3_img)
-      float wr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = __shfl(me.w_row, 4 * g + r);
-      float wsum = me.w_row;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
-      float* dst = a.partial + ((long)me.node * a.TPN + me.kt) * NAMP_H + m;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const f4 v = gelu_prec<PREC_BF16>(y[t]);
-        float s_ = (v.x * wr[0] + v.y * wr[1]) + (v.z * wr[2] + v.w * wr[3]);
-        s_ = xg_sum(s_);
-        if (g == 0) dst[16 * t] = s_;
-      }
-      if (lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)me.node * a.TPN + me.kt] = wsum;
-    }
+    const float* s0 = c.src[q] + row * NAMP_H + 16 * sp + 4 * hk;
+    const f4 lo = *(const f4*)s0, hi = *(const f4*)(s0 + 8);
+    *(bf8*)(c.dst[q] + row * NAMP_H + 8 * (2 * sp + hk)) = pack_bf16<false>(lo, hi);
   }
 }
 
@@ -2354,7 +2192,7 @@ struct NodeLinearArgs {
   ProjDesc p[8];
   unsigned* zero;      // optional: 64 words cleared by this launch (the grid-barrier state of the persistent launch that follows)
   __bf16* out16[8];    // optional per block: the projection ALSO (out == null: only) goes out as bf16 rows in fragment order — the tables
-                       // the bf16-storage edge launches gather (edge_mlp_bf16s_kernel); replaces a separate conversion launch
+                       // the bf16-storage edge launches gather (edge_mlp_bf16s32_kernel); replaces a separate conversion launch
 };
 
 template <bool X3>       // X3: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products
@@ -2409,10 +2247,10 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
 #pragma unroll
     for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
   }
-  if (valid && o16) {                                  // piece (s, g) of the row = this lane's channel tiles 2s, 2s+1
-    bf8* dst = (bf8*)(o16 + (long)row * NAMP_H) + g;
+  if (valid && o16) {                                  // fragment order B
+    __bf16* dst = o16 + (long)row * NAMP_H;
 #pragma unroll
-    for (int sq = 0; sq < 4; ++sq) dst[4 * sq] = pack_bf16<false>(acc[2 * sq], acc[2 * sq + 1]);
+    for (int t = 0; t < 8; ++t) st_frag4(dst, t, g, acc[t]);
   }
 }
 
@@ -2744,11 +2582,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         }
         }
         if (valid && d.out) *(f4*)(d.out + (long)row * NAMP_H + 16 * tn + 4 * g) = acc;
-        if (valid && a.out16[pi]) {                            // half a 16-byte piece: (s = tn / 2, g), values 4 (tn & 1) .. + 3
-          typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-          *(bf4*)(a.out16[pi] + (long)row * NAMP_H + 8 * (4 * (tn >> 1) + g) + 4 * (tn & 1)) =
-              (bf4){(__bf16)acc.x, (__bf16)acc.y, (__bf16)acc.z, (__bf16)acc.w};
-        }
+        if (valid && a.out16[pi]) st_frag4(a.out16[pi] + (long)row * NAMP_H, tn, g, acc);   // fragment order B
       }
     }
   }

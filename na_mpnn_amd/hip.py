@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NAMP_LIB_PATH") or os.path.join(_HERE, "lib", "libnamp_hip.so")   # env: tools/kbench.py ablations
 
-NAMP_ABI_VERSION = 3
+NAMP_ABI_VERSION = 4
 NAMP_MAX_LAYERS = 8
 NAMP_FLAG_BF16 = 1
 NAMP_FLAG_X3 = 2
@@ -33,7 +33,8 @@ class NampEncLayerW(C.Structure):
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
                         "W1b_bimg", "W2_bimg", "W3_bimg", "W11b_bimg", "W12_bimg", "W13_bimg",
                         "W1b_ximg", "W2_ximg", "W3_ximg", "W11b_ximg", "W12_ximg", "W13_ximg",
-                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1c_ximg", "W11a_ximg", "W11c_ximg"]) + [("flags", C.c_int64)]
+                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1c_ximg", "W11a_ximg", "W11c_ximg",
+                        "W1b_simg", "W2_simg", "W11b_simg", "W12_simg", "W13_simg"]) + [("flags", C.c_int64)]
 
 
 class NampDecLayerW(C.Structure):
@@ -41,7 +42,7 @@ class NampDecLayerW(C.Structure):
                         "W2_img", "b2", "W3_img", "b3", "Win_img", "b_in", "Wout_img", "b_out",
                         "ln1_g", "ln1_b", "ln2_g", "ln2_b",
                         "W1e_bimg", "W2_bimg", "W3_bimg", "W1e_ximg", "W2_ximg", "W3_ximg",
-                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1v_ximg"]) + [("flags", C.c_int64)]
+                        "Win_ximg", "Wout_ximg", "W1a_ximg", "W1v_ximg", "W1e_simg", "W2_simg"]) + [("flags", C.c_int64)]
 
 
 class NampFeatW(C.Structure):
@@ -53,7 +54,7 @@ class NampModelW(C.Structure):
                 ("Wv_img", c_fp), ("Wv_b", c_fp), ("We_img", c_fp), ("We_b", c_fp),
                 ("Wout_w", c_fp), ("Wout_b", c_fp),
                 ("enc", NampEncLayerW * NAMP_MAX_LAYERS), ("dec", NampDecLayerW * NAMP_MAX_LAYERS),
-                ("feat", NampFeatW), ("We_ximg", c_fp), ("Wv_ximg", c_fp), ("We_bimg", c_fp)]
+                ("feat", NampFeatW), ("We_ximg", c_fp), ("Wv_ximg", c_fp), ("We_bimg", c_fp), ("We_simg", c_fp)]
 
 
 class NampProj(C.Structure):
@@ -67,6 +68,8 @@ _PROTOTYPES = {
     "namp_last_error": (C.c_char_p, []),
     "namp_pack_image": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),
     "namp_pack_image_bf16": (i32, [c_fp, i32, i32, c_fp, vp]),
+    "namp_pack_image_bf16_32": (i32, [c_fp, i32, i32, c_fp, vp]),
+    "namp_bf16s_message": (i32, [i32, vp, c_ip, c_ip, c_ip, vp, vp, vp, vp, vp, c_fp, c_fp, i32, i32, i32, i32, vp]),
     "namp_pack_image_x3": (i32, [c_fp, i32, i32, c_fp, vp]),
     "namp_pack_feat_x3": (i32, [c_fp, i32, c_fp, vp]),
     "namp_pack_image_x3_general": (i32, [c_fp, i32, i32, i32, i32, c_fp, vp]),

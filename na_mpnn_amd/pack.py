@@ -46,6 +46,9 @@ def plan(n_enc: int, n_dec: int, vocab: int):
     def bimg(name, key, col0):                      # 32 KiB bf16 image = 8192 float slots
         add(name, H * H // 2, ("bimg", key, col0))
 
+    def simg(name, key, col0):                      # 32 KiB bf16 image in the 32x32x16 operand order
+        add(name, H * H // 2, ("simg", key, col0))
+
     def ximg(name, key, col0):                      # 64 KiB x3 image (bf16 hi | bf16 mid) = 16384 float slots
         add(name, H * H, ("ximg", key, col0))
 
@@ -54,6 +57,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
 
     img("Wv_img", "W_v.weight", 0); vec("Wv_b", "W_v.bias", H)
     ximg("We_ximg", "W_e.weight", 0); ximg("Wv_ximg", "W_v.weight", 0); bimg("We_bimg", "W_e.weight", 0)
+    simg("We_simg", "W_e.weight", 0)
     img("We_img", "W_e.weight", 0); vec("We_b", "W_e.bias", H)
     vec("Wout_w", "W_out.weight", vocab * H); vec("Wout_b", "W_out.bias", vocab)
     # featuriser (ProteinFeaturesNA): 5200-wide edge embedding as a 325-k-tile image
@@ -85,6 +89,8 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         xgimg(p + "Win_ximg", q + "dense.W_in.weight", 4 * H, H); xgimg(p + "Wout_ximg", q + "dense.W_out.weight", H, 4 * H)
         ximg(p + "W1a_ximg", q + "W1.weight", 0); ximg(p + "W1c_ximg", q + "W1.weight", 2 * H)
         ximg(p + "W11a_ximg", q + "W11.weight", 0); ximg(p + "W11c_ximg", q + "W11.weight", 2 * H)
+        simg(p + "W1b_simg", q + "W1.weight", H); simg(p + "W2_simg", q + "W2.weight", 0)
+        simg(p + "W11b_simg", q + "W11.weight", H); simg(p + "W12_simg", q + "W12.weight", 0); simg(p + "W13_simg", q + "W13.weight", 0)
     for l in range(n_dec):
         p, q = f"dec{l}.", f"decoder_layers.{l}."
         for nm, c0 in (("W1a", 0), ("W1e", H), ("W1s", 2 * H), ("W1v", 3 * H)):
@@ -101,6 +107,7 @@ def plan(n_enc: int, n_dec: int, vocab: int):
         ximg(p + "W1e_ximg", q + "W1.weight", H); ximg(p + "W2_ximg", q + "W2.weight", 0); ximg(p + "W3_ximg", q + "W3.weight", 0)
         xgimg(p + "Win_ximg", q + "dense.W_in.weight", 4 * H, H); xgimg(p + "Wout_ximg", q + "dense.W_out.weight", H, 4 * H)
         ximg(p + "W1a_ximg", q + "W1.weight", 0); ximg(p + "W1v_ximg", q + "W1.weight", 3 * H)
+        simg(p + "W1e_simg", q + "W1.weight", H); simg(p + "W2_simg", q + "W2.weight", 0)
     return items, off
 
 
@@ -172,6 +179,10 @@ class PackedWeights:
                 w = src(recipe[1])
                 hip.check(L.namp_pack_image_bf16(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
                           f"pack_image_bf16({name})")
+            elif recipe[0] == "simg":
+                w = src(recipe[1])
+                hip.check(L.namp_pack_image_bf16_32(w.data_ptr(), w.shape[1], recipe[2], self.addr(name), stream),
+                          f"pack_image_bf16_32({name})")
         # per-token tables need the packed W1s images: tok_l = W_s.weight @ W1s_l^T  [vocab,128]
         ws = src("W_s.weight")
         for l in range(self.n_dec):
@@ -201,6 +212,7 @@ class PackedWeights:
         m.We_ximg = self.addr("We_ximg")
         m.Wv_ximg = self.addr("Wv_ximg")
         m.We_bimg = self.addr("We_bimg")
+        m.We_simg = self.addr("We_simg")
         self.struct = m
 
     def set_precision(self, precision: str):

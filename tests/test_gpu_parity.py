@@ -649,6 +649,21 @@ def test_bf16_throughput_mode(L, dev, wt, golden_dir):
             assert float((lp_x.argmax(-1) == lp_f.argmax(-1))[valid].float().mean()) >= 0.97, (b, n, k)
 
 
+@pytest.mark.parametrize("B,N,K", [(3, 333, 48), (2, 257, 30), (1, 75, 16), (5, 201, 70)])
+def test_bf16_storage_message_kernel(dev, B, N, K):
+    """namp_bf16s_message (edge_mlp_bf16s32_kernel, v_mfma_f32_32x32x16_bf16 on rows stored in fragment order B) against a torch
+    restatement with the kernel's rounding points (operands in bf16, fp32 accumulation, exact-erf GELU): K-sums of the layer-2
+    activations of both message modes, incl. odd tile counts (a trailing half pair), K % 16 != 0 and random neighbour indices.
+    Bar 3e-3 on sums of up to 48 activations (the bf16-mode GELU polynomial is within 1.9e-4 per value); the weight sums exact."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("bf16s32_check", os.path.join(os.path.dirname(__file__), "..", "tools", "bf16s32_check.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    for mode, (err, smax, _, dw) in mod.case(B, N, K, dev, seed=B * 1000 + K).items():
+        assert err < 3e-3 and smax > 1.0, (mode, err, smax)
+        assert dw < 1e-6, (mode, dw)
+
+
 @pytest.mark.parametrize("prec", ["x3", "fp32"])
 @pytest.mark.parametrize("B,N,K,mf", [(1, 1000, 48, 0.0), (1, 333, 40, 0.1), (2, 400, 48, 0.05), (1, 37, 35, 0.0), (1, 1024, 48, 0.0)])
 def test_persistent_forward_equals_launch_chain(L, dev, wt, B, N, K, mf, prec):
