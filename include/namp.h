@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAMP_ABI_VERSION 4   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3; 3: namp_train_edge_bwd takes g_hE_in; 4: *_simg images in the weight structs */
+#define NAMP_ABI_VERSION 4   /* 2: message phases write K-sums + weight sums; namp_node_update takes the message MLP's W3 / b3; 3: namp_train_edge_bwd takes g_hE_in; 4: *_simg images in the weight structs; symmetry groups in the level decoders */
 #define NAMP_HIDDEN 128
 #define NAMP_MAX_LAYERS 8
 #define NAMP_MAX_K 192
@@ -446,39 +446,47 @@ int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, co
                          int ntensors, int nblocks, float max_norm, double beta1, double beta2, float step_size, float bias_correction2_sqrt,
                          float eps, float* ws, void* stream);
 
-/* Level-parallel form of the plain sampling branch (no symmetry groups, no pair_bias).  The step for residue i depends
- * only on the neighbours visited before it, so visits can be grouped into dependency levels and every level decoded in
- * one launch over all streams: ~64 launches instead of 1000 sequential steps at N = 1000, K = 48.  Same arithmetic per
- * residue and the same uniform per visit as namp_decoder_sample, hence identical draws.
+/* Level-parallel form of the sampler.  The step for residue i depends only on the neighbours visited before it, so visits can be
+ * grouped into dependency levels and every level decoded in one launch over all streams: ~64 launches instead of 1000 sequential
+ * steps at N = 1000, K = 48.  Same arithmetic per residue and the same uniform per visit as namp_decoder_sample, hence identical draws.
  *   namp_sample_levels: level[b][t] (int32, indexed by VISIT t of stream b) = 1 + max level of the earlier neighbours.
- *   namp_decoder_sample_levels: work = int32 pairs (stream, visit) sorted by level [B_dec*N][2] (device);
+ *   namp_decoder_sample_levels: work = int32 pairs (stream, visit) sorted by level [nwork][2] (device);
  *     level_counts = HOST array of n_levels counts (the caller reads the histogram back; this library never synchronises).
  *   namp_decoder_sample_walk (round 3): the same levels in ONE persistent launch — no kernel boundary per level (whose cold L2 made
  *     the level's workgroups re-fetch the decoder weights at ~45 GB/s) and no host read-back: level_off = DEVICE int32 array,
- *     level_off[l] = index of the first pair of level l in `work`, every entry behind the last level = B_dec*N (at least N + 2
+ *     level_off[l] = index of the first pair of level l in `work`, every entry behind the last level = nwork (at least N + 2
  *     entries).  namp_decoder_sample_walk_grid workgroups (<= 128, one per CU: the device must not be shared with other
  *     streams meanwhile) walk the levels with a grid barrier in between; a barrier that gives up (bounded spin) makes the launch
- *     overwrite log_probs with NaN.  K <= 128 (returns 0 workgroups otherwise: use the per-level launches).  Identical draws. */
+ *     overwrite log_probs with NaN.  K <= 128 (returns 0 workgroups otherwise: use the per-level launches).  Identical draws.
+ * Symmetry-tied sampling (model_utils.py:219-326; group_first / group_last / sym_weights as in namp_decoder_sample): a work item is a
+ *   GROUP — work = (stream, the group's first visit), work_n[item] = its number of (consecutive) visits, nwork = number of groups over
+ *   all streams; the item's workgroup slot runs the members one after the other (a member sees the decoder states of the members
+ *   before it, undrawn tokens as in the sequential walk) and draws once.  namp_sample_levels_dep with the group arrays gives every
+ *   visit of a group the group's level: 1 + the highest level among its members' dependencies in earlier groups.  Without symmetry
+ *   groups: group_first = group_last = sym_weights = work_n = NULL and nwork = B_dec * N. */
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream);
 /* ... with extra dependencies per residue, dep_idx int32 [B_enc][N][D] (-1 = none): `pair_bias` (optional argument of the two level
  * decoders below, [B_enc][N][vocab][N][vocab] as in namp_decoder_sample) makes the step of residue i read the token of every j whose
  * block pair_bias[i, :, j, :] is not all zero; with those j listed here the levels respect that, and the level decoders — which
  * treat every residue later in the decoding order as undecoded (PAD), like the sequential walk sees it — give identical draws. */
-int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D, int32_t* level,
+int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D,
+                           const int32_t* group_first, const int32_t* group_last, int32_t* level,
                            int B_dec, int B_enc, int N, int K, void* stream);
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                                const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
-                               const int32_t* work, const int32_t* level_counts, int n_levels,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
+                               const int32_t* work, const int32_t* work_n, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                                void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 
 int namp_decoder_sample_walk_grid(int B_dec, int N, int K);
 int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                              const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
-                             const int32_t* work, const int32_t* level_off,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
+                             const int32_t* work, const int32_t* work_n, int nwork, const int32_t* level_off,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 

@@ -1090,10 +1090,10 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
 }
 
 // the sampler kernel by (mode: 0 sequential walk / 1 one level per launch / 2 persistent level walk, precision, waves per workgroup)
-static void launch_sample(int mode, bool x3, int nwaves, int grid, hipStream_t s, const SampleArgs& a, const int32_t* work, int nwork,
-                          const int32_t* level_off = nullptr, unsigned* sync = nullptr) {
+static void launch_sample(int mode, bool x3, int nwaves, int grid, hipStream_t s, const SampleArgs& a, const int32_t* work,
+                          const int32_t* work_n, int nwork, const int32_t* level_off = nullptr, unsigned* sync = nullptr) {
   const dim3 g(grid), b(nwaves * 64);
-#define NAMP_LS(MD, X3, W) hipLaunchKernelGGL((dec_sample_kernel<MD, X3, W>), g, b, SAMPLE_LDS, s, a, work, nwork, level_off, sync)
+#define NAMP_LS(MD, X3, W) hipLaunchKernelGGL((dec_sample_kernel<MD, X3, W>), g, b, SAMPLE_LDS, s, a, work, work_n, nwork, level_off, sync)
   if (nwaves <= 8) {
     if (mode == 2)      { if (x3) NAMP_LS(2, true, 8); else NAMP_LS(2, false, 8); }
     else if (mode == 1) { if (x3) NAMP_LS(1, true, 8); else NAMP_LS(1, false, 8); }
@@ -1118,41 +1118,46 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
                           ws_bytes, B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, (hipStream_t)stream);
-  launch_sample(0, prec_of(w->dec[0].flags) == PREC_X3, nwaves, (B_dec + a.slots - 1) / a.slots, (hipStream_t)stream, a, nullptr, 0);
+  launch_sample(0, prec_of(w->dec[0].flags) == PREC_X3, nwaves, (B_dec + a.slots - 1) / a.slots, (hipStream_t)stream, a, nullptr, nullptr, 0);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
 
-int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D, int32_t* level,
+int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D,
+                           const int32_t* group_first, const int32_t* group_last, int32_t* level,
                            int B_dec, int B_enc, int N, int K, void* stream) {
   if (!E_idx || !order || !rank || !level) return fail(NAMP_EINVAL, "namp_sample_levels: null pointer argument");
   REQUIRE(B_dec >= 1 && B_enc >= 1 && B_dec % B_enc == 0 && N >= 1 && K >= 1 && N <= 16384,
           "namp_sample_levels: bad dims B_dec=%d B_enc=%d N=%d K=%d", B_dec, B_enc, N, K);
   REQUIRE(dep_idx == nullptr || D >= 1, "namp_sample_levels_dep: D=%d", D);
-  hipLaunchKernelGGL(sample_levels_kernel, dim3(B_dec), dim3(64), (size_t)N * 4, (hipStream_t)stream, E_idx, order, rank, dep_idx, D, level,
-                     B_enc, N, K);
+  REQUIRE((group_first == nullptr) == (group_last == nullptr), "namp_sample_levels_dep: group_first and group_last go together");
+  hipLaunchKernelGGL(sample_levels_kernel, dim3(B_dec), dim3(64), (size_t)N * 4, (hipStream_t)stream, E_idx, order, rank, dep_idx, D,
+                     group_first, group_last, level, B_enc, N, K);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
 
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream) {
-  return namp_sample_levels_dep(E_idx, order, rank, nullptr, 0, level, B_dec, B_enc, N, K, stream);
+  return namp_sample_levels_dep(E_idx, order, rank, nullptr, 0, nullptr, nullptr, level, B_dec, B_enc, N, K, stream);
 }
 
 int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                                const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
-                               const int32_t* work, const int32_t* level_counts, int n_levels,
+                               const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                               const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
+                               const int32_t* work, const int32_t* work_n, const int32_t* level_counts, int n_levels,
                                float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                                void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
   REQUIRE(work != nullptr && level_counts != nullptr && n_levels >= 1, "namp_decoder_sample_levels: work list / level counts missing");
+  REQUIRE((work_n != nullptr) == (group_first != nullptr), "namp_decoder_sample_levels: work_n goes with group_first / group_last");
   long total = 0;
   for (int l = 0; l < n_levels; ++l) { REQUIRE(level_counts[l] >= 0, "namp_decoder_sample_levels: negative level count"); total += level_counts[l]; }
-  REQUIRE(total == (long)B_dec * N, "namp_decoder_sample_levels: level counts sum to %ld, expected B_dec*N = %ld", total, (long)B_dec * N);
+  REQUIRE(work_n ? (total >= 1 && total <= (long)B_dec * N) : (total == (long)B_dec * N),
+          "namp_decoder_sample_levels: level counts sum to %ld, expected %sB_dec*N = %ld", total, work_n ? "<= " : "", (long)B_dec * N);
   SampleArgs a; int nwaves = 0;
-  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
-                          nullptr, nullptr, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, group_first,
+                          group_last, sym_weights, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
                           B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1164,14 +1169,12 @@ int namp_decoder_sample_levels(const NampModelW* w, const float* h_V_enc, const 
   for (int l = 0; l < n_levels; ++l) {
     const int cnt = level_counts[l];
     if (cnt == 0) continue;
-    launch_sample(1, x3, nwaves, (cnt + a.slots - 1) / a.slots, s, a, work + 2 * off, cnt);
+    launch_sample(1, x3, nwaves, (cnt + a.slots - 1) / a.slots, s, a, work + 2 * off, work_n ? work_n + off : nullptr, cnt);
     off += cnt;
   }
   CHECK_LAUNCH();
   return NAMP_OK;
 }
-
-
 
 int namp_decoder_sample_walk_grid(int B_dec, int N, int K) {
   if (B_dec < 1 || N < 1 || K < 1 || K > 128) return 0;                     // K > 128 (12-wave workgroups): no persistent form
@@ -1183,16 +1186,20 @@ int namp_decoder_sample_walk_grid(int B_dec, int N, int K) {
 
 int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                              const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
-                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced, const float* pair_bias,
-                             const int32_t* work, const int32_t* level_off,
+                             const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
+                             const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
+                             const int32_t* work, const int32_t* work_n, int nwork, const int32_t* level_off,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
   REQUIRE(work != nullptr && level_off != nullptr, "namp_decoder_sample_walk: work list / level offsets missing");
+  REQUIRE((work_n != nullptr) == (group_first != nullptr), "namp_decoder_sample_walk: work_n goes with group_first / group_last");
+  REQUIRE(nwork >= 1 && nwork <= (long)B_dec * N && (work_n || nwork == (long)B_dec * N),
+          "namp_decoder_sample_walk: nwork=%d work items for B_dec*N = %ld visits", nwork, (long)B_dec * N);
   const int grid = namp_decoder_sample_walk_grid(B_dec, N, K);
   REQUIRE(grid >= 1, "namp_decoder_sample_walk: no persistent form for B_dec=%d N=%d K=%d (K <= 128)", B_dec, N, K);
   SampleArgs a; int nwaves = 0;
-  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, nullptr,
-                          nullptr, nullptr, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
+  int rc = sample_prepare(w, h_V_enc, h_E, E_idx, mask, mask_dec, chain_mask, S_true, bias, order, rank, uniform, S_forced, group_first,
+                          group_last, sym_weights, pair_bias, temperature, special_tokens, S_out, probs_out, logp_out, ws, ws_bytes,
                           B_dec, B_enc, N, K, stream, &a, &nwaves);
   if (rc) return rc;
   REQUIRE(nwaves <= 8, "namp_decoder_sample_walk: needs the 8-wave workgroup form (K <= 128)");
@@ -1204,7 +1211,8 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
   if (e == hipSuccess) e = hipMemsetAsync(sync, 0, NAMP_SYNC_WORDS * sizeof(unsigned), s);
   if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_walk: hipMemsetAsync: %s", hipGetErrorString(e));
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
-  launch_sample(2, prec_of(w->dec[0].flags) == PREC_X3, nwaves, grid, s, a, work, B_dec * N, level_off, sync);
+  const int g2 = (nwork + a.slots - 1) / a.slots;
+  launch_sample(2, prec_of(w->dec[0].flags) == PREC_X3, nwaves, g2 < grid ? g2 : grid, s, a, work, work_n, nwork, level_off, sync);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

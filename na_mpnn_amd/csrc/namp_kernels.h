@@ -1814,35 +1814,44 @@ static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
 // neighbours, levels live in LDS.  level_out[b][t] is indexed by VISIT t.
 // dep_idx (optional, [B_enc][N][D], -1 = none): further residues a step depends on besides the graph neighbours — with `pair_bias` the
 // bias of residue i reads the token of every residue j whose block pair_bias[i, :, j, :] is not all zero (model_utils.py:169-172).
+// group_first / group_last (optional, [B_dec][N] by visit; symmetry-tied sampling): the visits of a group share ONE level — 1 + the
+// highest level among the members' dependencies in EARLIER groups (a member's neighbours inside its own group are handled by the
+// group's own work item, which runs its members one after the other).
 static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t* __restrict__ E_idx, const int32_t* __restrict__ order,
                                                           const int32_t* __restrict__ rank, const int32_t* __restrict__ dep_idx, int D,
+                                                          const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_last,
                                                           int32_t* __restrict__ level_out, int B_enc, int N, int K) {
   extern __shared__ int lv[];                                    // [N]
   const int b = blockIdx.x, lane = threadIdx.x;
   const int b_enc = b % B_enc;
   const int32_t* rk = rank + (long)b * N;
+  int dg = -1;                                                   // running maximum over the open group's members
   for (int t = 0; t < N; ++t) {
     const int i = order[(long)b * N + t];
+    const int vf = group_first ? group_first[(long)b * N + t] : t;       // rank[i] == t; the group's first visit
     int d = -1;
     for (int k = lane; k < K; k += 64) {
       const int j = E_idx[((long)b_enc * N + i) * K + k];
-      if (rk[j] < t) d = max(d, lv[j]);                          // rank[i] == t; earlier neighbours already have their level
+      if (rk[j] < vf) d = max(d, lv[j]);                         // earlier groups already have their level
     }
     if (dep_idx)
       for (int k = lane; k < D; k += 64) {
         const int j = dep_idx[((long)b_enc * N + i) * D + k];
-        if (j >= 0 && rk[j] < t) d = max(d, lv[j]);
+        if (j >= 0 && rk[j] < vf) d = max(d, lv[j]);
       }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) d = max(d, __shfl_xor(d, o));
-    if (lane == 0) { lv[i] = d + 1; level_out[(long)b * N + t] = d + 1; }
+    dg = (vf == t) ? d : max(dg, d);
+    const bool closes = group_last ? (group_last[(long)b * N + t] != 0) : true;
+    if (closes)
+      for (int v = vf + lane; v <= t; v += 64) { lv[order[(long)b * N + v]] = dg + 1; level_out[(long)b * N + v] = dg + 1; }
     __builtin_amdgcn_s_waitcnt(0);                               // LDS write visible to the wave's next iteration
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// LEVEL = false: the sequential walk, one workgroup per <= 4 streams (needed for symmetry groups and pair_bias, whose steps
-// depend on every earlier one).  LEVEL = true: ONE step for an arbitrary list of (stream, visit) pairs — the plain branch's
+// LEVEL = false: the sequential walk, one workgroup per <= 4 streams (a dense pair_bias, whose steps depend on every earlier one;
+// K > 128).  LEVEL = true: ONE step for an arbitrary list of (stream, visit) pairs — the plain branch's
 // step for residue i depends only on the neighbours decoded before it, so the host groups the visits of all streams into
 // dependency levels (sample_levels_kernel: level = 1 + max level of the earlier neighbours) and launches one grid per level:
 // ~64 launches instead of 1000 sequential steps at N = 1000, K = 48, with every workgroup of the chip busy.  Same arithmetic
@@ -1858,7 +1867,8 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
 // workgroups — the next layer's Pv rows — is stored write-through (sc1); tokens travel through agent-scope atomics as before; no
 // workgroup ever reads a row before the level that wrote it (rank order), so no reader holds a stale line.
 template <int MODE, bool X3 = false, int MAXW = 8>
-__global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work, int nwork,
+__global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work,
+                                                               const int32_t* __restrict__ work_n, int nwork,
                                                                const int32_t* __restrict__ level_off, unsigned* sync) {
   constexpr bool LEVEL = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1899,9 +1909,13 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     asm volatile("" ::: "memory");      // keep the step's (loop-invariant) vector loads inside the step, not in registers across steps
     NAMP_STAMP(0);                      // (time since the previous stamp: barrier / launch-side)
     const int item = item0 + slot;                                // LEVEL: index into the work list; else: the stream
-    const bool wave_active = (slot < a.slots) && (item < nitems);
-    const int bb = LEVEL ? work[2 * (wave_active ? item : item0)] : (wave_active ? item : 0);
-    const int t_level = LEVEL ? work[2 * (wave_active ? item : item0) + 1] : 0;
+    const bool in_list = (slot < a.slots) && (item < nitems);
+    const int wi = in_list ? item : item0;
+    // LEVEL: a work item is (stream, first visit) of a symmetry group of work_n[item] consecutive visits (null: single visits); t_seq counts
+    // the members — the slots of a workgroup step through their groups together, a slot whose group is shorter idles for the rest
+    const bool wave_active = in_list && (!LEVEL || !work_n || t_seq < work_n[wi]);
+    const int bb = LEVEL ? work[2 * wi] : (wave_active ? item : 0);
+    const int t_level = LEVEL ? work[2 * wi + 1] + (wave_active ? t_seq : 0) : 0;
     const int b_enc = bb % a.B_enc;
     const int t = LEVEL ? t_level : t_seq;
     const int i_loc = a.order[(long)bb * a.N + t];
@@ -1910,8 +1924,8 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     if (tid < NAMP_SAMPLE_SLOTS) {
       const int it = item0 + tid;
       if (LEVEL) {
-        const bool ok = tid < a.slots && it < nitems;
-        const int bs = ok ? work[2 * it] : 0, ts = ok ? work[2 * it + 1] : 0;
+        const bool ok = tid < a.slots && it < nitems && (!work_n || t_seq < work_n[it]);
+        const int bs = ok ? work[2 * it] : 0, ts = ok ? work[2 * it + 1] + t_seq : 0;
         node_lds[tid] = ok ? bs * a.N + a.order[(long)bs * a.N + ts] : -1;
         t_lds[tid] = ts;
       } else {
@@ -2151,11 +2165,21 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     NAMP_STAMP(6);                      // output head + draw
   };
 
+  // LEVEL: members of the largest symmetry group among the workgroup's items item0 .. (1 without groups)
+  auto members = [&](const int item0, const int nitems) {
+    int n = 1;
+    if (work_n)
+      for (int s_ = 0; s_ < a.slots; ++s_)
+        if (item0 + s_ < nitems) n = max(n, work_n[item0 + s_]);
+    return n;
+  };
   if constexpr (MODE == 0) {
 #pragma unroll 1
     for (int t_seq = 0; t_seq < a.N; ++t_seq) step(blockIdx.x * a.slots, a.B_dec, t_seq, t_seq + 1 < a.N);
   } else if constexpr (MODE == 1) {
-    step(blockIdx.x * a.slots, nwork, 0, false);
+    const int nmem = members(blockIdx.x * a.slots, nwork);
+#pragma unroll 1
+    for (int q = 0; q < nmem; ++q) step(blockIdx.x * a.slots, nwork, q, q + 1 < nmem);
   } else {
 #pragma unroll 1
     for (int lvl = 0;; ++lvl) {
@@ -2163,7 +2187,11 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
       if (off >= nwork) break;
       const int end = level_off[lvl + 1];
 #pragma unroll 1
-      for (int base = off + blockIdx.x * a.slots; base < end; base += gridDim.x * a.slots) step(base, end, 0, true);
+      for (int base = off + blockIdx.x * a.slots; base < end; base += gridDim.x * a.slots) {
+        const int nmem = members(base, end);
+#pragma unroll 1
+        for (int q = 0; q < nmem; ++q) step(base, end, q, true);
+      }
       grid_barrier(sync, (unsigned)lvl + 1u, tid);
     }
     // a barrier that gave up let its workgroup run ahead of data it needed: the failure travels with the outputs (cf. encdec_persistent_kernel)

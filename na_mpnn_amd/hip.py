@@ -125,13 +125,15 @@ _PROTOTYPES = {
     "namp_train_adam_chunk": (i32, []),
     "namp_train_adam_step": (i32, [vp, vp, vp, vp, i32, i32, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float, c_fp, vp]),
     "namp_sample_levels": (i32, [c_ip, c_ip, c_ip, c_ip, i32, i32, i32, i32, vp]),
-    "namp_sample_levels_dep": (i32, [c_ip, c_ip, c_ip, c_ip, i32, c_ip, i32, i32, i32, i32, vp]),
-    "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip, c_fp,
-                                         c_ip, C.POINTER(C.c_int32), i32,
+    "namp_sample_levels_dep": (i32, [c_ip, c_ip, c_ip, c_ip, i32, c_ip, c_ip, c_ip, i32, i32, i32, i32, vp]),
+    "namp_decoder_sample_levels": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+                                         c_ip, c_ip, c_fp, c_fp,
+                                         c_ip, c_ip, C.POINTER(C.c_int32), i32,
                                          C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_decoder_sample_walk_grid": (i32, [i32, i32, i32]),
-    "namp_decoder_sample_walk": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip, c_fp,
-                                       c_ip, c_ip,
+    "namp_decoder_sample_walk": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
+                                       c_ip, c_ip, c_fp, c_fp,
+                                       c_ip, c_ip, i32, c_ip,
                                        C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),

@@ -485,16 +485,20 @@ class ProteinMPNN(nn.Module):
             # member; every stream then uses that one order
             if B != 1:
                 raise ValueError("symmetry-tied sampling expects one input complex (B == 1)")
-            weights = torch.ones(L, dtype=torch.float32)
+            wl = [1.0] * L
             for i1, group in enumerate(sym):
                 for i2, item in enumerate(group):
-                    weights[item] = fd["symmetry_weights"][i1][i2]
+                    wl[item] = float(fd["symmetry_weights"][i1][i2])
+            weights = torch.tensor(wl, dtype=torch.float32)
+            group_of = {}
+            for g_ in sym:                                     # (the reference takes the FIRST listed group that holds a residue)
+                for item in g_:
+                    group_of.setdefault(int(item), g_)
             visited, groups = set(), []
             for t_dec in order[0].tolist():
                 if t_dec in visited:
                     continue
-                hit = [g for g in sym if t_dec in g]
-                groups.append(list(hit[0]) if hit else [t_dec])
+                groups.append(list(group_of.get(t_dec, (t_dec,))))
                 visited.update(groups[-1])
             flat = [t for g in groups for t in g]
             if sorted(flat) != list(range(L)):
@@ -531,7 +535,7 @@ class ProteinMPNN(nn.Module):
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
         dep_idx, n_dep = None, 0
         pb_levels = pair_bias is None
-        if pair_bias is not None and self.sample_level_parallel and not symmetric:
+        if pair_bias is not None and self.sample_level_parallel:
             # pair_bias (model_utils.py:116,169-172): the bias of residue i reads the token of every residue j whose block
             # pair_bias[i, :, j, :] is not all zero — the sequence neighbours for run.py's --pair_bias_AA (data_utils.py:7-16).  Those
             # j become extra dependencies of the levels; a dense bias (more than 64 partners for some residue) keeps the sequential walk.
@@ -545,36 +549,47 @@ class ProteinMPNN(nn.Module):
                     cols = torch.where(nz, torch.arange(L, device=dev)[None, None, :], torch.full((), L, device=dev))
                     cols = cols.sort(dim=-1).values[:, :, :n_dep]
                     dep_idx = torch.where(cols < L, cols, torch.full((), -1, device=dev)).to(torch.int32).contiguous()
-        if self.sample_level_parallel and not symmetric and pb_levels:
-            # plain branch: residue i depends only on the neighbours decoded before it -> decode by dependency level
-            # (one launch per level over all streams, ~64 levels at L = 1000 instead of 1000 sequential steps)
+        if self.sample_level_parallel and pb_levels:
+            # residue i depends only on the neighbours decoded before it -> decode by dependency level (one launch per level over all
+            # streams, ~64 levels at L = 1000 instead of 1000 sequential steps).  Symmetry-tied: the unit of work is a GROUP (its members
+            # run one after the other in the group's workgroup slot and share one draw); its level follows its members' dependencies
             level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
-            hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep, level.data_ptr(),
+            hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep,
+                                                hip.ptr(group_first), hip.ptr(group_last), level.data_ptr(),
                                                 B_dec, B, L, K, hip.current_stream()), "sample_levels")
-            flat = level.view(-1).long()
-            perm = torch.argsort(flat, stable=True)
-            work = torch.stack((perm // L, perm % L), 1).to(torch.int32).contiguous()
+            work_n = None
+            if symmetric:
+                heads = group_first == torch.arange(L, dtype=torch.int32, device=dev)[None, :]          # a group's first visit
+                sizes = torch.tensor([len(g_) for g_ in groups], dtype=torch.int32, device=dev).repeat(B_dec)
+                head_pos = heads.view(-1).nonzero().view(-1)                  # stream-major, visit order: matches `sizes`
+                flat = level.view(-1)[head_pos].long()
+                perm = torch.argsort(flat, stable=True)
+                flat = flat[perm]
+                sel = head_pos[perm]
+                work_n = sizes[perm].contiguous()
+            else:
+                flat = level.view(-1).long()
+                perm = torch.argsort(flat, stable=True)
+                flat = flat[perm]
+                sel = perm
+            nwork = int(sel.numel())
+            work = torch.stack((sel // L, sel % L), 1).to(torch.int32).contiguous()
             common = (W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),
                       St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced),
-                      hip.ptr(pair_bias), work.data_ptr())
+                      hip.ptr(group_first), hip.ptr(group_last), hip.ptr(sym_w), hip.ptr(pair_bias), work.data_ptr(), hip.ptr(work_n))
             tail = (float(fd["temperature"]), special, S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
                     B_dec, B, L, K, hip.current_stream())
             if self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0:
                 # one persistent launch: the level histogram stays on the device (levels < L, so L + 2 offsets; everything behind
-                # the last level equals B_dec * L) — nothing is read back, the call returns with the whole design enqueued
+                # the last level equals nwork) — nothing is read back, the call returns with the whole design enqueued
                 hist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
                 level_off = torch.cat((hist.new_zeros(1), hist.cumsum(0))).to(torch.int32).contiguous()
-                hip.check(Lb.namp_decoder_sample_walk(*common, level_off.data_ptr(), *tail), "decoder_sample_walk")
+                hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), *tail), "decoder_sample_walk")
                 return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                         "uniform": uniform, "levels": (hist > 0).sum()}
             counts = torch.bincount(flat).cpu().tolist()                       # per-level launches: the one host sync of the sampler
             counts_c = (C.c_int32 * len(counts))(*counts)
-            hip.check(Lb.namp_decoder_sample_levels(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),
-                                                    cm32.data_ptr(), St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(),
-                                                    r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced), hip.ptr(pair_bias), work.data_ptr(), counts_c,
-                                                    len(counts), float(fd["temperature"]), special, S_out.data_ptr(),
-                                                    probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(), B_dec, B, L, K,
-                                                    hip.current_stream()), "decoder_sample_levels")
+            hip.check(Lb.namp_decoder_sample_levels(*common, counts_c, len(counts), *tail), "decoder_sample_levels")
             return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                     "uniform": uniform, "levels": len(counts)}
         hip.check(Lb.namp_decoder_sample(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(),

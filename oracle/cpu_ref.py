@@ -450,6 +450,9 @@ def sample_symmetric(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
     rep = lambda a: a.repeat(bs, *([1] * (a.dim() - 1)))
     S_true, h_V, h_E, E_idx = rep(S_true), rep(h_V), rep(h_E), rep(E_idx)
     mask_fw, mask_bw, chain_mask, mask, bias = rep(mask_fw), rep(mask_bw), rep(chain_mask), rep(mask), rep(bias)
+    pair_bias = fd.get("pair_bias")
+    if pair_bias is not None:
+        pair_bias = rep(pair_bias)
     all_probs = torch.zeros((bs, L, nl))
     all_logp = torch.zeros((bs, L, nl))
     h_S = torch.zeros_like(h_V)
@@ -471,7 +474,9 @@ def sample_symmetric(w, fd, top_k, special=SPECIAL_TOKENS, S_forced=None):
             logits = _lin(w, "W_out", stack[-1][:, t])
             all_logp[:, t] = (cm_t[:, None] * F.log_softmax(logits, dim=-1)).float()
             total = total + sym_w[t] * logits
-        probs = F.softmax((total + bias_t) / T, dim=-1)
+            if pair_bias is not None:      # model_utils.py:273-276: the row of member t with the running S; the LAST member's is used (:300)
+                pb = torch.gather(pair_bias[:, t], -1, S[:, None, :, None].repeat(1, nl, 1, 1))[:, :, :, 0].sum(-1)
+        probs = F.softmax((total + bias_t + (pb if pair_bias is not None else 0.0)) / T, dim=-1)
         for tok in special:
             probs[:, tok] = 0
         probs = probs / torch.sum(probs, dim=-1, keepdim=True)

@@ -333,6 +333,16 @@ def g6_sample_variants(weights, n=40, k=16, bs=2):
     torch.manual_seed(12); p2 = cpu_ref.sample(w, fdp, k)
     assert torch.equal(p["S"], p2["S"])
     same(p2["log_probs"], p["log_probs"], "pair_bias log_probs"); same(p2["sampling_probs"], p["sampling_probs"], "pair_bias probs")
+    # symmetry-tied groups AND pair_bias (:273-276, :300-303: the bias row of the group's last member, undrawn members read as PAD)
+    fdq = dict(fds); fdq["pair_bias"] = fdp["pair_bias"]
+    torch.manual_seed(13); q = m.sample(fdq)
+    torch.manual_seed(13); q2 = cpu_ref.sample_symmetric(w, fdq, k)
+    assert torch.equal(q["S"], q2["S"]) and torch.equal(q["decoding_order"], q2["decoding_order"])
+    same(q2["log_probs"], q["log_probs"], "symmetric + pair_bias log_probs"); same(q2["sampling_probs"], q["sampling_probs"], "symmetric + pair_bias probs")
+    assert not torch.equal(q["sampling_probs"], o["sampling_probs"])
+    save("g6b_symmetric_pair_bias", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), randn=fd["randn"].numpy(), pair_bias_AA=pb_AA.numpy(),
+         S=q["S"].numpy().astype(np.int8), log_probs=q["log_probs"].numpy(), probs=q["sampling_probs"].numpy(),
+         order=q["decoding_order"].numpy().astype(np.int32))
     save("g6_sample_variants", in_digest=digest(*[cx[k_] for k_ in sorted(cx)]), randn=fd["randn"].numpy(), pair_bias_AA=pb_AA.numpy(),
          sym_S=o["S"].numpy().astype(np.int8), sym_log_probs=o["log_probs"].numpy(), sym_probs=o["sampling_probs"].numpy(),
          sym_order=o["decoding_order"].numpy().astype(np.int32),

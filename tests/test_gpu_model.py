@@ -266,6 +266,17 @@ def test_sample_symmetric_and_pair_bias_golden(golden_dir, weights_np):
     assert np.array_equal(out["S"].cpu().numpy(), g["pb_S"].astype(np.int64))
     assert maxdiff(out["log_probs"], g["pb_log_probs"]) < 1e-3
     assert maxdiff(out["sampling_probs"], g["pb_probs"]) < 1e-3
+    # both together (golden G6b): the bias row of a group's LAST member, undrawn members read as PAD
+    gb = np.load(os.path.join(golden_dir, "g6b_symmetric_pair_bias.npz"))
+    fdq = dict(fds); fdq["pair_bias"] = fdp["pair_bias"]
+    fdq["S_forced"] = torch.from_numpy(gb["S"].astype(np.int64)).to(dev)
+    for lvl in (True, False):
+        m.sample_level_parallel = lvl
+        out = m.sample(fdq)
+        assert np.array_equal(out["decoding_order"].cpu().numpy(), gb["order"])
+        assert np.array_equal(out["S"].cpu().numpy(), gb["S"].astype(np.int64))
+        assert maxdiff(out["log_probs"], gb["log_probs"]) < 1e-3
+        assert maxdiff(out["sampling_probs"], gb["probs"]) < 1e-3
 
 
 @pytest.mark.parametrize("variant", ["symmetric", "pair_bias"])
@@ -437,6 +448,61 @@ def test_pair_bias_sampling_by_level_equals_the_sequential_walk(weights_np, kind
     ref = cpu_ref.sample(w, fdc, k, S_forced=b["S"].cpu())
     valid = torch.from_numpy(cx["mask"].astype(bool))
     assert maxdiff(w_["log_probs"][:, valid], ref["log_probs"][:, valid]) < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["mixed_groups", "homo_dimer", "with_pair_bias"])
+def test_symmetric_sampling_by_level_equals_the_sequential_walk(weights_np, kind):
+    """Symmetry-tied sampling (model_utils.py:219-326) decoded by dependency level (round 3): a work item is a whole group, its members run
+    one after the other in one workgroup slot (a member gathers the decoder states of the members before it), the group's level is
+    1 + the highest level of its members' dependencies in earlier groups.  Tokens, probabilities and log-probabilities are bit-identical
+    to the sequential walk in both level forms; the walk itself is checked against the oracle's tied sampler, teacher-forced.
+    "mixed_groups": groups of 2-5 (one of consecutive residues, i.e. graph neighbours of each other; one with a fixed member; negative
+    weights) among free residues; "homo_dimer": every residue tied to its copy in the other chain; "with_pair_bias": groups + pair_bias."""
+    from na_mpnn_amd.cli import make_pair_bias
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    if kind == "homo_dimer":
+        n, k, bs = 120, 32, 2
+        cx = synth.make_complex(seed=901, n=n, n_chains=2)
+        groups = [[i, i + 60] for i in range(60)]
+        gw = [[0.5, 0.5] for _ in range(60)]
+    else:
+        n, k, bs = 96, 24, 3
+        cx = synth.make_complex(seed=902, n=n, n_chains=2, masked_frac=0.03)
+        cx["chain_mask"][[2, 40, 71]] = 0
+        groups = [[1, 2, 3], [10, 50], [40, 41], [20, 21, 22, 23, 24], [60, 7, 90, 33], [70, 71]]
+        gw = [[1., 1., 1.], [0.5, 1.5], [1., 2.], [1., -.5, 1., 1., 1.], [.25, .25, .25, .25], [1., 1.]]
+    fd = _sample_fd(cx, dev, bs, 0.6, torch.from_numpy(rng.standard_normal((bs, n)).astype(np.float32)))
+    fd.update({"symmetry_residues": groups, "symmetry_weights": gw})
+    if kind == "with_pair_bias":
+        fd["pair_bias"] = make_pair_bias(fd["chain_labels"][0], fd["R_idx"][0],
+                                         torch.from_numpy(2.0 * rng.standard_normal((33, 33)).astype(np.float32)).to(dev))
+    m = make_model(weights_np, k, dev)
+    outs = []
+    for lvl, walk in ((True, True), (True, False), (False, False)):
+        m.sample_level_parallel, m.sample_level_walk = lvl, walk
+        torch.manual_seed(11)
+        outs.append(m.sample(fd))
+    w_, a, b = outs
+    assert "levels" in a and "levels" not in b and int(w_["levels"]) == a["levels"]
+    n_groups = n - sum(len(g_) - 1 for g_ in groups)
+    assert a["levels"] < n_groups, (a["levels"], n_groups)
+    for o in (w_, a):
+        assert torch.equal(o["decoding_order"], b["decoding_order"])
+        assert torch.equal(o["S"], b["S"]) and torch.equal(o["sampling_probs"], b["sampling_probs"]) and torch.equal(o["log_probs"], b["log_probs"])
+    S = b["S"].cpu()
+    cm = (cx["mask"] * cx["chain_mask"]).astype(bool)
+    for grp in groups:
+        for t_prev, t in zip(grp[:-1], grp[1:]):
+            if cm[t]:
+                assert torch.equal(S[:, t], S[:, t_prev]), grp
+    w = {k_: torch.from_numpy(v) for k_, v in weights_np.items()}
+    fdc = {k_: (v.cpu() if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    ref = cpu_ref.sample_symmetric(w, fdc, k, S_forced=S)
+    valid = torch.from_numpy(cx["mask"].astype(bool))
+    assert torch.equal(ref["decoding_order"], w_["decoding_order"].cpu()) and torch.equal(ref["S"], S)
+    assert maxdiff(w_["log_probs"][:, valid], ref["log_probs"][:, valid]) < 1e-3
+    assert maxdiff(w_["sampling_probs"][:, valid], ref["sampling_probs"][:, valid]) < 1e-3
 
 
 def test_sampler_with_more_than_three_decoder_layers():

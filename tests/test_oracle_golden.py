@@ -174,6 +174,16 @@ def test_g6_symmetric_and_pair_bias_sampling(golden_dir, weights_np):
     exact(p["log_probs"], g["pb_log_probs"]); exact(p["sampling_probs"], g["pb_probs"])
 
 
+def test_g6b_symmetric_with_pair_bias(golden_dir, weights_np):
+    """Symmetry-tied groups together with pair_bias (model_utils.py:273-276, :300-303), teacher-forced with the reference's draws."""
+    g = load(golden_dir, "g6b_symmetric_pair_bias")
+    cx, k, fds, fdp = g6_inputs(g)
+    fds["pair_bias"] = fdp["pair_bias"]
+    o = cpu_ref.sample_symmetric(tw(weights_np), fds, k, S_forced=torch.from_numpy(g["S"].astype(np.int64)))
+    assert np.array_equal(o["decoding_order"].numpy(), g["order"]) and np.array_equal(o["S"].numpy(), g["S"])
+    exact(o["log_probs"], g["log_probs"]); exact(o["sampling_probs"], g["probs"])
+
+
 def g7_inputs():
     n, n2, k = 72, 55, 24
     a = synth.make_complex(seed=700, n=n, n_chains=3, masked_frac=0.04)
