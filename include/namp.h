@@ -463,7 +463,13 @@ int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, co
  *   all streams; the item's workgroup slot runs the members one after the other (a member sees the decoder states of the members
  *   before it, undrawn tokens as in the sequential walk) and draws once.  namp_sample_levels_dep with the group arrays gives every
  *   visit of a group the group's level: 1 + the highest level among its members' dependencies in earlier groups.  Without symmetry
- *   groups: group_first = group_last = sym_weights = work_n = NULL and nwork = B_dec * N. */
+ *   groups: group_first = group_last = sym_weights = work_n = NULL and nwork = B_dec * N.
+ *   Deferred group draw (namp_decoder_sample_walk only; close / close_off / zbuf all set or all NULL): a group may then be SPLIT over
+ *   several work items of the same level — consecutive runs of its visits, e.g. single members when no member is a graph neighbour of
+ *   another (a member that reads an earlier member's decoder state must share the earlier member's run) — which different workgroups
+ *   decode in parallel; each member's logits go to zbuf (float [B_dec][N][vocab], scratch), and after the level's grid barrier one wave
+ *   per group adds them in visit order (the walk's own fma chain: identical bits) and draws.  close = int32 pairs (stream, LAST visit)
+ *   of every group sorted by level, close_off[l] = first pair of level l (like level_off; entries behind the last level = number of groups). */
 int namp_sample_levels(const int32_t* E_idx, const int32_t* order, const int32_t* rank, int32_t* level, int B_dec, int B_enc,
                        int N, int K, void* stream);
 /* ... with extra dependencies per residue, dep_idx int32 [B_enc][N][D] (-1 = none): `pair_bias` (optional argument of the two level
@@ -487,6 +493,7 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
                              const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                              const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
                              const int32_t* work, const int32_t* work_n, int nwork, const int32_t* level_off,
+                             const int32_t* close, const int32_t* close_off, float* zbuf,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream);
 

@@ -1189,9 +1189,13 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
                              const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,
                              const int32_t* group_first, const int32_t* group_last, const float* sym_weights, const float* pair_bias,
                              const int32_t* work, const int32_t* work_n, int nwork, const int32_t* level_off,
+                             const int32_t* close, const int32_t* close_off, float* zbuf,
                              float temperature, uint64_t special_tokens, int32_t* S_out, float* probs_out, float* logp_out,
                              void* ws, size_t ws_bytes, int B_dec, int B_enc, int N, int K, void* stream) {
   REQUIRE(work != nullptr && level_off != nullptr, "namp_decoder_sample_walk: work list / level offsets missing");
+  REQUIRE((close != nullptr) == (close_off != nullptr) && (close != nullptr) == (zbuf != nullptr),
+          "namp_decoder_sample_walk: close, close_off and zbuf go together");
+  REQUIRE(close == nullptr || group_first != nullptr, "namp_decoder_sample_walk: the deferred group draw needs group_first / group_last");
   REQUIRE((work_n != nullptr) == (group_first != nullptr), "namp_decoder_sample_walk: work_n goes with group_first / group_last");
   REQUIRE(nwork >= 1 && nwork <= (long)B_dec * N && (work_n || nwork == (long)B_dec * N),
           "namp_decoder_sample_walk: nwork=%d work items for B_dec*N = %ld visits", nwork, (long)B_dec * N);
@@ -1209,7 +1213,11 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(S_out, 0xFF, (size_t)B_dec * N * sizeof(int32_t), s);          // every token "not drawn" (-1)
   if (e == hipSuccess) e = hipMemsetAsync(sync, 0, NAMP_SYNC_WORDS * sizeof(unsigned), s);
-  if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_walk: hipMemsetAsync: %s", hipGetErrorString(e));
+  if (e == hipSuccess && close) {
+    const unsigned long long defer[3] = {(unsigned long long)zbuf, (unsigned long long)close, (unsigned long long)close_off};
+    e = hipMemcpyAsync(sync + NAMP_SYNC_DEFER, defer, sizeof(defer), hipMemcpyHostToDevice, s);     // (pageable source: staged before the call returns)
+  }
+  if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_walk: hipMemsetAsync / hipMemcpyAsync: %s", hipGetErrorString(e));
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
   const int g2 = (nwork + a.slots - 1) / a.slots;
   launch_sample(2, prec_of(w->dec[0].flags) == PREC_X3, nwaves, g2 < grid ? g2 : grid, s, a, work, work_n, nwork, level_off, sync);

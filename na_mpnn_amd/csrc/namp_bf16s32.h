@@ -112,6 +112,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
     }
     return o;
   };
+  // (Tried: a phase shift of 2-8 k cycles between the two waves of a SIMD, so that one's MFMA-only layer 1 meets the other's GELU stretch:
+  // cfg3 5.64-5.67 ms with and without, profiles/r03e.)
   for (; pair < npairs; pair += stride) {
     asm volatile("" ::: "memory");
     bf8 xb[8];

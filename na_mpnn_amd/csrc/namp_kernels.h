@@ -1311,6 +1311,7 @@ __global__ __launch_bounds__(768) void edge_mlp_kernel(const EdgeArgs a) {
 #define NAMP_SYNC_TOP 8
 #define NAMP_SYNC_GEN 16
 #define NAMP_SYNC_TIMEOUT 32
+#define NAMP_SYNC_DEFER 40          // [40..45] three 64-bit device pointers of the sampler's deferred group draw (dec_sample_kernel, MODE 2)
 #ifndef NAMP_SPIN_LIMIT
 #define NAMP_SPIN_LIMIT (1u << 22)  // polls (each followed by s_sleep): several seconds — a hang becomes a reported failure
 #endif
@@ -1905,6 +1906,73 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
 #ifdef NAMP_ABL_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) namp_stamp_prev = wall_clock64();
 #endif
+  // MODE 2 with symmetry groups split over several work items (members that are not graph neighbours of each other run in parallel):
+  // every member's logits go to zbuf [B_dec][N][vocab]; after the level's grid barrier one wave per group sums them in visit order — the
+  // same fma chain as the running sum of the walk — and draws (close = (stream, last visit) per group sorted by level, close_off per level)
+  float* zbuf = nullptr; const int32_t* close_list = nullptr; const int32_t* close_off = nullptr;
+  if constexpr (MODE == 2) {
+    const unsigned long long* dp = (const unsigned long long*)(sync + NAMP_SYNC_DEFER);
+    zbuf = as_global((float*)dp[0]); close_list = as_global((const int32_t*)dp[1]); close_off = as_global((const int32_t*)dp[2]);
+  }
+  // softmax((total + bias_t [+ pair_bias_t]) / T) with bias of the group's last residue (visit t of stream bq), special tokens removed,
+  // renormalised (model_utils.py:194-205 / :300-312); inverse-CDF draw; the token goes to every member v_first .. t.  One wave.
+  auto draw = [&](const int bq, const int t, const int v_first, const float total) __attribute__((always_inline)) {
+    const int iq = a.order[(long)bq * a.N + t];
+    const int ne = (bq % a.B_enc) * a.N + iq;
+    const long vis = (long)bq * a.N + t;
+    float add = (lane < a.vocab) ? a.bias[(long)ne * a.vocab + lane] : 0.f;
+    if (a.pair_bias && lane < a.vocab) {
+      const float* pb = a.pair_bias + ((long)ne * a.vocab + lane) * a.N * a.vocab;
+      float acc_pb = 0.f;
+      const int rk_i = LEVEL ? a.rank[(long)bq * a.N + iq] : 0;
+      for (int j2 = 0; j2 < a.N; ++j2) {
+        int Sj2 = __hip_atomic_load(a.S_out + (long)bq * a.N + j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // decoded by dependency level, a residue that comes LATER in the decoding order may already hold its token (it sits in
+        // an earlier or in this level when nothing ties it to residue i): the sequential walk sees PAD there
+        if (LEVEL && a.rank[(long)bq * a.N + j2] >= rk_i) Sj2 = -1;
+        if (Sj2 < 0) Sj2 = a.vocab - 1;            // not decoded yet: the reference's initial S is PAD (:157)
+        acc_pb += pb[(long)j2 * a.vocab + Sj2];
+      }
+      add += acc_pb;
+    }
+    float zt = (lane < a.vocab) ? (total + add) * a.inv_T : -INFINITY;
+    float mt = zt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
+    float p = (lane < a.vocab) ? expf(zt - mt) : 0.f;
+    float ps = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) ps += __shfl_xor(ps, o);
+    p = p / ps;
+    if ((a.special >> lane) & 1ull) p = 0.f;
+    float pr = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) pr += __shfl_xor(pr, o);
+    p = p / pr;
+    // inverse CDF: first token whose inclusive prefix sum exceeds u
+    float cdf = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(cdf, o);
+      if (lane >= o) cdf += up;
+    }
+    const float u = a.uniform[vis];
+    const unsigned long long hit = __ballot(p > 0.f && cdf > u);
+    const unsigned long long any = __ballot(p > 0.f);
+    int S_t = hit ? (int)__builtin_ctzll(hit) : (any ? 63 - (int)__builtin_clzll(any) : 0);
+    // assign the draw to every member of the group, in visit order; a fixed member (chain_mask 0) replaces the
+    // running token by its own and passes THAT on — the reference's behaviour (model_utils.py:318-324)
+    for (int v = v_first; v <= t; ++v) {
+      const int im = a.order[(long)bq * a.N + v];
+      const int nem = (bq % a.B_enc) * a.N + im;
+      const long ndm = (long)bq * a.N + im;
+      if (a.S_forced) S_t = a.S_forced[ndm];
+      const int cm = a.chain_mask[nem];
+      if (!cm) S_t = a.S_true[nem];
+      if (lane < a.vocab) a.probs_out[ndm * a.vocab + lane] = cm ? p : 0.f;
+      if (lane == 0) __hip_atomic_store(a.S_out + ndm, S_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   auto step = [&](const int item0, const int nitems, const int t_seq, const bool more) __attribute__((always_inline)) {
     asm volatile("" ::: "memory");      // keep the step's (loop-invariant) vector loads inside the step, not in registers across steps
     NAMP_STAMP(0);                      // (time since the previous stamp: barrier / launch-side)
@@ -2098,6 +2166,10 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         if (lane < a.vocab) a.logp_out[(long)nd * a.vocab + lane] = a.chain_mask[ne] ? logp : 0.f;
         // group logit sum: total += symmetry_weight[i] * logits          (model_utils.py:298)
         const int t = t_lds[n];                          // this slot's visit (== the walk's step unless LEVEL)
+        if (MODE == 2 && zbuf) {                         // deferred group draw: the member's logits wait for the level's closing pass
+          if (lane < a.vocab) __hip_atomic_store(zbuf + (long)nd * a.vocab + lane, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          continue;
+        }
         const long vis = (long)bq * a.N + t;
         const int v_first = a.group_first ? a.group_first[vis] : t;
         const float wsym = a.sym_w ? a.sym_w[ne] : 1.0f;
@@ -2105,60 +2177,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         tot = (v_first == t) ? wsym * zz : fmaf(wsym, zz, tot);
         const bool closes = a.group_last ? (a.group_last[vis] != 0) : true;
         if (!closes) continue;
-        // softmax((total + bias_t [+ pair_bias_t]) / T) with bias of the group's last residue, special tokens removed,
-        // renormalised                                                   (model_utils.py:194-205 / :300-312)
-        float add = (lane < a.vocab) ? a.bias[(long)ne * a.vocab + lane] : 0.f;
-        if (a.pair_bias && lane < a.vocab) {
-          const float* pb = a.pair_bias + ((long)ne * a.vocab + lane) * a.N * a.vocab;
-          float acc_pb = 0.f;
-          const int rk_i = LEVEL ? a.rank[(long)bq * a.N + iq] : 0;
-          for (int j2 = 0; j2 < a.N; ++j2) {
-            int Sj2 = __hip_atomic_load(a.S_out + (long)bq * a.N + j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // decoded by dependency level, a residue that comes LATER in the decoding order may already hold its token (it sits in
-            // an earlier or in this level when nothing ties it to residue i): the sequential walk sees PAD there
-            if (LEVEL && a.rank[(long)bq * a.N + j2] >= rk_i) Sj2 = -1;
-            if (Sj2 < 0) Sj2 = a.vocab - 1;            // not decoded yet: the reference's initial S is PAD (:157)
-            acc_pb += pb[(long)j2 * a.vocab + Sj2];
-          }
-          add += acc_pb;
-        }
-        float zt = (lane < a.vocab) ? (tot + add) * a.inv_T : -INFINITY;
-        float mt = zt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
-        float p = (lane < a.vocab) ? expf(zt - mt) : 0.f;
-        float ps = p;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) ps += __shfl_xor(ps, o);
-        p = p / ps;
-        if ((a.special >> lane) & 1ull) p = 0.f;
-        float pr = p;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) pr += __shfl_xor(pr, o);
-        p = p / pr;
-        // inverse CDF: first token whose inclusive prefix sum exceeds u
-        float cdf = p;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const float up = __shfl_up(cdf, o);
-          if (lane >= o) cdf += up;
-        }
-        const float u = a.uniform[vis];
-        const unsigned long long hit = __ballot(p > 0.f && cdf > u);
-        const unsigned long long any = __ballot(p > 0.f);
-        int S_t = hit ? (int)__builtin_ctzll(hit) : (any ? 63 - (int)__builtin_clzll(any) : 0);
-        // assign the draw to every member of the group, in visit order; a fixed member (chain_mask 0) replaces the
-        // running token by its own and passes THAT on — the reference's behaviour (model_utils.py:318-324)
-        for (int v = v_first; v <= t; ++v) {
-          const int im = a.order[(long)bq * a.N + v];
-          const int nem = (bq % a.B_enc) * a.N + im;
-          const long ndm = (long)bq * a.N + im;
-          if (a.S_forced) S_t = a.S_forced[ndm];
-          const int cm = a.chain_mask[nem];
-          if (!cm) S_t = a.S_true[nem];
-          if (lane < a.vocab) a.probs_out[ndm * a.vocab + lane] = cm ? p : 0.f;
-          if (lane == 0) __hip_atomic_store(a.S_out + ndm, S_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        draw(bq, t, v_first, tot);
       }
     }
     __syncthreads();              // S of this step is published before the next step's neighbours read it
@@ -2181,6 +2200,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
 #pragma unroll 1
     for (int q = 0; q < nmem; ++q) step(blockIdx.x * a.slots, nwork, q, q + 1 < nmem);
   } else {
+    unsigned epoch = 0;
 #pragma unroll 1
     for (int lvl = 0;; ++lvl) {
       const int off = level_off[lvl];
@@ -2192,7 +2212,25 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
 #pragma unroll 1
         for (int q = 0; q < nmem; ++q) step(base, end, q, true);
       }
-      grid_barrier(sync, (unsigned)lvl + 1u, tid);
+      grid_barrier(sync, ++epoch, tid);
+      if (zbuf) {
+        // the level's groups: one wave each sums its members' logits in visit order and draws
+        const int c1 = close_off[lvl + 1];
+#pragma unroll 1
+        for (int gi = close_off[lvl] + blockIdx.x * nwaves + wave; gi < c1; gi += gridDim.x * nwaves) {
+          const int bq = close_list[2 * gi], tl = close_list[2 * gi + 1];
+          const int vf = a.group_first ? a.group_first[(long)bq * a.N + tl] : tl;
+          float tt = 0.f;
+          for (int v = vf; v <= tl; ++v) {
+            const int im = a.order[(long)bq * a.N + v];
+            const float zv = (lane < a.vocab) ? __hip_atomic_load(zbuf + ((long)bq * a.N + im) * a.vocab + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            const float wsym = a.sym_w ? a.sym_w[(bq % a.B_enc) * a.N + im] : 1.0f;
+            tt = (v == vf) ? wsym * zv : fmaf(wsym, zv, tt);
+          }
+          draw(bq, tl, vf, tt);
+        }
+        grid_barrier(sync, ++epoch, tid);
+      }
     }
     // a barrier that gave up let its workgroup run ahead of data it needed: the failure travels with the outputs (cf. encdec_persistent_kernel)
     if (__hip_atomic_load((gu32*)sync + NAMP_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {

@@ -133,7 +133,7 @@ _PROTOTYPES = {
     "namp_decoder_sample_walk_grid": (i32, [i32, i32, i32]),
     "namp_decoder_sample_walk": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                        c_ip, c_ip, c_fp, c_fp,
-                                       c_ip, c_ip, i32, c_ip,
+                                       c_ip, c_ip, i32, c_ip, c_ip, c_ip, c_fp,
                                        C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_profile_enable": (i32, [i32]),
     "namp_profile_collect": (i32, [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]),

@@ -457,6 +457,8 @@ class ProteinMPNN(nn.Module):
     sample_level_parallel = True
     # ... as ONE persistent launch walking the levels (no host read-back, warm L2); False: one launch per level
     sample_level_walk = True
+    # symmetry-tied groups whose members are not graph neighbours of each other: members decoded in parallel, one deferred draw per group
+    sample_split_groups = True
 
     @torch.no_grad()
     def sample(self, feature_dict):
@@ -558,10 +560,36 @@ class ProteinMPNN(nn.Module):
                                                 hip.ptr(group_first), hip.ptr(group_last), level.data_ptr(),
                                                 B_dec, B, L, K, hip.current_stream()), "sample_levels")
             work_n = None
+            walk = self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0
+            close = close_off = zbuf = None
             if symmetric:
-                heads = group_first == torch.arange(L, dtype=torch.int32, device=dev)[None, :]          # a group's first visit
-                sizes = torch.tensor([len(g_) for g_ in groups], dtype=torch.int32, device=dev).repeat(B_dec)
-                head_pos = heads.view(-1).nonzero().view(-1)                  # stream-major, visit order: matches `sizes`
+                ar = torch.arange(L, dtype=torch.int32, device=dev)
+                gf0 = group_first[0]
+                gsize = torch.bincount(gf0.long(), minlength=L).to(torch.int32)                       # by first visit
+                whole = torch.ones(L, dtype=torch.bool, device=dev)                                    # visit v belongs to a group run as ONE item
+                if walk and self.sample_split_groups:
+                    # groups none of whose members is a graph neighbour of another member are split into single-member items that different
+                    # workgroups decode in parallel; their draw is deferred to the level's closing pass (namp.h: deferred group draw)
+                    ord0 = order[0].long()
+                    gid_res = torch.empty(L, dtype=torch.int32, device=dev).scatter_(0, ord0, gf0)    # residue -> its group's first visit
+                    nb = E_idx[0].long()
+                    intra = ((gid_res[nb] == gid_res[:, None]) & (nb != ar[:, None].long())).any(1)   # residue has a neighbour in its own group
+                    gdep = torch.zeros(L, dtype=torch.int32, device=dev).scatter_reduce_(0, gf0.long(), intra[ord0].to(torch.int32), "amax")
+                    whole = gdep[gf0.long()] > 0
+                    lastv = (group_last[0] != 0).nonzero().view(-1)                                    # one closing entry per group and stream
+                    cl_v = lastv.repeat(B_dec)
+                    cl_b = torch.arange(B_dec, device=dev).repeat_interleave(lastv.numel())
+                    cl_lv = level[cl_b, cl_v].long()
+                    cperm = torch.argsort(cl_lv, stable=True)
+                    close = torch.stack((cl_b[cperm], cl_v[cperm]), 1).to(torch.int32).contiguous()
+                    chist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, cl_lv, torch.ones_like(cl_lv))
+                    close_off = torch.cat((chist.new_zeros(1), chist.cumsum(0))).to(torch.int32).contiguous()
+                    zbuf = torch.empty(B_dec, L, self.num_letters, device=dev)
+                heads0 = (~whole) | (gf0 == ar)                                                        # an item starts at this visit
+                n0 = torch.where(whole, gsize[gf0.long()], torch.ones_like(gsize))
+                head_pos0 = heads0.nonzero().view(-1)
+                head_pos = (torch.arange(B_dec, device=dev)[:, None] * L + head_pos0[None, :]).view(-1)   # stream-major
+                sizes = n0[head_pos0].repeat(B_dec)
                 flat = level.view(-1)[head_pos].long()
                 perm = torch.argsort(flat, stable=True)
                 flat = flat[perm]
@@ -579,14 +607,15 @@ class ProteinMPNN(nn.Module):
                       hip.ptr(group_first), hip.ptr(group_last), hip.ptr(sym_w), hip.ptr(pair_bias), work.data_ptr(), hip.ptr(work_n))
             tail = (float(fd["temperature"]), special, S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
                     B_dec, B, L, K, hip.current_stream())
-            if self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0:
+            if walk:
                 # one persistent launch: the level histogram stays on the device (levels < L, so L + 2 offsets; everything behind
                 # the last level equals nwork) — nothing is read back, the call returns with the whole design enqueued
                 hist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
                 level_off = torch.cat((hist.new_zeros(1), hist.cumsum(0))).to(torch.int32).contiguous()
-                hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), *tail), "decoder_sample_walk")
+                hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), hip.ptr(close), hip.ptr(close_off), hip.ptr(zbuf),
+                                                      *tail), "decoder_sample_walk")
                 return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
-                        "uniform": uniform, "levels": (hist > 0).sum()}
+                        "uniform": uniform, "levels": (hist > 0).sum(), "work_items": nwork}
             counts = torch.bincount(flat).cpu().tolist()                       # per-level launches: the one host sync of the sampler
             counts_c = (C.c_int32 * len(counts))(*counts)
             hip.check(Lb.namp_decoder_sample_levels(*common, counts_c, len(counts), *tail), "decoder_sample_levels")

@@ -455,7 +455,8 @@ def test_symmetric_sampling_by_level_equals_the_sequential_walk(weights_np, kind
     """Symmetry-tied sampling (model_utils.py:219-326) decoded by dependency level (round 3): a work item is a whole group, its members run
     one after the other in one workgroup slot (a member gathers the decoder states of the members before it), the group's level is
     1 + the highest level of its members' dependencies in earlier groups.  Tokens, probabilities and log-probabilities are bit-identical
-    to the sequential walk in both level forms; the walk itself is checked against the oracle's tied sampler, teacher-forced.
+    to the sequential walk in both level forms — and with the groups whose members are not graph neighbours of each other split into
+    single-member work items with a deferred draw (`sample_split_groups`); the walk itself is checked against the oracle's tied sampler.
     "mixed_groups": groups of 2-5 (one of consecutive residues, i.e. graph neighbours of each other; one with a fixed member; negative
     weights) among free residues; "homo_dimer": every residue tied to its copy in the other chain; "with_pair_bias": groups + pair_bias."""
     from na_mpnn_amd.cli import make_pair_bias
@@ -479,15 +480,17 @@ def test_symmetric_sampling_by_level_equals_the_sequential_walk(weights_np, kind
                                          torch.from_numpy(2.0 * rng.standard_normal((33, 33)).astype(np.float32)).to(dev))
     m = make_model(weights_np, k, dev)
     outs = []
-    for lvl, walk in ((True, True), (True, False), (False, False)):
-        m.sample_level_parallel, m.sample_level_walk = lvl, walk
+    for lvl, walk, split in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        m.sample_level_parallel, m.sample_level_walk, m.sample_split_groups = lvl, walk, split
         torch.manual_seed(11)
         outs.append(m.sample(fd))
-    w_, a, b = outs
-    assert "levels" in a and "levels" not in b and int(w_["levels"]) == a["levels"]
+    w_, ws_, a, b = outs
+    assert "levels" in a and "levels" not in b and int(w_["levels"]) == a["levels"] == int(ws_["levels"])
     n_groups = n - sum(len(g_) - 1 for g_ in groups)
     assert a["levels"] < n_groups, (a["levels"], n_groups)
-    for o in (w_, a):
+    # groups without internal graph edges were split into single-member items (more items than groups), the others kept whole
+    assert ws_["work_items"] == bs * n_groups and bs * n_groups < w_["work_items"] <= bs * n, (w_["work_items"], n_groups)
+    for o in (w_, ws_, a):
         assert torch.equal(o["decoding_order"], b["decoding_order"])
         assert torch.equal(o["S"], b["S"]) and torch.equal(o["sampling_probs"], b["sampling_probs"]) and torch.equal(o["log_probs"], b["log_probs"])
     S = b["S"].cpu()
