@@ -234,6 +234,9 @@ __device__ __forceinline__ void split_x3(const f4 a, const f4 b, bf8& hi, bf8& m
 }
 // acc += W . x for one fragment pair (hi, mid images of the same tile): the three split products
 __device__ __forceinline__ f4 mfma_x3(const bf8 wh, const bf8 wm, const bf8 hi, const bf8 mid, f4 acc) {
+#ifdef NAMP_ABL_X1
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc, 0, 0, 0);
+#endif
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mid, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc, 0, 0, 0);
