@@ -455,7 +455,7 @@ int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, co
  *   namp_decoder_sample_walk (round 3): the same levels in ONE persistent launch — no kernel boundary per level (whose cold L2 made
  *     the level's workgroups re-fetch the decoder weights at ~45 GB/s) and no host read-back: level_off = DEVICE int32 array,
  *     level_off[l] = index of the first pair of level l in `work`, every entry behind the last level = nwork (at least N + 2
- *     entries).  namp_decoder_sample_walk_grid workgroups (<= 128, one per CU: the device must not be shared with other
+ *     entries).  namp_decoder_sample_walk_grid workgroups (<= min(128, half the device's CUs), one per CU: the device must not be shared with other
  *     streams meanwhile) walk the levels with a grid barrier in between; a barrier that gives up (bounded spin) makes the launch
  *     overwrite log_probs with NaN.  K <= 128 (returns 0 workgroups otherwise: use the per-level launches).  Identical draws.
  * Symmetry-tied sampling (model_utils.py:219-326; group_first / group_last / sym_weights as in namp_decoder_sample): a work item is a

@@ -1181,7 +1181,10 @@ int namp_decoder_sample_walk_grid(int B_dec, int N, int K) {
   const int tpn = (K + 15) / 16;
   int slots = 8 / tpn; if (slots > NAMP_SAMPLE_SLOTS) slots = NAMP_SAMPLE_SLOTS; if (slots < 1) slots = 1;
   long g = ((long)B_dec * N + slots - 1) / slots;
-  return (int)(g < NAMP_WALK_MAX_GRID ? g : NAMP_WALK_MAX_GRID);
+  // every workgroup must be resident at once (155 KiB of LDS: one per CU) — half the device's CUs at most, so that a partitioned
+  // device (e.g. 32 CUs per partition) still co-schedules them
+  const int cap = device_cus() / 2 < NAMP_WALK_MAX_GRID ? device_cus() / 2 : NAMP_WALK_MAX_GRID;
+  return (int)(g < cap ? g : (cap < 1 ? 1 : cap));
 }
 
 int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
