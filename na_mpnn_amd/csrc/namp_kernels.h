@@ -2196,9 +2196,13 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
 #pragma unroll 1
     for (int t_seq = 0; t_seq < a.N; ++t_seq) step(blockIdx.x * a.slots, a.B_dec, t_seq, t_seq + 1 < a.N);
   } else if constexpr (MODE == 1) {
-    const int nmem = members(blockIdx.x * a.slots, nwork);
+    if (!work_n) {
+      step(blockIdx.x * a.slots, nwork, 0, false);
+    } else {
+      const int nmem = members(blockIdx.x * a.slots, nwork);
 #pragma unroll 1
-    for (int q = 0; q < nmem; ++q) step(blockIdx.x * a.slots, nwork, q, q + 1 < nmem);
+      for (int q = 0; q < nmem; ++q) step(blockIdx.x * a.slots, nwork, q, q + 1 < nmem);
+    }
   } else {
     unsigned epoch = 0;
 #pragma unroll 1
