@@ -36,6 +36,35 @@ __device__ __forceinline__ bf8 gelu_pack8(const f16v& v, const int u) {
   return pack_bf16<true>(lo, hi);
 }
 
+// One 32-row x 128 x 128 product on v_mfma_f32_32x32x16_bf16 with the weight fragments of K-step s + 1 requested from LDS before the MFMAs
+// of step s issue (two fragment sets in flight: 32 VGPRs).  Left to itself the compiler reads two fragments, waits for them, issues two
+// MFMAs, and so on: every pair of MFMAs then pays a full LDS round trip, with only two waves per SIMD to cover it.
+//   FLIP: F orientation (A = activations, B = weights).  op(s) returns the activation operand of K-step s (a stored row piece, or the
+//   GELU of eight accumulators of the previous layer, evaluated while the fragments are on their way).
+// PIN: a scheduling barrier behind the requests that only VALU instructions may cross (`__builtin_amdgcn_sched_barrier(2)`) keeps them ahead
+// of the step's MFMAs.  Measured (cfg3, same box, alternating): decoder message 0.407-0.412 -> 0.387-0.390 ms, but the edge update
+// 0.59 -> 0.71 and the embedding variant slower too (they are at 256 VGPRs: the barrier makes them spill) — so only the plain message launches pin
+// (pinning just layer 1 of the edge update / the embedding variant: +1 % / +4 % on those launches, profiles/r03e).
+template <bool FLIP, bool PIN, class Op>
+__device__ __forceinline__ void gemm32(f16v (&out)[4], const bf8* w, Op op) {
+  bf8 wf[2][4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) wf[0][tn] = w[tn * 64];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s + 1 < 8) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) wf[(s + 1) & 1][tn] = w[((s + 1) * 4 + tn) * 64];
+    }
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(2);
+    const bf8 ab = op(s);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+      out[tn] = FLIP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, wf[s & 1][tn], out[tn], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][tn], ab, out[tn], 0, 0, 0);
+  }
+}
+
 // LDS: W1 | W2 | W3 or W_e (32 KiB each) | constants (2 KiB) | per wave: two Pa rows (512 B) + 32 row weights (128 B)
 #define BF16S32_LDS (3 * NAMP_BIMG_BYTES + 2048 + 8 * 512 + 8 * 128)
 
@@ -45,6 +74,7 @@ template <int MODE, bool EMB = false>
 __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a) {
   static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
   constexpr bool EDGE = MODE == MODE_ENC_EDGE;
+  constexpr bool PIN = !EDGE && !EMB;                 // see gemm32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,10 +154,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       f16v he[4];
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) he[tn] = vec16(cst + 128, tn);
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) he[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[(s * 4 + tn) * 64], xn[s], he[tn], 0, 0, 0);
+      gemm32<false, false>(he, w3, [&](const int s) { return xn[s]; });
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int tin = s >> 1, u = s & 1;
@@ -167,10 +194,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
     pa_fetch(cur);
     row_fetch(cur);
     // ---- layer 1 (T): the stored row IS the operand
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[(s * 4 + tn) * 64], xb[s], acc[tn], 0, 0, 0);
+    gemm32<false, PIN>(acc, w1, [&](const int s) { return xb[s]; });
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
@@ -181,20 +205,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       // ---- layers 2 and 3 (T), residual, LayerNorm 3, the row back as bf16
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) y[tn] = vec16(cst, tn);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bf8 ab = gelu_pack8(acc[s >> 1], s & 1);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) y[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[(s * 4 + tn) * 64], ab, y[tn], 0, 0, 0);
-      }
+      gemm32<false, false>(y, w2, [&](const int s) { return gelu_pack8(acc[s >> 1], s & 1); });
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tn] = vec16(cst + 128, tn);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bf8 ab = gelu_pack8(y[s >> 1], s & 1);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[(s * 4 + tn) * 64], ab, acc[tn], 0, 0, 0);
-      }
+      gemm32<false, false>(acc, w3, [&](const int s) { return gelu_pack8(y[s >> 1], s & 1); });
       float sum = 0.f;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
@@ -235,12 +249,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) y[tn][v] = b;
       }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bf8 ab = gelu_pack8(acc[s >> 1], s & 1);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) y[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, w2[(s * 4 + tn) * 64], y[tn], 0, 0, 0);
-      }
+      gemm32<true, PIN>(y, w2, [&](const int s) { return gelu_pack8(acc[s >> 1], s & 1); });
       // ---- K-sums of the layer-2 activations, per 16-row half
       f4 wv[4];
 #pragma unroll
