@@ -242,6 +242,8 @@ __device__ __forceinline__ f4 mfma_x3(const bf8 wh, const bf8 wm, const bf8 hi, 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc, 0, 0, 0);
 }
 
+// (Tried, round 3: the hi fragments of the next group requested before this group's twelve MFMAs, pinned by a scheduling barrier as in
+// namp_bf16s32.h's gemm32 — the 168-VGPR kernels spill: cfg3 split-bf16 13.2 -> 14.3-17.4 ms per step, cfg2 unchanged.)
 template <bool FLIP, bool ACT>
 __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
 #pragma unroll
