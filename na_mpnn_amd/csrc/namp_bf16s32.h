@@ -1,4 +1,6 @@
-// edge_mlp_bf16s32_kernel — the bf16-storage message launches on v_mfma_f32_32x32x16_bf16 (round 3 prototype).
+// edge_mlp_bf16s32_kernel — the edge launches of the bf16-storage path (large batches of the bf16 mode, namp.hip: encdec_bf16_storage) on
+// v_mfma_f32_32x32x16_bf16: EncLayer message (model_utils.py:666-672; optionally with h_E = W_e . E + b_e, :89, in front), EncLayer edge
+// update (:697-702), DecLayer message on the implicit context (:636-646).  Round 3; the 16x16x32 form it replaced: profiles/r03e.
 //
 // One wave = 32 rows = two consecutive 16-row tiles of the flat tile list (the halves may belong to different residues).
 //   v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8(l>>5) + j], B[k = 8(l>>5) + j][n = l&31], j = 0..7, and receives
@@ -22,11 +24,6 @@ static __global__ void pack_image_bf16_32_kernel(const float* __restrict__ W, in
   const int j = e & 7, lane = (e >> 3) & 63, tn = (e >> 9) & 3, s = e >> 11;
   const int n = 32 * tn + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
   img[e] = (__bf16)W[(size_t)n * ld + col0 + k];
-}
-
-__device__ __forceinline__ void bf8_to_f32x8(const bf8 v, float* o) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
 }
 
 // GELU (bf16-mode polynomial) of eight accumulators -> the bf16 operand of one K-step
