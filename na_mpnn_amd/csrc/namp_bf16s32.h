@@ -40,8 +40,8 @@ __device__ __forceinline__ bf8 gelu_pack8(const f16v& v, const int u) {
 //   GELU of eight accumulators of the previous layer, evaluated while the fragments are on their way).
 // PIN: a scheduling barrier behind the requests that only VALU instructions may cross (`__builtin_amdgcn_sched_barrier(2)`) keeps them ahead
 // of the step's MFMAs.  Measured (cfg3, same box, alternating): decoder message 0.407-0.412 -> 0.387-0.390 ms, but the edge update
-// 0.59 -> 0.71 and the embedding variant slower too (they are at 256 VGPRs: the barrier makes them spill) — so only the plain message launches pin
-// (pinning just layer 1 of the edge update / the embedding variant: +1 % / +4 % on those launches, profiles/r03e).
+// 0.59 -> 0.71 and the embedding variant slower too (they are at 256 VGPRs: the barrier makes them spill).  The edge update pins once its
+// next-row prefetch is issued late (see the kernel); the embedding variant does not pin.
 template <bool FLIP, bool PIN, class Op>
 __device__ __forceinline__ void gemm32(f16v (&out)[4], const bf8* w, Op op) {
   bf8 wf[2][4];
@@ -72,6 +72,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
   static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
   constexpr bool EDGE = MODE == MODE_ENC_EDGE;
   constexpr bool PIN = !EDGE && !EMB;                 // see gemm32
+  // the edge update pins all three products and requests the next pair's rows late (behind layer 2) instead of at the top of the step: 32
+  // registers less across layers 1 and 2, which pays for the second fragment set (4 spilled registers; 0.565 -> 0.533 ms per launch).  The
+  // embedding variant (fp32 rows in flight) spills 23 registers with the same treatment and keeps the compiler's schedule.
+  constexpr bool EPIN = EDGE, LATE_ROW = EDGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,9 +193,9 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
     cur = meta_of(np < npairs ? np : pair);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     pa_fetch(cur);
-    row_fetch(cur);
+    if constexpr (!LATE_ROW) row_fetch(cur);
     // ---- layer 1 (T): the stored row IS the operand
-    gemm32<false, PIN>(acc, w1, [&](const int s) { return xb[s]; });
+    gemm32<false, PIN || EPIN>(acc, w1, [&](const int s) { return xb[s]; });
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
@@ -202,10 +206,11 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       // ---- layers 2 and 3 (T), residual, LayerNorm 3, the row back as bf16
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) y[tn] = vec16(cst, tn);
-      gemm32<false, false>(y, w2, [&](const int s) { return gelu_pack8(acc[s >> 1], s & 1); });
+      gemm32<false, EPIN>(y, w2, [&](const int s) { return gelu_pack8(acc[s >> 1], s & 1); });
+      row_fetch(cur);                                       // the next pair's rows (LATE_ROW)
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tn] = vec16(cst + 128, tn);
-      gemm32<false, false>(acc, w3, [&](const int s) { return gelu_pack8(y[s >> 1], s & 1); });
+      gemm32<false, EPIN>(acc, w3, [&](const int s) { return gelu_pack8(y[s >> 1], s & 1); });
       float sum = 0.f;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
