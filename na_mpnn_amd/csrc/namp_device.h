@@ -243,7 +243,9 @@ __device__ __forceinline__ f4 mfma_x3(const bf8 wh, const bf8 wm, const bf8 hi, 
 }
 
 // (Tried, round 3: the hi fragments of the next group requested before this group's twelve MFMAs, pinned by a scheduling barrier as in
-// namp_bf16s32.h's gemm32 — the 168-VGPR kernels spill: cfg3 split-bf16 13.2 -> 14.3-17.4 ms per step, cfg2 unchanged.)
+// namp_bf16s32.h's gemm32 — the 168-VGPR kernels spill: cfg3 split-bf16 13.2 -> 14.3-17.4 ms per step, cfg2 unchanged; the persistent kernel
+// with 8 waves per workgroup (208-241 VGPRs, no spills) and that prefetch: 12.3 -> 12.6 ms, 13.2 without the prefetch — the third wave per SIMD
+// is worth more than the fragments in flight.)
 template <bool FLIP, bool ACT>
 __device__ __forceinline__ void chain_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
 #pragma unroll
