@@ -81,6 +81,51 @@ def _require_device(t, what):
                            "(no CPU fallback — use the reference or oracle/cpu_ref.py for CPU checks)")
 
 
+def level_work_lists(level, group_first, group_last, order0, E_idx0, split):
+    """Work lists of the level-parallel sampler (include/namp.h: namp_decoder_sample_levels / _walk) from the per-visit levels.
+
+    level [B_dec, L] int32 by visit (namp_sample_levels_dep); group_first / group_last [B_dec, L] int32 by visit, or None without
+    symmetry groups (every stream has the same groups); order0 [L] the residues in visit order, E_idx0 [L, K] the neighbour lists.
+    Returns (sel, flat, work_n, close, close_off): sel = stream * L + first visit of every work item, sorted by level (flat = those
+    levels); work_n = visits per item (None without groups); close / close_off = the deferred-draw lists when `split`, else None.
+    split: a group none of whose members has another member among its graph neighbours becomes single-member items (decoded in
+    parallel, one deferred draw per group); a group with internal edges stays ONE item whose members run one after the other."""
+    B_dec, L = level.shape
+    dev = level.device
+    if group_first is None:
+        flat = level.reshape(-1).long()
+        perm = torch.argsort(flat, stable=True)
+        return perm, flat[perm], None, None, None
+    ar = torch.arange(L, dtype=torch.int32, device=dev)
+    gf0 = group_first[0].to(torch.int32)
+    gsize = torch.bincount(gf0.long(), minlength=L).to(torch.int32)                       # by first visit
+    whole = torch.ones(L, dtype=torch.bool, device=dev)                                    # visit v belongs to a group run as ONE item
+    close = close_off = None
+    if split:
+        ord0 = order0.long()
+        gid_res = torch.empty(L, dtype=torch.int32, device=dev).scatter_(0, ord0, gf0)    # residue -> its group's first visit
+        nb = E_idx0.long()
+        intra = ((gid_res[nb] == gid_res[:, None]) & (nb != ar[:, None].long())).any(1)   # residue has a neighbour in its own group
+        gdep = torch.zeros(L, dtype=torch.int32, device=dev).scatter_reduce_(0, gf0.long(), intra[ord0].to(torch.int32), "amax")
+        whole = gdep[gf0.long()] > 0
+        lastv = (group_last[0] != 0).nonzero().view(-1)                                    # one closing entry per group and stream
+        cl_v = lastv.repeat(B_dec)
+        cl_b = torch.arange(B_dec, device=dev).repeat_interleave(lastv.numel())
+        cl_lv = level[cl_b, cl_v].long()
+        cperm = torch.argsort(cl_lv, stable=True)
+        close = torch.stack((cl_b[cperm], cl_v[cperm]), 1).to(torch.int32).contiguous()
+        chist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, cl_lv, torch.ones_like(cl_lv))
+        close_off = torch.cat((chist.new_zeros(1), chist.cumsum(0))).to(torch.int32).contiguous()
+    heads0 = (~whole) | (gf0 == ar)                                                        # an item starts at this visit
+    n0 = torch.where(whole, gsize[gf0.long()], torch.ones_like(gsize))
+    head_pos0 = heads0.nonzero().view(-1)
+    head_pos = (torch.arange(B_dec, device=dev)[:, None] * L + head_pos0[None, :]).view(-1)   # stream-major
+    sizes = n0[head_pos0].repeat(B_dec)
+    flat = level.reshape(-1)[head_pos].long()
+    perm = torch.argsort(flat, stable=True)
+    return head_pos[perm], flat[perm], sizes[perm].contiguous(), close, close_off
+
+
 class ProteinMPNN(nn.Module):
     """Same constructor keywords as the inference copy (model_utils.py:9-23); the training copy's
     extra keywords (na_model_utils.py:520-539) are accepted as well."""
@@ -559,47 +604,13 @@ class ProteinMPNN(nn.Module):
             hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep,
                                                 hip.ptr(group_first), hip.ptr(group_last), level.data_ptr(),
                                                 B_dec, B, L, K, hip.current_stream()), "sample_levels")
-            work_n = None
             walk = self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0
-            close = close_off = zbuf = None
-            if symmetric:
-                ar = torch.arange(L, dtype=torch.int32, device=dev)
-                gf0 = group_first[0]
-                gsize = torch.bincount(gf0.long(), minlength=L).to(torch.int32)                       # by first visit
-                whole = torch.ones(L, dtype=torch.bool, device=dev)                                    # visit v belongs to a group run as ONE item
-                if walk and self.sample_split_groups:
-                    # groups none of whose members is a graph neighbour of another member are split into single-member items that different
-                    # workgroups decode in parallel; their draw is deferred to the level's closing pass (namp.h: deferred group draw)
-                    ord0 = order[0].long()
-                    gid_res = torch.empty(L, dtype=torch.int32, device=dev).scatter_(0, ord0, gf0)    # residue -> its group's first visit
-                    nb = E_idx[0].long()
-                    intra = ((gid_res[nb] == gid_res[:, None]) & (nb != ar[:, None].long())).any(1)   # residue has a neighbour in its own group
-                    gdep = torch.zeros(L, dtype=torch.int32, device=dev).scatter_reduce_(0, gf0.long(), intra[ord0].to(torch.int32), "amax")
-                    whole = gdep[gf0.long()] > 0
-                    lastv = (group_last[0] != 0).nonzero().view(-1)                                    # one closing entry per group and stream
-                    cl_v = lastv.repeat(B_dec)
-                    cl_b = torch.arange(B_dec, device=dev).repeat_interleave(lastv.numel())
-                    cl_lv = level[cl_b, cl_v].long()
-                    cperm = torch.argsort(cl_lv, stable=True)
-                    close = torch.stack((cl_b[cperm], cl_v[cperm]), 1).to(torch.int32).contiguous()
-                    chist = torch.zeros(L + 1, dtype=torch.int64, device=dev).scatter_add_(0, cl_lv, torch.ones_like(cl_lv))
-                    close_off = torch.cat((chist.new_zeros(1), chist.cumsum(0))).to(torch.int32).contiguous()
-                    zbuf = torch.empty(B_dec, L, self.num_letters, device=dev)
-                heads0 = (~whole) | (gf0 == ar)                                                        # an item starts at this visit
-                n0 = torch.where(whole, gsize[gf0.long()], torch.ones_like(gsize))
-                head_pos0 = heads0.nonzero().view(-1)
-                head_pos = (torch.arange(B_dec, device=dev)[:, None] * L + head_pos0[None, :]).view(-1)   # stream-major
-                sizes = n0[head_pos0].repeat(B_dec)
-                flat = level.view(-1)[head_pos].long()
-                perm = torch.argsort(flat, stable=True)
-                flat = flat[perm]
-                sel = head_pos[perm]
-                work_n = sizes[perm].contiguous()
-            else:
-                flat = level.view(-1).long()
-                perm = torch.argsort(flat, stable=True)
-                flat = flat[perm]
-                sel = perm
+            zbuf = None
+            sel, flat, work_n, close, close_off = level_work_lists(
+                level, group_first if symmetric else None, group_last if symmetric else None, order[0], E_idx[0],
+                split=bool(symmetric and walk and self.sample_split_groups))
+            if close is not None:
+                zbuf = torch.empty(B_dec, L, self.num_letters, device=dev)
             nwork = int(sel.numel())
             work = torch.stack((sel // L, sel % L), 1).to(torch.int32).contiguous()
             common = (W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),

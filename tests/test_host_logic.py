@@ -235,3 +235,82 @@ def test_device_gelu_formula_accuracy():
     per_edge = ((a2 @ W3.T + b3) * w[:, None]).sum(0)
     hoisted = W3 @ (a2 * w[:, None]).sum(0) + b3 * w.sum()
     assert np.abs(per_edge - hoisted).max() < 1e-12
+
+
+def _levels_ref(E_idx, order, gf, gl):
+    """sample_levels_kernel (csrc/namp_kernels.h) restated: one level per symmetry group = 1 + the highest level among its members'
+    earlier neighbours in EARLIER groups."""
+    L = len(order)
+    rank = np.empty(L, dtype=np.int64); rank[order] = np.arange(L)
+    lv = np.full(L, -1); out = np.zeros(L, dtype=np.int32)
+    dg = -1
+    for t in range(L):
+        i, vf = order[t], gf[t]
+        d = max([lv[j] for j in E_idx[i] if rank[j] < vf], default=-1)
+        dg = d if vf == t else max(dg, d)
+        if gl[t]:
+            for v in range(vf, t + 1):
+                lv[order[v]] = dg + 1; out[v] = dg + 1
+    return out, rank
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_level_work_lists_of_the_symmetric_sampler(split):
+    """Host side of the level-parallel sampler (model.level_work_lists): every visit belongs to exactly one work item, items come sorted by
+    level, a symmetry group is one item unless `split` and none of its members is a graph neighbour of another member, every earlier
+    neighbour outside the group sits in a lower level, and the deferred-draw lists name every group once per stream."""
+    from na_mpnn_amd.model import level_work_lists
+    rng = np.random.default_rng(5)
+    L, K, B_dec = 60, 8, 3
+    E_idx = np.stack([np.concatenate(([i], rng.choice(np.delete(np.arange(L), i), K - 1, replace=False))) for i in range(L)])
+    groups_in = [[3, 4, 5], [10, 40], [20, 50, 7, 33], [11, 12]]
+    E_idx[10, 1:] = [x for x in range(L) if x not in (10, 40)][:K - 1]                    # group [10, 40]: no internal edge
+    E_idx[40, 1:] = [x for x in range(L) if x not in (10, 40)][5:5 + K - 1]
+    E_idx[4, 1] = 3                                                                       # group [3, 4, 5]: 4 neighbours 3
+    for a in (20, 50, 7, 33):
+        E_idx[a, 1:] = [x for x in range(L) if x not in (20, 50, 7, 33)][a % 9:a % 9 + K - 1]
+    E_idx[12, 2] = 11
+    group_of = {r: g for g in groups_in for r in g}
+    seen, groups = set(), []
+    for r in rng.permutation(L).tolist():
+        if r not in seen:
+            groups.append(list(group_of.get(r, (r,)))); seen.update(groups[-1])
+    order = np.array([r for g in groups for r in g])
+    gf, gl, v = [], [], 0
+    for g in groups:
+        gf += [v] * len(g); gl += [0] * (len(g) - 1) + [1]; v += len(g)
+    lev, rank = _levels_ref(E_idx, order, gf, gl)
+    T = lambda a, dt=torch.int32: torch.tensor(np.asarray(a)).to(dt)
+    level = T(lev).repeat(B_dec, 1)
+    sel, flat, work_n, close, close_off = level_work_lists(level, T(gf).repeat(B_dec, 1), T(gl).repeat(B_dec, 1), T(order, torch.int64),
+                                                           T(E_idx, torch.int64), split=split)
+    assert torch.equal(flat, flat.sort().values) and int(work_n.sum()) == B_dec * L
+    covered = np.zeros((B_dec, L), dtype=int)
+    for s_, n_, f_ in zip(sel.tolist(), work_n.tolist(), flat.tolist()):
+        b, v0 = divmod(s_, L)
+        covered[b, v0:v0 + n_] += 1
+        assert gf[v0] == gf[v0 + n_ - 1] and f_ == lev[v0]                                 # one group, the group's level
+        members = order[gf[v0]:gf[v0] + gf.count(gf[v0])]
+        internal = any(j in members and j != i for i in members for j in E_idx[i])
+        assert n_ == (len(members) if (internal or not split) else 1), (members, internal, n_)
+        for i in order[v0:v0 + n_]:                                                        # dependencies sit in lower levels
+            for j in E_idx[i]:
+                if rank[j] < gf[v0]:
+                    assert lev[rank[j]] < f_
+    assert (covered == 1).all()
+    if not split:
+        assert close is None and close_off is None
+        assert len(sel) == B_dec * len(groups)
+    else:
+        assert len(sel) > B_dec * len(groups)                                              # [10, 40] and [20, 50, 7, 33] were split
+        assert close.shape == (B_dec * len(groups), 2)
+        lv_c = [lev[v_] for _, v_ in close.tolist()]
+        assert lv_c == sorted(lv_c) and all(gl[v_] for _, v_ in close.tolist())
+        assert sorted(map(tuple, close.tolist())) == sorted((b, v_) for b in range(B_dec) for v_ in range(L) if gl[v_])
+        off = close_off.tolist()
+        for l_ in range(max(lev) + 1):
+            assert [lv_c[q] for q in range(off[l_], off[l_ + 1])] == [l_] * (off[l_ + 1] - off[l_])
+        assert off[max(lev) + 1] == len(lv_c)
+    # without groups: one item per visit
+    sel1, flat1, wn1, c1, co1 = level_work_lists(level, None, None, T(order, torch.int64), T(E_idx, torch.int64), split=False)
+    assert wn1 is None and c1 is None and sel1.numel() == B_dec * L and torch.equal(flat1, flat1.sort().values)
