@@ -242,6 +242,50 @@ __device__ __forceinline__ f4 mfma_x3(const bf8 wh, const bf8 wm, const bf8 hi, 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc, 0, 0, 0);
 }
 
+// chain_gemm_x3 with the fragments requested ahead: the hi fragments of the NEXT group of four channel tiles and this group's mid fragments are
+// requested before this group's twelve MFMAs issue, pinned there by a scheduling barrier that only VALU instructions may cross.  The compiler's
+// own schedule of chain_gemm_x3 waits for an LDS round trip every one or two MFMAs; the throughput kernels cover that with three waves per SIMD
+// (and spill with this form: see below), the sampler — one or two active waves per SIMD, a latency chain — cannot.
+template <bool FLIP, bool ACT>
+__device__ __forceinline__ void chain_gemm_x3_ahead(f4 (&acc)[8], const f4 (&x)[8], const bf8* w) {
+  bf8 wh[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wh[0][q] = w[q * 64];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const f4 a = ACT ? gelu4_scalar(x[2 * s]) : x[2 * s], b = ACT ? gelu4_scalar(x[2 * s + 1]) : x[2 * s + 1];
+    bf8 hi, mid;
+    split_x3(a, b, hi, mid);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = 2 * s + h;
+      bf8 wm[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wm[q] = w[(NAMP_BIMG_BYTES / 16) + (s * 8 + 4 * h + q) * 64];
+      if (g + 1 < 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wh[(g + 1) & 1][q] = w[(((g + 1) >> 1) * 8 + 4 * ((g + 1) & 1) + q) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mid, wh[g & 1][q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g & 1][q], mid, acc[4 * h + q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wm[q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[q], hi, acc[4 * h + q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FLIP) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wh[g & 1][q], acc[4 * h + q], 0, 0, 0);
+        else      acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g & 1][q], hi, acc[4 * h + q], 0, 0, 0);
+      }
+    }
+  }
+}
+
 // (Tried, round 3: the hi fragments of the next group requested before this group's twelve MFMAs, pinned by a scheduling barrier as in
 // namp_bf16s32.h's gemm32 — the 168-VGPR kernels spill: cfg3 split-bf16 13.2 -> 14.3-17.4 ms per step, cfg2 unchanged; the persistent kernel
 // with 8 waves per workgroup (208-241 VGPRs, no spills) and that prefetch: 12.3 -> 12.6 ms, 13.2 without the prefetch — the third wave per SIMD

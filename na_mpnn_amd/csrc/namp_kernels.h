@@ -1867,6 +1867,16 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
 // 90 us at B = 1), and the host has to read the level histogram back before it can launch.  What later levels gather from other
 // workgroups — the next layer's Pv rows — is stored write-through (sc1); tokens travel through agent-scope atomics as before; no
 // workgroup ever reads a row before the level that wrote it (rank order), so no reader holds a stale line.
+#ifndef NAMP_SAMPLE_AHEAD
+#define NAMP_SAMPLE_AHEAD 1
+#endif
+// the sampler's three tile GEMMs: split-bf16 with the fragments requested ahead (chain_gemm_x3_ahead) in the 8-wave forms
+#define SGEMM(FLIP, ACT) sample_gemm<X3, MAXW == 8 && NAMP_SAMPLE_AHEAD, FLIP, ACT>
+template <bool X3, bool AHEAD, bool FLIP, bool ACT>
+__device__ __forceinline__ void sample_gemm(f4 (&acc)[8], const f4 (&x)[8], const f4* w) {
+  if constexpr (X3 && AHEAD) chain_gemm_x3_ahead<FLIP, ACT>(acc, x, (const bf8*)w);
+  else gemm128<X3, FLIP, ACT>(acc, x, w);
+}
 template <int MODE, bool X3 = false, int MAXW = 8>
 __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs a, const int32_t* __restrict__ work,
                                                                const int32_t* __restrict__ work_n, int nwork,
@@ -2062,7 +2072,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
       // A wave whose slot holds no residue (a level of B = 1 has ~2.5 of 4) skips the three tile GEMMs — it would only take matrix-pipe
       // and issue time from the wave it shares a SIMD with — but keeps every barrier and its share of the image copies.
       if (wave_active) {
-        gemm128<X3, false, false>(acc, x, w0);
+        SGEMM(false, false)(acc, x, w0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
       }
@@ -2072,7 +2082,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
       if (wave_active) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(b2p + 16 * q + 4 * g);
-        gemm128<X3, false, true>(x, acc, w1);
+        SGEMM(false, true)(x, acc, w1);
       }
       wait_dma_and_sync();
       NAMP_STAMP(3);                    // GEMM 2 (+ W3 landed)
@@ -2082,7 +2092,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
           const float bq = b3p[16 * q + m];
           acc[q] = (f4){bq, bq, bq, bq};
         }
-        gemm128<X3, true, true>(acc, x, w0);
+        SGEMM(true, true)(acc, x, w0);
         float wr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[r] = __shfl(w_row, 4 * g + r);
