@@ -211,21 +211,31 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tn] = vec16(cst + 128, tn);
       gemm32<false, EPIN>(acc, w3, [&](const int s) { return gelu_pack8(y[s >> 1], s & 1); });
-      float sum = 0.f;
+      // LayerNorm statistics over the lane's 64 channels as packed pairs in two independent chains each (one scalar chain of 64 dependent
+      // adds / FMAs before), then one cross-lane step for the row's other half
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 sA = (f2){0.f, 0.f}, sB = (f2){0.f, 0.f};
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[tn][j] += (float)xb[2 * tn][j]; acc[tn][8 + j] += (float)xb[2 * tn + 1][j]; }   // residual
 #pragma unroll
-        for (int v = 0; v < 16; ++v) sum += acc[tn][v];
+        for (int v = 0; v < 16; v += 4) { sA += (f2){acc[tn][v], acc[tn][v + 1]}; sB += (f2){acc[tn][v + 2], acc[tn][v + 3]}; }
       }
+      float sum = (sA.x + sA.y) + (sB.x + sB.y);
       sum += __shfl_xor(sum, 32);
       const float mean = sum * (1.0f / 128.0f);
-      float sq = 0.f;
+      const f2 m2 = (f2){mean, mean};
+      f2 qA = (f2){0.f, 0.f}, qB = (f2){0.f, 0.f};
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { acc[tn][v] -= mean; sq += acc[tn][v] * acc[tn][v]; }
+        for (int v = 0; v < 16; v += 4) {
+          const f2 d0 = (f2){acc[tn][v], acc[tn][v + 1]} - m2, d1 = (f2){acc[tn][v + 2], acc[tn][v + 3]} - m2;
+          acc[tn][v] = d0.x; acc[tn][v + 1] = d0.y; acc[tn][v + 2] = d1.x; acc[tn][v + 3] = d1.y;
+          qA = __builtin_elementwise_fma(d0, d0, qA); qB = __builtin_elementwise_fma(d1, d1, qB);
+        }
+      float sq = (qA.x + qA.y) + (qB.x + qB.y);
       sq += __shfl_xor(sq, 32);
       const float rstd = rsqrtf(sq * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
@@ -253,9 +263,14 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       }
       gemm32<true, PIN>(y, w2, [&](const int s) { return gelu_pack8(acc[s >> 1], s & 1); });
       // ---- K-sums of the layer-2 activations, per 16-row half
-      f4 wv[4];
+      // (packed pairs: .x = the first 16-row half (accumulator elements 0..7), .y = the second (8..15))
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 wp[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wv[q] = *(const f4*)(w_slot + 8 * q + 4 * hk);
+      for (int q = 0; q < 2; ++q) {
+        const f4 wa = *(const f4*)(w_slot + 8 * q + 4 * hk), wb = *(const f4*)(w_slot + 8 * (2 + q) + 4 * hk);
+        wp[4 * q] = (f2){wa.x, wb.x}; wp[4 * q + 1] = (f2){wa.y, wb.y}; wp[4 * q + 2] = (f2){wa.z, wb.z}; wp[4 * q + 3] = (f2){wa.w, wb.w};
+      }
       float wsum = me.w_row;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) wsum += __shfl_xor(wsum, o);
@@ -265,14 +280,17 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       float* dst = a.partial + ((long)node_h * a.TPN + kt_h) * NAMP_H + r;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
-        float s0 = 0.f, s1 = 0.f;
+        f2 s01 = (f2){0.f, 0.f}, t01 = (f2){0.f, 0.f};            // two chains
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f4 g0 = gelu_prec<PREC_BF16>((f4){y[tn][4 * q], y[tn][4 * q + 1], y[tn][4 * q + 2], y[tn][4 * q + 3]});
           const f4 g1 = gelu_prec<PREC_BF16>((f4){y[tn][8 + 4 * q], y[tn][9 + 4 * q], y[tn][10 + 4 * q], y[tn][11 + 4 * q]});
-          s0 += (g0.x * wv[q].x + g0.y * wv[q].y) + (g0.z * wv[q].z + g0.w * wv[q].w);
-          s1 += (g1.x * wv[2 + q].x + g1.y * wv[2 + q].y) + (g1.z * wv[2 + q].z + g1.w * wv[2 + q].w);
+          s01 = __builtin_elementwise_fma((f2){g0.x, g1.x}, wp[4 * q], s01);
+          t01 = __builtin_elementwise_fma((f2){g0.y, g1.y}, wp[4 * q + 1], t01);
+          s01 = __builtin_elementwise_fma((f2){g0.z, g1.z}, wp[4 * q + 2], s01);
+          t01 = __builtin_elementwise_fma((f2){g0.w, g1.w}, wp[4 * q + 3], t01);
         }
+        const float s0 = s01.x + t01.x, s1 = s01.y + t01.y;
         const float t = __shfl_xor(hk ? s0 : s1, 32);
         const float mine = (hk ? s1 : s0) + t;
         if (hk == 0 || okB) dst[32 * tn] = mine;
