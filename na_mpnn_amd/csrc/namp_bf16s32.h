@@ -242,7 +242,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       for (int tn = 0; tn < 4; ++tn) {
         const f16v ga = vec16(cst + 256, tn), be = vec16(cst + 384, tn);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[tn][v] = acc[tn][v] * rstd * ga[v] + be[v];
+        for (int v = 0; v < 16; v += 2) {
+          const f2 o = __builtin_elementwise_fma((f2){acc[tn][v], acc[tn][v + 1]} * (f2){rstd, rstd}, (f2){ga[v], ga[v + 1]}, (f2){be[v], be[v + 1]});
+          acc[tn][v] = o.x; acc[tn][v + 1] = o.y;
+        }
       }
       if (me.valid) {
         bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + hk;
