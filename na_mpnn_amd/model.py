@@ -625,6 +625,7 @@ class ProteinMPNN(nn.Module):
                 level_off = torch.cat((hist.new_zeros(1), hist.cumsum(0))).to(torch.int32).contiguous()
                 hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), hip.ptr(close), hip.ptr(close_off), hip.ptr(zbuf),
                                                       *tail), "decoder_sample_walk")
+                self._walk_sync = ws[Lb.namp_sample_workspace_bytes(B, B_dec, L, K) - 4096:][:256].view(torch.int32)   # (sample_walk_status)
                 return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                         "uniform": uniform, "levels": (hist > 0).sum(), "work_items": nwork}
             counts = torch.bincount(flat).cpu().tolist()                       # per-level launches: the one host sync of the sampler
@@ -641,6 +642,12 @@ class ProteinMPNN(nn.Module):
         # (no host sync needed: temporaries are stream-ordered allocations, see _featurize_hip)
         return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                 "uniform": uniform}
+
+    def sample_walk_status(self):
+        """Barrier state of the last persistent level walk (synchronises): 0 = every grid barrier completed; otherwise the code of the barrier
+        that gave up (the device was shared with other work and the walk's workgroups were not all resident: that call's log_probs are NaN)."""
+        w = getattr(self, "_walk_sync", None)
+        return 0 if w is None else int(w[32].item())          # NAMP_SYNC_TIMEOUT
 
     # positional convenience wrapper in the upstream ProteinMPNN argument order (SURVEY §0 F3)
     def forward_positional(self, X, S, mask, chain_M, residue_idx, chain_encoding_all, randn, *, X_m,

@@ -485,6 +485,7 @@ def test_symmetric_sampling_by_level_equals_the_sequential_walk(weights_np, kind
         torch.manual_seed(11)
         outs.append(m.sample(fd))
     w_, ws_, a, b = outs
+    assert m.sample_walk_status() == 0
     assert "levels" in a and "levels" not in b and int(w_["levels"]) == a["levels"] == int(ws_["levels"])
     n_groups = n - sum(len(g_) - 1 for g_ in groups)
     assert a["levels"] < n_groups, (a["levels"], n_groups)
