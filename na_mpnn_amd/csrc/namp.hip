@@ -146,8 +146,9 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
-  set((const void*)node_update_multi_kernel<2>, NODE_MULTI_LDS(2));
-  set((const void*)(node_update_multi_kernel<2, true>), NODE_MULTI_LDS_X3(2));
+  set((const void*)(node_update_multi_kernel<2, 0>), NODE_MULTI_LDS(2));
+  set((const void*)(node_update_multi_kernel<2, 1>), NODE_MULTI_LDS_X3(2));
+  set((const void*)(node_update_multi_kernel<2, 2>), NODE_MULTI_LDS_X3(2));
   set((const void*)dec_sample_kernel<0, false, 8>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<1, false, 8>, SAMPLE_LDS);
   set((const void*)dec_sample_kernel<2, false, 8>, SAMPLE_LDS);
@@ -340,6 +341,10 @@ int check_proj(const char* fn, const NampProj* proj, int nproj, const int32_t* S
 // tells the caller whether the launch that ran supports it (the one-tile fp32 residue kernel does not).
 struct Out16Req { __bf16* p[8]; int n; bool honoured; };
 thread_local Out16Req* g_out16 = nullptr;
+// Set by encdec_bf16_storage around its residue-level launches: the bf16 throughput mode runs them as plain bf16 products (hi . hi of the
+// x3 images, fp32 accumulation) — the reference's AMP autocasts the whole model (na_run.py:216-218).  NAMP_BF16S_RESIDUE_X3=1 restores the
+// split-bf16 (fp32-equivalent) residue GEMMs of rounds 2-3 for A/B runs (measured: profiles/r03e, r04*).
+thread_local bool g_residue_x1 = false;
 
 int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, int N,
                        const NampProj* proj, int nproj, const NampProj* pre, hipStream_t s, bool x3 = false, unsigned* zero = nullptr) {
@@ -355,8 +360,9 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
   }
   if (g_out16) g_out16->honoured = true;
   const int units = ((G_out + 15) / 16) * nproj;
-  if (x3) hipLaunchKernelGGL(node_linear_kernel<true>, dim3((units + 3) / 4), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(node_linear_kernel<false>, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  if (x3 && g_residue_x1) hipLaunchKernelGGL(node_linear_kernel<2>, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  else if (x3) hipLaunchKernelGGL(node_linear_kernel<1>, dim3((units + 3) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(node_linear_kernel<0>, dim3((units + 3) / 4), dim3(256), 0, s, a);
   return NAMP_OK;
 }
 
@@ -379,10 +385,12 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   if (multi && g_out16) g_out16->honoured = true;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
-  if (x3)                      // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
-    hipLaunchKernelGGL((node_update_multi_kernel<2, true>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
+  if (x3 && g_residue_x1)      // bf16 throughput mode: hi . hi products out of the same x3 images
+    hipLaunchKernelGGL((node_update_multi_kernel<2, 2>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
+  else if (x3)                 // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
+    hipLaunchKernelGGL((node_update_multi_kernel<2, 1>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
   else if (G >= 32 * 2 * device_cus())
-    hipLaunchKernelGGL((node_update_multi_kernel<2, false>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
+    hipLaunchKernelGGL((node_update_multi_kernel<2, 0>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS(2), s, a);
   else
     hipLaunchKernelGGL(node_update_kernel, dim3((G + 15) / 16), dim3(512), NODE_TAIL_LDS, s, a);
   return NAMP_OK;
@@ -1404,6 +1412,8 @@ static int encdec_bf16_storage(const NampModelW* w, const float* V, const float*
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_attributes();
   if (rc) return rc;
+  static const bool residue_x3 = [] { const char* e = getenv("NAMP_BF16S_RESIDUE_X3"); return e && atoi(e) != 0; }();   // A/B switch
+  struct X1Scope { bool prev; X1Scope(bool on) : prev(g_residue_x1) { g_residue_x1 = on; } ~X1Scope() { g_residue_x1 = prev; } } x1scope_(!residue_x3);
   Carver c(ws, ws_bytes);
   float* hv[2] = {c.take((size_t)G * NAMP_HIDDEN), c.take((size_t)G * NAMP_HIDDEN)};
   float* P[6];

@@ -2275,7 +2275,7 @@ struct NodeLinearArgs {
                        // the bf16-storage edge launches gather (edge_mlp_bf16s32_kernel); replaces a separate conversion launch
 };
 
-template <bool X3>       // X3: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products
+template <int X3>        // X3 = 1: every image is an x3 image (namp_pack_image_x3), the GEMMs run as split-bf16 products; 2: hi . hi products only (bf16 mode)
 __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2303,7 +2303,7 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   if (a.pre.img) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = a.pre.bias ? *(const f4*)(a.pre.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (X3) chain_gemm_global_x3(acc, x, (const bf8*)a.pre.img + lane);
+    if constexpr (X3) chain_gemm_global_x3<X3 == 2>(acc, x, (const bf8*)a.pre.img + lane);
     else chain_gemm_global<8, 8, false>(acc, x, (const f4*)a.pre.img + lane, 8);
     if (pi == 0 && valid && a.pre.out) {
       float* dst = a.pre.out + (long)row * NAMP_H + 4 * g;
@@ -2315,7 +2315,7 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs a
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = d.bias ? *(const f4*)(d.bias + 16 * t + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-  if constexpr (X3) chain_gemm_global_x3(acc, x, (const bf8*)d.img + lane);
+  if constexpr (X3) chain_gemm_global_x3<X3 == 2>(acc, x, (const bf8*)d.img + lane);
   else chain_gemm_global<8, 8, false>(acc, x, (const f4*)d.img + lane, 8);
   if (d.tok) {
     const float* tk = d.tok + (long)a.S[rr] * NAMP_H + 4 * g;
@@ -2388,7 +2388,7 @@ static __global__ __launch_bounds__(512) void node_update_kernel(const NodeUpdat
 
 // X3: Win_img / Wout_img / every projection image are x3 images (pack_image_x3_general_kernel / pack_image_x3_kernel) and
 // the three GEMM phases run as split-bf16 products: 144 bf16 MFMAs per tile instead of 384 fp32 MFMAs (5.3x fewer cycles).
-template <int T, bool X3 = false>
+template <int T, int X3 = 0>       // X3: 0 exact fp32 MFMA, 1 split-bf16 products, 2 hi . hi products of the same images (bf16 mode)
 __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = (float*)smem;                       // [T][16][FFN_LD]  LN1 outputs
@@ -2403,7 +2403,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
       bf8 hi, mid;
       split_x3(v[2 * s_], v[2 * s_ + 1], hi, mid);
       *(bf8*)(base + row * (FFN_LD * 4) + 16 * (4 * s_ + g_)) = hi;
-      *(bf8*)(base + row * (FFN_LD * 4) + 256 + 16 * (4 * s_ + g_)) = mid;
+      if constexpr (X3 != 2) *(bf8*)(base + row * (FFN_LD * 4) + 256 + 16 * (4 * s_ + g_)) = mid;
     }
   };
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2446,7 +2446,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const char* xr = xsp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
-          o = mfma_x3(wh[s], wm[s], *(const bf8*)xr, *(const bf8*)(xr + 256), o);
+          o = mfma_xs<X3 == 2>(wh[s], wm[s], *(const bf8*)xr, *(const bf8*)(xr + 256), o);
         }
         *(f4*)(ys + (q * 16 + m) * FFN_LD + 16 * wave + 4 * g) = o;
       }
@@ -2510,7 +2510,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
         const char* xr = xsp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
         const bf8 hi = *(const bf8*)xr, mid = *(const bf8*)(xr + 256);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma_x3(wh[s][tn], wm[s][tn], hi, mid, hacc[q][tn]);
+        for (int tn = 0; tn < 4; ++tn) hacc[q][tn] = mfma_xs<X3 == 2>(wh[s][tn], wm[s][tn], hi, mid, hacc[q][tn]);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) hacc[q][c] = gelu4(hacc[q][c]);
@@ -2566,7 +2566,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
           bf8 hi, mid;
           split_x3(hacc[q][2 * s], hacc[q][2 * s + 1], hi, mid);
 #pragma unroll
-          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma_x3(woh[s][tn], wom[s][tn], hi, mid, oacc[tn]);
+          for (int tn = 0; tn < 8; ++tn) oacc[tn] = mfma_xs<X3 == 2>(woh[s][tn], wom[s][tn], hi, mid, oacc[tn]);
         }
       } else {
 #pragma unroll
@@ -2608,7 +2608,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
                                 (__bf16)(y.w - (float)hi[3])};
           char* yp = ysp + (q * 16 + r) * (FFN_LD * 4) + 16 * (4 * (tile_ >> 1) + g_) + 8 * (tile_ & 1);
           *(bf4*)yp = hi;
-          *(bf4*)(yp + 256) = mid;
+          if constexpr (X3 != 2) *(bf4*)(yp + 256) = mid;
         }
         if (ok) *(f4*)(t.hV_out + (long)orow * NAMP_H + c) = y;
       }
@@ -2651,7 +2651,7 @@ __global__ __launch_bounds__(512) void node_update_multi_kernel(const NodeUpdate
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const char* yr = ysp + (q * 16 + m) * (FFN_LD * 4) + 16 * (4 * s + g);
-            acc = mfma_x3(wfh[s], wfm[s], *(const bf8*)yr, *(const bf8*)(yr + 256), acc);
+            acc = mfma_xs<X3 == 2>(wfh[s], wfm[s], *(const bf8*)yr, *(const bf8*)(yr + 256), acc);
           }
         } else {
 #pragma unroll

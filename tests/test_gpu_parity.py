@@ -601,7 +601,9 @@ def test_cfg3_sized_batch(L, dev, wt, packed):
     err = maxdiff(lp16, logp.cpu())
     agree = float((lp16.argmax(-1) == logp.argmax(-1)).float().mean())
     print(f"cfg3-sized bf16: max|dlogp| vs parity mode = {err:.4f}, arg-max agreement = {agree:.4f}")
-    assert err < 0.15 and agree >= 0.97
+    # the bf16 accuracy CLASS the reference's own whole-model autocast reaches (0.055, 99.3 %) — round 4 spends the
+    # budget rounds 2-3 left unused (0.016 / 99.64 %): plain-bf16 residue-level GEMMs and a degree-4 GELU polynomial
+    assert err <= 0.055 and agree >= 0.99
 
 
 def test_bf16_throughput_mode(L, dev, wt, golden_dir):
@@ -655,13 +657,15 @@ def test_bf16_storage_message_kernel(dev, B, N, K):
     """namp_bf16s_message (edge_mlp_bf16s32_kernel, v_mfma_f32_32x32x16_bf16 on rows stored in fragment order B) against a torch
     restatement with the kernel's rounding points (operands in bf16, fp32 accumulation, exact-erf GELU): K-sums of the layer-2
     activations of both message modes, incl. odd tile counts (a trailing half pair), K % 16 != 0 and random neighbour indices.
-    Bar 3e-3 on sums of up to 48 activations (the bf16-mode GELU polynomial is within 1.9e-4 per value); the weight sums exact."""
+    Bar 5e-3 on sums of up to 48 activations weighted 1/30 (the bf16-mode GELU polynomial is within 1.3e-3 per value since round 4, its
+    errors partly systematic in sign; measured 8.4e-4 with round 3's degree-6 form); the weight sums exact."""
     import importlib.util
     spec_ = importlib.util.spec_from_file_location("bf16s32_check", os.path.join(os.path.dirname(__file__), "..", "tools", "bf16s32_check.py"))
     mod = importlib.util.module_from_spec(spec_)
     spec_.loader.exec_module(mod)
     for mode, (err, smax, _, dw) in mod.case(B, N, K, dev, seed=B * 1000 + K).items():
-        assert err < 3e-3 and smax > 1.0, (mode, err, smax)
+        print(f"bf16s32 {mode}: max abs dS = {err:.2e} (max abs S {smax:.2f})")
+        assert err < 5e-3 and smax > 1.0, (mode, err, smax)
         assert dw < 1e-6, (mode, dw)
 
 

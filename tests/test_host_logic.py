@@ -237,6 +237,31 @@ def test_device_gelu_formula_accuracy():
     assert np.abs(per_edge - hoisted).max() < 1e-12
 
 
+def test_device_gelu_bf16_mode_polynomial():
+    """The bf16 throughput mode's GELU (csrc/namp_device.h: gelu4_bf16mode, x * clamp01(1/2 + x Q(x^2)), Q of degree 4 since round 4)
+    restated in float32 numpy with the shipped branch's constants parsed from the header: <= 1.4e-3 absolute over [-14, 14] (a third of
+    the bf16 rounding step of its result at |y| >= 1), saturating correctly beyond the fit range, exact at 0."""
+    from math import erf, sqrt
+    src = open(os.path.join(ROOT, "na_mpnn_amd", "csrc", "namp_device.h")).read()
+    body = src[src.index("#else\n  // round 4: degree 4 in x^2"):]
+    body = body[:body.index("#endif")]
+    lead = np.float32(re.search(r"f4 q = \(f4\)\{(-?[0-9.e+-]+)f", body).group(1))
+    rest = [np.float32(v) for v in re.findall(r"q = q \* t \+ (-?[0-9.e+-]+)f;", body)]
+    assert len(rest) == 4
+    xs = np.linspace(-14.0, 14.0, 560001)
+    x = xs.astype(np.float32)
+    t = x * x
+    q = np.full_like(x, lead)
+    for c in rest:
+        q = q * t + c
+    y = (x * np.clip(x * q + np.float32(0.5), 0, 1)).astype(np.float64)
+    ref = np.array([0.5 * v * (1.0 + erf(v / sqrt(2.0))) for v in xs])
+    assert np.abs(y - ref).max() <= 1.4e-3
+    far = np.abs(xs) > 6
+    assert np.abs(y - ref)[far].max() <= 1e-6            # saturated: x or 0
+    assert y[len(xs) // 2] == 0.0
+
+
 def _levels_ref(E_idx, order, gf, gl):
     """sample_levels_kernel (csrc/namp_kernels.h) restated: one level per symmetry group = 1 + the highest level among its members'
     earlier neighbours in EARLIER groups."""
