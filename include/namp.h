@@ -382,6 +382,21 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
                         const float* b2, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                         float* g_hE, const float* g_hE_in, float* g_Pa, float* g_Pj0, float* g_Pj1, float* S3, float* w3, int x3, int B, int N,
                         int K, void* stream);
+/* Message-stage backward that owns its weight gradients (round 4; modes 0 / 1, precision codes 1 / 2 with the same flag bits 4 and 8
+ * as namp_train_edge_bwd): ONE persistent launch recomputes the chain, walks it backwards AND contracts the row operands over the
+ * edges on chip — the A1 / G2 row tensors and the namp_train_wgrad launches of na_model_utils.py:196-283's W1 / W2 gradients
+ * disappear.  Outputs: G1 rows (bf16 in precision code 2; for namp_train_scatter_rows), g_hE, g_Pa as namp_train_edge_bwd, and per
+ * workgroup c < namp_train_edge_bwd_dw_groups(B, N, K): dW_part[c][0] = partial of dW2 = G2^T A1, dW_part[c][1] = partial of
+ * dW1b = G1^T h_E ([128][128] each), db_part[c] = partial of db2 = sum G2 ([128]); the caller adds the partials. */
+int namp_train_edge_bwd_dw_groups(int B, int N, int K);
+/* Rows G1 and g_hE must have room for (g_Pa: one row per 16 of them when the per-tile flag is set): the launches store whole 64-row rounds,
+ * rows past B*N*K into this padding (no vector-memory instruction of their round loop sits under a branch). */
+long namp_train_edge_bwd_dw_rows(int B, int N, int K);
+int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                           const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                           const float* W2_img, const float* W2t_img, const float* W1t_img, const float* b2, const float* g_out,
+                           float* G1, float* g_hE, const float* g_hE_in, float* g_Pa, float* dW_part, float* db_part, int x3, int B,
+                           int N, int K, void* stream);
 /* dL/dPj = transpose of the neighbour gather, as a gather over the reverse adjacency: rev_edge [B*N*K] = edge ids sorted by
  * the table row they gathered (global row b*N + E_idx), rev_off [B*N+1] their offsets per row; out0[j] = sum of G1[e] over the
  * edges of row j (sel[e] != 0 when sel is given; the others go to out1: DecLayer's Pbw / Pfw).  Deterministic. */

@@ -215,6 +215,7 @@ def run_one(args, model, pdb, name, fixed_residues, device, seed, ckpt_name, bia
         S_l, lp_l, sp_l, loss_l, lpr_l = [], [], [], [], []
         cmask = (fd["mask"] * fd["chain_mask"]).float()
         forced = np.load(args.forced_draws_npz) if args.forced_draws_npz else None
+        model.sample_check_walk = True      # verify the persistent level walk's barriers per design call; falls back to per-level launches
         for ib in range(args.number_of_batches):
             fd["randn"] = torch.randn(args.batch_size, L, device=device)
             if forced is not None:

@@ -1349,10 +1349,10 @@ __device__ __forceinline__ void grid_barrier(unsigned* sync, const unsigned epoc
     const unsigned old = __hip_atomic_fetch_add(sy + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1 == in_group * epoch) {                           // last arriver of the group: arrive on the top counter,
       __hip_atomic_fetch_add(sy + NAMP_SYNC_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      spin_until_ge(sy + NAMP_SYNC_TOP, ngroups * epoch, sy + NAMP_SYNC_TIMEOUT, 0x100u + epoch);
+      spin_until_ge(sy + NAMP_SYNC_TOP, ngroups * epoch, sy + NAMP_SYNC_TIMEOUT, 0x10000000u | epoch);
       __hip_atomic_store(sy + NAMP_SYNC_GEN + grp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... release the group
     } else {
-      spin_until_ge(sy + NAMP_SYNC_GEN + grp, epoch, sy + NAMP_SYNC_TIMEOUT, 0x200u + epoch);
+      spin_until_ge(sy + NAMP_SYNC_GEN + grp, epoch, sy + NAMP_SYNC_TIMEOUT, 0x20000000u | epoch);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }

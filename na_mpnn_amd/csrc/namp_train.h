@@ -36,6 +36,9 @@ __device__ __forceinline__ void gelu_val_grad(float x, float& val, float& grad) 
 
 // in: pre-activations z; out: z <- gelu'(z), returns gelu(z) — one exp / rcp pair serves both
 __device__ __forceinline__ f4 gelu_split4(f4& z) {
+#ifdef DW_EXP_NOGELU
+  { const f4 v_ = z; z = z * 0.5f; return v_; }
+#endif
   float v0, v1, v2, v3, d0, d1, d2, d3;
   gelu_val_grad(z.x, v0, d0); gelu_val_grad(z.y, v1, d1); gelu_val_grad(z.z, v2, d2); gelu_val_grad(z.w, v3, d3);
   z = (f4){d0, d1, d2, d3};

@@ -1,6 +1,7 @@
 // Training (backward) entry points of libnamp_hip.so — see include/namp.h "training" section and namp_train.h.
 #include "../../include/namp.h"
 #include "namp_train.h"
+#include "namp_train_dw.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -48,6 +49,19 @@ int ensure_attributes() {
 #define NAMP_SET3(M, ...) set((const void*)(edge_chain_bwd_kernel<M, 0 __VA_ARGS__>)); set((const void*)(edge_chain_bwd_kernel<M, 1 __VA_ARGS__>)); \
                           set((const void*)(edge_chain_bwd_kernel<M, 2 __VA_ARGS__>))
     NAMP_SET3(BWD_ENC_MSG); NAMP_SET3(BWD_DEC_MSG); NAMP_SET3(BWD_ROWS); NAMP_SET3(BWD_EDGE_LN);
+    auto set_dw = [](const void* f) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+      if (e != hipSuccess) g_attr_err = e;
+    };
+    set_dw((const void*)(edge_bwd_dw_kernel<BWD_ENC_MSG, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<BWD_ENC_MSG, 2>));
+    set_dw((const void*)(edge_bwd_dw_kernel<BWD_DEC_MSG, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<BWD_DEC_MSG, 2>));
+    auto set_dw16 = [](const void* f) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW16_LDS);
+      if (e != hipSuccess) g_attr_err = e;
+    };
+#define NAMP_SET_DW16(M) set_dw16((const void*)(edge_bwd_dw16_kernel<M, false, 1>)); set_dw16((const void*)(edge_bwd_dw16_kernel<M, true, 1>)); \
+                         set_dw16((const void*)(edge_bwd_dw16_kernel<M, false, 2>)); set_dw16((const void*)(edge_bwd_dw16_kernel<M, true, 2>))
+    NAMP_SET_DW16(BWD_ENC_MSG); NAMP_SET_DW16(BWD_DEC_MSG);
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -101,6 +115,87 @@ int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const 
   if (mode == 0) NAMP_LAUNCH_BWD(BWD_ENC_MSG);
   else if (mode == 1) NAMP_LAUNCH_BWD(BWD_DEC_MSG);
   else NAMP_LAUNCH_BWD(BWD_ROWS);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+// Workgroups of the persistent message backward (namp_train_edge_bwd_dw): one per CU, never more than there are 128-row rounds.
+static int dw_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+long namp_train_edge_bwd_dw_rows(int B, int N, int K) {
+  if (B < 1 || N < 1 || K < 1) return 0;
+  return (((long)B * N * K + DW_ROWS - 1) / DW_ROWS) * DW_ROWS;
+}
+
+int namp_train_edge_bwd_dw_groups(int B, int N, int K) {
+  if (B < 1 || N < 1 || K < 1) return 0;
+  const long rounds = ((long)B * N * K + DW_ROWS - 1) / DW_ROWS;
+  return (int)(rounds < dw_cus() ? rounds : dw_cus());
+}
+
+int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
+                           const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
+                           const float* W2_img, const float* W2t_img, const float* W1t_img, const float* b2, const float* g_out,
+                           float* G1, float* g_hE, const float* g_hE_in, float* g_Pa, float* dW_part, float* db_part, int x3, int B,
+                           int N, int K, void* stream) {
+  REQUIRE(mode == 0 || mode == 1, "namp_train_edge_bwd_dw: mode=%d must be 0 (enc message) or 1 (dec message)", mode);
+  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pj0); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img);
+  REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(g_out);
+  REQUIRE_PTR(G1); REQUIRE_PTR(g_hE); REQUIRE_PTR(dW_part); REQUIRE_PTR(db_part);
+  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_bwd_dw: null E_idx");
+  if (mode == 1) { REQUIRE_PTR(Pj1); REQUIRE(rank != nullptr, "namp_train_edge_bwd_dw: decoder message needs rank"); }
+  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_bwd_dw: bad dims B=%d N=%d K=%d", B, N, K);
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  EdgeBwdDwArgs aa = {};
+  EdgeBwdArgs& a = aa.b;
+  a.hE = h_E; a.E_idx = E_idx; a.mask = mask; a.mask_attend = mask_attend; a.rank = rank; a.Pa = Pa; a.Pj0 = Pj0; a.Pj1 = Pj1;
+  a.W1_img = W1_img; a.W2_img = W2_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img; a.b2 = b2; a.g_node = g_out;
+  a.G1 = G1; a.g_hE = g_hE; a.g_Pa = g_Pa;
+  a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
+  a.acc_hE = (x3 & 4) ? 1 : 0;
+  a.g_hE_in = g_hE_in;
+#ifdef DW_EXP_STAMPS
+  { const char* e = getenv("NAMP_DW_STAMPS"); a.S3 = e ? (float*)strtoull(e, nullptr, 0) : nullptr; }   // device address of the stamp buffer (tools/dw_time.py)
+#endif
+  REQUIRE(!a.acc_hE || g_hE_in != nullptr, "namp_train_edge_bwd_dw: the accumulate flag needs g_hE_in");
+  a.gpa_tiles = (x3 & 8) ? 1 : 0;
+  REQUIRE(!a.gpa_tiles || (K % 16) == 0, "namp_train_edge_bwd_dw: per-tile g_Pa sums need K %% 16 == 0 (K=%d)", K);
+  x3 &= 3;
+  REQUIRE(x3 == 1 || x3 == 2, "namp_train_edge_bwd_dw: precision code %d (1 = split-bf16, 2 = bf16 products)", x3);
+  aa.dW_part = dW_part; aa.db_part = db_part;
+  aa.nrounds = (a.E + DW_ROWS - 1) / DW_ROWS;
+  const int grid = namp_train_edge_bwd_dw_groups(B, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  // bf16 products: the weight-stationary kernel (all four images resident); NAMP_DW16_RING=1 selects the ring form for A/B runs
+  static const bool ring16 = [] { const char* e = getenv("NAMP_DW16_RING"); return e && atoi(e) != 0; }();
+  const bool acc_ = a.acc_hE != 0;
+  const int gpa_ = a.gpa_tiles ? 1 : 2;
+  REQUIRE(x3 != 2 || ring16 || g_Pa != nullptr, "namp_train_edge_bwd_dw: the bf16 launch needs g_Pa");
+  REQUIRE(x3 != 2 || ring16 || mode != 0 || mask != nullptr || mask_attend != nullptr, "namp_train_edge_bwd_dw: the bf16 encoder launch needs mask or mask_attend");
+#define NAMP_LAUNCH_DW16(M)                                                                                                          \
+  do {                                                                                                                                \
+    if (acc_ && gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, true, 1>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);   \
+    else if (acc_) hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, true, 2>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);           \
+    else if (gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, false, 1>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);     \
+    else hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, false, 2>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);                    \
+  } while (0)
+  if (mode == 0) {
+    if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_ENC_MSG);
+    else if (x3 == 2) hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_ENC_MSG, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+    else hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_ENC_MSG, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+  } else {
+    if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_DEC_MSG);
+    else if (x3 == 2) hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_DEC_MSG, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+    else hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_DEC_MSG, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+  }
   CHECK_LAUNCH();
   return NAMP_OK;
 }

@@ -502,6 +502,11 @@ class ProteinMPNN(nn.Module):
     sample_level_parallel = True
     # ... as ONE persistent launch walking the levels (no host read-back, warm L2); False: one launch per level
     sample_level_walk = True
+    # Read the walk's barrier status back after every sample() (one small host sync per design call) and re-run with per-level launches
+    # if a grid barrier gave up — on by default in cli.py (the walk needs all its workgroups co-resident; on a shared or
+    # partitioned device the kernel only poisons log_probs and S would be garbage); off by default here (sample() then returns with the
+    # whole design merely enqueued; call sample_walk_status() yourself).
+    sample_check_walk = False
     # symmetry-tied groups whose members are not graph neighbours of each other: members decoded in parallel, one deferred draw per group
     sample_split_groups = True
 
@@ -565,7 +570,7 @@ class ProteinMPNN(nn.Module):
             m0 = mask[0][order[0]]                                             # stream 0's mask along the steps
             mask_dec = torch.empty_like(mask_dec).scatter_(1, order, m0.expand(B_dec, L).contiguous())
         pair_bias = fd["pair_bias"].float().contiguous() if "pair_bias" in fd else None
-        uniform = torch.rand(B_dec, L, device=dev)
+        uniform = fd["_uniform"] if fd.get("_uniform") is not None else torch.rand(B_dec, L, device=dev)   # (_uniform: the re-run below)
         special = 0
         for name in ("UNK", "DX", "RX", "MAS", "PAD"):                        # model_utils.py:199-203
             special |= 1 << int(self.restype_to_int[name])
@@ -588,7 +593,13 @@ class ProteinMPNN(nn.Module):
             # j become extra dependencies of the levels; a dense bias (more than 64 partners for some residue) keeps the sequential walk.
             if tuple(pair_bias.shape) != (B, L, self.num_letters, L, self.num_letters):
                 raise ValueError(f"pair_bias must be [B, L, {self.num_letters}, L, {self.num_letters}]; got {tuple(pair_bias.shape)}")
-            nz = pair_bias.abs().amax(dim=(2, 4)) > 0                          # [B, L, L]
+            # (row block by row block: one amax over the whole [B, L, 33, L, 33] tensor would materialise a second copy of it — 4.4 GB at
+            # L = 1000; a non-finite entry counts as a dependency: NaN > 0 is False and would silently drop it from the levels)
+            nz = torch.empty(B, L, L, dtype=torch.bool, device=dev)
+            step_ = max(1, (1 << 26) // max(1, self.num_letters * L * self.num_letters))
+            for i0 in range(0, L, step_):
+                blk = pair_bias[:, i0:i0 + step_]
+                nz[:, i0:i0 + step_] = ((blk != 0) | ~torch.isfinite(blk)).any(dim=4).any(dim=2)
             n_dep = int(nz.sum(-1).max())
             if n_dep <= 64:
                 pb_levels = True
@@ -625,9 +636,24 @@ class ProteinMPNN(nn.Module):
                 level_off = torch.cat((hist.new_zeros(1), hist.cumsum(0))).to(torch.int32).contiguous()
                 hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), hip.ptr(close), hip.ptr(close_off), hip.ptr(zbuf),
                                                       *tail), "decoder_sample_walk")
-                self._walk_sync = ws[Lb.namp_sample_workspace_bytes(B, B_dec, L, K) - 4096:][:256].view(torch.int32)   # (sample_walk_status)
-                return {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
-                        "uniform": uniform, "levels": (hist > 0).sum(), "work_items": nwork}
+                # the 64 barrier words, copied out of the per-call workspace (a view would keep the whole workspace alive on the model)
+                self._walk_sync = ws[Lb.namp_sample_workspace_bytes(B, B_dec, L, K) - 4096:][:256].view(torch.int32).clone()
+                out = {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
+                       "uniform": uniform, "levels": (hist > 0).sum(), "work_items": nwork}   # "levels": a device scalar (no read-back here)
+                if self.sample_check_walk and self.sample_walk_status() != 0:
+                    # the walk's grid barriers gave up (its workgroups were not all resident: a shared or partitioned device) — that
+                    # call's outputs are poisoned; decode again with one launch per level, which needs no co-residency
+                    import warnings
+                    warnings.warn(f"persistent level walk timed out (code {self.sample_walk_status():#x}); re-running with per-level launches")
+                    prev, self.sample_level_walk = self.sample_level_walk, False
+                    try:
+                        fd2 = dict(feature_dict)
+                        fd2["S_forced"] = fd.get("S_forced")
+                        fd2["_uniform"] = uniform
+                        out = self.sample(fd2)
+                    finally:
+                        self.sample_level_walk = prev
+                return out
             counts = torch.bincount(flat).cpu().tolist()                       # per-level launches: the one host sync of the sampler
             counts_c = (C.c_int32 * len(counts))(*counts)
             hip.check(Lb.namp_decoder_sample_levels(*common, counts_c, len(counts), *tail), "decoder_sample_levels")

@@ -34,6 +34,10 @@ ENC_MSG, DEC_MSG, ENC_EDGE = 0, 1, 2
 # forward_train from model.message_precision ("fp32" / "x3" / "bf16").
 X3 = 1
 PREC_CODE = {"fp32": 0, "x3": 1, "bf16": 2}
+# Message-stage backward that accumulates its weight gradients on chip (csrc/namp_train_dw.h; split-bf16 and bf16 products).
+# NAMP_TRAIN_DW=0 restores the row tensors + row-contraction launches of rounds 1-3 (A/B runs, tests of both forms).
+import os as _os
+DW_ONCHIP = _os.environ.get("NAMP_TRAIN_DW", "1") != "0"
 
 
 # Fragment images made during ONE training step (forward_train and the backward pass that follows it), keyed by (storage
@@ -222,6 +226,8 @@ class _EdgeMLP(torch.autograd.Function):
             db3 = (g2d * wsum).sum(0)
             g = (g2d @ W3.detach()).contiguous()
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
+        if mode != ENC_EDGE and int(ctx.x3) in (1, 2) and DW_ONCHIP:
+            return _EdgeMLP._backward_dw(ctx, g, g_pass, dW3, db3)
         A1, G1, G2 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(3))
         # the later consumer's dL/dh_E arrives as g_pass: the launch reads it and writes the SUM to a fresh buffer (same HBM
         # traffic as adding in place — one read and one write of [E,128] — without mutating a gradient autograd handed in,
@@ -254,6 +260,54 @@ class _EdgeMLP(torch.autograd.Function):
             (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         else:
             (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
+        if gpa_tiles:
+            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
+        g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
+        g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
+        return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
+
+
+    @staticmethod
+    def _backward_dw(ctx, g, g_pass, dW3, db3):
+        """Message stages, split-bf16 / bf16 products: ONE persistent launch that also contracts (G2, A1) and (G1, h_E) over the edges
+        on chip (csrc/namp_train_dw.h) — no A1 / G2 row tensors, no row-contraction launches.  g = dL/d(K-sum) per residue."""
+        h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32, msum, wsum = ctx.saved_tensors
+        mode = ctx.mode
+        B, N, K = E_idx32.shape
+        E = B * N * K
+        dev = h_E.device
+        L = hip.lib()
+        img1, img2 = _image(W1b.detach(), ctx.x3, step=ctx.step), _image(W2.detach(), ctx.x3, step=ctx.step)
+        img2t, img1t = _image_t(W2, ctx.x3, ctx.step), _image_t(W1b, ctx.x3, ctx.step)
+        rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32
+        Ep = L.namp_train_edge_bwd_dw_rows(B, N, K)            # whole 64-row rounds: the launch stores rows past E into this padding
+        G1 = torch.empty(Ep, H, device=dev, dtype=rdt)[:E]
+        acc = g_pass is not None
+        if acc and not (g_pass.is_contiguous() and g_pass.dtype == torch.float32):
+            g_pass = g_pass.contiguous().float()
+        g_hE = torch.empty(Ep, H, device=dev)[:E]
+        b2c = b2.detach().contiguous()
+        gpa_tiles = K % 16 == 0
+        g_Pa = torch.empty(Ep // 16, H, device=dev)[:E // 16] if gpa_tiles else torch.zeros(B * N, H, device=dev)
+        n = L.namp_train_edge_bwd_dw_groups(B, N, K)
+        dWp = torch.empty(n, 2, H, H, device=dev)
+        dbp = torch.empty(n, H, device=dev)
+        hip.check(L.namp_train_edge_bwd_dw(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
+                                           hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
+                                           img2.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(), g.data_ptr(),
+                                           G1.data_ptr(), g_hE.data_ptr(), (g_pass.data_ptr() if acc else None), g_Pa.data_ptr(),
+                                           dWp.data_ptr(), dbp.data_ptr(), int(ctx.x3) | (4 if acc else 0) | (8 if gpa_tiles else 0),
+                                           B, N, K, hip.current_stream()), "train_edge_bwd_dw")
+        rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
+        if mode == DEC_MSG:
+            r = rank32.view(-1)
+            sel = (r[rev.jflat] < r.repeat_interleave(K)).to(torch.uint8).contiguous()
+            g_Pj0, g_Pj1 = rev.scatter(G1, sel)
+        else:
+            g_Pj0, g_Pj1 = rev.scatter(G1)
+        dW = dWp.sum(0)
+        dW2, dW1b = dW[0], dW[1]
+        db2 = dbp.sum(0)
         if gpa_tiles:
             g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)

@@ -51,6 +51,20 @@ def test_two_ranks_on_one_device(workload, scaling):
         assert 1.0 <= sh["lpt_imbalance"] < 1.1
 
 
+def test_two_ranks_emit_both_scaling_points():
+    """`bench.py --gpus 2` (the driver's SCALE shape, no --no-secondary): ONE invocation yields the cfg2 weak-scaling value AND a
+    `cfg4_strong` sub-object — a timed region of passes over the LPT-sharded split with per-rank min / mean / max."""
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-gather", "--no-pmc", "--split-limit", "60",
+                "--min-seconds", "0.3"], {"NAMP_BENCH_ONE_DEVICE": "1", "NAMP_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    c4 = out["cfg4_strong"]
+    assert "error" not in c4, c4
+    assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["value"] > 0 and c4["backend"] == "gloo"
+    assert c4["passes"] * c4["ms_per_pass"] >= 0.3e3 * 0.9
+    ps = c4["per_rank_seconds"]
+    assert 0 < ps["min"] <= ps["mean"] <= ps["max"] and 1.0 <= c4["lpt_imbalance"] < 1.1
+
+
 def test_eight_ranks_on_one_device():
     """The driver's N = 8 launch shape — `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` — with the eight ranks
     sharing the box's one device over gloo: weak scaling of cfg2, every rank's complex collated (8 x 1000 residues)."""
@@ -83,8 +97,16 @@ def test_default_line_contract():
     assert out["dtype"] == "f32" and rf["peak"] == 157.3 and rf["bound"] == "mfma" and rf["basis"] == "executed FLOPs"
     # `frac` prices the FLOPs the launch EXECUTES; the dense formulation's rate sits beside it and may come close to the peak
     assert 0 < rf["frac"] <= 1.0 and rf["frac"] < rf["algorithmic_frac"] <= 1.05
-    assert rf["traffic"] is None or 0.5 * rf["traffic_algorithmic"] < rf["traffic"] < 3 * rf["traffic_algorithmic"], rf
     assert rf["traffic"] is not None, rf.get("traffic_source")
+    assert 0.5 * rf["traffic_algorithmic"] < rf["traffic"] < 1.6 * rf["traffic_algorithmic"], rf
+    # the clock the dominant launch ran at under the profiler sits beside frac (peaks are quoted at 2.4 GHz)
+    assert 1000 < rf["clock_mhz"] <= 2500 and rf["frac_at_measured_clock"] >= rf["frac"] * 0.99
+    ft = out["features"]
+    assert "error" not in ft, ft
+    assert ft["kernel"] == "edge_features_kernel" and 0 < ft["frac"] <= 1 and 0 < ft["algorithmic_frac"] <= 1.5
+    assert ft["cfg2_from_X"]["avg_launch_ms"] > 0 and ft["cfg4_batch"]["avg_launch_ms"] > 0 and ft["cfg4_batch"]["knn_select_ms"] > 0
+    assert ft["cfg4_batch"]["tokens"] <= 32000 and ft["traffic"] is not None
+    assert keys.index("features") < keys.index("secondary")
     g = out["gather"]
     assert 0 < g["frac"] <= 1.0 and g["peak"] == 8000.0 and g["traffic"] is not None
     assert 0.8 * g["bytes_per_launch"] < g["traffic"] < 2 * g["bytes_per_launch"]
@@ -95,7 +117,8 @@ def test_default_line_contract():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["one_thread"] > 0 and cb["full_forward_from_X"] > 0
     sec = {s_["workload"]: s_ for s_ in out["secondary"]}
-    assert set(sec) == {"cfg3", "cfg5", "cfg1", "cfg4"}, list(sec)
+    assert set(sec) == {"cfg3", "cfg5", "cfg1", "cfg1s", "cfg4"}, list(sec)
+    assert sec["cfg1s"]["cpu_baseline"] > 0 and sec["cfg1s"]["value"] > sec["cfg1"]["value"]        # 30 sequences per call
     for name, s_ in sec.items():
         assert "error" not in s_, (name, s_.get("error"))
         assert s_["value"] > 0
@@ -104,4 +127,4 @@ def test_default_line_contract():
     if "detail_file" in out:
         with open(os.path.join(ROOT, out["detail_file"])) as f:
             det = json.load(f)
-        assert "per_kernel" in det and len(det["secondary"]) == 4
+        assert "per_kernel" in det and len(det["secondary"]) == 5

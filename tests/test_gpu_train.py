@@ -82,6 +82,51 @@ def test_edge_mlp_backward_matches_autograd(mode, B, N, K):
         assert rel(a.grad, b.grad) < 5e-5, (name, rel(a.grad, b.grad))
 
 
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("mode,B,N,K", [(0, 2, 700, 48), (1, 2, 700, 48), (0, 1, 333, 30), (1, 1, 40, 16)])
+def test_edge_mlp_backward_on_chip_weight_gradients(mode, B, N, K, prec, monkeypatch):
+    """The persistent message backward that contracts (G2, A1) and (G1, h_E) on chip (csrc/namp_train_dw.h) against the round-3 form
+    (row tensors to HBM + row-contraction launches) on the same inputs, at sizes where a workgroup walks several rounds (67,200 rows =
+    1,050 rounds of 64 over <= 256 workgroups), with a ragged last round, K % 16 != 0 (atomic dL/dPa path) and a pass-through
+    gradient.  Split-bf16 products: every gradient within 2e-5 of the other form (relative to its largest entry); bf16 products:
+    within 1.5 % (both forms round the same operands to bf16; the summation orders differ)."""
+    g = torch.Generator(device="cpu").manual_seed(7 + 10 * mode + K)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    h_E, Pa, Pj0, Pj1 = rn(B, N, K, 128), rn(B, N, 128), rn(B, N, 128), rn(B, N, 128)
+    W1b, W2, W3 = rn(128, 128, sc=0.08), rn(128, 128, sc=0.1), rn(128, 128, sc=0.1)
+    b2, b3 = rn(128, sc=0.1), rn(128, sc=0.1)
+    E_idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(DEV).to(torch.int32).contiguous()
+    mask = (torch.rand(B, N, generator=g) > 0.15).to(DEV).to(torch.int32).contiguous()
+    rank = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(DEV).to(torch.int32).contiguous()
+    R, R2 = rn(B, N, 128), rn(B, N, K, 128)
+    leaves = [h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, b3]
+    monkeypatch.setattr(train, "X3", prec)
+
+    def run(on_chip):
+        monkeypatch.setattr(train, "DW_ONCHIP", on_chip)
+        with torch.enable_grad():
+            ins = [t.clone().requires_grad_(True) for t in leaves]
+            hE, pa, pj0, pj1, w1b, w2, bb2, w3, bb3 = ins
+            out, h_pass = train._EdgeMLP.apply(mode, hE, pa, pj0, pj1 if mode == 1 else None, w1b, w2, bb2, w3, bb3, E_idx,
+                                               mask if mode == 0 else None, None, rank if mode == 1 else None)
+            ((out * R).sum() + (h_pass * R2).sum()).backward()
+        torch.cuda.synchronize()
+        return out.detach(), [t.grad for t in ins]
+
+    out_a, ga = run(False)
+    out_b, gb = run(True)
+    assert torch.equal(out_a, out_b)
+    bar = 2e-5 if prec == 1 else 1.5e-2
+    worst = {}
+    for name, a, b in zip(["h_E", "Pa", "Pj0", "Pj1", "W1b", "W2", "b2", "W3", "b3"], ga, gb):
+        if name == "Pj1" and mode != 1:
+            continue
+        assert a is not None and b is not None and torch.isfinite(b).all(), name
+        worst[name] = rel(b, a)
+        assert worst[name] < bar, (name, worst[name])
+    print(f"on-chip dW vs row tensors (mode {mode}, prec {prec}, {B}x{N}x{K}):", {k_: f"{v:.1e}" for k_, v in worst.items()})
+
+
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_edge_update_backward(p):
     """_EdgeUpdate (message + dropout3 + residual + LayerNorm3 in one launch each way).  p = 0: against fp64 autograd of the

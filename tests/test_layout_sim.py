@@ -129,3 +129,96 @@ def test_plan_offsets_are_aligned_and_disjoint():
             assert f"enc{l}.{f}" in items
         for f in ("W1a_img", "W1e_img", "W1s_img", "W1v_img", "tok", "ln2_b"):
             assert f"dec{l}.{f}" in items
+
+
+# ---- round 4: the K-major staged operands of the weight-gradient contraction inside the backward launch (csrc/namp_train_dw.h) ----
+DW_WAVES, DW_ROWS = 4, 64
+DW_ROWB = 2 * DW_ROWS            # bytes per channel row of a staged plane
+DW_B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),          # ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS)
+                  list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+                  list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+                  list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+
+def _dw_stage_addr(wave, lane, t, r):
+    """dw_stage: byte address (within a plane) that lane (m, g) of `wave` writes element (t, r) of its tile to."""
+    m, g = lane & 15, lane >> 4
+    chunkv = 2 * wave + (m >> 3)
+    chl = 4 * g + r
+    f = (chl >> 1) & 7
+    return (16 * t + chl) * DW_ROWB + ((chunkv ^ f) << 4) + ((m & 7) << 1)
+
+
+def _dw_read_addr(c0, lane, ks):
+    """dw_contract: byte address of the 16-byte fragment lane (n, g) reads for channel block c0 (a multiple of 16) and K-step ks."""
+    n, g = lane & 15, lane >> 4
+    return (c0 + n) * DW_ROWB + (((4 * ks + g) ^ ((n >> 1) & 7)) << 4)
+
+
+def test_dw_staged_operand_layout():
+    """Writer (register-chain layout: lane (m, g) holds channels 16t + 4g + r of row m) and reader (MFMA 16x16x32 operand: lane (n, g)
+    holds rows 32ks + 8g + j, j = 0..7, of channel c0 + n) of the K-major staged planes agree; every byte of the plane is written
+    exactly once per round; fragment reads are 16-byte aligned and conflict-free within each ds_read_b128 lane group."""
+    rng = np.random.default_rng(0)
+    tiles = rng.integers(1, 60000, size=(DW_WAVES, 16, 128))                      # [wave][row m][channel] -> a unique-ish tag
+    plane = np.full(128 * DW_ROWB // 2, -1, dtype=np.int64)                       # one int per bf16 element
+    for wave in range(DW_WAVES):
+        for lane in range(64):
+            m, g = lane & 15, lane >> 4
+            for t in range(8):
+                for r in range(4):
+                    a = _dw_stage_addr(wave, lane, t, r)
+                    assert a % 2 == 0 and plane[a // 2] == -1
+                    plane[a // 2] = tiles[wave, m, 16 * t + 4 * g + r]
+    assert (plane >= 0).all()
+    S = tiles.reshape(DW_ROWS, 128)                                                # S[row][channel], row = 16 wave + m
+    for c0 in range(0, 128, 16):
+        for ks in range(DW_ROWS // 32):
+            addrs = np.array([_dw_read_addr(c0, lane, ks) for lane in range(64)])
+            assert (addrs % 16 == 0).all()
+            for lane in range(64):
+                n, g = lane & 15, lane >> 4
+                frag = plane[addrs[lane] // 2: addrs[lane] // 2 + 8]
+                assert (frag == S[32 * ks + 8 * g: 32 * ks + 8 * g + 8, c0 + n]).all()
+            for grp in DW_B128_GROUPS:                                             # 64 banks of 4 bytes, 16-byte accesses
+                banks = np.concatenate([((addrs[l] // 4) + np.arange(4)) % 64 for l in grp])
+                assert len(set(banks.tolist())) == 64
+
+
+def test_dw_contraction_tile_ownership():
+    """dW[o][c] = sum_rows G[row][o] A[row][c] from v_mfma_f32_16x16x32_bf16 with A-operand = G^T fragments, B-operand = A fragments:
+    lane (n, g) supplies A[i = n][k = 8g + j], B[k = 8g + j][n], receives D[4g + r][n]; wave (wo, wc) owns o in [64wo, +64), c in
+    [64wc, +64) — the store map of edge_bwd_dw_kernel's epilogue.  Also the bias trick: G^T . ones puts the column sums in every column."""
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((DW_ROWS, 128)); A = rng.standard_normal((DW_ROWS, 128))
+    dW = np.zeros((128, 128)); cover = np.zeros((128, 128), dtype=int)
+    db = np.zeros(128)
+    lanes = np.arange(64); n, g = lanes & 15, lanes >> 4
+    for wave in range(DW_WAVES):
+        wo, wc = wave >> 1, wave & 1
+        for q in range(4):
+            for t in range(4):
+                D = np.zeros((16, 16))
+                for ks in range(DW_ROWS // 32):
+                    Aop = np.zeros((16, 32)); Bop = np.zeros((32, 16))
+                    for j in range(8):
+                        Aop[n, 8 * g + j] = G[32 * ks + 8 * g + j, 64 * wo + 16 * q + n]
+                        Bop[8 * g + j, n] = A[32 * ks + 8 * g + j, 64 * wc + 16 * t + n]
+                    D += Aop @ Bop
+                for r in range(4):
+                    o = 64 * wo + 16 * q + 4 * g + r; c = 64 * wc + 16 * t + n
+                    dW[o, c] = D[4 * g + r, n]; cover[o, c] += 1
+        for u in range(2):
+            q = 2 * wc + u
+            Db = np.zeros((16, 16))
+            for ks in range(DW_ROWS // 32):
+                Aop = np.zeros((16, 32))
+                for j in range(8):
+                    Aop[n, 8 * g + j] = G[32 * ks + 8 * g + j, 64 * wo + 16 * q + n]
+                Db += Aop @ np.ones((32, 16))
+            for r in range(4):
+                sel = n == 0
+                db[64 * wo + 16 * q + 4 * g[sel] + r] = Db[4 * g[sel] + r, 0]
+    assert (cover == 1).all()
+    assert np.abs(dW - G.T @ A).max() < 1e-12
+    assert np.abs(db - G.sum(0)).max() < 1e-12

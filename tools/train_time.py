@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--B", type=int, default=16); ap.add_argument("--N", type=int, default=1500)
     ap.add_argument("--K", type=int, default=48); ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--precision", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rti = spec.restype_to_int()
@@ -34,6 +35,8 @@ def main():
                     restype_to_int=rti, polytype_to_int=spec.polytype_to_int(), augment_eps=0.1)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0).items()})
     m.to(dev).train()
+    if a.precision:
+        m.message_precision = a.precision
     fd = make_batch(a.B, a.N, dev)
     opt = train.get_std_opt(m.parameters(), 128, 0)
     rm, rn = train.polymer_restype_tables(rti, 33, dev)
@@ -47,6 +50,13 @@ def main():
         loss, _ = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    # host side: how long does Python take to ENQUEUE a step (no sync inside), against the step's device time?
+    th = []
+    for _ in range(a.steps):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter(); step(); t2 = time.perf_counter(); torch.cuda.synchronize(); t3 = time.perf_counter()
+        th.append((t2 - t1, t3 - t1))
+    print("host enqueue / step total (ms), device idle at the start of each:", ", ".join(f"{x * 1e3:.1f} / {y * 1e3:.1f}" for x, y in th))
     print(f"B={a.B} N={a.N} K={a.K}: {dt * 1e3:.1f} ms/step, {a.B * a.N / dt:.0f} residues/s trained, loss {float(loss):.4f}, "
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if a.profile:
