@@ -192,35 +192,21 @@ def live_pmc_traffic(timeout_s=150):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     per = {}
-    clock = {}
     tmp = tempfile.mkdtemp(prefix="namp_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", NAMP_BENCH_NO_PMC="1")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            # (GRBM_GUI_ACTIVE rides in the first pass — GRBM has its own counter slots: cycles the device was busy under a dispatch;
-            # over the dispatch's duration that is the clock it ran at, MI355X_MICROARCH.md "DVFS give-back")
-            pmc = [counter, "GRBM_GUI_ACTIVE"] if counter == "FETCH_SIZE" else [counter]
-            cmd = [exe, "--kernel-trace", "--pmc", *pmc, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "k", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             if p.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-200:]}"
-            rows = sqlite3.connect(dbs[0]).execute("select kernel_name, dispatch_id, counter_name, value, duration from counters_collection").fetchall()
+            rows = sqlite3.connect(dbs[0]).execute("select kernel_name, dispatch_id, counter_name, value from counters_collection").fetchall()
             acc = defaultdict(float)
-            gui, dur = defaultdict(float), {}
-            for k, disp, c, v, du in rows:
+            for k, disp, c, v in rows:
                 if c == counter:
                     acc[(re.sub(r"\(.*", "", k), disp)] += v
-                elif c == "GRBM_GUI_ACTIVE":
-                    gui[(re.sub(r"\(.*", "", k), disp)] = max(gui[(re.sub(r"\(.*", "", k), disp)], v)
-                    dur[(re.sub(r"\(.*", "", k), disp)] = du
-            if gui:
-                ck = defaultdict(list)
-                for kd, cyc in gui.items():
-                    if dur.get(kd):
-                        ck[kd[0]].append(cyc / dur[kd] * 1e3)            # cycles per ns -> MHz
-                clock = {k: sum(v) / len(v) for k, v in ck.items()}
             agg = defaultdict(list)
             for (k, _), v in acc.items():
                 agg[k].append(v)
@@ -229,7 +215,7 @@ def live_pmc_traffic(timeout_s=150):
         return None, f"{type(e).__name__}: {e}"[:200]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    out = {"fp32": {}, "x3": {}, "gather": None, "features": None, "clock_mhz": clock}
+    out = {"fp32": {}, "x3": {}, "gather": None, "features": None}
     for k in set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]):
         nbytes = round((2 * per["FETCH_SIZE"].get(k, 0.0) + per["WRITE_SIZE"].get(k, 0.0)) * 1024)
         m = re.search(r"edge_mlp_kernel<(\d+), (\d+), (\d+), (\d+)>", k)
@@ -726,6 +712,53 @@ def cpu_train_baseline(cx, K, rti, n=300):
                       f"eager PyTorch CPU, best of 3 ({', '.join(f'{t:.2f}s' for t in times)})"}
 
 
+class ClockSampler:
+    """Shader clock (MHz) the device reports while a timed region runs: a host thread polls the driver's current-sclk reading
+    (torch.cuda.clock_rate -> amdsmi, else the starred level of pp_dpm_sclk in sysfs) every millisecond.  Peaks are quoted at the
+    2.4 GHz maximum; DVFS runs loaded kernels lower (MI355X_MICROARCH.md "DVFS give-back"), so `frac` is also given rescaled to the
+    measured clock.  Returns None when the box exposes neither interface."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self._stop = [], threading.Event()
+        self._idx = dev.index or 0
+        self._sysfs = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            return float(torch.cuda.clock_rate(self._idx))
+        except Exception:                                       # noqa: BLE001
+            pass
+        for f in self._sysfs[self._idx:self._idx + 1] or self._sysfs[:1]:
+            try:
+                for ln in open(f).read().splitlines():
+                    if ln.strip().endswith("*"):
+                        return float(ln.split(":")[1].strip().split("M")[0])
+            except Exception:                                   # noqa: BLE001
+                pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(0.001)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=1.0)
+
+    def mean(self):
+        return round(sum(self.samples) / len(self.samples)) if self.samples else None
+
+
 def coll_device(dev, dist):
     """Device of the collectives' buffers: the GPU under RCCL; host memory when the harness is exercised over gloo."""
     return torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else dev
@@ -764,6 +797,15 @@ def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmu
         elapsed = float(t.item())
     ms_per_step = elapsed / steps * 1e3
     value = world * B * N * steps / elapsed
+    # the clock under this workload (outside the timed region: ~0.2 s of the same steps with a poller thread beside them)
+    clock_mhz = None
+    if rank == 0:
+        with ClockSampler(dev) as cs:
+            t_c = time.perf_counter()
+            while time.perf_counter() - t_c < 0.2:
+                runner.step()
+            torch.cuda.synchronize()
+        clock_mhz = cs.mean()
 
     # reporting-only collective: all-gather of the arg-max sequences (north_star: "RCCL all-gather ... only
     # for throughput reporting"); outside the timed region.
@@ -802,6 +844,9 @@ def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmu
                 "algorithmic_achieved": round(algo / avg_s / 1e12, 3), "algorithmic_frac": round(algo / avg_s / 1e12 / peak, 4),
                 "traffic": None, "flop_per_launch_algorithmic": algo, "flop_per_launch_executed": exec_flop,
                 "avg_launch_ms": per_kernel[dom]["avg_ms"], "launch_kind": dom}
+    if clock_mhz:
+        roofline["clock_mhz"] = clock_mhz
+        roofline["frac_at_measured_clock"] = round(roofline["frac"] * 2400.0 / max(float(clock_mhz), 1.0), 4)
     dtype = {"fp32": "f32", "x3": "bf16x3 (per-edge GEMMs as three bf16 products of split fp32 operands, fp32 accumulate: "
                                    "fp32-equivalent to 2^-16; fp32 everywhere else)",
              "bf16": "bf16 (per-edge GEMMs; fp32 accumulate, fp32 elsewhere)"}[precision]
@@ -881,6 +926,8 @@ def compact_secondary(o):
         r = o["roofline"]
         c["roofline"] = {"kernel": r["kernel"], "frac": r["frac"], "algorithmic_frac": r.get("algorithmic_frac"),
                          "avg_launch_ms": r.get("avg_launch_ms")}
+        if "clock_mhz" in r:
+            c["roofline"]["clock_mhz"] = r["clock_mhz"]
     if "cpu_baseline" in o:
         c["cpu_baseline"] = o["cpu_baseline"]["value"]
     for k in ("hip_kernel_share", "checks", "levels"):
@@ -1098,12 +1145,7 @@ def main():
                     f["traffic"] = traffic.get("features")
                     # compulsory bytes of the launch: the h_E rows it writes, E_idx, the 18-atom frames of the residues (gathered frames hit in cache)
                     f["traffic_algorithmic"] = f["cfg4_batch"]["tokens"] * (48 * 128 * 4 + 48 * 4 + 54 * 4 + 4 * 4)
-                # the clock the dominant launch ran at under the profiler (GRBM_GUI_ACTIVE / duration): peaks are quoted at 2.4 GHz
-                kname = "edge_mlp_kernel<0, 4, 0, 3>" if precision == "fp32" else "edge_mlp_kernel<0, 4, 2, 3>"
-                ck = [v for k, v in (traffic.get("clock_mhz") or {}).items() if kname in k]
-                if ck:
-                    out["roofline"]["clock_mhz"] = round(ck[0])
-                    out["roofline"]["frac_at_measured_clock"] = round(out["roofline"]["frac"] * 2400.0 / max(ck[0], 1.0), 4)
+
         if not args.no_cpu_baseline:
             ref_out, cb = cpu_baseline(runner)
             out["cpu_baseline"] = cb

@@ -53,8 +53,9 @@ int ensure_attributes() {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
       if (e != hipSuccess) g_attr_err = e;
     };
-    set_dw((const void*)(edge_bwd_dw_kernel<BWD_ENC_MSG, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<BWD_ENC_MSG, 2>));
-    set_dw((const void*)(edge_bwd_dw_kernel<BWD_DEC_MSG, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<BWD_DEC_MSG, 2>));
+#define NAMP_SET_DWR(M, P) set_dw((const void*)(edge_bwd_dw_kernel<M, P, false, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<M, P, true, 1>)); \
+                           set_dw((const void*)(edge_bwd_dw_kernel<M, P, false, 2>)); set_dw((const void*)(edge_bwd_dw_kernel<M, P, true, 2>))
+    NAMP_SET_DWR(BWD_ENC_MSG, 1); NAMP_SET_DWR(BWD_DEC_MSG, 1); NAMP_SET_DWR(BWD_ENC_MSG, 2); NAMP_SET_DWR(BWD_DEC_MSG, 2);
     auto set_dw16 = [](const void* f) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW16_LDS);
       if (e != hipSuccess) g_attr_err = e;
@@ -178,8 +179,15 @@ int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, con
   static const bool ring16 = [] { const char* e = getenv("NAMP_DW16_RING"); return e && atoi(e) != 0; }();
   const bool acc_ = a.acc_hE != 0;
   const int gpa_ = a.gpa_tiles ? 1 : 2;
-  REQUIRE(x3 != 2 || ring16 || g_Pa != nullptr, "namp_train_edge_bwd_dw: the bf16 launch needs g_Pa");
+  REQUIRE(g_Pa != nullptr, "namp_train_edge_bwd_dw: null g_Pa");
   REQUIRE(x3 != 2 || ring16 || mode != 0 || mask != nullptr || mask_attend != nullptr, "namp_train_edge_bwd_dw: the bf16 encoder launch needs mask or mask_attend");
+#define NAMP_LAUNCH_DWR(M, P)                                                                                                       \
+  do {                                                                                                                                \
+    if (acc_ && gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw_kernel<M, P, true, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);    \
+    else if (acc_) hipLaunchKernelGGL((edge_bwd_dw_kernel<M, P, true, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);            \
+    else if (gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw_kernel<M, P, false, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);      \
+    else hipLaunchKernelGGL((edge_bwd_dw_kernel<M, P, false, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);                     \
+  } while (0)
 #define NAMP_LAUNCH_DW16(M)                                                                                                          \
   do {                                                                                                                                \
     if (acc_ && gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, true, 1>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);   \
@@ -189,12 +197,12 @@ int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, con
   } while (0)
   if (mode == 0) {
     if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_ENC_MSG);
-    else if (x3 == 2) hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_ENC_MSG, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
-    else hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_ENC_MSG, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+    else if (x3 == 2) NAMP_LAUNCH_DWR(BWD_ENC_MSG, 2);
+    else NAMP_LAUNCH_DWR(BWD_ENC_MSG, 1);
   } else {
     if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_DEC_MSG);
-    else if (x3 == 2) hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_DEC_MSG, 2>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
-    else hipLaunchKernelGGL((edge_bwd_dw_kernel<BWD_DEC_MSG, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);
+    else if (x3 == 2) NAMP_LAUNCH_DWR(BWD_DEC_MSG, 2);
+    else NAMP_LAUNCH_DWR(BWD_DEC_MSG, 1);
   }
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -40,6 +40,9 @@ struct EdgeBwdDwArgs {
 #define DW_STAGE_BYTES (4 * DW_ARR)              // G_hi, G_mid, A_hi, A_mid (bf16 products use planes 0 and 2)
 #define DW_LDS (2 * DW_SLOT_BYTES + DW_STAGE_BYTES + 512)
 
+// workgroup barrier that waits for LDS traffic only: vector-memory requests stay in flight across it (__syncthreads() drains them too)
+__device__ __forceinline__ void dw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Write this wave's 16-row tile v (register-chain layout: lane (m, g) holds channels 16t + 4g + r of row m) into the K-major staged
 // plane at `base`: S[ch][16 wave + m] = bf16(v); X3: the plane behind it takes bf16 of the remainder.  Row chunk c (8 rows = 16 bytes)
 // of channel ch sits at chunk position c ^ ((ch >> 1) & 7): with 128-byte channel rows a quarter-wave of fragment reads (16 channels, one
@@ -172,7 +175,8 @@ __device__ __forceinline__ void dw_half_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], 
 // 2 x 64 accumulator registers of weight gradients and two fragment sets in flight do not fit the 256 of a two-waves-per-SIMD launch
 // (measured with the 8-wave form of this kernel: 55-190 spilled registers).  Matrix and vector time add up on this chip whichever wave
 // issues them, so the second wave was only ever covering memory round trips — here that is the prefetches' job.
-template <int MODE, int PREC>
+// ACC / GPA as in edge_bwd_dw16_kernel below; rows past E store into the buffers' padding (namp_train_edge_bwd_dw_rows).
+template <int MODE, int PREC, bool ACC, int GPA>
 __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw_kernel(const EdgeBwdDwArgs aa) {
   static_assert(MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG, "message stages only");
   static_assert(PREC == 1 || PREC == 2, "split-bf16 or bf16 products");
@@ -263,9 +267,8 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw_kernel(const EdgeBw
   // before a ring point would make s_waitcnt vmcnt(0) wait for its acknowledgement)
   bool have_prev = false;
   long e_prev = 0;
-  bool valid_prev = false;
   auto store_prev = [&]() {
-    if (have_prev && valid_prev) {
+    if (have_prev) {
       float* d = a.g_hE + e_prev * NAMP_H + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = acc[t];
@@ -330,27 +333,31 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw_kernel(const EdgeBw
     else if (more) issue_fill(0);
     dw_stage<X3>(SG, gr, wave, m, g);
     dw_stage<X3>(SA, x, wave, m, g);
-    __syncthreads();
+    dw_lds_barrier();                                                // (LDS only: the row requests stay in flight)
     // G1 rows (for the table-gradient gather) and the per-tile sums for dL/dPa go out behind a barrier, with the contraction and the
     // last product to retire under
-    if (me.valid) {
+    {
+      const long e_st = (round * DW_WAVES + wave) * 16 + m;         // unclamped: rows past E go to the buffers' padding
 #pragma unroll
-      for (int t = 0; t < 8; ++t) st_row4<RB>(a.G1, me.e * NAMP_H + 4 * g + 16 * t, gr[t]);
+      for (int t = 0; t < 8; ++t) st_row4<RB>(a.G1, e_st * NAMP_H + 4 * g + 16 * t, gr[t]);
     }
-    if (a.g_Pa && a.gpa_tiles) {
+    if constexpr (GPA == 1) {
       const long tile = round * DW_WAVES + wave;
+      f4 keep = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         f4 v = me.valid ? gr[t] : (f4){0.f, 0.f, 0.f, 0.f};
-        v.x = dw_row_sum_to_lane15(v.x); v.y = dw_row_sum_to_lane15(v.y); v.z = dw_row_sum_to_lane15(v.z); v.w = dw_row_sum_to_lane15(v.w);
-        if (m == 15 && tile * 16 < a.E) *(f4*)(a.g_Pa + tile * NAMP_H + 16 * t + 4 * g) = v;
+        v.x = dw_row_allsum(v.x); v.y = dw_row_allsum(v.y); v.z = dw_row_allsum(v.z); v.w = dw_row_allsum(v.w);
+        keep = ((m & 7) == t) ? v : keep;
       }
-    } else if (a.g_Pa && me.valid) {
+      *(f4*)(a.g_Pa + tile * NAMP_H + 16 * (m & 7) + 4 * g) = keep;
+    } else if constexpr (GPA == 2) {
       float* d = a.g_Pa + (long)me.node * NAMP_H + 4 * g;
+      const float vz = me.valid ? 1.f : 0.f;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        unsafeAtomicAdd(d + 16 * t + 0, gr[t].x); unsafeAtomicAdd(d + 16 * t + 1, gr[t].y);
-        unsafeAtomicAdd(d + 16 * t + 2, gr[t].z); unsafeAtomicAdd(d + 16 * t + 3, gr[t].w);
+        unsafeAtomicAdd(d + 16 * t + 0, gr[t].x * vz); unsafeAtomicAdd(d + 16 * t + 1, gr[t].y * vz);
+        unsafeAtomicAdd(d + 16 * t + 2, gr[t].z * vz); unsafeAtomicAdd(d + 16 * t + 3, gr[t].w * vz);
       }
     }
     f4 nob[2];
@@ -359,9 +366,9 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw_kernel(const EdgeBw
     if (more) load_hE(cur);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
-      acc[t] = (a.acc_hE && me.valid) ? *(const f4*)(a.g_hE_in + me.e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
+      acc[t] = ACC ? *(const f4*)(a.g_hE_in + me.e * NAMP_H + 4 * g + 16 * t) : (f4){0.f, 0.f, 0.f, 0.f};
     gemm(acc, gr, X3 ? 6 : 3, more);
-    have_prev = true; e_prev = me.e; valid_prev = me.valid;
+    have_prev = true; e_prev = (round * DW_WAVES + wave) * 16 + m;
   }
   store_prev();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA in flight when the workgroup's LDS is released
@@ -395,7 +402,6 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw_kernel(const EdgeBw
 // 128 KiB of weights per 64 rows at LDS-DMA's ~25 GB/s per CU: 5.2 us per round before any arithmetic.
 #define DW16_LDS (4 * NAMP_BIMG_BYTES + 2 * DW_ARR)
 
-__device__ __forceinline__ void dw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One 16-row x 128 x 128 bf16 product out of a resident image with the eight weight fragments of K-step s + 1 requested before the
 // MFMAs of step s issue (two fragment sets in flight).  One wave per SIMD has nobody to cover an LDS round trip: the compiler's own
