@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — separate runs, as the PMC slots require).
 
-    python tools/make_pmc_traffic.py <fetch.db> <write.db> <commit> <round> > profiles/pmc_traffic.json
+    python tools/make_pmc_traffic.py <fetch.db> <write.db> <commit> <round> [<cfg5 fetch.db> <cfg5 write.db> <precision>]... > profiles/pmc_traffic.json
 
 HBM-side bytes per launch = 2 x FETCH_SIZE x 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads,
 MI355X_MICROARCH.md §HBM) + WRITE_SIZE x 1024, averaged over the dispatches of a kernel.  Kernel -> launch kind of bench.py:
@@ -30,7 +30,42 @@ def per_kernel(path, counter):
 KIND = {(0, 1): "enc_message", (0, 3): "enc_edge_message", (1, 3): "enc_edge_dec_message", (1, 0): "dec_message"}
 
 
-def main(fetch_db, write_db, commit, rnd):
+# cfg5 (B = 16, N = 1500, K = 48): compulsory HBM bytes per launch of the per-edge backward kernels — rows that MUST move (h_E rows in, the
+# other consumer's dL/dh_E rows in where added, dL/dh_E rows out, G1 rows out for the table-gradient gather, E_idx, per-tile sums; the
+# residue tables count as cache-resident like in SURVEY 8(d)).  The round-3 kernels additionally write A1 / G2 (/ A2 / G3) rows that exist
+# only to be re-read by the row contractions: NOT compulsory, so their measured / algorithmic ratio shows the waste.
+def cfg5_algorithmic(kernel, prec):
+    E, G = 16 * 1500 * 48, 16 * 1500
+    row16 = 256 if prec == "bf16" else 512            # G1 row bytes
+    base = E * 4 + E // 16 * 512 + 3 * G * 512
+    if "edge_bwd_dw" in kernel:
+        acc = "true" in kernel                         # <MODE, [PREC,] ACC, GPA>
+        return E * (512 + (512 if acc else 0) + row16 + 512) + base
+    if "edge_chain_bwd_kernel<3" in kernel:            # edge update: h_E in, dL/dh_E' in, dL/dh_E out, G1 out
+        return E * (512 + 512 + 512 + row16) + base
+    if "edge_chain_bwd_kernel<0" in kernel or "edge_chain_bwd_kernel<1" in kernel:
+        return E * (512 + 512 + 512 + row16) + base
+    return None
+
+
+def cfg5_section(fetch_db, write_db, prec):
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    sec = {}
+    for k in sorted(set(f) | set(w)):
+        if not any(t in k for t in ("edge_bwd_dw", "edge_chain_bwd", "wgrad", "scatter_rows", "edge_mlp_x3_persistent", "edge_mlp_bf16_persistent",
+                                    "feat_wgrad", "edge_features")):
+            continue
+        nbytes = (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024
+        e = {"measured_bytes": round(nbytes)}
+        alg = cfg5_algorithmic(k, prec)
+        if alg:
+            e["algorithmic_bytes"] = alg
+            e["measured_over_algorithmic"] = round(nbytes / alg, 3)
+        sec[k.replace("void ", "")[:70]] = e
+    return sec
+
+
+def main(fetch_db, write_db, commit, rnd, *extra):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     out = {"_commit": commit, "_round": rnd,
            "_source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
@@ -48,8 +83,13 @@ def main(fetch_db, write_db, commit, rnd):
                 out["cfg2" if prec == 2 else "cfg2_fp32"][kind] = round((2 * fk + wk) * 1024, 1)
         if "gather_cat_kernel" in k:
             out["gather_cfg3"] = round((2 * fk + wk) * 1024, 1)
+    for i in range(0, len(extra) - 2, 3):
+        out["cfg5_" + extra[i + 2]] = cfg5_section(extra[i], extra[i + 1], extra[i + 2])
+    if extra:
+        out["_cfg5_source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --workload cfg5 --precision <p> --steps 2 "
+                               "--warmup 1`; per-dispatch averages per kernel; algorithmic = compulsory rows (tools/make_pmc_traffic.py:cfg5_algorithmic)")
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:])
