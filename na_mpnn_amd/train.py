@@ -864,10 +864,17 @@ class FusedAdam(torch.optim.Adam):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         steps = [self.state[p]["step"] for p in params]
+        # the step counts are read (and checked equal) ONCE per set of state tensors — at the first step and after load_state_dict —
+        # and counted on the host afterwards: with capturable / device-side state every .item() would be a device synchronisation
+        skey = tuple(id(s_) for s_ in steps)
+        if getattr(self, "_t_key", None) != skey:
+            t0 = int(steps[0].item())
+            if any(int(s_.item()) != t0 for s_ in steps[1:]):
+                raise RuntimeError("FusedAdam: parameters with different step counts (load a consistent optimizer_state_dict)")
+            self._t, self._t_key = t0, skey
         torch._foreach_add_(steps, 1)
-        t = int(steps[0].item())
-        if any(int(s_.item()) != t for s_ in steps[1:]):
-            raise RuntimeError("FusedAdam: parameters with different step counts (load a consistent optimizer_state_dict)")
+        self._t += 1
+        t = self._t
         key = tuple((p.data_ptr(), p.numel()) for p in params)
         if getattr(self, "_plan_key", None) != key:
             chunk = hip.lib().namp_train_adam_chunk()
@@ -880,9 +887,24 @@ class FusedAdam(torch.optim.Adam):
             self._ws = torch.empty(len(bt) + 2, dtype=torch.float32, device=dev)
             self._plan_key = key
         bt, bo, numel, nb = self._plan
-        ptrs = torch.tensor([[p.data_ptr() for p in params], [p.grad.data_ptr() for p in params],
-                             [self.state[p]["exp_avg"].data_ptr() for p in params], [self.state[p]["exp_avg_sq"].data_ptr() for p in params]],
-                            dtype=torch.int64).to(dev, non_blocking=False)
+        # The 4 x ntensors pointer table: cached on the device while the parameter / gradient / state addresses are unchanged (the caching
+        # allocator hands the same gradient blocks back step after step), otherwise uploaded from a PINNED staging buffer without blocking —
+        # a pageable .to(dev) waits for the whole backward pass on the stream and leaves the device idle until the host has restarted
+        # (measured: ~0.5 ms of every cfg5 step)
+        rows = ([p.data_ptr() for p in params], [p.grad.data_ptr() for p in params],
+                [self.state[p]["exp_avg"].data_ptr() for p in params], [self.state[p]["exp_avg_sq"].data_ptr() for p in params])
+        pkey = tuple(map(tuple, rows))
+        if getattr(self, "_ptr_key", None) != pkey:
+            ring = getattr(self, "_ptr_ring", None)
+            if ring is None or ring[0].shape[1] != len(params):
+                ring = self._ptr_ring = [torch.empty(4, len(params), dtype=torch.int64).pin_memory() for _ in range(4)]
+                self._ptr_dev = [torch.empty(4, len(params), dtype=torch.int64, device=dev) for _ in range(4)]
+                self._ptr_i = 0
+            self._ptr_i = (self._ptr_i + 1) % 4            # (four staging buffers: a buffer is rewritten four uploads later at the earliest)
+            ring[self._ptr_i].copy_(torch.tensor(rows, dtype=torch.int64))
+            self._ptr_dev[self._ptr_i].copy_(ring[self._ptr_i], non_blocking=True)
+            self._ptrs, self._ptr_key = self._ptr_dev[self._ptr_i], pkey
+        ptrs = self._ptrs
         b1, b2 = grp["betas"]
         lr = float(grp["lr"])
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t

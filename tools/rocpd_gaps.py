@@ -20,12 +20,16 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--top", type=int, default=25)
     ap.add_argument("--min-gap-us", type=float, default=15.0)
+    ap.add_argument("--last-ms", type=float, default=0.0, help="analyse only the last so many milliseconds of the trace (steady state)")
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     ncol = "name" if "name" in cols else "kernel_name"
     rows = sorted(db.execute(f"select {ncol}, start, end from kernels").fetchall(), key=lambda r: r[1])
-    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    t1 = max(r[2] for r in rows)
+    if a.last_ms > 0:
+        rows = [r for r in rows if r[1] >= t1 - a.last_ms * 1e6]
+    t0 = rows[0][1]
     busy = 0.0
     cur_end = rows[0][1]
     gaps = []
