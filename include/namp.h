@@ -358,6 +358,13 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  *   features, g_pre [B*L*K][128] = dL/d(pre-LayerNorm edge embedding); dW_part [namp_train_feat_wgrad_chunks][128][5200];
  *   x3 != 0: the contraction over edges as split-bf16 products (as namp_train_wgrad).
  * namp_featurize with w->feat.ln_g == NULL writes the pre-LayerNorm rows to E (the training forward). */
+/* namp_edge_embed / namp_node_linear with the product evaluation of the training step's precision code (0 exact fp32 MFMA with fp32
+ * images, 1 split-bf16 with x3 images, 2 plain bf16: bf16 image for the edge embedding, the hi plane of x3 images for the residue
+ * products) — W_e (na_model_utils.py:598) and the hoisted first-layer tables of EncLayer / DecLayer (:218-236, 610-636) and their
+ * data gradients inside the training step. */
+int namp_edge_embed_prec(const float* We_img, const float* We_b, const float* E, float* h_E, int prec, int B, int N, int K,
+                         void* stream);
+int namp_node_linear_prec(const float* X, int G, const NampProj* proj, int nproj, int prec, void* stream);
 int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,
                         const float* W2_img, const float* W3_img, const float* b2, const float* b3,

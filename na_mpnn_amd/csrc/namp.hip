@@ -627,6 +627,48 @@ int namp_edge_embed(const float* We_img, const float* We_b, const float* E, floa
   return NAMP_OK;
 }
 
+// The same launch with the product evaluation chosen by the training precision code: 0 exact fp32 MFMA (fp32 image), 1 split-bf16
+// products (x3 image), 2 plain bf16 products (bf16 image) — the edge embedding W_e and its data gradient in the training step ran on
+// the fp32 matrix pipe (1/16 of the bf16 rate) whatever the step's precision: 0.39 ms per launch at cfg5.
+int namp_edge_embed_prec(const float* We_img, const float* We_b, const float* E, float* h_E, int prec, int B, int N, int K,
+                         void* stream) {
+  REQUIRE_PTR(We_img); REQUIRE_PTR(We_b); REQUIRE_PTR(E); REQUIRE_PTR(h_E);
+  REQUIRE(prec >= 0 && prec <= 2, "namp_edge_embed_prec: precision code %d (0 fp32, 1 split-bf16, 2 bf16)", prec);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = E; a.hE_out = h_E; a.W1_img = We_img; a.b1 = We_b;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_EDGE_EMBED, (hipStream_t)stream);
+  if (prec == 1) rc = launch_edge<MODE_EMBED, 0, PREC_X3>(a, (hipStream_t)stream);
+  else if (prec == 2) rc = launch_edge<MODE_EMBED, 0, PREC_BF16>(a, (hipStream_t)stream);
+  else rc = launch_edge<MODE_EMBED>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+// namp_node_linear with split-bf16 (1) or plain bf16 (2) products: every image is then an x3 image (namp_pack_image_x3; the bf16
+// evaluation reads its hi plane only).  No pre-stage, no token tables (the training path's hoisted first-layer tables and their data
+// gradients: [B*N,128] x [128,128] products that ran as exact fp32 MFMA).
+int namp_node_linear_prec(const float* X, int G, const NampProj* proj, int nproj, int prec, void* stream) {
+  REQUIRE_PTR(X);
+  REQUIRE(proj != nullptr && nproj >= 1 && nproj <= 8, "namp_node_linear_prec: nproj=%d must be in [1,8]", nproj);
+  REQUIRE(G >= 1, "namp_node_linear_prec: G=%d", G);
+  REQUIRE(prec >= 0 && prec <= 2, "namp_node_linear_prec: precision code %d (0 fp32, 1 split-bf16, 2 bf16)", prec);
+  for (int i = 0; i < nproj; ++i) {
+    REQUIRE_PTR(proj[i].img); REQUIRE_PTR(proj[i].out); OPTIONAL_PTR(proj[i].bias);
+    REQUIRE(proj[i].tok == nullptr, "namp_node_linear_prec: token tables are not supported");
+  }
+  ProfScope prof_(NAMP_KIND_NODE_LINEAR, (hipStream_t)stream);
+  const bool prev = g_residue_x1;
+  g_residue_x1 = (prec == 2);
+  launch_node_linear(X, nullptr, G, G, G, proj, nproj, nullptr, (hipStream_t)stream, prec != 0);
+  g_residue_x1 = prev;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
                      const int32_t* mask_attend, const float* Pa, const float* Pc, float* partial, int B, int N,
                      int K, void* stream) {

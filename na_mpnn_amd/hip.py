@@ -79,6 +79,8 @@ _PROTOTYPES = {
     "namp_cat_neighbors_nodes_f32": (i32, [c_fp, c_fp, c_ip, c_fp, i32, i32, i32, i32, i32, vp]),
     "namp_node_linear": (i32, [c_fp, c_ip, i32, i32, i32, C.POINTER(NampProj), i32, C.POINTER(NampProj), vp]),
     "namp_edge_embed": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
+    "namp_edge_embed_prec": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, vp]),
+    "namp_node_linear_prec": (i32, [c_fp, i32, C.POINTER(NampProj), i32, i32, vp]),
     "namp_enc_message": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
     "namp_enc_edge_update": (i32, [C.POINTER(NampEncLayerW), c_fp, c_ip, c_fp, c_fp, c_fp, i32, i32, i32, vp]),
     "namp_node_update": (i32, [c_fp] * 8 + [c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, C.POINTER(NampProj), i32, c_ip, i32, i32, vp]),

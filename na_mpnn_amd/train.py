@@ -406,9 +406,9 @@ class _EdgeLinear(torch.autograd.Function):
         B, N, K, _ = x.shape
         x = x.contiguous()
         y = torch.empty_like(x)
-        hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
-                                            y.data_ptr(), B, N, K, hip.current_stream()), "edge_embed")
-        ctx.x3 = X3
+        hip.check(hip.lib().namp_edge_embed_prec(_image(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), x.data_ptr(),
+                                                 y.data_ptr(), int(X3), B, N, K, hip.current_stream()), "edge_embed")
+        ctx.x3, ctx.step = X3, _STEP
         ctx.save_for_backward(x, W)
         return y
 
@@ -419,8 +419,8 @@ class _EdgeLinear(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty_like(x)
         zero = torch.zeros(H, device=x.device)
-        hip.check(hip.lib().namp_edge_embed(_image_f32(W.detach().t().contiguous()).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), B, N, K,
-                                            hip.current_stream()), "edge_embed (dgrad)")
+        hip.check(hip.lib().namp_edge_embed_prec(_image_t(W, ctx.x3, ctx.step).data_ptr(), zero.data_ptr(), g.data_ptr(), gx.data_ptr(), int(ctx.x3),
+                                                 B, N, K, hip.current_stream()), "edge_embed (dgrad)")
         dW, db = _wgrad(g.view(-1, H), x.view(-1, H), False, True, x3=ctx.x3)
         return gx, dW, db
 
@@ -523,15 +523,21 @@ def _ln(x, norm):
     return F.layer_norm(x, (H,), norm.weight, norm.bias, 1e-5)
 
 
-def _node_linear_call(x2, blocks, biases):
-    """y_q = x2 @ blocks[q]^T (+ biases[q]) for up to 8 [128 x 128] blocks in ONE node_linear launch -> list of [G,128]."""
+def _node_linear_call(x2, blocks, biases, x3=None, transposed=False, step=None):
+    """y_q = x2 @ blocks[q]^T (+ biases[q]) — transposed: x2 @ blocks[q] — for up to 8 [128 x 128] blocks in ONE node_linear launch
+    -> list of [G,128].  Products at the step's precision: exact fp32 MFMA (code 0), split-bf16 (1), plain bf16 (2: the hi plane of
+    the x3 images)."""
     G = x2.shape[0]
+    prec = int(X3 if x3 is None else x3)
     outs = [torch.empty(G, H, device=x2.device) for _ in blocks]
-    keep = [_image_f32(b_) for b_ in blocks]
+    if prec == 0:
+        keep = [_image_f32(b_.t().contiguous() if transposed else b_) for b_ in blocks]
+    else:
+        keep = [_image(b_, 1, transposed=transposed, step=step) for b_ in blocks]          # x3 images serve codes 1 and 2
     bc = [None if b_ is None else b_.detach().contiguous() for b_ in biases]
     proj = (hip.NampProj * len(blocks))(*[hip.NampProj(keep[q].data_ptr(), hip.ptr(bc[q]), None, outs[q].data_ptr())
                                           for q in range(len(blocks))])
-    hip.check(hip.lib().namp_node_linear(x2.data_ptr(), None, 1, 1, G, proj, len(blocks), None, hip.current_stream()), "node_linear")
+    hip.check(hip.lib().namp_node_linear_prec(x2.data_ptr(), G, proj, len(blocks), prec, hip.current_stream()), "node_linear")
     return outs
 
 
@@ -546,7 +552,7 @@ class _NodeLinears(torch.autograd.Function):
         Ws, bs = wb[:nb], wb[nb:]
         x2 = x.contiguous().view(-1, H)
         outs = _node_linear_call(x2, [w.detach() for w in Ws], bs)
-        ctx.nb, ctx.shape, ctx.has_b, ctx.x3 = nb, x.shape, [b is not None for b in bs], X3
+        ctx.nb, ctx.shape, ctx.has_b, ctx.x3, ctx.step = nb, x.shape, [b is not None for b in bs], X3, _STEP
         ctx.save_for_backward(x2, *Ws)
         return tuple(o.view(*x.shape[:-1], H) for o in outs)
 
@@ -556,7 +562,7 @@ class _NodeLinears(torch.autograd.Function):
         g2 = [g.contiguous().view(-1, H) for g in gs]
         gx = None
         for q, w in enumerate(Ws):                                  # dL/dx = sum_q g_q W_q
-            t = _node_linear_call(g2[q], [w.detach().t().contiguous()], [None])[0]
+            t = _node_linear_call(g2[q], [w.detach()], [None], x3=ctx.x3, transposed=True, step=ctx.step)[0]
             gx = t if gx is None else gx + t
         res = _wgrad_many([(g2[q], x2, ctx.has_b[q]) for q in range(ctx.nb)], x3=ctx.x3)      # one reduction for all blocks
         gW, gb = [r[0] for r in res], [r[1] for r in res]
