@@ -438,12 +438,13 @@ def train_bench(args, dev, rank, world, dist):
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -573,13 +574,14 @@ def split_bench(args, dev, rank, world, dist):
     steps_requested = args.steps
     args.steps = max(args.steps, int(np.ceil(args.min_seconds / max(t_pass, 1e-6))))
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    my_elapsed = time.perf_counter() - t0                     # this rank's own passes, before waiting for the others
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        my_elapsed = time.perf_counter() - t0                 # this rank's own passes, before waiting for the others
+        barrier()
+        elapsed = time.perf_counter() - t0
     my_res = int(sum(lengths[i] for i in mine))
     per_rank = [[float(my_res), my_elapsed]]
     if dist is not None:
@@ -650,12 +652,13 @@ def design_bench(args, dev, rank, world, dist, specificity=False):
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -710,6 +713,24 @@ def cpu_train_baseline(cx, K, rti, n=300):
     return {"value": round(n / min(times), 1), "unit": "residues/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/cpu_ref.py training step (features + fwd + loss + autograd bwd + Adam), B=1 N={n} K={K}, "
                       f"eager PyTorch CPU, best of 3 ({', '.join(f'{t:.2f}s' for t in times)})"}
+
+
+class quiet_gc:
+    """Python's cyclic garbage collector paused over a timed region (collected right before, re-enabled after): a generation-2 pass
+    over the process's ~10^6 objects stalls the launching thread for 90-150 ms — one such pass inside a 4-step cfg5 region doubles the
+    reported step time (measured: 40 steps, one 100 ms outlier with the collector on, none with it off; profiles/r04e)."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
 
 
 class ClockSampler:
@@ -785,12 +806,13 @@ def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmu
     for _ in range(warmup):
         runner.step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
