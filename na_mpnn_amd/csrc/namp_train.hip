@@ -55,7 +55,7 @@ int ensure_attributes() {
     };
 #define NAMP_SET_DWR(M, P) set_dw((const void*)(edge_bwd_dw_kernel<M, P, false, 1>)); set_dw((const void*)(edge_bwd_dw_kernel<M, P, true, 1>)); \
                            set_dw((const void*)(edge_bwd_dw_kernel<M, P, false, 2>)); set_dw((const void*)(edge_bwd_dw_kernel<M, P, true, 2>))
-    NAMP_SET_DWR(BWD_ENC_MSG, 1); NAMP_SET_DWR(BWD_DEC_MSG, 1); NAMP_SET_DWR(BWD_ENC_MSG, 2); NAMP_SET_DWR(BWD_DEC_MSG, 2);
+    NAMP_SET_DWR(BWD_ENC_MSG, 1); NAMP_SET_DWR(BWD_DEC_MSG, 1);
     auto set_dw16 = [](const void* f) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW16_LDS);
       if (e != hipSuccess) g_attr_err = e;
@@ -175,12 +175,11 @@ int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, con
   aa.nrounds = (a.E + DW_ROWS - 1) / DW_ROWS;
   const int grid = namp_train_edge_bwd_dw_groups(B, N, K);
   hipStream_t s = (hipStream_t)stream;
-  // bf16 products: the weight-stationary kernel (all four images resident); NAMP_DW16_RING=1 selects the ring form for A/B runs
-  static const bool ring16 = [] { const char* e = getenv("NAMP_DW16_RING"); return e && atoi(e) != 0; }();
+  // bf16 products: the weight-stationary kernel (all four images resident); split-bf16: the LDS-DMA ring of half images
   const bool acc_ = a.acc_hE != 0;
   const int gpa_ = a.gpa_tiles ? 1 : 2;
   REQUIRE(g_Pa != nullptr, "namp_train_edge_bwd_dw: null g_Pa");
-  REQUIRE(x3 != 2 || ring16 || mode != 0 || mask != nullptr || mask_attend != nullptr, "namp_train_edge_bwd_dw: the bf16 encoder launch needs mask or mask_attend");
+  REQUIRE(x3 != 2 || mode != 0 || mask != nullptr || mask_attend != nullptr, "namp_train_edge_bwd_dw: the bf16 encoder launch needs mask or mask_attend");
 #define NAMP_LAUNCH_DWR(M, P)                                                                                                       \
   do {                                                                                                                                \
     if (acc_ && gpa_ == 1) hipLaunchKernelGGL((edge_bwd_dw_kernel<M, P, true, 1>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, s, aa);    \
@@ -196,12 +195,10 @@ int namp_train_edge_bwd_dw(int mode, const float* h_E, const int32_t* E_idx, con
     else hipLaunchKernelGGL((edge_bwd_dw16_kernel<M, false, 2>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);                    \
   } while (0)
   if (mode == 0) {
-    if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_ENC_MSG);
-    else if (x3 == 2) NAMP_LAUNCH_DWR(BWD_ENC_MSG, 2);
+    if (x3 == 2) NAMP_LAUNCH_DW16(BWD_ENC_MSG);
     else NAMP_LAUNCH_DWR(BWD_ENC_MSG, 1);
   } else {
-    if (x3 == 2 && !ring16) NAMP_LAUNCH_DW16(BWD_DEC_MSG);
-    else if (x3 == 2) NAMP_LAUNCH_DWR(BWD_DEC_MSG, 2);
+    if (x3 == 2) NAMP_LAUNCH_DW16(BWD_DEC_MSG);
     else NAMP_LAUNCH_DWR(BWD_DEC_MSG, 1);
   }
   CHECK_LAUNCH();

@@ -106,28 +106,44 @@ __device__ __forceinline__ void dw_contract(f4 (&acc)[4][4], f4 (&accb)[2], cons
   for (int ks = 0; ks < DW_ROWS / 32; ++ks) {
     const int off = ((4 * ks + g) ^ fsw) << 4;
     bf8 gh[4], gm[4], ah[4], am[4];
+    if constexpr (X3) {
+      // split-bf16: the G fragments (hi, mid) stay for the step, the A fragments come two channel tiles at a time (48 fragment registers
+      // instead of 64); product-major inside a pass: eight independent accumulators between two MFMAs on the same one
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gh[q] = *(const bf8*)(gb + q * 16 * DW_ROWB + off);
-      ah[q] = *(const bf8*)(ab + q * 16 * DW_ROWB + off);
-      if (X3) { gm[q] = *(const bf8*)(gb + DW_ARR + q * 16 * DW_ROWB + off); am[q] = *(const bf8*)(ab + DW_ARR + q * 16 * DW_ROWB + off); }
-    }
-    __builtin_amdgcn_sched_barrier(2);               // all of the step's fragment reads go out before its MFMAs (one wait instead of one per read)
-    // product-major: sixteen independent accumulators between two MFMAs on the same one
-    if (X3) {
+      for (int q = 0; q < 4; ++q) { gh[q] = *(const bf8*)(gb + q * 16 * DW_ROWB + off); gm[q] = *(const bf8*)(gb + DW_ARR + q * 16 * DW_ROWB + off); }
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ah[u] = *(const bf8*)(ab + (2 * tp + u) * 16 * DW_ROWB + off);
+          am[u] = *(const bf8*)(ab + DW_ARR + (2 * tp + u) * 16 * DW_ROWB + off);
+        }
+        __builtin_amdgcn_sched_barrier(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[q][2 * tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[q], ah[u], acc[q][2 * tp + u], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[q][2 * tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], am[u], acc[q][2 * tp + u], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[q][2 * tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], ah[u], acc[q][2 * tp + u], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gh[q] = *(const bf8*)(gb + q * 16 * DW_ROWB + off);
+        ah[q] = *(const bf8*)(ab + q * 16 * DW_ROWB + off);
+      }
+      __builtin_amdgcn_sched_barrier(2);             // all of the step's fragment reads go out before its MFMAs (one wait instead of one per read)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[q], ah[t], acc[q][t], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], am[t], acc[q][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], ah[t], acc[q][t], 0, 0, 0);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[q], ah[t], acc[q][t], 0, 0, 0);
     if (BIAS) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -143,33 +159,40 @@ __device__ __forceinline__ void dw_contract(f4 (&acc)[4][4], f4 (&accb)[2], cons
 // byte 16384, fragment (s_local, tn) at (8 s_local + tn) KiB.  Same product order as chain_gemm_x3 (namp_device.h).
 template <int HALF>
 __device__ __forceinline__ void dw_half_gemm_x3(f4 (&acc)[8], const f4 (&x)[8], const char* slot, const int lane) {
-  // four groups (K-step sl, channel-tile half h) of 12 MFMAs; the eight fragments (hi and mid of four channel tiles) of group i + 1 are
-  // requested before the MFMAs of group i issue (one wave per SIMD: nobody else covers the LDS round trip)
+  // four groups (K-step sl, channel-tile half h) of 12 MFMAs; the hi fragments of group i + 1 are requested before the MFMAs of group i
+  // issue, the mid fragments of group i right before its own (48 fragment registers; a full group ahead for both planes, 64, spills
+  // beside the fill registers of edge_bwd_dw3_kernel)
   const bf8* wh = (const bf8*)slot + lane;
   const bf8* wm = (const bf8*)(slot + 16384) + lane;
-  bf8 fh[2][4], fm[2][4];
+  bf8 fh[2][4], fm[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { fh[0][q] = wh[q * 64]; fm[0][q] = wm[q * 64]; }
+  for (int q = 0; q < 4; ++q) fh[0][q] = wh[q * 64];
   bf8 hi, mid;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int sl = i >> 1, h = i & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fm[q] = wm[(sl * 8 + 4 * h + q) * 64];
     if (i + 1 < 4) {
       const int sn = (i + 1) >> 1, hn = (i + 1) & 1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { fh[(i + 1) & 1][q] = wh[(sn * 8 + 4 * hn + q) * 64]; fm[(i + 1) & 1][q] = wm[(sn * 8 + 4 * hn + q) * 64]; }
+      for (int q = 0; q < 4; ++q) fh[(i + 1) & 1][q] = wh[(sn * 8 + 4 * hn + q) * 64];
     }
     __builtin_amdgcn_sched_barrier(2);
     if (h == 0) split_x3(x[4 * HALF + 2 * sl], x[4 * HALF + 2 * sl + 1], hi, mid);
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i & 1][q], mid, acc[4 * h + q], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[i & 1][q], hi, acc[4 * h + q], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[q], hi, acc[4 * h + q], 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i & 1][q], hi, acc[4 * h + q], 0, 0, 0);
   }
 }
 
+// (Tried, round 4: the same ring filled THROUGH REGISTERS — each lane carries one 32-KiB fill as 8 x 16 bytes, requested from L2 half a
+// product ahead and written with ds_write_b128 behind it, LDS-only barriers, the request schedule of edge_bwd_dw16_kernel — so that no
+// wait drains the rows' requests: correct, but 1.89-1.99 ms per cfg5-sized launch against 1.62 ms for the LDS-DMA ring below and 1.72 ms
+// for the round-3 launches; 50-60 spilled registers with the fill registers beside the split-bf16 fragments.  profiles/r04c.)
 // MODE: BWD_ENC_MSG / BWD_DEC_MSG.  PREC: 1 split-bf16 products, 2 plain bf16 products (mixed precision; G1 rows bf16).
 // One wave per SIMD (4 waves, __launch_bounds__(256): the 512-entry unified register file is one wave's): the chain's ~200 registers,
 // 2 x 64 accumulator registers of weight gradients and two fragment sets in flight do not fit the 256 of a two-waves-per-SIMD launch
