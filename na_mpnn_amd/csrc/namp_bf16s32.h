@@ -62,8 +62,13 @@ __device__ __forceinline__ void gemm32(f16v (&out)[4], const bf8* w, Op op) {
   }
 }
 
-// LDS: W1 | W2 | W3 or W_e (32 KiB each) | constants (2 KiB) | per wave: two Pa rows (512 B) + 32 row weights (128 B)
-#define BF16S32_LDS (3 * NAMP_BIMG_BYTES + 2048 + 8 * 512 + 8 * 128)
+// Every store of the step loop is issued by every lane on every step (rows of a missing second tile go to these dump words): the number of
+// stores behind a step's row / Pa requests is then a constant, for the explicit vmcnt waits below and for the compiler's own.
+__device__ float g_bf16s32_dump[256];
+__device__ __bf16 g_bf16s32_dump16[16 * NAMP_H];
+
+// LDS: W1 | W2 | W3 or W_e (32 KiB each) | constants (2 KiB) | per wave: 32 row weights (128 B); edge update: + two Pa rows per wave (512 B)
+#define BF16S32_LDS (3 * NAMP_BIMG_BYTES + 2048 + 8 * 128 + 8 * 512)
 
 // EMB (first encoder message): the rows arrive as the fp32 edge features E (a.hE); h_E = W_e . E + b_e (a.eW1_img, a.eb2) is evaluated
 // here, stored as bf16 rows (a.hE16_out) and fed straight into the message MLP (as edge_mlp_bf16s_kernel<MODE_ENC_MSG, true>).
@@ -85,14 +90,24 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
   const long npairs = (ntiles + 1) >> 1;
   const long stride = (long)gridDim.x * nwaves;
   long pair = (long)blockIdx.x * nwaves + wave;
-  auto meta_of = [&](const long p) {
+  auto meta_of = [&](const long p, const int j_pre) {
     const long t = 2 * p + half;
     const bool ok = t < ntiles;
-    TileMeta mt = tile_meta<MODE>(a, ok ? t : (ntiles - 1), m, 0);
+    TileMeta mt = EDGE ? tile_meta<MODE>(a, ok ? t : (ntiles - 1), m, 0) : tile_meta_pre<MODE>(a, ok ? t : (ntiles - 1), m, j_pre);
     if (!ok) { mt.valid = false; mt.w_row = 0.f; }
     return mt;
   };
-  TileMeta cur = meta_of(pair < npairs ? pair : 0);
+  // the neighbour id a step's metadata starts from is requested a whole step before that metadata is evaluated: its dependent reads
+  // (rank / mask of the neighbour) then never wait on a fresh request
+  // (past the end: the last pair's ids, and the metadata below is then evaluated for that pair too — never used, but its addresses are real)
+  auto pair_c = [&](const long p) { return p < npairs ? p : npairs - 1; };
+  auto idx_of = [&](const long p) {
+    if constexpr (EDGE) return 0;      // (the edge update has no register for it: its metadata reads the id itself)
+    const long t = 2 * pair_c(p) + half;
+    return a.E_idx[tile_erow<MODE>(a, t < ntiles ? t : (ntiles - 1), m)];
+  };
+  TileMeta cur = meta_of(pair_c(pair), idx_of(pair));
+  int idx_n1 = idx_of(pair + stride);
   bf8 xn[8];
   auto row_fetch = [&](const TileMeta& mt) {
     if constexpr (EMB) {
@@ -107,17 +122,20 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
     }
   };
   row_fetch(cur);
-  char* pa_slot = smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 512;                       // two Pa rows (one per 16-row half)
-  float* w_slot = (float*)(smem + 3 * NAMP_BIMG_BYTES + 2048 + 8 * 512 + wave * 128);   // 32 row weights
+  float* w_slot = (float*)(smem + 3 * NAMP_BIMG_BYTES + 2048 + wave * 128);   // 32 row weights
+  // Pa, edge update only (PA_DMA): the two rows of a step by LDS-DMA a step ahead, read back as the accumulators' initial value.  The
+  // message modes read Pa with plain loads next to the gathered term instead (below); the edge update has no 32 registers for that.
+  constexpr bool PA_DMA = EDGE;
+  char* pa_slot = smem + 3 * NAMP_BIMG_BYTES + 2048 + 8 * 128 + wave * 512;
   auto pa_fetch = [&](const TileMeta& mt) {
-    const long rowA = __shfl(mt.pa_row, 0), rowB = __shfl(mt.pa_row, 16);
+    const long rowA = __builtin_amdgcn_readlane(mt.node, 0), rowB = __builtin_amdgcn_readlane(mt.node, 16);     // pa_row == node
     if (lane < 32) {
       const long row = lane < 16 ? rowA : rowB;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Pa16 + row * NAMP_H + 8 * (lane & 15)),
                                        (__attribute__((address_space(3))) void*)pa_slot, 16, 0, 0);
     }
   };
-  pa_fetch(cur);
+  if constexpr (PA_DMA) pa_fetch(cur);
   dma_to_lds(smem, a.W1_img, 32, wave, nwaves, lane);
   dma_to_lds(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, nwaves, lane);
   if (EDGE) dma_to_lds(smem + 2 * NAMP_BIMG_BYTES, a.W3_img, 32, wave, nwaves, lane);
@@ -149,7 +167,11 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
     asm volatile("" ::: "memory");
     bf8 xb[8];
     const TileMeta me = cur;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Message modes: no LDS-DMA inside the step loop.  A global->LDS load touches both memories, and the compiler's wait-count pass answers
+    // one in flight with a FULL drain of both counters at the next dependency of either kind (the first weight-fragment read of layer 1
+    // drained the gathered-term and Pa requests: one exposed memory latency per step).  With plain loads only — every one issued by every
+    // lane on every step, the stores included — it counts exactly: the next rows are awaited behind this step's stores without draining them.
+    if constexpr (PA_DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // rows + Pa landed; the eight row stores may be in flight
     if constexpr (EMB) {
       // h_E = W_e . E + b_e for these 32 rows, rounded to bf16: stored for the later launches and used as this launch's operand
       f16v he[4];
@@ -162,8 +184,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
         xb[s] = pack_bf16<false>((f4){he[tin][8 * u], he[tin][8 * u + 1], he[tin][8 * u + 2], he[tin][8 * u + 3]},
                                  (f4){he[tin][8 * u + 4], he[tin][8 * u + 5], he[tin][8 * u + 6], he[tin][8 * u + 7]});
       }
-      if (me.valid) {
-        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + hk;
+      {
+        bf8* dst = (bf8*)(me.valid ? a.hE16_out + me.erow * NAMP_H : g_bf16s32_dump16 + m * NAMP_H) + hk;
 #pragma unroll
         for (int s = 0; s < 8; ++s) dst[2 * s] = xb[s];
       }
@@ -178,29 +200,55 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
 #pragma unroll
       for (int s = 0; s < 8; ++s) pj[s] = src[2 * s];
     }
+    // the residue's own first-layer term Pa (same fragment order; one row per 16-row half, so the lanes of a half read the same 16 bytes)
+    bf8 pa[8];
     f16v acc[4];
-    {
-      const bf8* pa = (const bf8*)(pa_slot + half * 256) + hk;
+    if constexpr (PA_DMA) {
+      const bf8* pl = (const bf8*)(pa_slot + half * 256) + hk;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
-        const bf8 lo = pa[2 * (2 * tn)], hi = pa[2 * (2 * tn + 1)];
+        const bf8 lo = pl[2 * (2 * tn)], hi = pl[2 * (2 * tn + 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[tn][j] = (float)lo[j]; acc[tn][8 + j] = (float)hi[j]; }
       }
+    } else {
+      const bf8* src = (const bf8*)(a.Pa16 + me.pa_row * NAMP_H) + hk;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) pa[s] = src[2 * s];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[tn][v] = 0.f;
     }
     if (!EDGE && hk == 0) w_slot[r] = me.w_row;
     const long np = pair + stride;
-    cur = meta_of(np < npairs ? np : pair);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    pa_fetch(cur);
+    cur = meta_of(pair_c(np), idx_n1);
+    idx_n1 = idx_of(pair + 2 * stride);
+    if constexpr (PA_DMA) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pa_fetch(cur);
+    }
+#ifdef NAMP_ABL_EARLY_ROW
     if constexpr (!LATE_ROW) row_fetch(cur);
+#endif
     // ---- layer 1 (T): the stored row IS the operand
     gemm32<false, PIN || EPIN>(acc, w1, [&](const int s) { return xb[s]; });
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { acc[tn][j] += (float)pj[2 * tn][j]; acc[tn][8 + j] += (float)pj[2 * tn + 1][j]; }
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (PA_DMA) {
+          acc[tn][j] += (float)pj[2 * tn][j];
+          acc[tn][8 + j] += (float)pj[2 * tn + 1][j];
+        } else {
+          acc[tn][j] += (float)pa[2 * tn][j] + (float)pj[2 * tn][j];
+          acc[tn][8 + j] += (float)pa[2 * tn + 1][j] + (float)pj[2 * tn + 1][j];
+        }
+      }
     }
+#ifndef NAMP_ABL_EARLY_ROW
+    if constexpr (!LATE_ROW) row_fetch(cur);                // behind the gathered term's wait (see the top of the step)
+#endif
     f16v y[4];
     if constexpr (EDGE) {
       // ---- layers 2 and 3 (T), residual, LayerNorm 3, the row back as bf16
@@ -247,8 +295,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
           acc[tn][v] = o.x; acc[tn][v + 1] = o.y;
         }
       }
-      if (me.valid) {
-        bf8* dst = (bf8*)(a.hE16_out + me.erow * NAMP_H) + hk;
+      {
+        bf8* dst = (bf8*)(me.valid ? a.hE16_out + me.erow * NAMP_H : g_bf16s32_dump16 + m * NAMP_H) + hk;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           const int tin = s >> 1, u = s & 1;
@@ -280,7 +328,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
       const int nodeA = __shfl(me.node, 0), ktA = __shfl(me.kt, 0), nodeB = __shfl(me.node, 16), ktB = __shfl(me.kt, 16);
       const bool okB = 2 * pair + 1 < ntiles;
       const int node_h = hk ? nodeB : nodeA, kt_h = hk ? ktB : ktA;
-      float* dst = a.partial + ((long)node_h * a.TPN + kt_h) * NAMP_H + r;
+      float* dst = (hk == 0 || okB) ? a.partial + ((long)node_h * a.TPN + kt_h) * NAMP_H + r : g_bf16s32_dump + r;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
         f2 s01 = (f2){0.f, 0.f}, t01 = (f2){0.f, 0.f};            // two chains
@@ -296,10 +344,11 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16s32_kernel(const EdgeArgs a)
         const float s0 = s01.x + t01.x, s1 = s01.y + t01.y;
         const float t = __shfl_xor(hk ? s0 : s1, 32);
         const float mine = (hk ? s1 : s0) + t;
-        if (hk == 0 || okB) dst[32 * tn] = mine;
+        dst[32 * tn] = mine;
       }
-      if (lane == 0) a.partial[(long)a.G * a.TPN * NAMP_H + (long)nodeA * a.TPN + ktA] = wsum;
-      if (lane == 16 && okB) a.partial[(long)a.G * a.TPN * NAMP_H + (long)nodeB * a.TPN + ktB] = wsum;
+      float* wdst = lane == 0 ? a.partial + (long)a.G * a.TPN * NAMP_H + (long)nodeA * a.TPN + ktA
+                  : (lane == 16 && okB) ? a.partial + (long)a.G * a.TPN * NAMP_H + (long)nodeB * a.TPN + ktB : g_bf16s32_dump + 128 + lane;
+      *wdst = wsum;
     }
   }
 }

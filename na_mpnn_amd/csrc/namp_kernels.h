@@ -1446,6 +1446,18 @@ struct TileMeta {
   long erow; float w_row; int node, kt; bool valid;
 };
 
+// The edge row (index into E_idx / h_E) of lane m of a tile: what tile_meta reads its neighbour id from.
+template <int MODE>
+__device__ __forceinline__ long tile_erow(const EdgeArgs& a, long tile, int m) {
+  const int node = (int)((unsigned)tile / (unsigned)a.TPN);
+  const int kt = (int)tile - node * a.TPN;
+  const int b_dec = node / a.N;
+  const int i_loc = node - b_dec * a.N;
+  const int node_enc = (MODE == MODE_DEC_MSG) ? ((b_dec % (a.G_enc / a.N)) * a.N + i_loc) : node;
+  const int k = 16 * kt + m;
+  return (long)node_enc * a.K + (k < a.K ? k : 0);
+}
+
 template <int MODE>
 __device__ __forceinline__ TileMeta tile_meta(const EdgeArgs& a, long tile, int m, int g) {
   TileMeta t;
@@ -1473,6 +1485,46 @@ __device__ __forceinline__ TileMeta tile_meta(const EdgeArgs& a, long tile, int 
       int ma;
       if (a.mask_attend) ma = a.mask_attend[t.erow];
       else ma = a.mask ? (a.mask[t.node] * a.mask[j]) : 1;
+      t.w_row = t.valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
+    }
+  }
+  t.pa_row = t.node;
+  return t;
+}
+
+// tile_meta for a step loop that must not wait on its own requests: the neighbour id j_loc = E_idx[tile_erow] was requested by the caller
+// earlier, and the mask / rank reads are issued without control flow around them (a load behind a branch makes the compiler drain the
+// in-order memory counter at the join): absent mask arrays read the constant 1.
+__device__ const int32_t g_meta_one = 1;
+template <int MODE>
+__device__ __forceinline__ TileMeta tile_meta_pre(const EdgeArgs& a, long tile, int m, int j_loc) {
+  TileMeta t;
+  t.node = (int)((unsigned)tile / (unsigned)a.TPN);
+  t.kt = (int)tile - t.node * a.TPN;
+  const int b_dec = t.node / a.N;
+  const int i_loc = t.node - b_dec * a.N;
+  const int node_enc = (MODE == MODE_DEC_MSG) ? ((b_dec % (a.G_enc / a.N)) * a.N + i_loc) : t.node;
+  const int k = 16 * t.kt + m;
+  t.valid = k < a.K;
+  t.erow = (long)node_enc * a.K + (t.valid ? k : 0);
+  t.w_row = 0.f;
+  if (MODE == MODE_DEC_MSG) {
+    const int j_dec = b_dec * a.N + j_loc;
+    const bool bwd = a.rank[j_dec] < a.rank[t.node];
+    t.pj_from1 = !bwd;
+    t.pj_row = bwd ? (long)j_dec : (long)(node_enc - i_loc + j_loc);
+    t.w_row = t.valid ? (1.0f / 30.0f) : 0.f;
+  } else {
+    const int j = t.node - i_loc + j_loc;
+    t.pj_from1 = false;
+    t.pj_row = j;
+    if (MODE == MODE_ENC_MSG) {
+      // (global address space stated: a select of generic pointers would become flat loads, which retire out of order with the rest)
+      typedef const __attribute__((address_space(1))) int32_t* gptr;
+      const gptr one = (gptr)&g_meta_one;
+      const gptr p0 = a.mask_attend ? (gptr)(a.mask_attend + t.erow) : a.mask ? (gptr)(a.mask + t.node) : one;
+      const gptr p1 = (!a.mask_attend && a.mask) ? (gptr)(a.mask + j) : one;
+      const int ma = *p0 * *p1;
       t.w_row = t.valid ? ((float)ma * (1.0f / 30.0f)) : 0.f;
     }
   }
