@@ -169,8 +169,14 @@ __device__ long long namp_stamp_prev;
       namp_stamp_prev = now_;                                                                     \
     }                                                                                             \
   } while (0)
+#define NAMP_STAMP_BEGIN()                                                                         \
+  do {                                                                                            \
+    __syncthreads();                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) namp_stamp_prev = wall_clock64();                    \
+  } while (0)
 #else
 #define NAMP_STAMP(slot) do {} while (0)
+#define NAMP_STAMP_BEGIN() do {} while (0)
 #endif
 struct ProjDesc {
   const float* img;    // 64 KiB image of the [128x128] block
@@ -430,7 +436,7 @@ __device__ __forceinline__ void rows_fma(float (&acc)[R], const f4 (&wf)[8], con
   for (int q = 0; q < R / 2; ++q) { acc[2 * q] = a2[q].x; acc[2 * q + 1] = a2[q].y; }
 }
 
-#define ROWS_TAIL_LDS_FLOATS(R) ((128 + 512 + 4 * 128 + 128) * (R) + 64)
+#define ROWS_TAIL_LDS_FLOATS(R) ((128 + 512 + 4 * 128 + 128) * (R) + 64 + 128 * (R))
 
 // RowFn: int operator()(int n) -> global row of tile row n (any runtime n in [0,R)), < 0 for padding.
 struct ConsecutiveRows {
@@ -451,11 +457,16 @@ __device__ __forceinline__ void st_out(float* p, const float v) {
 // is bound by L2 bandwidth chip-wide and a deeper queue measured nothing, profiles/r02k).  PF = true (the sampler: ONE workgroup per
 // <= 4 residues with the chip idle around it — the phase is bound by the latency of each unit's 8 KiB): the next unit's fragments
 // are requested before the current unit's FMAs, so two units are in flight per wave.  frag(u, tk) -> address of fragment tk.
+// rot (PF = false; total a power of two): the units are visited as (u + rot) % total.  Every workgroup of a fused launch streams the SAME
+// weights in the same order, so at any moment the whole chip asks a few L2 channels for the same ~100 KiB; rot = the workgroup's index
+// within its XCD spreads the 32 CUs of an XCD over the whole matrix (profiles/r04g).  The result does not depend on the order.
 template <bool PF, class FragFn, class BodyFn>
-__device__ __forceinline__ void tail_units(const int u0, const int total, const int step, const int lane, FragFn frag, BodyFn body) {
+__device__ __forceinline__ void tail_units(const int u0, const int total, const int step, const int lane, FragFn frag, BodyFn body,
+                                           const int rot = 0) {
   if constexpr (!PF) {
 #pragma unroll 1
-    for (int u = u0; u < total; u += step) {
+    for (int u_ = u0; u_ < total; u_ += step) {
+      const int u = (u_ + rot) & (total - 1);
       f4 wf[8];
 #pragma unroll
       for (int tk = 0; tk < 8; ++tk) wf[tk] = frag(u, tk)[lane];
@@ -489,10 +500,332 @@ __device__ __forceinline__ void tail_units(const int u0, const int total, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// node_tail_mfma4<R> — the residue tail of <= R (4 or 8) rows on v_mfma_f32_4x4x1_16b_f32 (round 4).  The VALU form below reads the
+// rows' activations from LDS for every weight element (one broadcast ds_read_b128 per two packed FMAs): at 4 rows the tail of the fused
+// cfg2 launches was bound by LDS bandwidth (~10 us of its 18 us; an 8-row tail on half of the workgroups — half the weight bytes — took 27 us,
+// profiles/r04g).  The 4x4x1 MFMA is 16 independent 4 x 4 outer products per instruction (D[b][i][j] += A[b][i] B[b][j], lane = 4b + i for
+// A, 4b + j for B and D; exact fp32 FMAs at ~23 MAC / clk / SIMD, the rate of the packed VALU FMAs it replaces) — exactly the shape of "4
+// channels x 4 rows at one k".  With block b = (kb, cb): 4 k-slots x 4 channel quads,
+//     A: lane (kb, cb, i) <- W[16u + 4cb + i][16S + 4kb + r]      = register r of fragment S of the EXISTING fp32 MFMA image, same lane
+//     B: lane (kb, cb, j) <- x[16S + 4kb + r][row j]              = 32 registers for a 128-long reduction, loaded once per phase
+// one unit (16 channels x 128 k) is 32 MFMAs on registers only, then one sum over the four kb lane groups.  Row tiles are kept in LDS in
+// "B order" ([S][kb][row][r] floats) so that operand loads and the 16-channel results are 16-byte accesses.  Units, weight images,
+// LDS regions 0-3 and the arguments are those of node_tail_rows (which forwards here unless NAMP_TAIL_VALU is defined); results differ from
+// the VALU form in the order of the fp32 additions only.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tail4_off(const int k, const int j) { return (((k >> 4) * 4 + ((k >> 2) & 3)) * 4 + j) * 4 + (k & 3); }
+
+template <int NB>
+__device__ __forceinline__ void tail4_x(f4 (&xr)[NB][8], const float* xB, const int lane) {
+  const float* p = xB + ((lane >> 4) * 4 + (lane & 3)) * 4;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int S = 0; S < 8; ++S) xr[nb][S] = *(const f4*)(p + nb * 512 + S * 64);
+}
+
+// o[nb][i] = sum_k W[16u + 4cb + i][k] x[k][4nb + j] on every lane (kb, cb, j)
+template <int NB>
+__device__ __forceinline__ void tail4_unit(f4 (&o)[NB], const f4 (&wf)[8], const f4 (&xr)[NB][8]) {
+  f4 c0[NB], c1[NB];
+#ifdef NAMP_ABL_T4_NOMFMA
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    o[nb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < 8; ++S) o[nb] += wf[S] * xr[nb][S];
+  }
+  return;
+#endif
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { c0[nb] = (f4){0.f, 0.f, 0.f, 0.f}; c1[nb] = (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int S = 0; S < 8; ++S) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      c0[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[S].x, xr[nb][S].x, c0[nb], 0, 0, 0);
+      c1[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[S].y, xr[nb][S].y, c1[nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      c0[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[S].z, xr[nb][S].z, c0[nb], 0, 0, 0);
+      c1[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[S].w, xr[nb][S].w, c1[nb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f4 v = c0[nb] + c1[nb];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { v[c] += __shfl_xor(v[c], 16); v[c] += __shfl_xor(v[c], 32); }
+    o[nb] = v;
+  }
+}
+
+// The fragments of a wave's first (up to) three units of a phase, requested together and AHEAD of the barrier that precedes the phase — the
+// weights do not depend on the rows.  With the arithmetic on the matrix pipe a unit costs ~0.15 us; requesting its 8 KiB when the unit starts
+// left three exposed L2 round trips per phase (1.4-1.6 us each with 250 workgroups asking at once, profiles/r04g).
+#define TAIL4_AHEAD 3
+template <class FragFn>
+__device__ __forceinline__ void tail4_request1(f4 (&wf)[8], const int u, const int lane, FragFn frag) {
+#ifdef NAMP_ABL_T4_NOLOAD
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk) wf[tk] = (f4){1.f * u, 2.f * lane, 3.f, 4.f * tk};
+  return;
+#endif
+#pragma unroll
+  for (int tk = 0; tk < 8; ++tk) wf[tk] = frag(u, tk)[lane];
+}
+template <class FragFn>
+__device__ __forceinline__ void tail4_request(f4 (&wf)[TAIL4_AHEAD][8], const int u0, const int total, const int step, const int lane, FragFn frag) {
+#pragma unroll
+  for (int t = 0; t < TAIL4_AHEAD; ++t) {
+    const int u = u0 + t * step;
+    tail4_request1(wf[t], u < total ? u : u0, lane, frag);           // (no branch around the loads; a repeated unit is an L1 hit)
+  }
+}
+// the phase itself: the requested units — slot t is refilled by next(t) as soon as its unit is done, so that the NEXT phase's fragments travel
+// while this phase's other units and the barrier run — then (workgroups of fewer than 11 waves) the remaining units on demand
+template <class FragFn, class BodyFn, class NextFn>
+__device__ __forceinline__ void tail4_phase(f4 (&wf)[TAIL4_AHEAD][8], const int u0, const int total, const int step, const int lane, FragFn frag,
+                                            BodyFn body, NextFn next) {
+#pragma unroll
+  for (int t = 0; t < TAIL4_AHEAD; ++t) {
+    const int u = u0 + t * step;
+    if (u < total) body(u, wf[t]);
+    next(t);
+  }
+  tail_units<false>(u0 + TAIL4_AHEAD * step, total, step, lane, frag, body);
+}
+
+template <int R, typename RowFn, bool SC1, bool M3, bool PF, bool AH>
+__device__ __forceinline__ void node_tail_mfma4(const NodeTail& a, f4 (&x)[8], const float wsum_m, const RowFn orow, float* lds,
+                                                const int tid, const int wave, const int nwaves, const int lane) {
+  static_assert(R == 4 || R == 8, "node_tail_mfma4: 4 or 8 rows");
+  constexpr int NB = R / 4;
+  // AH (the fused launches at 4 rows): a phase's fragments requested ahead of it.  PF (the sampler's lone workgroups): two units in flight
+  // per wave, as node_tail_rows.  Neither: one unit at a time.
+  constexpr bool AHEAD = AH && !PF && R == 4;
+  float* xB = lds;                    // [NB][512]      x = LN1(...) in B order                      (region 0 of node_tail_rows)
+  float* hB = xB + 128 * R;           // [4][NB][512]   gelu(W_in x + b_in), per 128-wide quarter of the hidden layer, B order
+  float* oP = hB + 512 * R;           // [4][R][128]    W_out partials over the quarters, row-major; before that: [R][128] layer-3 rows
+  float* yT = oP + 4 * 128 * R;       // [128][R]       h_V' (k-major, as node_tail_rows leaves it: output head, sampler)
+  float* red = yT + 128 * R;          // [2][32]
+  float* yB = red + 64;               // [NB][512]      h_V' in B order for the projections
+  const int m = lane & 15, g = lane >> 4;
+  const int cb = (lane >> 2) & 3, j = lane & 3;        // as an operand / result lane (kb = g)
+  const bool st_lane = lane < 16;                      // the kb = 0 group stores a unit's results
+  const auto win_frag = [&](const int u, const int tk) { return (const f4*)a.Win_img + (tk * 32 + u) * 64; };
+  const auto wout_frag = [&](const int u, const int tk) { return (const f4*)a.Wout_img + ((8 * (u >> 3) + tk) * 8 + (u & 7)) * 64; };
+
+  NAMP_STAMP_BEGIN();
+  f4 wa[AHEAD ? TAIL4_AHEAD : 1][8];
+  float bin_a[TAIL4_AHEAD] = {0.f, 0.f, 0.f};
+  if constexpr (AHEAD) {
+    tail4_request(wa, wave, 32, nwaves, lane, win_frag);
+#pragma unroll
+    for (int t = 0; t < TAIL4_AHEAD; ++t) {
+      const int u = wave + t * nwaves;
+      bin_a[t] = a.b_in[16 * (u < 32 ? u : wave) + 4 * cb + g];
+    }
+  }
+  if (M3 && a.m3_img) {
+    if (wave == 0 && m < R) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(xB + (m >> 2) * 512 + t * 64 + g * 16 + (m & 3) * 4) = x[t];
+      if (g == 0) red[m] = wsum_m;
+    }
+    __syncthreads();
+    {
+      f4 xr[NB][8];
+      tail4_x<NB>(xr, xB, lane);
+      tail_units<PF>(wave, 8, nwaves, lane,
+                     [&](const int u, const int tk) { return (const f4*)a.m3_img + (tk * 8 + u) * 64; },
+                     [&](const int u, const f4 (&wf)[8]) {
+                       f4 o[NB];
+                       tail4_unit<NB>(o, wf, xr);
+                       if (st_lane) {
+                         const f4 b = *(const f4*)(a.m3_b + 16 * u + 4 * cb);
+#pragma unroll
+                         for (int nb = 0; nb < NB; ++nb) *(f4*)(oP + (4 * nb + j) * NAMP_H + 16 * u + 4 * cb) = o[nb] + b * red[4 * nb + j];
+                       }
+                     });
+    }
+    __syncthreads();
+    const int mr = m < R ? m : 0;
+    int hr = orow(mr);
+    if (hr < 0) hr = orow(0) < 0 ? 0 : orow(0);
+    const float* hsrc = a.hV + (long)hr * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(hsrc + 16 * t) + *(const f4*)(oP + mr * NAMP_H + 16 * t + 4 * g);
+  }
+
+  NAMP_STAMP(7);                       // hoisted layer 3 (when done here)
+  layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
+  if (wave == 0 && m < R) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(xB + (m >> 2) * 512 + t * 64 + g * 16 + (m & 3) * 4) = x[t];
+  }
+  __syncthreads();
+  NAMP_STAMP(8);                       // LayerNorm 1
+  // ---- hidden = gelu(W_in x + b_in): 32 units; every lane holds a unit's sums after the kb reduction, lane group kb takes component kb
+  {
+    f4 xr[NB][8];
+    tail4_x<NB>(xr, xB, lane);
+    const auto body = [&](const int u, const f4 (&wf)[8]) {
+      f4 o[NB];
+      tail4_unit<NB>(o, wf, xr);
+      const int t_ = AHEAD ? (u - wave) / nwaves : 0;
+      const float b = (AHEAD && t_ < TAIL4_AHEAD) ? (t_ == 0 ? bin_a[0] : t_ == 1 ? bin_a[1] : bin_a[2]) : a.b_in[16 * u + 4 * cb + g];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float v = g == 0 ? o[nb].x : g == 1 ? o[nb].y : g == 2 ? o[nb].z : o[nb].w;
+        hB[((u >> 3) * NB + nb) * 512 + (u & 7) * 64 + cb * 16 + j * 4 + g] = gelu_erf(v + b);
+      }
+    };
+    if constexpr (AHEAD)
+      tail4_phase(wa, wave, 32, nwaves, lane, win_frag, body, [&](const int t) {
+        const int u = wave + t * nwaves;
+        tail4_request1(wa[t], u < 32 ? u : wave, lane, wout_frag);
+      });
+    else tail_units<PF>(wave, 32, nwaves, lane, win_frag, body);
+  }
+  __syncthreads();
+  NAMP_STAMP(9);                       // W_in + GELU
+  // ---- W_out: units (channel tile tn, hidden quarter q); partials summed in the LayerNorm2 pass
+  {
+    const auto body = [&](const int u, const f4 (&wf)[8]) {
+      const int tn = u & 7, q = u >> 3;
+      f4 xr[NB][8];
+      tail4_x<NB>(xr, hB + q * NB * 512, lane);
+      f4 o[NB];
+      tail4_unit<NB>(o, wf, xr);
+      if (st_lane) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(oP + (q * R + 4 * nb + j) * NAMP_H + 16 * tn + 4 * cb) = o[nb];
+      }
+    };
+    // (refill: the wave's unit of projection block pi = t — at most one per block with >= 8 waves: channel tile (wave - 8 pi) mod nwaves, if < 8)
+    if constexpr (AHEAD)
+      tail4_phase(wa, wave, 32, nwaves, lane, wout_frag, body, [&](const int pi) {
+        if (pi < a.nproj) {
+          const int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves;
+          const f4* img = (const f4*)(pi == 0 ? a.p[0].img : pi == 1 ? a.p[1].img : a.p[2].img) + ((tn < 8 ? tn : 0)) * 64 + lane;
+#pragma unroll
+          for (int tk = 0; tk < 8; ++tk) wa[pi][tk] = img[tk * 8 * 64];
+        }
+      });
+    else tail_units<PF>(wave, 32, nwaves, lane, wout_frag, body);
+  }
+  __syncthreads();
+  NAMP_STAMP(10);                      // W_out partials
+  // ---- LayerNorm2 over channels: thread -> (row n = tid / 128, channel c = tid % 128), 128 * R threads
+  const int n_ = tid >> 7, c_ = tid & 127;
+  const bool ln_thr = tid < 128 * R;
+  const int boff = ln_thr ? (n_ >> 2) * 512 + tail4_off(c_, n_ & 3) : 0;
+  float v = 0.f;
+  if (ln_thr) {
+    v = xB[boff] + a.b_out[c_];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v += oP[(q * R + n_) * NAMP_H + c_];
+    float s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+  }
+  __syncthreads();
+  float d = 0.f;
+  if (ln_thr) {
+    const float mean = (red[2 * n_] + red[2 * n_ + 1]) * (1.0f / 128.0f);
+    d = v - mean;
+    float q = d * d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[32 + wave] = q;
+  }
+  __syncthreads();
+  if (ln_thr) {
+    const float rstd = rsqrtf((red[32 + 2 * n_] + red[32 + 2 * n_ + 1]) * (1.0f / 128.0f) + 1e-5f);
+    const int orw = orow(n_);
+    const float mk = (a.mask && orw >= 0) ? (float)a.mask[orw] : 1.0f;
+    const float y = (d * rstd * a.ln2_g[c_] + a.ln2_b[c_]) * mk;
+    yT[c_ * R + n_] = y;
+    yB[boff] = y;
+    if (orw >= 0) st_out<SC1>(a.hV_out + (long)orw * NAMP_H + c_, y);
+  }
+  NAMP_STAMP(11);                      // partial sums + LayerNorm 2 + h_V' out
+  if (a.nproj == 0 && !a.head_w) return;
+  __syncthreads();
+  if (a.head_w) {
+    for (int n = wave; n < R; n += nwaves) {
+      const int orw = orow(n);
+      if (orw >= 0) tail_head_row(a, yT + n, R, orw, lane);
+    }
+  }
+  // ---- projections of h_V': unit v = 8 pi + tn (block pi, channel tile tn) -> wave v % nwaves
+  f4 xr[NB][8];
+  tail4_x<NB>(xr, yB, lane);
+  int orw[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) orw[nb] = orow(4 * nb + j);
+  auto proj_out = [&](const f4 (&o)[NB], const float* bias, const float* tok, float* out, const int tn) {
+    if (!st_lane) return;
+    const int c = 16 * tn + 4 * cb;
+    const f4 b = bias ? *(const f4*)(bias + c) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (orw[nb] < 0) continue;
+      f4 r = o[nb] + b;
+      if (tok) r += *(const f4*)(tok + (long)a.S[orw[nb]] * NAMP_H + c);
+      float* dst = out + (long)orw[nb] * NAMP_H + c;
+      if (SC1) { st_out<true>(dst, r.x); st_out<true>(dst + 1, r.y); st_out<true>(dst + 2, r.z); st_out<true>(dst + 3, r.w); }
+      else *(f4*)dst = r;
+    }
+  };
+  if constexpr (PF) {
+    // (the sampler's tails have at most two blocks: a runtime index into a.p[] would copy the descriptors to scratch)
+    tail_units<true>(wave, 8 * (a.nproj < 2 ? a.nproj : 2), nwaves, lane,
+                     [&](const int v, const int tk) { return (const f4*)((v >> 3) ? a.p[1].img : a.p[0].img) + (tk * 8 + (v & 7)) * 64; },
+                     [&](const int v, const f4 (&wf)[8]) {
+                       const bool second = (v >> 3) != 0;
+                       f4 o[NB];
+                       tail4_unit<NB>(o, wf, xr);
+                       proj_out(o, second ? a.p[1].bias : a.p[0].bias, second ? a.p[1].tok : a.p[0].tok, second ? a.p[1].out : a.p[0].out, v & 7);
+                     });
+    NAMP_STAMP(12);
+    return;
+  }
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) {
+    if (pi >= a.nproj) break;
+    const ProjDesc pd = a.p[pi];
+    bool first = AHEAD && pi < TAIL4_AHEAD;
+#pragma unroll 1
+    for (int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn < 8; tn += nwaves) {
+      f4 o[NB];
+      if (first) {
+        tail4_unit<NB>(o, wa[pi < TAIL4_AHEAD ? pi : 0], xr);
+      } else {
+        f4 wf[8];
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)pd.img)[(tk * 8 + tn) * 64 + lane];
+        tail4_unit<NB>(o, wf, xr);
+      }
+      first = false;
+      proj_out(o, pd.bias, pd.tok, pd.out, tn);
+    }
+  }
+  NAMP_STAMP(12);                      // output head + projections
+}
+
 // M3 = false: the caller has already applied the hoisted message layer 3 (x = h_V + message), whatever a.m3_img says
-template <int R, typename RowFn, bool SC1 = false, bool M3 = true, bool PF = false>
+template <int R, typename RowFn, bool SC1 = false, bool M3 = true, bool PF = false, bool AH = false>
 __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], const float wsum_m, const RowFn orow, float* lds,
                                                const int tid, const int wave, const int nwaves, const int lane) {
+#ifndef NAMP_TAIL_VALU
+  node_tail_mfma4<R, RowFn, SC1, M3, PF, AH>(a, x, wsum_m, orow, lds, tid, wave, nwaves, lane);
+  return;
+#endif
   float* xT = lds;                    // [128][R]    x = LN1(...)          (k-major, residue-minor)
   float* hT = xT + 128 * R;           // [512][R]    gelu(W_in x + b_in)
   float* oP = hT + 512 * R;           // [4][128][R] W_out partials over k-quarters
@@ -500,6 +833,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
   float* red = yT + 128 * R;          // [2][32]     LayerNorm2 cross-wave sums
   const int m = lane & 15, g = lane >> 4;
 
+  NAMP_STAMP_BEGIN();
   if (M3 && a.m3_img) {
     // hoisted message layer 3 (see NodeTail): x = K-sums of the layer-2 activations -> x = h_V + W3 . x + b3 * wsum
     if (wave == 0 && m < R) {
@@ -540,6 +874,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
     }
   }
 
+  NAMP_STAMP(7);
   layernorm_row_T(x, a.ln1_g, a.ln1_b, g);
   if (wave == 0 && m < R) {
 #pragma unroll
@@ -549,8 +884,19 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
     }
   }
   __syncthreads();
+  NAMP_STAMP(8);
   // ---- hidden = gelu(W_in x + b_in): 32 channel tiles dealt over the waves
-  tail_units<PF>(wave, 32, nwaves, lane,
+#ifdef NAMP_ABL_NOROT
+  const int rot = 0;
+#else
+  const int rot = PF ? 0 : (int)((blockIdx.x >> 3) & 31);       // the workgroup's index within its XCD (see tail_units)
+#endif
+#ifdef NAMP_ABL_TAILPF
+  constexpr bool PFU = true;
+#else
+  constexpr bool PFU = PF;
+#endif
+  tail_units<PFU>(wave, 32, nwaves, lane,
                  [&](const int tn, const int tk) { return (const f4*)a.Win_img + (tk * 32 + tn) * 64; },
                  [&](const int tn, const f4 (&wf)[8]) {
                    float acc[R];
@@ -564,10 +910,11 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
 #pragma unroll
                      for (int n = 0; n < R; ++n) hT[(16 * tn + m) * R + n] = gelu_erf(acc[n] + b);
                    }
-                 });
+                 }, rot);
   __syncthreads();
+  NAMP_STAMP(9);
   // ---- W_out: units (channel tile tn, k-quarter kq); partials reduced in the LayerNorm2 pass
-  tail_units<PF>(wave, 32, nwaves, lane,
+  tail_units<PFU>(wave, 32, nwaves, lane,
                  [&](const int u, const int tk) { return (const f4*)a.Wout_img + ((8 * (u >> 3) + tk) * 8 + (u & 7)) * 64; },
                  [&](const int u, const f4 (&wf)[8]) {
                    const int tn = u & 7, kq = u >> 3;
@@ -581,8 +928,9 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
 #pragma unroll
                      for (int n = 0; n < R; ++n) oP[(kq * 128 + 16 * tn + m) * R + n] = acc[n];
                    }
-                 });
+                 }, rot);
   __syncthreads();
+  NAMP_STAMP(10);
   // ---- LayerNorm2 over channels: thread -> (residue n = tid / 128, channel c = tid % 128), 128*R threads
   const int n_ = tid >> 7, c_ = tid & 127;
   const bool ln_thr = tid < 128 * R;
@@ -615,6 +963,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
     yT[c_ * R + n_] = y;
     if (orw >= 0) st_out<SC1>(a.hV_out + (long)orw * NAMP_H + c_, y);
   }
+  NAMP_STAMP(11);
   if (a.nproj == 0 && !a.head_w) return;
   __syncthreads();
   if (a.head_w) {
@@ -661,7 +1010,8 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
     if (pi >= a.nproj) break;
     const ProjDesc pd = a.p[pi];
 #pragma unroll 1
-    for (int tn = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn < 8; tn += nwaves) {
+    for (int tn_ = ((wave - pi * 8) % nwaves + nwaves) % nwaves; tn_ < 8; tn_ += nwaves) {
+      const int tn = (tn_ + rot) & 7;
       f4 wf[8];
 #pragma unroll
       for (int tk = 0; tk < 8; ++tk) wf[tk] = ((const f4*)pd.img)[(tk * 8 + tn) * 64 + lane];
@@ -686,6 +1036,7 @@ __device__ __forceinline__ void node_tail_rows(const NodeTail& a, f4 (&x)[8], co
       }
     }
   }
+  NAMP_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,6 +1277,9 @@ enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_X3 = 2 };
 // given, and the kernel's LDS is re-used stage after stage (the caller separates stages by a grid barrier).
 template <int MODE, int TAIL, int PREC, int PRE, int PERSIST, class Args>
 __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem) {
+#ifndef NAMP_ABL_NOL2PF
+  f4 l2pf0 = (f4){0.f, 0.f, 0.f, 0.f}, l2pf1 = l2pf0;
+#endif
   constexpr bool BF16 = (PREC == PREC_BF16);
   constexpr bool X3 = (PREC == PREC_X3);
   static_assert(PRE == PRE_NONE || (!BF16 && TAIL != 0 && (MODE == MODE_ENC_MSG || MODE == MODE_DEC_MSG)), "PRE: fp32-class message + tail only");
@@ -1143,6 +1497,24 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
     if (PRE != PRE_NONE) wait_dma_and_sync();             // W2 (issued one GEMM ago) landed; buf0 (W1) is free
     else if (M3_LDS) __syncthreads();                     // every wave is done with buf0 (W1)
     if (M3_LDS) dma_to_lds(buf0, a.W3_img, 64, wave, nwaves, lane);   // for the per-residue layer 3 behind the K-sum
+#ifndef NAMP_ABL_NOL2PF
+    if (TAIL == 4 || TAIL == 8) {
+      // The residue tail's weights (W_in, W_out, the projections: 0.6-0.8 MB that every workgroup reads) are pulled into this XCD's L2 one
+      // GEMM ahead, each workgroup asking for the 1/32 slice of its index within the XCD (blockIdx / 8: a speed choice only); the rows of
+      // h_E streamed since the previous launch's tail have evicted them.  Two registers per lane until the K-sum (cfg2 0.496 -> 0.490 ms).
+      const int slice = (blockIdx.x >> 3) & 31;
+      const f4* p0; const f4* p1;
+      if (wave < 8) {
+        p0 = (const f4*)a.tail.Win_img + (slice * 8 + wave) * 64; p1 = (const f4*)a.tail.Wout_img + (slice * 8 + wave) * 64;
+      } else {
+        const int q = wave - 8;
+        const float* img = q == 0 ? a.tail.p[0].img : q == 1 ? a.tail.p[1].img : q == 2 ? a.tail.p[2].img : a.tail.p[3].img;
+        if (q >= a.tail.nproj) img = a.tail.Win_img;
+        p0 = (const f4*)img + (slice * 2) * 64; p1 = p0 + 64;
+      }
+      l2pf0 = p0[lane]; l2pf1 = p1[lane];
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) { const float b = a.b2[16 * t + m]; y[t] = (f4){b, b, b, b}; }
     gemm128<X3, true, true>(y, acc, w1);
@@ -1229,6 +1601,9 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
         if (g == 0) dpart[wave * NAMP_H + 16 * t + m] = s;
       }
       if (lane == 0) dws[wave] = wsum;
+#ifndef NAMP_ABL_NOL2PF
+      asm volatile("" :: "v"(l2pf0), "v"(l2pf1));               // (the prefetch above has landed)
+#endif
       if (M3_LDS) wait_dma_and_sync();                          // all tiles summed; W3 landed in buf0
       else __syncthreads();                                     // all tiles summed; weight ring is free
       // tile rows = this workgroup's residues: row m -> residue row0 + m
@@ -1253,9 +1628,18 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
       }
       return;
 #endif
+#ifdef NAMP_ABL_PAIRTAIL
+      // TIMING PROBE ONLY (wrong results): every other workgroup runs an 8-row tail (its rows + its neighbour's), the others none
+      if (blockIdx.x & 1) return;
+#endif
       if (TAIL == 4 || TAIL == 8) {
+#ifdef NAMP_ABL_PAIRTAIL
+        constexpr int R = 8;
+        const ConsecutiveRows orow = {row0, 2 * npw, a.G};
+#else
         constexpr int R = (TAIL == 4 || TAIL == 8) ? TAIL : 4;
         const ConsecutiveRows orow = {row0, npw, a.G};
+#endif
         if (M3_LDS) {
           // x = h_V + W3 . (K-sums) + b3 * wsum: wave w < 8 evaluates channel tile w of the (<= 8-row) tile, exchanged through
           // the K-sum area (8 rows x 128 floats <= 12 x 128)
@@ -1269,9 +1653,9 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
           const float* dsrc = dpart + (mm & 7) * NAMP_H + 4 * g;
 #pragma unroll
           for (int t = 0; t < 8; ++t) y[t] = *(const f4*)(hsrc + 16 * t) + *(const f4*)(dsrc + 16 * t);
-          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0), false>(a.tail, y, 0.f, orow, (float*)smem, tid, wave, nwaves, lane);
+          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0), false, false, !BF16>(a.tail, y, 0.f, orow, (float*)smem, tid, wave, nwaves, lane);
         } else {
-          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0)>(a.tail, y, wsum_m, orow, (float*)smem, tid, wave, nwaves, lane);
+          node_tail_rows<R, ConsecutiveRows, (PERSIST != 0), true, false, !BF16>(a.tail, y, wsum_m, orow, (float*)smem, tid, wave, nwaves, lane);
         }
       } else {
         node_tail<false>(a.tail, y, wsum_m, row0, npw, a.G, (float*)smem, tid, wave, nwaves, lane);
@@ -1793,7 +2177,7 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 #define NAMP_WALK_MAX_GRID 128      // workgroups of the persistent level walk (all must be resident: one 155 KiB-LDS workgroup per CU)
 // LDS of the sampler: the 2 x 64 KiB weight ring | the residue tail's scratch (its own region: the next layer's images stream into the ring
 // while the tail runs) | per-wave partial K-sums | node / visit ids
-#define SAMPLE_TAIL_BYTES (((128 + 512 + 4 * 128 + 128) * NAMP_SAMPLE_SLOTS + 64) * 4)
+#define SAMPLE_TAIL_BYTES (ROWS_TAIL_LDS_FLOATS(NAMP_SAMPLE_SLOTS) * 4)
 #define SAMPLE_LDS (2 * NAMP_IMG_BYTES + SAMPLE_TAIL_BYTES + 12 * NAMP_H * 4 + 64)
 
 // generic -> global: a pointer loaded from memory has no address space; every pointer of this ABI is device global memory

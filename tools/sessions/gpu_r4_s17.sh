@@ -1,7 +1,8 @@
 R=$GRAFT_REPO_ROOT; cd $R
-NAMP_LIB_PATH=$R/tools/_variants/stamps.so timeout 300 python tools/tail_stamps.py 2>&1 | tail -9
+NAMP_LIB_PATH=$R/tools/_variants/l2pf_stamps.so timeout 300 python tools/tail_stamps.py 2>&1 | tail -9
 run() { python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --no-pmc --no-gather 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], (d.get('x3') or {}).get('ms_per_step'))"; }
 for i in 1 2; do
   NAMP_LIB_PATH=$R/tools/_variants/head.so run head
   run new
+  NAMP_LIB_PATH=$R/tools/_variants/l2pf.so run l2pf
 done
