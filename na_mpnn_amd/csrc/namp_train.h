@@ -796,6 +796,19 @@ __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict
 // than the fp32 form; results differ from it by the split's 2^-16 per product.
 #define FEATW_LDT 72            // bf16 elements per channel row of the transposed planes (64 edges + pad: conflict-free b128 writes)
 
+// Round 4 form of the kernel (both precisions): (i) the tile's 64 distances reach the operand lanes through LDS (one write per lane and block, two 16-byte
+// broadcast reads per 8 edges, instead of one ds_bpermute per element); (ii) the exponent is one subtraction, one product and a v_exp_f32:
+// exp(-((D - mu) / 1.25)^2) = 2^(-(c D - c mu)^2), c = 0.8 sqrt(log2 e), with c D stored once per edge and block; (iii) bf16 mode (MID = false): all 32
+// staging requests of a thread go out first, past-the-end rows clamped and zeroed afterwards (a `row < end` test around each load makes the compiler drain
+// the in-order memory counter behind each), and a step's eight g_pre fragments are read once with each live block's eight products behind one branch.
+// cfg5: 3.43 -> 3.18 ms (split-bf16), 3.03 -> 2.77 ms (bf16) per step.  Measured and NOT kept: (iii) in the split-bf16 instantiation (4.1-6.3 ms: the
+// compiler serialises differently and loses a wave per SIMD); four blocks per wave — twice the products per staged tile — at half the occupancy (6.8 ms).
+#ifndef FEATW_NBW
+#define FEATW_NBW 2
+#endif
+#define FEATW_WG_BLOCKS (4 * FEATW_NBW)
+#define FEATW_GRID_X ((FEATW_BLOCKS + FEATW_WG_BLOCKS - 1) / FEATW_WG_BLOCKS)
+
 template <bool MID>      // MID = false: hi . hi products only (mixed-precision mode)
 __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                             const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
@@ -803,26 +816,28 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
                                                             long E, long edges_per_chunk, int L, int K,
                                                             float* __restrict__ dW_part) {
   __shared__ __attribute__((aligned(16))) __bf16 gh[NAMP_H * FEATW_LDT];
-  __shared__ __attribute__((aligned(16))) __bf16 gm[NAMP_H * FEATW_LDT];
+  __shared__ __attribute__((aligned(16))) __bf16 gm[MID ? NAMP_H * FEATW_LDT : 8];
+  __shared__ __attribute__((aligned(16))) float dsc[4][FEATW_NBW][FEATW_TILE];      // c * distance per (wave, block, edge of the tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int blk0 = (blockIdx.x * 4 + wave) * 2;
-  const int wg_blk0 = blockIdx.x * 8;
+  const int blk0 = (blockIdx.x * 4 + wave) * FEATW_NBW;
+  const int wg_blk0 = blockIdx.x * FEATW_WG_BLOCKS;
   const long e_begin = (long)blockIdx.y * edges_per_chunk;
   long e_end = e_begin + edges_per_chunk;
   if (e_end > E) e_end = E;
-  const float mu = 2.0f + (float)n * (20.0f / 15.0f);
-  int pa[2], pb[2];
+  constexpr float C = 0.9608979270291599f;                     // 0.8 * sqrt(log2 e)
+  const float cmu = (2.0f + (float)n * (20.0f / 15.0f)) * C;
+  int pa[FEATW_NBW], pb[FEATW_NBW];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < FEATW_NBW; ++q) {
     const int p = blk0 + q - 1;
     pa[q] = p >= 0 ? p / 18 : 0;
     pb[q] = p >= 0 ? p % 18 : 0;
   }
-  f4 acc[2][8];
+  f4 acc[FEATW_NBW][8];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < FEATW_NBW; ++q)
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
   auto block_live = [](int blk, uint32_t pi, uint32_t pj) {
@@ -832,56 +847,81 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
     return (((pi >> (p / 18)) & (pj >> (p % 18))) & 1u) != 0u;
   };
   const int sc = tid & 127, sh = tid >> 7;                     // staging: channel, edge half (32 edges) of this thread
+  float* dw = &dsc[wave][0][0];
   bool staged = false;
   for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE) {
     const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE)]);
     const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE) + 1]);
     bool any_live = false;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) any_live = any_live || block_live(wg_blk0 + q, pi, pj);
+    for (int q = 0; q < FEATW_WG_BLOCKS; ++q) any_live = any_live || block_live(wg_blk0 + q, pi, pj);
     if (!any_live) continue;
-    const bool live0 = block_live(blk0, pi, pj), live1 = block_live(blk0 + 1, pi, pj);
+    bool live[FEATW_NBW], wave_live = false;
+#pragma unroll
+    for (int q = 0; q < FEATW_NBW; ++q) { live[q] = block_live(blk0 + q, pi, pj); wave_live = wave_live || live[q]; }
     if (staged) __syncthreads();
     staged = true;
     // stage + split + transpose g_pre rows e0 .. e0+63: this thread's channel, 4 groups of 8 edges
+    if constexpr (MID) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v[8];
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const long er = e0 + 32 * sh + 8 * i + j;
-        v[j] = (er < e_end) ? g_pre[er * NAMP_H + sc] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const long er = e0 + 32 * sh + 8 * i + j;
+          v[j] = (er < e_end) ? g_pre[er * NAMP_H + sc] : 0.f;
+        }
+        bf8 hi, mid;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)v[j]; mid[j] = (__bf16)(v[j] - (float)hi[j]); }
+        *(bf8*)(gh + sc * FEATW_LDT + 32 * sh + 8 * i) = hi;
+        *(bf8*)(gm + sc * FEATW_LDT + 32 * sh + 8 * i) = mid;
       }
-      bf8 hi, mid;
+    } else {
+      float v[32];
+      const long rb = e0 + 32 * sh;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)v[j]; mid[j] = (__bf16)(v[j] - (float)hi[j]); }
-      *(bf8*)(gh + sc * FEATW_LDT + 32 * sh + 8 * i) = hi;
-      *(bf8*)(gm + sc * FEATW_LDT + 32 * sh + 8 * i) = mid;
+      for (int j = 0; j < 32; ++j) v[j] = g_pre[(rb + j < e_end ? rb + j : e_end - 1) * NAMP_H + sc];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi[j] = (__bf16)((rb + 8 * i + j < e_end) ? v[8 * i + j] : 0.f);
+        *(bf8*)(gh + sc * FEATW_LDT + 32 * sh + 8 * i) = hi;
+      }
     }
-    float dist[2] = {1e30f, 1e30f};
-    if (live0 || live1) {
+    // this lane's edge of the tile: scaled distances of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
+    if (wave_live) {
       const long el = e0 + lane;
       const bool eok = el < e_end;
       const long ec = eok ? el : e_begin;
       const int node = (int)(ec / K);
       const int j = node - node % L + E_idx[ec];
+      float xi_[FEATW_NBW][3], xj_[FEATW_NBW][3], mi_[FEATW_NBW], mj_[FEATW_NBW];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < FEATW_NBW; ++q) {                    // every block's requests first (dead blocks included), then the arithmetic
         const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
         const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
-        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-        const float mk = M18[(long)node * 18 + pa[q]] * M18[(long)j * 18 + pb[q]];
-        dist[q] = (eok && mk != 0.f) ? sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xi_[q][c] = xi[c]; xj_[q][c] = xj[c]; }
+        mi_[q] = M18[(long)node * 18 + pa[q]]; mj_[q] = M18[(long)j * 18 + pb[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < FEATW_NBW; ++q) {
+        const float dx = xi_[q][0] - xj_[q][0], dy = xi_[q][1] - xj_[q][1], dz = xi_[q][2] - xj_[q][2];
+        dw[q * FEATW_TILE + lane] = (eok && mi_[q] * mj_[q] != 0.f) ? C * sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
       }
     }
     __syncthreads();
-    if (live0 || live1) {
+    if (wave_live) {
 #pragma unroll
       for (int st = 0; st < FEATW_TILE / 32; ++st) {
         const int row0 = 32 * st + 8 * g;                      // this lane's 8 edges of the step
-        bf8 bh[2], bm[2];
+        bf8 bh[FEATW_NBW], bm[FEATW_NBW];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < FEATW_NBW; ++q) {
+          if (!live[q]) continue;
           float b[8];
           if (blk0 + q == 0) {
 #pragma unroll
@@ -890,33 +930,41 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
               b[j] = (er < e_end) ? E_pos[er * 16 + n] : 0.f;
             }
           } else {
+            const f4 d0 = *(const f4*)(dw + q * FEATW_TILE + row0), d1 = *(const f4*)(dw + q * FEATW_TILE + row0 + 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float d = __shfl(dist[q], row0 + j);
-              const float u = (d - mu) * 0.8f;
-              b[j] = __expf(-(u * u));
+              const float u = (j < 4 ? d0[j & 3] : d1[j & 3]) - cmu;
+              b[j] = __builtin_amdgcn_exp2f(-(u * u));
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { bh[q][j] = (__bf16)b[j]; bm[q][j] = (__bf16)(b[j] - (float)bh[q][j]); }
+          for (int j = 0; j < 8; ++j) { bh[q][j] = (__bf16)b[j]; if (MID) bm[q][j] = (__bf16)(b[j] - (float)bh[q][j]); }
         }
+        if constexpr (MID) {
+          // split-bf16: fragment by fragment (two 16-byte reads feed up to six products; holding all sixteen fragments costs a wave per SIMD)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const bf8 ah = *(const bf8*)(gh + (16 * t + n) * FEATW_LDT + row0);
-          const bf8 am = *(const bf8*)(gm + (16 * t + n) * FEATW_LDT + row0);
-          if (live0) {
-            if (MID) {
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[0][t], 0, 0, 0);
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[0], acc[0][t], 0, 0, 0);
+          for (int t = 0; t < 8; ++t) {
+            const bf8 ah = *(const bf8*)(gh + (16 * t + n) * FEATW_LDT + row0);
+            const bf8 am = *(const bf8*)(gm + (16 * t + n) * FEATW_LDT + row0);
+#pragma unroll
+            for (int q = 0; q < FEATW_NBW; ++q) {
+              if (!live[q]) continue;
+              acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[q], acc[q][t], 0, 0, 0);
+              acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[q], acc[q][t], 0, 0, 0);
+              acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[q], acc[q][t], 0, 0, 0);
             }
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], acc[0][t], 0, 0, 0);
           }
-          if (live1) {
-            if (MID) {
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[1][t], 0, 0, 0);
-              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[1], acc[1][t], 0, 0, 0);
-            }
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], acc[1][t], 0, 0, 0);
+        } else {
+          // bf16: the step's eight fragments once, then each live block's eight products behind ONE branch (a liveness test per product made
+          // the compiler wait for every fragment read on its own)
+          bf8 ah[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) ah[t] = *(const bf8*)(gh + (16 * t + n) * FEATW_LDT + row0);
+#pragma unroll
+          for (int q = 0; q < FEATW_NBW; ++q) {
+            if (!live[q]) continue;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[q], acc[q][t], 0, 0, 0);
           }
         }
       }
@@ -924,7 +972,7 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
   }
   float* out = dW_part + (long)blockIdx.y * NAMP_H * FEATW_COLS;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < FEATW_NBW; ++q) {
     if (blk0 + q >= FEATW_BLOCKS) continue;
 #pragma unroll
     for (int t = 0; t < 8; ++t)

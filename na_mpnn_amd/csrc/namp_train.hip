@@ -421,10 +421,10 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M18, E_idx, E, L, K,
                      tile_ws);
   if (x3 == 2)            // mixed precision: plain bf16 products
-    hipLaunchKernelGGL(feat_wgrad_x3_kernel<false>, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
+    hipLaunchKernelGGL(feat_wgrad_x3_kernel<false>, dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
                        tile_ws, E, per, L, K, dW_part);
   else if (x3)
-    hipLaunchKernelGGL(feat_wgrad_x3_kernel<true>, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
+    hipLaunchKernelGGL(feat_wgrad_x3_kernel<true>, dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
                        tile_ws, E, per, L, K, dW_part);
   else
     hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
