@@ -1047,8 +1047,9 @@ def respawn(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default per workload; cfg2: 500 = 0.25 s — a 20-50-step region reads 4-10 %% high: ~1 ms of fixed start / drain cost)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20 for cfg2, 5 otherwise)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--precision", choices=["x3", "fp32", "bf16"], default=None,
                     help="per-edge GEMM evaluation of the headline: default fp32 for cfg2 (exact fp32 MFMA, BASELINE configs[1]; the "
@@ -1068,6 +1069,11 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg5 / cfg1 runs appended to the default line")
     args = ap.parse_args()
+    # default step counts per workload: the timed region is >= ~0.2 s everywhere (cfg5: a training step is ~100x a cfg2 forward)
+    if args.steps is None:
+        args.steps = {"cfg2": 500, "cfg3": 50, "cfg1": 20, "cfg4": 2, "cfg5": 10}.get(args.workload, 50)
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == "cfg2" else 5
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.pmc_child:
@@ -1128,17 +1134,11 @@ def main():
             dist.destroy_process_group()
 
     if args.workload == "cfg1":
-        if args.steps == 50:
-            args.steps = 20
         return finish(design_bench(args, dev, rank, world, dist))
     if args.workload == "cfg4":
-        if args.steps == 50:
-            args.steps = 2
         args.warmup = min(args.warmup, 1)
         return finish(split_bench(args, dev, rank, world, dist))
     if args.workload == "cfg5":
-        if args.steps == 50:
-            args.steps = 10                      # a training step is ~100x a cfg2 forward
         return finish(train_bench(args, dev, rank, world, dist))
 
     precision = args.precision or ("bf16" if args.workload == "cfg3" else "fp32")
