@@ -127,6 +127,43 @@ def test_edge_mlp_backward_on_chip_weight_gradients(mode, B, N, K, prec, monkeyp
     print(f"on-chip dW vs row tensors (mode {mode}, prec {prec}, {B}x{N}x{K}):", {k_: f"{v:.1e}" for k_, v in worst.items()})
 
 
+@pytest.mark.parametrize("B,N,K,p", [(2, 700, 48, 0.1), (1, 333, 30, 0.0), (1, 40, 16, 0.25)])
+def test_edge_update_backward_on_chip_weight_gradients(B, N, K, p, monkeypatch):
+    """Mixed precision: the edge update's backward that contracts (G2, A1) and (G1, h_E) on chip (edge_update_bwd_dw16_kernel) against the
+    round-3 form on the same inputs — several rounds per workgroup, a ragged last round, K % 16 != 0 (atomic dL/dPa path), dropout on and
+    off.  Both forms round the same operands to bf16; summation orders (and the GELU polynomial) differ: every gradient within 1.5 %
+    of the other form, relative to its largest entry."""
+    g = torch.Generator(device="cpu").manual_seed(23 + K)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    h_E, Pa, Pc = rn(B, N, K, 128), rn(B, N, 128), rn(B, N, 128)
+    W1b, W2, W3 = rn(128, 128, sc=0.08), rn(128, 128, sc=0.1), rn(128, 128, sc=0.1)
+    b2, b3, lw, lb = rn(128, sc=0.1), rn(128, sc=0.1), 1 + rn(128, sc=0.1), rn(128, sc=0.1)
+    E32 = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(DEV).to(torch.int32).contiguous()
+    R = rn(B, N, K, 128)
+    leaves = [h_E, Pa, Pc, W1b, W2, b2, W3, b3, lw, lb]
+    names = ["h_E", "Pa", "Pc", "W1b", "W2", "b2", "W3", "b3", "ln_w", "ln_b"]
+    monkeypatch.setattr(train, "X3", 2)
+
+    def run(on_chip):
+        monkeypatch.setattr(train, "DW_ONCHIP_EDGE", on_chip)
+        with torch.enable_grad():
+            ins = [t.clone().requires_grad_(True) for t in leaves]
+            out = train._EdgeUpdate.apply(*ins, E32, p, 4321)
+            (out * R).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach(), [t.grad for t in ins]
+
+    out_a, ga = run(False)
+    out_b, gb = run(True)
+    assert torch.equal(out_a, out_b)
+    worst = {}
+    for name, a, b in zip(names, ga, gb):
+        assert a is not None and b is not None and torch.isfinite(b).all(), name
+        worst[name] = rel(b, a)
+        assert worst[name] < 1.5e-2, (name, worst[name])
+    print(f"edge update, on-chip dW vs row tensors ({B}x{N}x{K}, p={p}):", {k_: f"{v:.1e}" for k_, v in worst.items()})
+
+
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_edge_update_backward(p):
     """_EdgeUpdate (message + dropout3 + residual + LayerNorm3 in one launch each way).  p = 0: against fp64 autograd of the

@@ -23,6 +23,46 @@ __global__ __launch_bounds__(768) void stream_k(const f4* __restrict__ w, long n
   if (s.x + s.y + s.z + s.w == 12345.f) out[blockIdx.x] = s.x;
 }
 
+// the tail's own request pattern: W_in image = [tk 8][unit 32][lane 64] f4; wave w takes units w, w + 12, w + 24 (8 fragments of 1 KiB, 32 KiB
+// apart, per unit), then the same over a second and third matrix (W_out, projections).  AHEAD: all of a phase's fragments requested at once.
+template <bool AHEAD>
+__global__ __launch_bounds__(768) void tail_pattern_k(const f4* __restrict__ w, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int phase = 0; phase < 3; ++phase) {
+    const f4* img = w + (long)phase * 16384;                 // 256 KiB per phase
+    if (AHEAD) {
+      f4 v[3][8];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int u = wave + 12 * t < 32 ? wave + 12 * t : wave;
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) v[t][tk] = img[(tk * 32 + u) * 64 + lane];
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) s += v[t][tk];
+    } else {
+      for (int u = wave; u < 32; u += 12) {
+        f4 v[8];
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) v[tk] = img[(tk * 32 + u) * 64 + lane];
+#pragma unroll
+        for (int tk = 0; tk < 8; ++tk) s += v[tk];
+      }
+    }
+    __syncthreads();
+  }
+  if (s.x + s.y + s.z + s.w == 12345.f) out[blockIdx.x] = s.x;
+}
+
+__global__ void thrash_k(const f4* __restrict__ big, long n_f4, float* out) {
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_f4; i += (long)gridDim.x * blockDim.x) s += big[i];
+  if (s.x == 12345.f) out[0] = s.x;
+}
+
 __global__ void map_k(float* out) {
   // A = 100 + lane, B = 1000 * (lane + 1): D[r] printed per lane tells which (A lane, B lane) pair lands where
   const int lane = threadIdx.x;
@@ -68,6 +108,47 @@ int main() {
   time_stream(stream_k<8>, "depth8", 63, 768);
   time_stream(stream_k<8>, "depth8", 1, 768);
   time_stream(stream_k<4>, "depth4", 250, 256);
+  {
+    f4* big; const long big_bytes = 64l << 20;
+    hipMalloc(&big, big_bytes); hipMemset(big, 0, big_bytes);
+    auto time_pat = [&](auto kern, const char* name, bool thrash) {
+      float tot = 0.f;
+      const int reps = 30;
+      for (int i = 0; i < reps + 3; ++i) {
+        if (thrash) hipLaunchKernelGGL(thrash_k, dim3(1024), dim3(256), 0, 0, big, big_bytes / 16, out);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(250), dim3(768), 0, 0, w, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (i >= 3) tot += ms;
+      }
+      printf("tail pattern %-22s %s: %7.2f us per launch (one launch between events: incl. ~5-6 us of launch + event overhead)\n", name,
+             thrash ? "after 64 MiB streamed through L2" : "weights L2-resident            ", tot * 1e3 / reps);
+    };
+    time_pat(tail_pattern_k<false>, "unit by unit", false);
+    time_pat(tail_pattern_k<true>, "phase requested at once", false);
+    time_pat(tail_pattern_k<false>, "unit by unit", true);
+    time_pat(tail_pattern_k<true>, "phase requested at once", true);
+    // the contiguous stream under the same single-launch timing, for reference
+    float tot = 0.f;
+    for (int i = 0; i < 33; ++i) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(stream_k<8>, dim3(250), dim3(768), 0, 0, w, bytes / 16, out);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (i >= 3) tot += ms;
+    }
+    printf("contiguous stream depth8, single-launch timing: %7.2f us\n", tot * 1e3 / 30);
+    tot = 0.f;
+    for (int i = 0; i < 33; ++i) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(stream_k<1>, dim3(250), dim3(768), 0, 0, w, 0L, out);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (i >= 3) tot += ms;
+    }
+    printf("empty launch, single-launch timing: %7.2f us\n", tot * 1e3 / 30);
+  }
   // empty-ish launch for the overhead
   hipLaunchKernelGGL(stream_k<1>, dim3(250), dim3(768), 0, 0, w, 0L, out);
   hipEventRecord(e0);
