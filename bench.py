@@ -895,7 +895,8 @@ def secondary_runs(args, dev):
     Each entry is a full bench line of that workload (its own metric / roofline / cpu_baseline) or {"error": ...}."""
     import copy
     res = []
-    for wl, steps, warm in (("cfg3", 6, 2), ("cfg5", 4, 2), ("cfg1", 10, 3), ("cfg1s", 5, 2), ("cfg4", 1, 1)):
+    # (step counts: every timed region >= ~0.15 s — at 6 steps of 5 ms cfg3 read 5.35 ms where 30 steps read 5.0: fixed start / drain cost)
+    for wl, steps, warm in (("cfg3", 30, 5), ("cfg5", 6, 3), ("cfg1", 40, 5), ("cfg1s", 20, 3), ("cfg4", 1, 1)):
         a = copy.copy(args)
         a.steps, a.warmup, a.workload = steps, warm, ("cfg1" if wl == "cfg1s" else wl)
         t0 = time.perf_counter()

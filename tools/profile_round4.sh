@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-secondary --no-pmc"
 db() { ls $1/*/*.db $1/*.db 2>/dev/null | head -1; }
