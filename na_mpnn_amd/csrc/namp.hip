@@ -145,6 +145,7 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
+  set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_X3>), NAMP_IMG_BYTES);
   set((const void*)node_update_kernel, NODE_TAIL_LDS);
   set((const void*)(node_update_multi_kernel<2, 0>), NODE_MULTI_LDS(2));
   set((const void*)(node_update_multi_kernel<2, 1>), NODE_MULTI_LDS_X3(2));

@@ -250,18 +250,19 @@ class ProteinMPNN(nn.Module):
 
     # ---------------------------------------------------------------------------------------
     # a11: featurisation (ProteinFeaturesNA.forward, model_utils.py:528-593).  The product path is the fused HIP
-    # featuriser (`_featurize_hip`: prep_atoms / knn_select / edge_features kernels); `featurize_torch` below —
-    # stock PyTorch-ROCm tensor ops chunked over residues — is only reached for a non-standard atom order and serves
-    # as an on-device cross-check in the tests.
+    # featuriser (`_featurize_hip`: prep_atoms / knn_select / edge_features kernels) and nothing else: a non-standard atom
+    # order raises.  (A stock-ops restatement used as an on-device cross-check lives in tests/featurize_torch.py.)
     # ---------------------------------------------------------------------------------------
     def _virtual(self, p0, p1, p2, wa, wb, wc):
         b, c = p1 - p0, p2 - p1
         return wa * torch.cross(b, c, dim=-1) + wb * b + wc * c + p1
 
-    def _hip_featuriser_ok(self):
-        """The HIP featuriser hard-codes the reference's atom order (run.py:15-19)."""
-        return [self.atom_dict.get(a) for a in spec.ATOM_TYPES] == list(range(spec.N_ATOMS)) and \
-            self.na_ref_atom in self.atom_dict
+    def _require_reference_atom_order(self):
+        """The HIP featuriser hard-codes the reference's atom order (run.py:15-19); there is no other featuriser."""
+        if [self.atom_dict.get(a) for a in spec.ATOM_TYPES] != list(range(spec.N_ATOMS)) or \
+                self.na_ref_atom not in self.atom_dict:
+            raise NotImplementedError("na_mpnn_amd's featuriser needs the reference's atom order (inference/run.py:15-19): "
+                                      f"atom_dict must map {list(spec.ATOM_TYPES)} to 0..{spec.N_ATOMS - 1}")
 
     def _noised_X(self, fd):
         X = fd["X"]
@@ -279,6 +280,7 @@ class ProteinMPNN(nn.Module):
     @torch.no_grad()
     def _featurize_hip(self, fd, want_E=True, want_hE=False):
         """a11 on the HIP kernels (prep_atoms, knn, edge_features): returns V, E (or None), h_E0 (or None), E_idx."""
+        self._require_reference_atom_order()
         X = self._noised_X(fd).float().contiguous()
         _require_device(X, "X")
         W = self._weights()
@@ -302,56 +304,8 @@ class ProteinMPNN(nn.Module):
     @torch.no_grad()
     def featurize(self, fd):
         """ProteinFeaturesNA.forward (model_utils.py:528-593) -> V, E, E_idx (int64 like the reference)."""
-        if not self._hip_featuriser_ok():
-            return self.featurize_torch(fd)
         V, E, _, E_idx = self._featurize_hip(fd, want_E=True, want_hE=False)
         return V, E, E_idx.long()
-
-    @torch.no_grad()
-    def featurize_torch(self, fd, chunk=128):
-        """The same featurisation as stock PyTorch-ROCm ops, chunked over residues (used for non-standard atom
-        orders and as an on-device cross-check of the HIP featuriser)."""
-        X, mask = fd["X"], fd["mask"]
-        _require_device(X, "X")
-        ad = self.atom_dict
-        X = self._noised_X(fd)
-        B, L = X.shape[:2]
-        K = int(min(self.k_neighbors, L))
-        Ca = X[:, :, ad["CA"]]
-        Cb = self._virtual(X[:, :, ad["N"]], Ca, X[:, :, ad["C"]], -0.58273431, 0.56802827, -0.54067466)
-        C1p = X[:, :, ad["C1'"]]
-        Nna = self._virtual(X[:, :, ad["O4'"]], C1p, X[:, :, ad["C2'"]], -0.56967352, 0.51055973, -0.53122153)
-        X18 = torch.cat((X, Cb[:, :, None], Nna[:, :, None]), -2)
-        dna_m, rna_m = self._na_masks(fd)
-        M18 = torch.cat((fd["X_m"], fd["protein_mask"][:, :, None], (rna_m + dna_m)[:, :, None]), -1).float()
-        P = Ca + X[:, :, ad[self.na_ref_atom]]
-        mf = mask.float()
-        m2 = mf[:, None, :] * mf[:, :, None]
-        D = m2 * torch.sqrt(((P[:, None] - P[:, :, None]) ** 2).sum(-1) + 1e-6)
-        D = D + (1. - m2) * D.max(-1, keepdim=True)[0]
-        E_idx = torch.topk(D, K, dim=-1, largest=False)[1]
-        del D, m2
-        fp = self.features
-        mu = torch.linspace(2., 22., spec.NUM_RBF, device=X.device)
-        R_idx, chain = fd["R_idx"].long(), fd["chain_labels"].long()
-        bidx = torch.arange(B, device=X.device)[:, None, None]
-        Wpos, bpos = fp.embeddings.linear.weight, fp.embeddings.linear.bias
-        E = torch.empty(B, L, K, self.edge_features, device=X.device)
-        for i0 in range(0, L, chunk):
-            i1 = min(L, i0 + chunk)
-            j = E_idx[:, i0:i1]                                        # [B,c,K]
-            Xj, Mj = X18[bidx, j], M18[bidx, j]                         # [B,c,K,18,3], [B,c,K,18]
-            Dab = torch.sqrt(((X18[:, i0:i1, None, :, None, :] - Xj[:, :, :, None, :, :]) ** 2).sum(-1) + 1e-6)
-            rbf = torch.exp(-(((Dab[..., None] - mu) / 1.25) ** 2))
-            rbf = rbf * M18[:, i0:i1, None, :, None, None] * Mj[:, :, :, None, :, None]
-            off = R_idx[:, i0:i1, None] - R_idx[bidx, j]
-            same = (chain[:, i0:i1, None] == chain[bidx, j]).long()
-            d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
-            pos = Wpos.t()[d] + bpos                                   # one-hot @ W^T == column select
-            feat = torch.cat((pos, rbf.reshape(B, i1 - i0, K, -1)), -1)
-            E[:, i0:i1] = nn.functional.layer_norm(feat @ self.edge_weight18().t(), (self.edge_features,),
-                                                   fp.norm_edges.weight, fp.norm_edges.bias, 1e-5)
-        return self._node_features(fd), E, E_idx
 
     # ---------------------------------------------------------------------------------------
     # a7: encoder
@@ -378,10 +332,6 @@ class ProteinMPNN(nn.Module):
     def encode(self, feature_dict):
         """ProteinMPNN.encode (model_utils.py:71-99).  With the HIP featuriser W_e is applied inside the feature
         kernel, so E itself is never written."""
-        if not self._hip_featuriser_ok():
-            V, E, E_idx = self.featurize_torch(feature_dict)
-            h_V, h_E = self.encode_graph(V, E, E_idx, feature_dict["mask"])
-            return h_V, h_E, E_idx
         V, _, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
         h_V, h_E = self.encode_graph(V, None, E_idx, feature_dict["mask"], h_E_embedded=h_E)
         return h_V, h_E, E_idx.long()
@@ -426,11 +376,7 @@ class ProteinMPNN(nn.Module):
         kernels fuse across the encoder/decoder boundary.  Returns h_V, h_E, E_idx, log_probs(, logits)."""
         mask = feature_dict["mask"]
         self._check_tokens(S)
-        if self._hip_featuriser_ok():
-            V, E, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
-        else:
-            V, E, E_idx = self.featurize_torch(feature_dict)
-            h_E = torch.empty(*E_idx.shape, H, device=V.device)
+        V, E, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
         W = self._weights()
         B, N, K = E_idx.shape
         V = V.float().contiguous()
@@ -480,8 +426,7 @@ class ProteinMPNN(nn.Module):
         ``decoding_randn`` replaces the internal torch.randn (:623) when reproducibility is needed."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import train                      # differentiable path: HIP per-edge forward/backward + torch autograd
-            if not self._hip_featuriser_ok():
-                raise NotImplementedError("training needs the reference's atom order (run.py:15-19)")
+            self._require_reference_atom_order()
             return train.forward_train(self, feature_dict, decoding_randn)
         with torch.no_grad():
             mask = feature_dict["mask"]

@@ -9,6 +9,7 @@ import torch
 from na_mpnn_amd import spec, synth
 from na_mpnn_amd.model import ProteinMPNN
 from oracle import cpu_ref
+from featurize_torch import featurize_torch
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -80,7 +81,7 @@ def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw, prec):
         assert maxdiff(E[0, i][perm], g["E_rows"][q]) < 2e-4
         compared += 1
     assert compared >= 4
-    Vt, Et, It = m.featurize_torch(fd)
+    Vt, Et, It = featurize_torch(m, fd)
     assert torch.equal(torch.sort(It[0][valid], -1)[0], torch.sort(E_idx[0][valid], -1)[0])
     if torch.equal(It[0][valid], E_idx[0][valid]):
         assert maxdiff(E[0][valid], Et[0][valid].cpu()) < 2e-4
@@ -191,7 +192,7 @@ def test_include_pred_na_N_0(golden_dir, prec):
         compared += 1
     assert compared >= 4
     # the stock-ops featuriser takes the same expanded weight
-    Vt, Et, It = m.featurize_torch(fd)
+    Vt, Et, It = featurize_torch(m, fd)
     if torch.equal(It[0][valid], E_idx[0][valid]):
         assert maxdiff(E[0][valid], Et[0][valid].cpu()) < 2e-4
     lp, p = m.forward(fd, decoding_randn=torch.from_numpy(g["randn"]).to(dev))

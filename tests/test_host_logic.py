@@ -75,6 +75,21 @@ def test_cpu_tensors_fail_loudly():
                        torch.ones(1, 4))
 
 
+def test_non_reference_atom_order_raises():
+    """There is one featuriser (the HIP kernels, reference atom order run.py:15-19) and no stock-ops fallback behind it."""
+    ad = spec.atom_dict()
+    ad["N"], ad["CA"] = ad["CA"], ad["N"]
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=8, atom_dict=ad,
+                    restype_to_int=spec.restype_to_int(), polytype_to_int=spec.polytype_to_int())
+    cx = synth.make_complex(seed=1, n=20)
+    fd = {k: torch.from_numpy(np.ascontiguousarray(v))[None] for k, v in cx.items()}
+    fd["batch_size"] = 1
+    for call in (m.featurize, m.encode, m.score):
+        with pytest.raises(NotImplementedError, match="atom order"):
+            call(fd)
+    assert not hasattr(m, "featurize_torch")
+
+
 def test_decoding_rank_helpers():
     order = torch.tensor([[2, 0, 3, 1], [1, 2, 3, 0]])
     rank = ProteinMPNN.ranks_of(order)
