@@ -435,6 +435,7 @@ def train_bench(args, dev, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    quiet_gc.collect()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -557,6 +558,7 @@ def split_bench(args, dev, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    quiet_gc.collect()
     for _ in range(max(args.warmup, 1)):
         step()
     # Strong scaling divides one pass by the rank count (~40 ms per pass at N = 8): a timed region of a few passes would be
@@ -649,6 +651,7 @@ def design_bench(args, dev, rank, world, dist, specificity=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    quiet_gc.collect()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -716,14 +719,21 @@ def cpu_train_baseline(cx, K, rti, n=300):
 
 
 class quiet_gc:
-    """Python's cyclic garbage collector paused over a timed region (collected right before, re-enabled after): a generation-2 pass
+    """Python's cyclic garbage collector paused over a timed region (collected before the warm-up steps, re-enabled after): a generation-2 pass
     over the process's ~10^6 objects stalls the launching thread for 90-150 ms — one such pass inside a 4-step cfg5 region doubles the
     reported step time (measured: 40 steps, one 100 ms outlier with the collector on, none with it off; profiles/r04e)."""
+
+    @staticmethod
+    def collect():
+        """Call BEFORE the warm-up steps, never between warm-up and t0: a full collection walks ~10^6 objects and leaves the host's
+        caches cold — the first launches behind it enqueue slower than the device executes them, which put ~0.9 ms of device idle
+        into a 20-step cfg2 region (0.483 -> 0.528 ms per step, HEAD and the round-3 kernels alike; profiles/r05a_region_probe.md)."""
+        import gc
+        gc.collect()
 
     def __enter__(self):
         import gc
         self._was = gc.isenabled()
-        gc.collect()
         gc.disable()
         return self
 
@@ -799,6 +809,7 @@ def encdec_bench(args, dev, rank, world, dist, workload, precision, steps, warmu
 
     # set-up, not measurement: bring the device out of its idle clocks before the W warm-up steps (a 20-step timed region of
     # this path is ~10 ms — one clock ramp inside it shows as +25 %; measured once in profiles/r02i)
+    quiet_gc.collect()
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.05:
         runner.step()

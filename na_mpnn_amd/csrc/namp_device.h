@@ -136,6 +136,12 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 // with its two quarter-rate transcendentals per value is wasted there.  x * Phi(x) with Phi(x) - 1/2 = x * Q(x^2), Q a
 // polynomial (round 4: degree 4, max |error| 1.3e-3 over the real line; rounds 1-3: degree 6, 1.9e-4), written on 4-vectors so that the
 // packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32) can be selected.
+// Phi(x) - 1/2 = x Q(x^2), Q of degree 4 (round 4): Q(t) = Q0 + Q1 t + Q2 t^2 + Q3 t^3 + Q4 t^4
+#define NAMP_GELU4_Q4 1.2247244342e-05f
+#define NAMP_GELU4_Q3 -4.6204919395e-04f
+#define NAMP_GELU4_Q2 7.1675247900e-03f
+#define NAMP_GELU4_Q1 -6.1600986289e-02f
+#define NAMP_GELU4_Q0 3.9660173626e-01f
 __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
 #ifdef NAMP_ABL_NOGELU
   return x;
@@ -176,13 +182,14 @@ __device__ __forceinline__ f4 gelu4_bf16mode(const f4 x) {
 #else
   // round 4: degree 4 in x^2 (minimax over the real line, the [0, 1] clamp included; positive leading coefficient, x Q(x^2) >= 0.62 beyond
   // |x| = 4): max |error| 1.3e-3 — a third of the bf16 rounding step of the result at |y| >= 1 (2^-8 |y|) and below it for |y| > 0.33;
-  // near 0 the error is x^2 (Q - Q*), i.e. vanishes.  Two packed FMAs per value pair less than the degree-6 form (tests/test_gpu_parity.py
-  // restates the constants: test_device_gelu_formula_accuracy).
-  f4 q = (f4){1.2247244342e-05f, 1.2247244342e-05f, 1.2247244342e-05f, 1.2247244342e-05f};
-  q = q * t + -4.6204919395e-04f;
-  q = q * t + 7.1675247900e-03f;
-  q = q * t + -6.1600986289e-02f;
-  q = q * t + 3.9660173626e-01f;
+  // near 0 the error is x^2 (Q - Q*), i.e. vanishes.  Two packed FMAs per value pair less than the degree-6 form.  The constants are the
+  // NAMP_GELU4_Q* macros above (shared with the training backward's dw_gelu_split4_bf16, namp_train_dw.h); tests/test_host_logic.py
+  // parses them: test_device_gelu_bf16_mode_polynomial.
+  f4 q = (f4){NAMP_GELU4_Q4, NAMP_GELU4_Q4, NAMP_GELU4_Q4, NAMP_GELU4_Q4};
+  q = q * t + NAMP_GELU4_Q3;
+  q = q * t + NAMP_GELU4_Q2;
+  q = q * t + NAMP_GELU4_Q1;
+  q = q * t + NAMP_GELU4_Q0;
 #endif
   // (written as instructions: the compiler emits a separate `v_max_f32 ... clamp` per value instead of folding the clamp into the packed FMA)
   typedef float f2 __attribute__((ext_vector_type(2)));

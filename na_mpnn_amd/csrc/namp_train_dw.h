@@ -500,11 +500,11 @@ __device__ __forceinline__ f4 dw_gelu_split4_bf16(f4& z) {
 #endif
   const f4 x = z;
   const f4 t = x * x;
-  f4 q = (f4){1.2247244342e-05f, 1.2247244342e-05f, 1.2247244342e-05f, 1.2247244342e-05f};
-  q = q * t + -4.6204919395e-04f;
-  q = q * t + 7.1675247900e-03f;
-  q = q * t + -6.1600986289e-02f;
-  q = q * t + 3.9660173626e-01f;
+  f4 q = (f4){NAMP_GELU4_Q4, NAMP_GELU4_Q4, NAMP_GELU4_Q4, NAMP_GELU4_Q4};       // the constants of gelu4_bf16mode (namp_device.h)
+  q = q * t + NAMP_GELU4_Q3;
+  q = q * t + NAMP_GELU4_Q2;
+  q = q * t + NAMP_GELU4_Q1;
+  q = q * t + NAMP_GELU4_Q0;
   f4 p = x * q + 0.5f;
   p = (f4){__builtin_amdgcn_fmed3f(p.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(p.y, 0.f, 1.f), __builtin_amdgcn_fmed3f(p.z, 0.f, 1.f),
            __builtin_amdgcn_fmed3f(p.w, 0.f, 1.f)};
@@ -803,336 +803,3 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw16_kernel(const Edge
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// edge_update_bwd_dw16_kernel — the EncLayer edge update h_E' = LN3(h_E + dropout(W13 gelu(W12 gelu(W11b h_E + Pa + Pc) + b12) + b13)),
-// backward, mixed precision (plain bf16 products), in the weight-gradient-owning form of edge_bwd_dw16_kernel (round 4, late).
-// The chain has six products and three weight gradients; six bf16 images are 192 KiB and three gradients 192 accumulator registers on top
-// of the chain.  Hence: the four images of the two OUTER layers (W11b, W12 and their transposes) are resident in LDS and their two
-// gradients (dW12 = G2^T A1 with db12, dW11b = G1^T h_E) are contracted on chip exactly as in the message kernel; the MIDDLE of the chain —
-// z3 = W13 a2 + b13 for the LayerNorm, and g_a2 = W13^T g3 — reads its fragments from global memory (the 32-KiB images sit in L1 / L2: the four
-// waves of a workgroup sweep them nearly in step), one K-step ahead, and leaves the rows A2 and G3 in bf16 for the row-contraction kernel
-// (dW13, db13).  Against the round-3 launch this drops the rows A1, G2, the parked gelu'(z1) and dL/dx rows, and two of three row contractions.
-// LayerNorm's d(weight) / d(bias): the row tiles g and g * xhat staged like a G plane and summed by MFMAs against ones.
-// Rows past E compute on clamped inputs with a zero upstream gradient and store into padding (A2, G3, G1, g_hE: 64 * ceil(E / 64) rows).
-// STATUS (end of round 4): parity-green against the round-3 launch (tests/test_gpu_train.py) but NOT the default (train.DW_ONCHIP_EDGE): the
-// chain's working sets, four packed operand copies, two accumulator blocks and the column-sum fragments want ~520 vector registers per
-// lane; the compiler spills 160 of them to scratch — whose traffic shares the in-order memory counter — and the launch takes 2.7 ms
-// where the round-3 launch plus the two row contractions it replaces take 1.56 + 0.3 ms.  What it needs is a smaller live set (the
-// LayerNorm section and the first staging are the peak), not more tuning of this form.
-// ------------------------------------------------------------------------------------------
-struct EdgeUpdDwArgs {
-  EdgeBwdArgs b;              // hE, E_idx, Pa, Pj0 (= Pc), W1/W2/W2t/W1t/W3/W3t images, b2, b3, ln_g, g_rows, A2, G3, G1, g_hE, g_Pa, drop_*
-  float* dW_part;             // [grid][2][128][128]: 0 = dW12, 1 = dW11b
-  float* db_part;             // [grid][128]: db12
-  float* dgb_part;            // [grid][2][128]: per-workgroup sums of g * xhat and g
-  long nrounds;
-};
-
-// a 16-row product whose weight fragments come from a global bf16 image (fragment (s, tn) of lane l at ((s * 8 + tn) * 64 + l) * 16 bytes): the eight
-// fragments of K-step s + 1 are requested before the MFMAs of step s issue
-__device__ __forceinline__ void dw_gemm16_global(f4 (&acc)[8], const f4 (&x)[8], const bf8* __restrict__ w) {
-  bf8 wf[2][8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) wf[0][q] = w[q * 64];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s + 1 < 4) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) wf[(s + 1) & 1][q] = w[((s + 1) * 8 + q) * 64];
-    }
-    const bf8 xb = pack_bf16<false>(x[2 * s], x[2 * s + 1]);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][q], xb, acc[q], 0, 0, 0);
-  }
-}
-
-// Column sums over the 64 staged rows of two planes (both indexed like a G plane) as MFMAs against a fragment of ones: wave (wo, wc) owns
-// channel tiles 64 wo + 16 (2 wc + u), u = 0, 1 — the layout of dw_contract's bias sums.
-__device__ __forceinline__ void dw_colsum2(f4 (&s0)[2], f4 (&s1)[2], const char* S0, const char* S1, const int wo, const int wc, const int n,
-                                           const int g) {
-  const int fsw = (n >> 1) & 7;
-  bf8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-  bf8 f0[2][2], f1[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int off = ((4 * ks + g) ^ fsw) << 4;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = (64 * wo + 16 * (2 * wc + u) + n) * DW_ROWB + off;
-      f0[ks][u] = *(const bf8*)(S0 + row); f1[ks][u] = *(const bf8*)(S1 + row);
-    }
-  }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      s0[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[ks][u], ones, s0[u], 0, 0, 0);
-      s1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[ks][u], ones, s1[u], 0, 0, 0);
-    }
-}
-
-template <int GPA>        // 1 = per-tile sums of G1 for dL/dPa (K % 16 == 0); 2 = fp32 atomics
-__global__ __launch_bounds__(64 * DW_WAVES) void edge_update_bwd_dw16_kernel(const EdgeUpdDwArgs aa) {
-  const EdgeBwdArgs& a = aa.b;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* SG = smem + 4 * NAMP_BIMG_BYTES;
-  char* SA = SG + DW_ARR;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 15, g = lane >> 4;
-  const int wo = wave >> 1, wc = wave & 1;
-  const bf8* w1 = (const bf8*)smem + lane;
-  const bf8* w2 = (const bf8*)(smem + NAMP_BIMG_BYTES) + lane;
-  const bf8* w2t = (const bf8*)(smem + 2 * NAMP_BIMG_BYTES) + lane;
-  const bf8* w1t = (const bf8*)(smem + 3 * NAMP_BIMG_BYTES) + lane;
-  const bf8* w3 = (const bf8*)a.W3_img + lane;                       // global
-  const bf8* w3t = (const bf8*)a.W3t_img + lane;
-  copy_to_lds<4>(smem, a.W1_img, 32, wave, DW_WAVES, lane);
-  copy_to_lds<4>(smem + NAMP_BIMG_BYTES, a.W2_img, 32, wave, DW_WAVES, lane);
-  copy_to_lds<4>(smem + 2 * NAMP_BIMG_BYTES, a.W2t_img, 32, wave, DW_WAVES, lane);
-  copy_to_lds<4>(smem + 3 * NAMP_BIMG_BYTES, a.W1t_img, 32, wave, DW_WAVES, lane);
-
-  f4 dW2[4][4], dW1[4][4], db2[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { dW2[q][t] = (f4){0.f, 0.f, 0.f, 0.f}; dW1[q][t] = (f4){0.f, 0.f, 0.f, 0.f}; }
-  // LayerNorm d(weight) = sum g * xhat and d(bias) = sum g over the rows: the two row tiles are staged like a contraction's G plane and summed
-  // by MFMAs against ones (bf16 operands, as every product of this mode).  (Tried: 64 DPP all-reduce chains per round kept per lane — ~100
-  // more live registers, the launch spilled 212; LDS fp32 adds as in the round-3 launch — no kilobyte left beside 4 images + 2 planes.)
-  f4 kw[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}}, kb[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
-
-  auto row_of = [&](const long round) {                             // clamped edge row of this lane in `round`
-    const long e_raw = (round * DW_WAVES + wave) * 16 + m;
-    return e_raw < a.E ? e_raw : (a.E - 1);
-  };
-  auto nbr_of = [&](const long e, const int idx) {                  // global row of the neighbour (EncLayer addressing: same complex)
-    const int node = (int)(e / a.K);
-    return node - node % a.N + idx;
-  };
-  // register roles: x = h_E rows, from the first product on this round's dL/dh_E' rows, from the first staging on the next round's h_E rows;
-  // z1 = Pa (+ Pc), first product, later z3 / xhat, from g1 on the next round's Pa;  A = Pc rows, b12 / z2, the h_E rows again (fp32, for the
-  // LayerNorm's residual: L2), the W13^T and W12^T products, from g1 on the next round's Pc;  y = a1, then a2;  gr = g3, g2, g1;
-  // P = dL/dx of the LayerNorm (the residual path), accumulates the last product.  h_E, a1, gelu'(z1), gelu'(z2) wait as packed bf16.
-  f4 x[8], z1[8], A[8], y[8], gr[8], P[8];
-  bf2 h16[16], a16[16], d16[16], e16[16];
-  long round = blockIdx.x;
-  {
-    const long r0 = round < aa.nrounds ? round : 0;
-    const long e0 = row_of(r0);
-    const int j0 = nbr_of(e0, a.E_idx[e0]);
-    const float* src = a.hE + e0 * NAMP_H + 4 * g;
-    const float* pa = a.Pa + (e0 / a.K) * NAMP_H + 4 * g;
-    const float* pj = a.Pj0 + (long)j0 * NAMP_H + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { x[t] = *(const f4*)(src + 16 * t); z1[t] = *(const f4*)(pa + 16 * t); A[t] = *(const f4*)(pj + 16 * t); }
-  }
-  int idx_n1 = a.E_idx[row_of(round + gridDim.x < aa.nrounds ? round + gridDim.x : round)];
-  __syncthreads();                                                   // the images are in place
-
-  for (; round < aa.nrounds; round += gridDim.x) {
-    const long e_raw = (round * DW_WAVES + wave) * 16 + m;          // unclamped: rows past E store into the buffers' padding
-    const bool valid = e_raw < a.E;
-    const long e = valid ? e_raw : (a.E - 1);
-    const long round_n = round + gridDim.x;
-    const long rn = round_n < aa.nrounds ? round_n : round;        // (last rounds: their own rows again — no branch around the requests)
-    const long e_n = row_of(rn);
-    const int j_n = nbr_of(e_n, idx_n1);
-    const long round_n2 = round_n + gridDim.x;
-    idx_n1 = a.E_idx[row_of(round_n2 < aa.nrounds ? round_n2 : round)];
-    // (loop-invariant vectors: their addresses are made opaque per round, or the compiler keeps all 96 registers of them across the loop)
-    const float* b2p = a.b2; const float* b3p = a.b3; const float* lgp = a.ln_g;
-    asm volatile("" : "+s"(b2p), "+s"(b3p), "+s"(lgp));
-    // ---- z1 = W11b . h_E + (Pa + Pc)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) z1[t] += A[t];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) A[t] = *(const f4*)(b2p + 16 * t + 4 * g);
-    dw_gemm16_ahead(z1, x, w1);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      h16[2 * t] = (bf2){(__bf16)x[t].x, (__bf16)x[t].y};             // h_E as packed bf16 for the second contraction
-      h16[2 * t + 1] = (bf2){(__bf16)x[t].z, (__bf16)x[t].w};
-    }
-    // dL/dh_E' rows of this round (HBM) -> x: consumed behind the third product
-#pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.g_rows + e * NAMP_H + 4 * g + 16 * t);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      y[t] = dw_gelu_split4_bf16(z1[t]);                              // y <- a1, z1 <- gelu'(z1)
-      d16[2 * t] = (bf2){(__bf16)z1[t].x, (__bf16)z1[t].y};
-      d16[2 * t + 1] = (bf2){(__bf16)z1[t].z, (__bf16)z1[t].w};
-    }
-    // ---- z2 = W12 . a1 + b12
-    dw_gemm16_ahead(A, y, w2);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      a16[2 * t] = (bf2){(__bf16)y[t].x, (__bf16)y[t].y};
-      a16[2 * t + 1] = (bf2){(__bf16)y[t].z, (__bf16)y[t].w};
-      y[t] = dw_gelu_split4_bf16(A[t]);                               // y <- a2, A <- gelu'(z2)
-      e16[2 * t] = (bf2){(__bf16)A[t].x, (__bf16)A[t].y};
-      e16[2 * t + 1] = (bf2){(__bf16)A[t].z, (__bf16)A[t].w};
-    }
-    // ---- z3 = W13 . a2 + b13 (fragments from global memory), dropout, x_ln = h_E + z3, LayerNorm statistics
-#pragma unroll
-    for (int t = 0; t < 8; ++t) z1[t] = *(const f4*)(b3p + 16 * t + 4 * g);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) A[t] = *(const f4*)(a.hE + e * NAMP_H + 4 * g + 16 * t);      // the residual's h_E rows in fp32 (L2)
-    {
-      const bf8* w3r = w3;
-      asm volatile("" : "+v"(w3r));                                 // (the image's address is loop-invariant: keep its 32 fragment loads IN the round)
-      dw_gemm16_global(z1, y, w3r);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.A2, e_raw * NAMP_H + 4 * g + 16 * t, y[t]);
-    const uint32_t key = drop_row_key(a.drop_seed, e);
-    float s1 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (a.drop_thresh) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z1[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
-      }
-      z1[t] += A[t];
-      s1 += (z1[t].x + z1[t].y) + (z1[t].z + z1[t].w);
-    }
-    const float mean = xg_sum(s1) * (1.0f / 128.0f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { z1[t] -= mean; s2 += (z1[t].x * z1[t].x + z1[t].y * z1[t].y) + (z1[t].z * z1[t].z + z1[t].w * z1[t].w); }
-    const float rstd = rsqrtf(xg_sum(s2) * (1.0f / 128.0f) + 1e-5f);
-    const float vz = valid ? 1.f : 0.f;
-    float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      z1[t] *= rstd;                                                  // xhat
-      x[t] = x[t] * vz;                                                // g = dL/dh_E' (zero past E)
-      const f4 gg = x[t] * *(const f4*)(lgp + 16 * t + 4 * g);
-      P[t] = gg;
-      m1 += (gg.x + gg.y) + (gg.z + gg.w);
-      m2 += (gg.x * z1[t].x + gg.y * z1[t].y) + (gg.z * z1[t].z + gg.w * z1[t].w);
-    }
-    // column sums for d(ln weight), d(ln bias): planes g (-> SA) and g * xhat (-> SG)
-    dw_lds_barrier();                                                // the previous round's second contraction has been read out
-    dw_stage<false>(SA, x, wave, m, g);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = x[t] * z1[t];
-    dw_stage<false>(SG, x, wave, m, g);
-    dw_lds_barrier();
-    dw_colsum2(kw, kb, SG, SA, wo, wc, m, g);
-    m1 = xg_sum(m1) * (1.0f / 128.0f);
-    m2 = xg_sum(m2) * (1.0f / 128.0f);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      gr[t] = (P[t] - m1 - z1[t] * m2) * rstd;                         // dL/dx of the LayerNorm = the residual part of dL/dh_E:
-      *(f4*)(a.g_hE + e_raw * NAMP_H + 4 * g + 16 * t) = gr[t];         // parked in the output row (L2), picked up by the last product
-      if (a.drop_thresh) {                                             // through the (regenerated) dropout mask: g3 = dL/dz3
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gr[t][r] *= drop_factor(key, 16 * t + 4 * g + r, a.drop_thresh, a.drop_scale);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.G3, e_raw * NAMP_H + 4 * g + 16 * t, gr[t]);
-    // ---- g2 = (W13^T g3) * gelu'(z2)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) A[t] = (f4){0.f, 0.f, 0.f, 0.f};
-    {
-      const bf8* w3r = w3t;
-      asm volatile("" : "+v"(w3r));
-      dw_gemm16_global(A, gr, w3r);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      gr[t] = A[t] * (f4){(float)e16[2 * t][0], (float)e16[2 * t][1], (float)e16[2 * t + 1][0], (float)e16[2 * t + 1][1]};
-    // ---- contraction 1: dW12 += G2^T A1, db12 += sum G2
-    dw_lds_barrier();                                                // the previous round's second contraction has been read out
-    dw_stage<false>(SG, gr, wave, m, g);
-    dw_stage_packed(SA, a16, wave, m, g);
-    {                                                                // the next round's h_E rows
-      const float* src = a.hE + e_n * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(src + 16 * t);
-    }
-    dw_lds_barrier();
-    dw_contract<false, true>(dW2, db2, SG, SA, wo, wc, m, g);
-    // ---- g1 = (W12^T g2) * gelu'(z1)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) A[t] = (f4){0.f, 0.f, 0.f, 0.f};
-    dw_gemm16_ahead(A, gr, w2t);
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      gr[t] = A[t] * (f4){(float)d16[2 * t][0], (float)d16[2 * t][1], (float)d16[2 * t + 1][0], (float)d16[2 * t + 1][1]};
-    {                                                                // the next round's table rows (L2): Pa -> z1, Pc -> A
-      const float* pa = a.Pa + (e_n / a.K) * NAMP_H + 4 * g;
-      const float* pj = a.Pj0 + (long)j_n * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { z1[t] = *(const f4*)(pa + 16 * t); A[t] = *(const f4*)(pj + 16 * t); }
-    }
-    // ---- contraction 2: dW11b += G1^T h_E
-    dw_lds_barrier();                                                // contraction 1 has been read out
-    dw_stage<false>(SG, gr, wave, m, g);
-    dw_stage_packed(SA, h16, wave, m, g);
-    dw_lds_barrier();
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.G1, e_raw * NAMP_H + 4 * g + 16 * t, gr[t]);
-    if constexpr (GPA == 1) {
-      const long tile = round * DW_WAVES + wave;
-      f4 keep = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        f4 v = gr[t] * vz;
-        v.x = dw_row_allsum(v.x); v.y = dw_row_allsum(v.y); v.z = dw_row_allsum(v.z); v.w = dw_row_allsum(v.w);
-        keep = ((m & 7) == t) ? v : keep;
-      }
-      *(f4*)(a.g_Pa + tile * NAMP_H + 16 * (m & 7) + 4 * g) = keep;
-    } else {
-      float* d = a.g_Pa + (e / a.K) * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        unsafeAtomicAdd(d + 16 * t + 0, gr[t].x * vz); unsafeAtomicAdd(d + 16 * t + 1, gr[t].y * vz);
-        unsafeAtomicAdd(d + 16 * t + 2, gr[t].z * vz); unsafeAtomicAdd(d + 16 * t + 3, gr[t].w * vz);
-      }
-    }
-    f4 nob[2];
-    dw_contract<false, false>(dW1, nob, SG, SA, wo, wc, m, g);
-    // ---- dL/dh_E = dL/dx + W11b^T g1
-#pragma unroll
-    for (int t = 0; t < 8; ++t) P[t] = *(const f4*)(a.g_hE + e_raw * NAMP_H + 4 * g + 16 * t);
-    dw_gemm16_ahead(P, gr, w1t);
-    {
-      float* d = a.g_hE + e_raw * NAMP_H + 4 * g;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(d + 16 * t) = P[t];
-    }
-  }
-  float* o2 = aa.dW_part + (long)blockIdx.x * 2 * NAMP_H * NAMP_H;
-  float* o1 = o2 + NAMP_H * NAMP_H;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 64 * wo + 16 * q + 4 * g + r, c = 64 * wc + 16 * t + m;
-        o2[o * NAMP_H + c] = dW2[q][t][r];
-        o1[o * NAMP_H + c] = dW1[q][t][r];
-      }
-  if (m == 0) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) aa.db_part[(long)blockIdx.x * NAMP_H + 64 * wo + 16 * (2 * wc + u) + 4 * g + r] = db2[u][r];
-  }
-  if (m == 0) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* dg = aa.dgb_part + (long)blockIdx.x * 2 * NAMP_H + 64 * wo + 16 * (2 * wc + u) + 4 * g + r;
-        dg[0] = kw[u][r];
-        dg[NAMP_H] = kb[u][r];
-      }
-  }
-}

@@ -258,11 +258,14 @@ def test_device_gelu_bf16_mode_polynomial():
     the bf16 rounding step of its result at |y| >= 1), saturating correctly beyond the fit range, exact at 0."""
     from math import erf, sqrt
     src = open(os.path.join(ROOT, "na_mpnn_amd", "csrc", "namp_device.h")).read()
-    body = src[src.index("#else\n  // round 4: degree 4 in x^2"):]
-    body = body[:body.index("#endif")]
-    lead = np.float32(re.search(r"f4 q = \(f4\)\{(-?[0-9.e+-]+)f", body).group(1))
-    rest = [np.float32(v) for v in re.findall(r"q = q \* t \+ (-?[0-9.e+-]+)f;", body)]
-    assert len(rest) == 4
+    c = {k: np.float32(v) for k, v in re.findall(r"#define NAMP_GELU4_(Q[0-4]) (-?[0-9.e+-]+)f", src)}
+    assert sorted(c) == ["Q0", "Q1", "Q2", "Q3", "Q4"]
+    lead, rest = c["Q4"], [c["Q3"], c["Q2"], c["Q1"], c["Q0"]]
+    # the training backward's gelu / gelu' pair (namp_train_dw.h) evaluates the SAME polynomial: no second copy of the constants
+    dw = open(os.path.join(ROOT, "na_mpnn_amd", "csrc", "namp_train_dw.h")).read()
+    fn = dw[dw.index("f4 dw_gelu_split4_bf16("):]
+    fn = fn[:fn.index("\n}\n")]
+    assert "NAMP_GELU4_Q4" in fn and "NAMP_GELU4_Q0" in fn and not re.search(r"[0-9]e-0[0-9]f", fn.split("fmed3f")[0])
     xs = np.linspace(-14.0, 14.0, 560001)
     x = xs.astype(np.float32)
     t = x * x
