@@ -383,15 +383,17 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
                                const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
                                uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                                float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int x3, int B, int N, int K, void* stream);
-/* The same backward in the weight-gradient-owning form (round 4; mixed precision only: x3 & 3 == 2, bit 3 as above): one persistent launch that
- * also contracts dW2 = G2^T A1 (+ db2) and dW1b = G1^T h_E over the edges on chip — no A1 / G2 rows.  Row buffers A2, G3, G1 (bf16) and g_hE hold
- * namp_train_edge_bwd_dw_rows() rows, g_Pa one row per 16 of those (bit 3) or [G][128] zeroed; dW_part [groups][2][128][128] (0 = dW2, 1 = dW1b),
- * db_part [groups][128], dgb_part [groups][2][128], groups = namp_train_edge_bwd_dw_groups().  dW3 / db3: namp_train_wgrad over (G3, A2).
- * Replaces namp_train_edge_update_bwd + two of its three row contractions (na_model_utils.py:236-240). */
+/* The same backward as TWO persistent launches that own their weight gradients (round 5; mixed precision only: x3 & 3 == 2, bit 3 as above) — no
+ * A1 / A2 / G3 rows and no row contractions behind it.  Launch A: recompute, LayerNorm3 + dropout backward (dL/dx rows parked in g_hE, d ln sums),
+ * dW3 / db3 on chip, G2 rows (bf16 workspace).  Launch B: dW2 / db2 and dW1b on chip, dL/dh_E = dL/dx + W1b^T g1 (in place in g_hE), G1 rows (bf16,
+ * for namp_train_scatter_rows_bf16), g_Pa.  Row buffers G2, G1 and g_hE hold namp_train_edge_bwd_dw_rows() rows, g_Pa one row per 16 of those
+ * (bit 3) or [G][128] zeroed.  With groups = namp_train_edge_bwd_dw_groups(): dW_part = [groups][128][128] (dW3) followed by [groups][2][128][128]
+ * (0 = dW2, 1 = dW1b); db_part = [groups][128] (db3) followed by [groups][128] (db2); dgb_part [groups][2][128] (sum g * xhat, sum g).
+ * Replaces namp_train_edge_update_bwd + its three row contractions (na_model_utils.py:236-240). */
 int namp_train_edge_update_bwd_dw(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
                                   const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
                                   const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
-                                  uint32_t drop_seed, const float* g_out, float* A2, float* G3, float* G1, float* g_hE, float* g_Pa,
+                                  uint32_t drop_seed, const float* g_out, float* G2, float* G1, float* g_hE, float* g_Pa,
                                   float* dW_part, float* db_part, float* dgb_part, int x3, int B, int N, int K, void* stream);
 int namp_train_edge_bwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,

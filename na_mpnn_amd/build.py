@@ -16,7 +16,8 @@ INC = os.path.join("..", "..", "include", "namp.h")
 # translation unit -> files it depends on (each unit is compiled to its own object, in parallel, then linked)
 UNITS = {"namp.hip": ["namp.hip", "namp_kernels.h", "namp_bf16s32.h", "namp_device.h", INC],
          "namp_persist.hip": ["namp_persist.hip", "namp_kernels.h", "namp_device.h"],
-         "namp_train.hip": ["namp_train.hip", "namp_train.h", "namp_train_dw.h", "namp_device.h", INC]}
+         "namp_train.hip": ["namp_train.hip", "namp_train.h", "namp_train_dw.h", "namp_device.h", INC],
+         "namp_train_eu.hip": ["namp_train_eu.hip", "namp_train_eu.h", "namp_train_dw.h", "namp_train.h", "namp_device.h", INC]}
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 TIMEOUT_S = 1500

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   }
 }
 
+#ifndef NAMP_TRAIN_EDGE_ONLY      // (namp_train_eu.hip takes the per-edge chain above and nothing below)
 // ------------------------------------------------------------------------------------------
 // wgrad_kernel: dW[o][c] = sum_rows G[row][o] * act(A[row][c]),  db[o] = sum_rows G[row][o]   (128 x 128, rows ~ 10^6).
 // The contraction index is the row, 4 rows per v_mfma_f32_16x16x4_f32: with k-slot g of MFMA r standing for
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const __bf16* __restric
 // tile_presence_kernel: for every 64-edge tile, which of the 18 atoms occur on the residue side (word 0) and on the
 // neighbour side (word 1) of any of its edges.  An (a, b) block can only be non-zero on a tile that has a on one side and
 // b on the other; feat_wgrad_kernel reads these two words instead of voting across the workgroup for every tile.
-__global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restrict__ M18, const int32_t* __restrict__ E_idx, long E,
+static __global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restrict__ M18, const int32_t* __restrict__ E_idx, long E,
                                                            int L, int K, int32_t* __restrict__ pres) {
   const int lane = threadIdx.x & 63;
   const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restr
   if (lane == 0) { pres[2 * tile] = (int32_t)bi; pres[2 * tile + 1] = (int32_t)bj; }
 }
 
-__global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
+static __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                          const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
                                                          const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
                                                          long E, long edges_per_chunk, int L, int K,
@@ -994,7 +995,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+static __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ out, long rows) {
   const int c4 = threadIdx.x & 31;
   const f4 ga = *(const f4*)(gamma + 4 * c4), be = *(const f4*)(beta + 4 * c4);
@@ -1008,7 +1009,7 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ gamma, float* __restrict__ gx,
                                                           float* __restrict__ dgb_part, long rows) {
   __shared__ float red[8][2][128];
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void tail_load_B(bf8 (&woh)[2][8], bf8 (&wom)[2][8], 
     for (int tn = 0; tn < 8; ++tn) { woh[s][tn] = w[(s * 8 + tn) * 64]; wom[s][tn] = w[128 * 512 / 8 + (s * 8 + tn) * 64]; }
 }
 
-__global__ __launch_bounds__(512) void tail_train_fwd_kernel(const TailTrainArgs a) {
+static __global__ __launch_bounds__(512) void tail_train_fwd_kernel(const TailTrainArgs a) {
   constexpr int T = TAIL_T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = (float*)smem;                       // [T][16][FFN_LD]  x1 = LN1(...)
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(512) void tail_train_fwd_kernel(const TailTrainArgs
   }
 }
 
-__global__ __launch_bounds__(512) void tail_train_bwd_kernel(const TailTrainArgs a) {
+static __global__ __launch_bounds__(512) void tail_train_bwd_kernel(const TailTrainArgs a) {
   constexpr int T = TAIL_T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* gf = (float*)smem;                       // [T][16][FFN_LD]  g_f = dropout2-mask * g_y
@@ -1482,4 +1483,4 @@ static __global__ __launch_bounds__(256) void adam_step_kernel(const AdamPlan p,
     w[i] = w[i] + (-step_size) * (mi / denom);                     // addcdiv_
   }
 }
-
+#endif  // NAMP_TRAIN_EDGE_ONLY

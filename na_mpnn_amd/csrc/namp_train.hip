@@ -63,13 +63,6 @@ int ensure_attributes() {
 #define NAMP_SET_DW16(M) set_dw16((const void*)(edge_bwd_dw16_kernel<M, false, 1>)); set_dw16((const void*)(edge_bwd_dw16_kernel<M, true, 1>)); \
                          set_dw16((const void*)(edge_bwd_dw16_kernel<M, false, 2>)); set_dw16((const void*)(edge_bwd_dw16_kernel<M, true, 2>))
     NAMP_SET_DW16(BWD_ENC_MSG); NAMP_SET_DW16(BWD_DEC_MSG);
-    {
-      auto set_eu = [](const void* f) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW16_LDS);
-        if (e != hipSuccess) g_attr_err = e;
-      };
-      set_eu((const void*)(edge_update_bwd_dw16_kernel<1>)); set_eu((const void*)(edge_update_bwd_dw16_kernel<2>));
-    }
   });
   if (g_attr_err != hipSuccess)
     return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(g_attr_err));
@@ -246,45 +239,6 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
     hipStream_t s = (hipStream_t)stream;
     NAMP_LAUNCH_BWD(BWD_EDGE_LN);
   }
-  CHECK_LAUNCH();
-  return NAMP_OK;
-}
-
-// The edge update's backward in the weight-gradient-owning form (mixed precision only; csrc/namp_train_dw.h, edge_update_bwd_dw16_kernel).
-// Row buffers A2, G3, G1 (bf16) and g_hE (fp32) hold namp_train_edge_bwd_dw_rows() rows, g_Pa one row per 16 of those (bit 3 of x3) or [G][128]
-// zeroed; dW_part [groups][2][128][128] (0 = dW2, 1 = dW1b), db_part [groups][128] (db2), dgb_part [groups][2][128] with
-// groups = namp_train_edge_bwd_dw_groups().  dW3 / db3 are left to the row contraction of (G3, A2).
-int namp_train_edge_update_bwd_dw(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
-                                  const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
-                                  const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
-                                  uint32_t drop_seed, const float* g_out, float* A2, float* G3, float* G1, float* g_hE, float* g_Pa,
-                                  float* dW_part, float* db_part, float* dgb_part, int x3, int B, int N, int K, void* stream) {
-  REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
-  REQUIRE_PTR(W3t_img); REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(ln_g);
-  REQUIRE_PTR(g_out); REQUIRE_PTR(A2); REQUIRE_PTR(G3); REQUIRE_PTR(G1); REQUIRE_PTR(g_hE); REQUIRE_PTR(g_Pa);
-  REQUIRE_PTR(dW_part); REQUIRE_PTR(db_part); REQUIRE_PTR(dgb_part);
-  if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_update_bwd_dw: null E_idx");
-  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_update_bwd_dw: drop_p=%g must be in [0,1)", (double)drop_p);
-  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_update_bwd_dw: bad dims B=%d N=%d K=%d", B, N, K);
-  REQUIRE((x3 & 3) == 2, "namp_train_edge_update_bwd_dw: precision code %d (bf16 products = 2 only)", x3 & 3);
-  int rc = ensure_attributes();
-  if (rc) return rc;
-  EdgeUpdDwArgs aa = {};
-  EdgeBwdArgs& a = aa.b;
-  a.hE = h_E; a.E_idx = E_idx; a.Pa = Pa; a.Pj0 = Pc;
-  a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img;
-  a.b2 = b2; a.b3 = b3; a.ln_g = ln_g; a.g_rows = g_out;
-  if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
-  a.A2 = A2; a.G3 = G3; a.G1 = G1; a.g_hE = g_hE; a.g_Pa = g_Pa;
-  a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
-  a.gpa_tiles = (x3 & 8) ? 1 : 0;
-  REQUIRE(!a.gpa_tiles || (K % 16) == 0, "namp_train_edge_update_bwd_dw: per-tile g_Pa sums need K %% 16 == 0 (K=%d)", K);
-  aa.dW_part = dW_part; aa.db_part = db_part; aa.dgb_part = dgb_part;
-  aa.nrounds = (a.E + DW_ROWS - 1) / DW_ROWS;
-  const int grid = namp_train_edge_bwd_dw_groups(B, N, K);
-  hipStream_t s = (hipStream_t)stream;
-  if (a.gpa_tiles) hipLaunchKernelGGL((edge_update_bwd_dw16_kernel<1>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);
-  else hipLaunchKernelGGL((edge_update_bwd_dw16_kernel<2>), dim3(grid), dim3(64 * DW_WAVES), DW16_LDS, s, aa);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

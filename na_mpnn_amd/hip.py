@@ -106,7 +106,7 @@ _PROTOTYPES = {
     "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, i32, vp]),
     "namp_train_edge_update_bwd_groups": (i32, [i32, i32, i32]),
     "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 10 + [i32, i32, i32, i32, vp]),
-    "namp_train_edge_update_bwd_dw": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 9 + [i32, i32, i32, i32, vp]),
+    "namp_train_edge_update_bwd_dw": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 8 + [i32, i32, i32, i32, vp]),
     "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 22 + [i32, i32, i32, i32, vp]),
     "namp_train_edge_bwd_dw_groups": (i32, [i32, i32, i32]),
     "namp_train_edge_bwd_dw_rows": (C.c_long, [i32, i32, i32]),

@@ -38,10 +38,9 @@ PREC_CODE = {"fp32": 0, "x3": 1, "bf16": 2}
 # NAMP_TRAIN_DW=0 restores the row tensors + row-contraction launches of rounds 1-3 (A/B runs, tests of both forms).
 import os as _os
 DW_ONCHIP = _os.environ.get("NAMP_TRAIN_DW", "1") != "0"
-# The edge update's backward in the same form (mixed precision; edge_update_bwd_dw16_kernel).  OFF by default: correct (tests/test_gpu_train.py)
-# but slower — the six-product chain plus two accumulator blocks needs ~520 vector registers per lane, the launch spills 160 and takes 2.7 ms
-# against 1.56 + 0.3 ms for the round-3 launch and the two row contractions it would replace (cfg5 29.3 vs 26.4 ms; profiles/r04g 5).
-DW_ONCHIP_EDGE = _os.environ.get("NAMP_TRAIN_DW_EDGE", "0") == "1"
+# The edge update's backward in the same form (mixed precision): two persistent launches cut at g2 = dL/dz2, all three weight gradients and the
+# LayerNorm sums on chip (csrc/namp_train_eu.h; round 5).  NAMP_TRAIN_DW_EDGE=0 restores the round-3 launch + its three row contractions.
+DW_ONCHIP_EDGE = _os.environ.get("NAMP_TRAIN_DW_EDGE", "1") != "0"
 
 
 # Fragment images made during ONE training step (forward_train and the backward pass that follows it), keyed by (storage
@@ -379,8 +378,8 @@ class _EdgeUpdate(torch.autograd.Function):
 
 
 def _edge_update_backward_dw(ctx, g, imgs):
-    """Mixed precision: ONE persistent launch that also contracts (G2, A1) and (G1, h_E) on chip (csrc/namp_train_dw.h,
-    edge_update_bwd_dw16_kernel); the middle layer's gradient stays a row contraction over the bf16 rows (G3, A2)."""
+    """Mixed precision: two persistent launches (csrc/namp_train_eu.h) that contract dW3 / db3 (launch A, with the LayerNorm and dropout backward) and
+    dW2 / db2, dW1b (launch B) over the edges on chip; between them only the bf16 rows G2 = dL/dz2 and the fp32 rows dL/dx (parked in g_hE)."""
     h_E, Pa, Pc, W1b, W2, b2, W3, b3, ln_w, E_idx32 = ctx.saved_tensors
     img1, img2, img3, img3t, img2t, img1t = imgs
     B, N, K = E_idx32.shape
@@ -388,29 +387,30 @@ def _edge_update_backward_dw(ctx, g, imgs):
     dev = h_E.device
     L = hip.lib()
     Ep = L.namp_train_edge_bwd_dw_rows(B, N, K)
-    A2, G3, G1 = (torch.empty(Ep, H, device=dev, dtype=torch.bfloat16)[:E] for _ in range(3))
+    G2, G1 = (torch.empty(Ep, H, device=dev, dtype=torch.bfloat16) for _ in range(2))
     g_hE = torch.empty(Ep, H, device=dev)[:E]
     gpa_tiles = K % 16 == 0
     g_Pa = torch.empty(Ep // 16, H, device=dev)[:E // 16] if gpa_tiles else torch.zeros(B * N, H, device=dev)
     n = L.namp_train_edge_bwd_dw_groups(B, N, K)
-    dWp = torch.empty(n, 2, H, H, device=dev)
-    dbp = torch.empty(n, H, device=dev)
+    dWp = torch.empty(3 * n, H, H, device=dev)               # [n] dW3 partials, then [n][2] (dW2, dW1b)
+    dbp = torch.empty(2 * n, H, device=dev)                  # [n] db3, then [n] db2
     part = torch.empty(n, 2, H, device=dev)
     b2c, b3c, lw = b2.detach().contiguous(), b3.detach().contiguous(), ln_w.detach().contiguous()
     hip.check(L.namp_train_edge_update_bwd_dw(h_E.data_ptr(), E_idx32.data_ptr(), Pa.data_ptr(), Pc.data_ptr(), img1.data_ptr(),
                                               img2.data_ptr(), img3.data_ptr(), img3t.data_ptr(), img2t.data_ptr(), img1t.data_ptr(),
                                               b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed, g.data_ptr(),
-                                              A2.data_ptr(), G3.data_ptr(), G1.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(),
+                                              G2.data_ptr(), G1.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(),
                                               dWp.data_ptr(), dbp.data_ptr(), part.data_ptr(), 2 | (8 if gpa_tiles else 0),
                                               B, N, K, hip.current_stream()), "train_edge_update_bwd_dw")
     if gpa_tiles:
         g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
     rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
-    g_Pc, _ = rev.scatter(G1)
-    ((dW3, db3),) = _wgrad_many([(G3, A2, True)], x3=ctx.x3)
-    dW = dWp.sum(0)
+    g_Pc, _ = rev.scatter(G1[:E])
+    dW3 = dWp[:n].sum(0)
+    dW21 = dWp[n:].view(n, 2, H, H).sum(0)
+    db = dbp.view(2, n, H).sum(1)
     dgb = part.sum(0)
-    return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW[1], dW[0], dbp.sum(0), dW3, db3, dgb[0], dgb[1],
+    return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW21[1], dW21[0], db[1], dW3, db[0], dgb[0], dgb[1],
             None, None, None, None)
 
 

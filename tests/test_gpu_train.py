@@ -129,10 +129,10 @@ def test_edge_mlp_backward_on_chip_weight_gradients(mode, B, N, K, prec, monkeyp
 
 @pytest.mark.parametrize("B,N,K,p", [(2, 700, 48, 0.1), (1, 333, 30, 0.0), (1, 40, 16, 0.25)])
 def test_edge_update_backward_on_chip_weight_gradients(B, N, K, p, monkeypatch):
-    """Mixed precision: the edge update's backward that contracts (G2, A1) and (G1, h_E) on chip (edge_update_bwd_dw16_kernel) against the
+    """Mixed precision: the edge update's two-launch backward that owns all three weight gradients (csrc/namp_train_eu.h) against the
     round-3 form on the same inputs — several rounds per workgroup, a ragged last round, K % 16 != 0 (atomic dL/dPa path), dropout on and
     off.  Both forms round the same operands to bf16; summation orders (and the GELU polynomial) differ: every gradient within 1.5 %
-    of the other form, relative to its largest entry."""
+    of the other form, relative to its largest entry.  (Against fp64 autograd directly: test_on_chip_backward_matches_fp64_autograd.)"""
     g = torch.Generator(device="cpu").manual_seed(23 + K)
     rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
     h_E, Pa, Pc = rn(B, N, K, 128), rn(B, N, 128), rn(B, N, 128)
@@ -162,6 +162,101 @@ def test_edge_update_backward_on_chip_weight_gradients(B, N, K, p, monkeypatch):
         worst[name] = rel(b, a)
         assert worst[name] < 1.5e-2, (name, worst[name])
     print(f"edge update, on-chip dW vs row tensors ({B}x{N}x{K}, p={p}):", {k_: f"{v:.1e}" for k_, v in worst.items()})
+
+
+def _mix32(x):
+    """mix32 of csrc/namp_device.h on int64 tensors holding uint32 values."""
+    M = 0xFFFFFFFF
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M
+    x = x ^ (x >> 15); x = (x * 0x846ca68b) & M
+    return x ^ (x >> 16)
+
+
+def hash_dropout_factor(seed, E, p, dev):
+    """The training path's counter-based dropout mask (drop_row_key / drop_factor, csrc/namp_device.h) restated in torch: [E,128] of
+    0 or 1 / (1 - p).  Edge rows < 2^32, so the key's high-word term is mix32(0x9E3779B9)."""
+    M = 0xFFFFFFFF
+    e = torch.arange(E, device=dev, dtype=torch.int64)
+    hi = _mix32(torch.full((1,), 0x9E3779B9, device=dev, dtype=torch.int64))
+    key = _mix32((int(seed) & M) ^ e ^ hi)
+    ch = torch.arange(128, device=dev, dtype=torch.int64)
+    h = _mix32((key[:, None] + ch[None, :] * 0x9E3779B9) & M)
+    thresh = int(float(p) * 4294967296.0)
+    return (h >= thresh).double() / (1.0 - p)
+
+
+@pytest.mark.parametrize("kind,prec", [("enc_msg", 1), ("enc_msg", 2), ("dec_msg", 1), ("dec_msg", 2), ("edge", 2)])
+def test_on_chip_backward_matches_fp64_autograd(kind, prec, monkeypatch):
+    """The weight-gradient-owning backward launches (message stages: csrc/namp_train_dw.h; edge update: csrc/namp_train_eu.h) against fp64
+    torch autograd of the dense formulas DIRECTLY, at a size where every persistent workgroup walks several rounds and the cross-round
+    accumulators matter (2 x 700 x 48 = 67,200 edge rows = 1,050 rounds of 64 over <= 256 workgroups; VERDICT r4 parity hole 1).  The edge
+    update runs with dropout 0.1, its hash mask restated in torch.  Split-bf16 products: 5e-5 of the largest entry; bf16 products (operands
+    rounded to bf16, degree-4 GELU): 3 %."""
+    B, N, K, p, seed = 2, 700, 48, 0.1, 4321
+    g = torch.Generator(device="cpu").manual_seed(99 + prec)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    h_E, Pa, Pj0, Pj1 = rn(B, N, K, 128), rn(B, N, 128), rn(B, N, 128), rn(B, N, 128)
+    W1b, W2, W3 = rn(128, 128, sc=0.08), rn(128, 128, sc=0.1), rn(128, 128, sc=0.1)
+    b2, b3, lw, lb = rn(128, sc=0.1), rn(128, sc=0.1), 1 + rn(128, sc=0.1), rn(128, sc=0.1)
+    E_idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(DEV)
+    E32 = E_idx.to(torch.int32).contiguous()
+    mask = (torch.rand(B, N, generator=g) > 0.15).to(DEV)
+    rank = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(DEV)
+    bidx = torch.arange(B, device=DEV)[:, None, None]
+    monkeypatch.setattr(train, "X3", prec)
+    monkeypatch.setattr(train, "DW_ONCHIP", True)
+    monkeypatch.setattr(train, "DW_ONCHIP_EDGE", True)
+    if kind == "edge":
+        R = rn(B, N, K, 128)
+        leaves = [h_E, Pa, Pj0, W1b, W2, b2, W3, b3, lw, lb]
+        names = ["h_E", "Pa", "Pc", "W1b", "W2", "b2", "W3", "b3", "ln_w", "ln_b"]
+        with torch.enable_grad():
+            ins = [t.clone().requires_grad_(True) for t in leaves]
+            out = train._EdgeUpdate.apply(*ins, E32, p, seed)
+            (out * R).sum().backward()
+            ref_in = [t.double().requires_grad_(True) for t in leaves]
+            hE, pa, pc, w1, w2, bb2, w3, bb3, w_, b_ = ref_in
+            z1 = hE @ w1.t() + pa[:, :, None] + pc[bidx, E_idx]
+            z3 = F.gelu(F.gelu(z1) @ w2.t() + bb2) @ w3.t() + bb3
+            drop = hash_dropout_factor(seed, B * N * K, p, DEV).view(B, N, K, 128)
+            ref = F.layer_norm(hE + z3 * drop, (128,), w_, b_, 1e-5)
+            (ref * R.double()).sum().backward()
+    else:
+        mode = 0 if kind == "enc_msg" else 1
+        R, R2 = rn(B, N, 128), rn(B, N, K, 128)
+        leaves = [h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, b3]
+        names = ["h_E", "Pa", "Pj0", "Pj1", "W1b", "W2", "b2", "W3", "b3"]
+        with torch.enable_grad():
+            ins = [t.clone().requires_grad_(True) for t in leaves]
+            hE, pa, pj0, pj1, w1, w2, bb2, w3, bb3 = ins
+            out, h_pass = train._EdgeMLP.apply(mode, hE, pa, pj0, pj1 if mode == 1 else None, w1, w2, bb2, w3, bb3, E32,
+                                               mask.to(torch.int32).contiguous() if mode == 0 else None, None,
+                                               rank.to(torch.int32).contiguous() if mode == 1 else None)
+            ((out * R).sum() + (h_pass * R2).sum()).backward()
+            ref_in = [t.double().requires_grad_(True) for t in leaves]
+            hE, pa, pj0, pj1, w1, w2, bb2, w3, bb3 = ref_in
+            if mode == 1:
+                bw = (rank[bidx, E_idx] < rank[:, :, None]).unsqueeze(-1)
+                pj = torch.where(bw, pj0[bidx, E_idx], pj1[bidx, E_idx])
+                wgt = torch.ones(B, N, K, device=DEV, dtype=torch.float64)
+            else:
+                pj = pj0[bidx, E_idx]
+                wgt = (mask[:, :, None] & mask[bidx, E_idx]).double()
+            z3 = F.gelu(F.gelu(hE @ w1.t() + pa[:, :, None] + pj) @ w2.t() + bb2) @ w3.t() + bb3
+            ref = (wgt.unsqueeze(-1) * z3).sum(2) / 30.0
+            ((ref * R.double()).sum() + (hE * R2.double()).sum()).backward()
+    torch.cuda.synchronize()
+    bar = 5e-5 if prec == 1 else 3e-2
+    assert rel(out, ref) < (2e-5 if prec == 1 else 2e-2)
+    worst = {}
+    for name, a, b in zip(names, ins, ref_in):
+        if name == "Pj1" and kind != "dec_msg":
+            continue
+        assert a.grad is not None and torch.isfinite(a.grad).all(), name
+        worst[name] = rel(a.grad, b.grad)
+    print(f"on-chip backward vs fp64 autograd ({kind}, prec {prec}):", {k_: f"{v:.1e}" for k_, v in worst.items()})
+    for name, v in worst.items():
+        assert v < bar, (name, v, worst)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.25])
@@ -462,7 +557,9 @@ def test_checkpoint_round_trip(tmp_path, weights_np):
 
 def test_cfg5_sized_training_step(weights_np):
     """BASELINE configs[4] at its real size (B=16 x N=1500, K=48: 1.15 M edges, ~11 GiB of transients): one optimisation
-    step in the split-bf16 and in the exact-fp32 evaluation — finite loss and gradients, and the two losses agree to 1e-4."""
+    step in the split-bf16 and in the exact-fp32 evaluation — finite loss and gradients, and the two losses agree to 1e-4 —, and in the
+    mixed-precision (bf16) mode the reference trains in (na_run.py:216-238): its loss within 0.5 % of the fp32 step's and the whole gradient
+    vector within 2 % of the fp32 step's in direction (cosine > 0.999)."""
     B, N, K = 16, 1500, 48
     rti = spec.restype_to_int()
     cxs = [synth.make_complex(seed=5000 + b, n=N, n_chains=4) for b in range(B)]
@@ -471,8 +568,8 @@ def test_cfg5_sized_training_step(weights_np):
     randn = torch.randn(B, N, generator=torch.Generator().manual_seed(5)).to(DEV)
     rm, rn = train.polymer_restype_tables(rti, 33, DEV)
     no_loss = torch.tensor([rti[t] for t in cpu_ref.NO_LOSS_TOKENS], device=DEV)
-    losses = {}
-    for prec in ("x3", "fp32"):
+    losses, gvec = {}, {}
+    for prec in ("x3", "fp32", "bf16"):
         m = make_model(weights_np, K).train()
         m.message_precision = prec
         opt = train.get_std_opt(m.parameters(), 128, 0)
@@ -482,9 +579,14 @@ def test_cfg5_sized_training_step(weights_np):
         for name, p in m.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
         losses[prec] = float(loss)
+        gvec[prec] = torch.cat([p.grad.detach().double().flatten() for _, p in sorted(m.named_parameters())]).cpu()
         del m, opt
         torch.cuda.empty_cache()
     assert abs(losses["x3"] - losses["fp32"]) <= 1e-4 * abs(losses["fp32"]), losses
+    assert abs(losses["bf16"] - losses["fp32"]) <= 5e-3 * abs(losses["fp32"]), losses
+    cos = float((gvec["bf16"] @ gvec["fp32"]) / (gvec["bf16"].norm() * gvec["fp32"].norm()))
+    print(f"cfg5-sized step: losses {losses}, cos(grad bf16, grad fp32) = {cos:.6f}")
+    assert cos > 0.999, cos
 
 
 def test_mixed_precision_training_mode(weights_np):
