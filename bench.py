@@ -464,7 +464,7 @@ def train_bench(args, dev, rank, world, dist):
             t_us = getattr(ev, "self_cuda_time_total", 0.0)
         if t_us > 0:
             kern[ev.key] = (t_us / 1e3, ev.count)
-    ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "edge_bwd_dw", "adam_", "loss_smoothed", "wgrad_kernel", "feat_wgrad", "edge_features",
+    ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "edge_bwd_dw", "edge_update_bwd_", "reduce_sum_kernel", "pack_multi", "table_rows", "adam_", "loss_smoothed", "wgrad_kernel", "feat_wgrad", "edge_features",
                                                                   "edge_mlp_kernel", "edge_mlp_x3_persistent", "edge_mlp_bf16", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
                                                                   "prep_atoms", "wgrad_x3", "wgrad_bf16", "tail_train", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
     total_dev_ms = sum(v[0] for v in kern.values())
@@ -472,11 +472,17 @@ def train_bench(args, dev, rank, world, dist):
     #   edge_bwd_dw*           message stage owning its weight gradients: 2 recompute + 2 data-gradient + 2 weight-gradient  (6, 4)
     #   edge_chain_bwd<0|1>    message stage of rounds 1-3 (weight gradients in separate launches)                            (4, 2)
     #   edge_chain_bwd<2|3>    three-layer stage / EncLayer edge update: 3 recompute + 3 data-gradient                        (6, 3)
+    #   edge_update_bwd_a16    edge update, launch A: 3 recompute + W13^T + the dW13 contraction                                   (5, 2)
+    #   edge_update_bwd_b16    edge update, launch B: 1 recompute + W12^T, W11b^T + the dW12, dW11b contractions                   (5, 4)
     def gemms_of(name):
+        if "edge_update_bwd_a16" in name:
+            return 5, 2
+        if "edge_update_bwd_b16" in name:
+            return 5, 4
         if "edge_bwd_dw" in name:
             return 6, 4
         return (4, 2) if ("edge_chain_bwd_kernel<0" in name or "edge_chain_bwd_kernel<1" in name) else (6, 3)
-    bwd = [(k, v) for k, v in ours.items() if "edge_chain_bwd" in k or "edge_bwd_dw" in k]
+    bwd = [(k, v) for k, v in ours.items() if "edge_chain_bwd" in k or "edge_bwd_dw" in k or "edge_update_bwd_" in k]
     bwd_ms = sum(v[0] for _, v in bwd); bwd_n = sum(v[1] for _, v in bwd)
     avg_s = bwd_ms / max(bwd_n, 1) * 1e-3
     edges = B * N * K

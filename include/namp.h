@@ -71,6 +71,13 @@ int namp_pack_image_x3(const float* W, int ld, int col0, void* img, void* stream
 /* x3 image of a general block [out_f x in_f] (out_f % 16 == 0, in_f % 32 == 0): the residue-level FFN weights
  * (PositionWiseFeedForward W_in [512 x 128], W_out [128 x 512], model_utils.py:595-604); out_f*in_f floats of output. */
 int namp_pack_image_x3_general(const float* W, int ld, int col0, int out_f, int in_f, void* img, void* stream);
+/* Many weight images in ONE launch (round 5; the training step packs ~116 per step).  `table_dev` is a DEVICE array of ndesc descriptors sorted by
+ * first_block: kind 1 = x3 image of a [128 x 128] block (namp_pack_image_x3), 2 = bf16 image of a [128 x 128] block (namp_pack_image_bf16), 3 = x3
+ * image of a general [out_f x in_f] block (namp_pack_image_x3_general); transposed != 0 packs the image of the block's TRANSPOSE from the same
+ * storage (element (n, k) = W[k * ld + n]; out_f / in_f then describe the transposed block).  Descriptor i owns workgroups [first_block_i,
+ * first_block_i + ceil(out_f * in_f / 256)); nblocks = their total. */
+typedef struct NampPack { const float* W; void* img; int ld, out_f, in_f, kind, transposed, first_block; } NampPack;
+int namp_pack_images(const NampPack* table_dev, int ndesc, int nblocks, void* stream);
 /* The featuriser's edge_embedding.weight [128 x 5200] (model_utils.py:484) for the split-bf16 form of its GEMM: positional
  * k-tile as an fp32 fragment tile, then one 48 KiB hi|mid block per group of 6 atom pairs; 128*5200 floats in all, the
  * size of namp_pack_image's output for the same matrix. */
@@ -479,6 +486,12 @@ int namp_train_adam_chunk(void);
 int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, const long long* numel, const unsigned long long* ptrs,
                          int ntensors, int nblocks, float max_norm, double beta1, double beta2, float step_size, float bias_correction2_sqrt,
                          float eps, float* ws, void* stream);
+
+/* Sums over partials, up to 16 segments in ONE launch (round 5): dst[a * Mb + b] = sum_{i < n} src[a * sa + i * sn + b] for a < A, b < Mb (element
+ * strides; fp32).  Covers the reductions behind the training launches — [n][M] partials of weight gradients (A = 1, sa = 0, sn = M), per-tile rows
+ * [G][T][128] -> [G][128] (A = G, sa = T * 128, sn = 128) — which were ~100 stock reduction launches per cfg5 step.  Deterministic (fixed order). */
+typedef struct NampReduce { const float* src; float* dst; long long A, Mb, sa, sn; int n; int reserved; } NampReduce;
+int namp_reduce_sum(const NampReduce* seg, int nseg, void* stream);
 
 /* Level-parallel form of the sampler.  The step for residue i depends only on the neighbours visited before it, so visits can be
  * grouped into dependency levels and every level decoded in one launch over all streams: ~64 launches instead of 1000 sequential

@@ -509,6 +509,15 @@ int namp_pack_image_x3_general(const float* W, int ld, int col0, int out_f, int 
   return NAMP_OK;
 }
 
+int namp_pack_images(const NampPack* table_dev, int ndesc, int nblocks, void* stream) {
+  REQUIRE_PTR(table_dev);
+  REQUIRE(ndesc >= 1 && nblocks >= 1, "namp_pack_images: ndesc=%d nblocks=%d", ndesc, nblocks);
+  static_assert(sizeof(NampPack) == sizeof(PackDesc), "NampPack (include/namp.h) and PackDesc (namp_kernels.h) must have one layout");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table_dev, ndesc);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_pack_feat_x3(const float* W, int ld, float* img, void* stream) {
   REQUIRE_PTR(W); REQUIRE_PTR(img);
   REQUIRE(ld >= 5200, "namp_pack_feat_x3: edge_embedding.weight rows hold 5200 columns, ld=%d", ld);

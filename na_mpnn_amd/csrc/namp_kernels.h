@@ -59,6 +59,31 @@ static __global__ void pack_image_x3_general_kernel(const float* __restrict__ W,
   img[(size_t)OUT * IN + e] = (__bf16)(v - (float)hi);
 }
 
+// All of a training step's weight images in ONE launch (round 5: 116 pack launches per cfg5 step before).  Descriptor table in device memory;
+// kind 1 = x3 image of a [128 x 128] block, 2 = bf16 image of a [128 x 128] block, 3 = x3 image of a general [OUT x IN] block; `transposed`
+// packs the image of the block's transpose straight from the untransposed storage (element (n, k) = W[k * ld + n]).
+struct PackDesc { const float* W; void* img; int ld, out_f, in_f, kind, transposed, first_block; };
+static __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ tab, int ndesc) {
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {                                              // last descriptor whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = tab[lo];
+  const int e = ((int)blockIdx.x - d.first_block) * 256 + threadIdx.x;
+  const int total = d.out_f * d.in_f;
+  if (e >= total) return;
+  const int ntn = d.out_f >> 4;
+  const int j = e & 7, lane = (e >> 3) & 63, t = e >> 9;
+  const int tn = t % ntn, s = t / ntn;
+  const int n = 16 * tn + (lane & 15), k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+  const float v = d.transposed ? d.W[(size_t)k * d.ld + n] : d.W[(size_t)n * d.ld + k];
+  __bf16* img = (__bf16*)d.img;
+  const __bf16 hi16 = (__bf16)v;
+  img[e] = hi16;
+  if (d.kind != 2) img[(size_t)total + e] = (__bf16)(v - (float)hi16);
+}
+
 // Split-bf16 image of edge_embedding.weight [128 x 5200] for edge_features_kernel<true>: the positional k-tile stays an
 // fp32 fragment tile (2048 floats), then one 48 KiB block per RBF chunk c = 3a + bg (6 atom pairs = 3 bf16 K-steps of two
 // pairs): [hi: 3 steps x 8 tn x 64 lanes x 8 bf16][mid: same].  Slot j of lane (m, g) in step s is RBF 4g + (j&3) of pair

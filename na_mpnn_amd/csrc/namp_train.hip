@@ -347,6 +347,30 @@ int namp_train_ln_rows_bwd(const float* x, const float* g, const float* gamma, f
   return NAMP_OK;
 }
 
+int namp_reduce_sum(const NampReduce* seg, int nseg, void* stream) {
+  REQUIRE(seg != nullptr, "namp_reduce_sum: null segment table");
+  REQUIRE(nseg >= 1 && nseg <= NAMP_REDUCE_MAX, "namp_reduce_sum: nseg=%d must be in [1,%d]", nseg, NAMP_REDUCE_MAX);
+  ReduceArgs ra = {};
+  ra.nseg = nseg;
+  long blocks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const NampReduce& d = seg[s];
+    REQUIRE(d.src != nullptr && d.dst != nullptr, "namp_reduce_sum: segment %d: null src / dst", s);
+    REQUIRE(d.A >= 1 && d.Mb >= 1 && d.n >= 1 && d.sa >= 0 && d.sn >= 1, "namp_reduce_sum: segment %d: A=%ld Mb=%ld n=%d sa=%ld sn=%ld", s,
+            (long)d.A, (long)d.Mb, d.n, (long)d.sa, (long)d.sn);
+    ReduceSeg& g = ra.seg[s];
+    g.src = d.src; g.dst = d.dst; g.A = d.A; g.Mb = d.Mb; g.sa = d.sa; g.sn = d.sn; g.n = d.n;
+    g.vec = (d.Mb % 4 == 0 && d.sa % 4 == 0 && d.sn % 4 == 0 && aligned16(d.src) && aligned16(d.dst)) ? 1 : 0;
+    ra.first_block[s] = (int)blocks;
+    blocks += (d.A * d.Mb + 255) / 256;
+    REQUIRE(blocks < (1L << 30), "namp_reduce_sum: too many outputs");
+  }
+  ra.first_block[nseg] = (int)blocks;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ra);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
   long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 2 workgroups per CU (the split-bf16

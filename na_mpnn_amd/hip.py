@@ -61,6 +61,16 @@ class NampProj(C.Structure):
     _fields_ = [("img", c_fp), ("bias", c_fp), ("tok", c_fp), ("out", c_fp)]
 
 
+class NampPack(C.Structure):
+    _fields_ = [("W", c_fp), ("img", c_fp), ("ld", C.c_int), ("out_f", C.c_int), ("in_f", C.c_int), ("kind", C.c_int),
+                ("transposed", C.c_int), ("first_block", C.c_int)]
+
+
+class NampReduce(C.Structure):
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("A", C.c_longlong), ("Mb", C.c_longlong), ("sa", C.c_longlong), ("sn", C.c_longlong),
+                ("n", C.c_int), ("reserved", C.c_int)]
+
+
 i32, vp, sz = C.c_int, C.c_void_p, C.c_size_t
 _PROTOTYPES = {
     # name: (restype, argtypes)      — must list every symbol include/namp.h declares
@@ -116,6 +126,8 @@ _PROTOTYPES = {
     "namp_train_tail_groups": (i32, [i32]),
     "namp_train_tail_fwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 8 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 4 + [i32, vp]),
     "namp_train_tail_bwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 4 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 10 + [i32, vp]),
+    "namp_reduce_sum": (i32, [C.POINTER(NampReduce), i32, vp]),
+    "namp_pack_images": (i32, [c_fp, i32, i32, vp]),
     "namp_train_ln_rows_groups": (i32, [C.c_long]),
     "namp_train_ln_rows_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),
     "namp_train_ln_rows_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),

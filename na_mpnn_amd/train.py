@@ -52,18 +52,92 @@ _STEP = None                      # token of the step being recorded by forward_
 _CACHE_STEP = None                # token the cache's entries belong to
 
 
+class _PackPlan:
+    """All fragment images of a training step from ONE launch (namp_pack_images).  Learned, not declared: `_image` / `_ximage_general` register
+    every (storage, strides, kind, transposed) they are asked for; from the next step on forward_train packs all registered blocks into one
+    arena with a single launch and the same calls return arena slices.  Blocks nobody asked for during a whole step are forgotten (a replaced
+    parameter set); registered blocks are kept alive by the plan, so a stale address is never read."""
+
+    KIND_BYTES = {1: lambda o, i: 4 * o * i, 2: lambda o, i: 2 * o * i, 3: lambda o, i: 4 * o * i}
+
+    def __init__(self):
+        self.entries = {}            # key -> dict(src, kind, transposed, out_f, in_f, used, img)
+        self.dirty = True
+        self.arena = self.table = None
+        self.nblocks = 0
+        self.valid_step = None
+
+    @staticmethod
+    def key(block, kind, transposed):
+        return (block.data_ptr(), tuple(block.shape), block.stride(0), block.stride(1), kind, bool(transposed), block.device.index)
+
+    def register(self, block, kind, transposed):
+        o, i = (block.shape[1], block.shape[0]) if transposed else (block.shape[0], block.shape[1])
+        self.entries[self.key(block, kind, transposed)] = dict(src=block, kind=kind, transposed=bool(transposed), out_f=o, in_f=i, used=True, img=None)
+        self.dirty = True
+
+    def lookup(self, block, kind, transposed, step):
+        if self.valid_step is not step:
+            return None
+        e = self.entries.get(self.key(block, kind, transposed))
+        if e is None or e["img"] is None:
+            return None
+        e["used"] = True
+        return e["img"]
+
+    def begin_step(self, step, dev):
+        stale = [k for k, e in self.entries.items() if not e["used"] or k[-1] != dev.index]
+        for k in stale:
+            del self.entries[k]
+        self.dirty = self.dirty or bool(stale)
+        self.valid_step = None
+        if not self.entries:
+            return
+        if self.dirty:
+            off, blocks, rows = 0, 0, []
+            for e in self.entries.values():
+                nbytes = self.KIND_BYTES[e["kind"]](e["out_f"], e["in_f"])
+                e["off"], e["nbytes"], e["first"] = off, nbytes, blocks
+                off += (nbytes + 255) // 256 * 256
+                blocks += (e["out_f"] * e["in_f"] + 255) // 256
+            self.arena = torch.empty(off // 4, dtype=torch.float32, device=dev)
+            base = self.arena.data_ptr()
+            tab = (hip.NampPack * len(self.entries))()
+            for q, e in enumerate(self.entries.values()):
+                src = e["src"]
+                assert src.stride(1) == 1 and src.dtype == torch.float32
+                tab[q] = hip.NampPack(src.data_ptr(), base + e["off"], src.stride(0), e["out_f"], e["in_f"], e["kind"], int(e["transposed"]), e["first"])
+                e["img"] = self.arena[e["off"] // 4:(e["off"] + e["nbytes"]) // 4]
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+            self.table = raw.to(dev)
+            self.nblocks, self.dirty = blocks, False
+        for e in self.entries.values():
+            e["used"] = False
+        hip.check(hip.lib().namp_pack_images(self.table.data_ptr(), len(self.entries), self.nblocks, hip.current_stream()), "pack_images")
+        self.valid_step = step
+
+
+_PLAN = _PackPlan()
+
+
 def _image(block, x3=None, transposed=False, step=None):
     """Fragment image (fp32, or x3 / bf16) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
     weight (or of its transpose).  x3 None: the module-level setting (forward passes); backward passes hand in the value
-    their forward saved."""
+    their forward saved.  Inside a training step (split-bf16 / bf16) the image comes out of the step's one packing launch (_PackPlan)."""
     prec = int(X3 if x3 is None else x3)
     step = _STEP if step is None else step
     use_cache = step is not None and step is _CACHE_STEP
+    if use_cache and prec in (1, 2):
+        hit = _PLAN.lookup(block, prec, transposed, step)
+        if hit is not None:
+            return hit
     key = (block.data_ptr(), block.stride(0), block.stride(1), block._version, prec, transposed, block.device.index)
     if use_cache:
         hit = _IMG_CACHE.get(key)
         if hit is not None:
             return hit
+        if prec in (1, 2) and block.stride(1) == 1 and block.dtype == torch.float32 and tuple(block.shape) == (H, H):
+            _PLAN.register(block.detach(), prec, transposed)
     if transposed:
         block = block.detach().t().contiguous()
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
@@ -93,6 +167,32 @@ def _image_t(block, x3=None, step=None):
     return _image(block.detach(), x3, transposed=True, step=step)
 
 
+def _reduce(*segs):
+    """Sums over partials in ONE HIP launch (namp_reduce_sum): segs = (src, A, Mb, sa, sn, n) with element strides into the contiguous fp32
+    tensor `src`  ->  list of [A, Mb] tensors, out[a, b] = sum_{i < n} src[a * sa + i * sn + b].  Up to 16 segments per launch."""
+    outs = [torch.empty(A, Mb, device=src.device) for src, A, Mb, sa, sn, n in segs]
+    for q0 in range(0, len(segs), 16):
+        grp = segs[q0:q0 + 16]
+        arr = (hip.NampReduce * len(grp))(*[hip.NampReduce(src.data_ptr(), outs[q0 + i].data_ptr(), A, Mb, sa, sn, n, 0)
+                                            for i, (src, A, Mb, sa, sn, n) in enumerate(grp)])
+        hip.check(hip.lib().namp_reduce_sum(arr, len(grp), hip.current_stream()), "reduce_sum")
+    return outs
+
+
+def _seg0(t):
+    """segment: sum of the contiguous tensor t over its leading dimension -> [1, t[0].numel()]"""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    M = t[0].numel()
+    return (t, 1, M, 0, M, t.shape[0])
+
+
+def _seg1(t):
+    """segment: sum of the contiguous tensor t [A, n, ...] over dimension 1 -> [A, prod(...)]"""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    M = t[0, 0].numel()
+    return (t, t.shape[0], M, t.shape[1] * M, M, t.shape[1])
+
+
 def _wgrad(G, A, gelu_A, want_bias, x3=None):
     """sum over rows of G^T act(A) (and of G): [128,128] (, [128])."""
     L = hip.lib()
@@ -102,7 +202,10 @@ def _wgrad(G, A, gelu_A, want_bias, x3=None):
     db = torch.empty(n, H, device=G.device) if want_bias else None
     hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), int(gelu_A), (0 if gelu_A else int(X3 if x3 is None else x3)), rows, dW.data_ptr(), hip.ptr(db),
                                  hip.current_stream()), "train_wgrad")
-    return dW.sum(0), (db.sum(0) if want_bias else None)
+    if want_bias:
+        dW_, db_ = _reduce(_seg0(dW), _seg0(db))
+        return dW_.view(H, H), db_.view(H)
+    return _reduce(_seg0(dW))[0].view(H, H), None
 
 
 def _wgrad_many(pairs, x3=None):
@@ -138,8 +241,11 @@ def _wgrad_many(pairs, x3=None):
             A = A.float()
         hip.check(L.namp_train_wgrad(G.data_ptr(), A.data_ptr(), 0, code, rows, tmp[q].data_ptr(), tmpb[q].data_ptr() if wb else None,
                                      hip.current_stream()), "train_wgrad")
-    dW = tmp.sum(1)
-    db = tmpb.sum(1) if any(wb for _, _, wb in pairs) else None
+    if any(wb for _, _, wb in pairs):
+        dW, db = _reduce(_seg1(tmp.view(k, n, H * H)), _seg1(tmpb))
+    else:
+        dW, db = _reduce(_seg1(tmp.view(k, n, H * H)))[0], None
+    dW = dW.view(k, H, H)
     return [(dW[q], (db[q] if wb else None)) for q, (_, _, wb) in enumerate(pairs)]
 
 
@@ -196,10 +302,12 @@ class _EdgeMLP(torch.autograd.Function):
         if mode == ENC_EDGE:
             ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32)
             return out
-        msum = out[:G * tpn * H].view(G, tpn, H).sum(1)
-        wsum = out[G * tpn * H:G * tpn * (H + 1)].view(G, tpn).sum(1, keepdim=True)
+        # (the launch's per-tile K-sums and weight sums -> per residue: one reduction launch)
+        msum, wsum = _reduce((out, G, H, tpn * H, H, tpn), (out[G * tpn * H:], G, 1, tpn, 1, tpn))
         ctx.save_for_backward(h_E, Pa, Pj0, Pj1, W1b, W2, b2, W3, E_idx32, mask32, mask_attend32, rank32, msum, wsum)
-        dh = torch.addmm(wsum * b3.detach(), msum, W3.detach().t())
+        # layer 3 behind the K-sum, per residue: W3 . msum + b3 * wsum — node_linear_kernel (fp32-equivalent split-bf16 products in both the
+        # split-bf16 and the mixed-precision mode: this is residue-level math), not the stock GEMM
+        dh = torch.addcmul(_node_linear_call(msum, [W3.detach()], [None], x3=min(int(X3), 1))[0], wsum, b3.detach())
         return dh.view(B, N, H), h_E.view_as(h_E)
         # (second output: h_E itself, for the NEXT consumer of the same edge rows (EncLayer's edge update, the next DecLayer).
         # Its gradient then arrives HERE, and the backward launch writes (that gradient + its own dL/dh_E) in one pass — autograd
@@ -229,7 +337,7 @@ class _EdgeMLP(torch.autograd.Function):
             # for this [128 x 24,000] x [24,000 x 128] shape: 85 us against ~30)
             dW3 = _wgrad_many([(g2d.contiguous(), msum.contiguous(), False)], x3=ctx.x3)[0][0]
             db3 = (g2d * wsum).sum(0)
-            g = (g2d @ W3.detach()).contiguous()
+            g = _node_linear_call(g2d.contiguous(), [W3.detach()], [None], x3=min(int(ctx.x3), 1), transposed=True, step=ctx.step)[0]
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         if mode != ENC_EDGE and int(ctx.x3) in (1, 2) and DW_ONCHIP:
             return _EdgeMLP._backward_dw(ctx, g, g_pass, dW3, db3)
@@ -266,7 +374,7 @@ class _EdgeMLP(torch.autograd.Function):
         else:
             (dW2, db2), (dW1b, _) = _wgrad_many([(G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         if gpa_tiles:
-            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
+            g_Pa = _reduce((g_Pa, B * N, H, (K // 16) * H, H, K // 16))[0]
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
@@ -310,11 +418,13 @@ class _EdgeMLP(torch.autograd.Function):
             g_Pj0, g_Pj1 = rev.scatter(G1, sel)
         else:
             g_Pj0, g_Pj1 = rev.scatter(G1)
-        dW = dWp.sum(0)
-        dW2, dW1b = dW[0], dW[1]
-        db2 = dbp.sum(0)
+        # the workgroups' partials and the per-tile dL/dPa rows: one reduction launch
+        segs = [_seg0(dWp), _seg0(dbp)] + ([(g_Pa, B * N, H, (K // 16) * H, H, K // 16)] if gpa_tiles else [])
+        red = _reduce(*segs)
+        dW2, dW1b = red[0].view(2, H, H)
+        db2 = red[1].view(H)
         if gpa_tiles:
-            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
+            g_Pa = red[2]
         g_Pa, g_Pj0 = g_Pa.view_as(Pa), g_Pj0.view_as(Pj0)
         g_Pj1 = g_Pj1.view_as(Pj1) if g_Pj1 is not None else None
         return (None, g_hE.view_as(h_E), g_Pa, g_Pj0, g_Pj1, dW1b, dW2, db2, dW3, db3, None, None, None, None, None)
@@ -367,12 +477,13 @@ class _EdgeUpdate(torch.autograd.Function):
                                                g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
                                                G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
                                                int(ctx.x3) | (8 if gpa_tiles else 0), B, N, K, hip.current_stream()), "train_edge_update_bwd")
+        red = _reduce(*([_seg0(part)] + ([(g_Pa, B * N, H, (K // 16) * H, H, K // 16)] if gpa_tiles else [])))
+        dgb = red[0].view(2, H)
         if gpa_tiles:
-            g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
+            g_Pa = red[1]
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
         (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
-        dgb = part.sum(0)
         return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
                 None, None, None, None)
 
@@ -402,14 +513,15 @@ def _edge_update_backward_dw(ctx, g, imgs):
                                               G2.data_ptr(), G1.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(),
                                               dWp.data_ptr(), dbp.data_ptr(), part.data_ptr(), 2 | (8 if gpa_tiles else 0),
                                               B, N, K, hip.current_stream()), "train_edge_update_bwd_dw")
-    if gpa_tiles:
-        g_Pa = g_Pa.view(B * N, K // 16, H).sum(1)
     rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
     g_Pc, _ = rev.scatter(G1[:E])
-    dW3 = dWp[:n].sum(0)
-    dW21 = dWp[n:].view(n, 2, H, H).sum(0)
-    db = dbp.view(2, n, H).sum(1)
-    dgb = part.sum(0)
+    # the two launches' partials and the per-tile dL/dPa rows: one reduction launch
+    segs = [_seg0(dWp[:n]), _seg0(dWp[n:].view(n, 2 * H * H)), _seg1(dbp.view(2, n, H)), _seg0(part)] + \
+        ([(g_Pa, B * N, H, (K // 16) * H, H, K // 16)] if gpa_tiles else [])
+    red = _reduce(*segs)
+    dW3, dW21, db, dgb = red[0].view(H, H), red[1].view(2, H, H), red[2], red[3].view(2, H)
+    if gpa_tiles:
+        g_Pa = red[4]
     return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW21[1], dW21[0], db[1], dW3, db[0], dgb[0], dgb[1],
             None, None, None, None)
 
@@ -538,7 +650,7 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
                                           part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
         g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
-        return None, part.sum(0), g_Epos, None, None, None
+        return None, _reduce(_seg0(part))[0].view(part.shape[1:]), g_Epos, None, None, None
 
 
 def edge_embedding(model, fd):
@@ -648,7 +760,7 @@ class _RowLayerNorm(torch.autograd.Function):
         part = torch.empty(hip.lib().namp_train_ln_rows_groups(rows), 2, H, device=x.device)
         hip.check(hip.lib().namp_train_ln_rows_bwd(x.data_ptr(), g.data_ptr(), w.data_ptr(), gx.data_ptr(), part.data_ptr(), rows,
                                                    hip.current_stream()), "train_ln_rows_bwd")
-        s = part.sum(0)
+        s = _reduce(_seg0(part))[0].view(2, H)
         return gx, s[0], s[1]
 
 
@@ -656,9 +768,15 @@ def _ximage_general(W, transposed=False, step=None):
     """x3 image of a general [out_f x in_f] block (residue-level FFN weights; namp_pack_image_x3_general), cached per step."""
     step = _STEP if step is None else step
     use_cache = step is not None and step is _CACHE_STEP
+    if use_cache:
+        hit = _PLAN.lookup(W, 3, transposed, step)
+        if hit is not None:
+            return hit
     key = (W.data_ptr(), W.stride(0), W.stride(1), W._version, "xg", transposed, W.device.index)
     if use_cache and key in _IMG_CACHE:
         return _IMG_CACHE[key]
+    if use_cache and W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.float32:
+        _PLAN.register(W.detach(), 3, transposed)
     Wc = (W.detach().t() if transposed else W.detach()).contiguous().float()
     img = torch.empty(Wc.numel(), dtype=torch.float32, device=W.device)
     hip.check(hip.lib().namp_pack_image_x3_general(Wc.data_ptr(), Wc.shape[1], 0, Wc.shape[0], Wc.shape[1], img.data_ptr(),
@@ -717,7 +835,7 @@ class _NodeTail(torch.autograd.Function):
         db_out = res[0][1]
         dW_in = torch.cat([res[4 + q][0] for q in range(4)], 0)           # [512, 128]: row block q = g_z_q^T x1
         db_in = torch.cat([res[4 + q][1] for q in range(4)], 0)
-        dln = part.sum(0)
+        dln = _reduce(_seg0(part))[0].view(4, H)
         return (g_hV.view(ctx.shape), g_dh.view(ctx.shape), None, dln[2], dln[3], dW_in, db_in, dW_out, db_out, dln[0], dln[1],
                 None, None, None)
 
@@ -745,6 +863,8 @@ def forward_train(model, fd, decoding_randn=None):
     X3 = PREC_CODE[getattr(model, "message_precision", "x3")]
     _STEP = _CACHE_STEP = object()                           # a new step: its own (empty) image cache
     _IMG_CACHE.clear()
+    if X3 and fd["mask"].is_cuda and torch.is_grad_enabled():
+        _PLAN.begin_step(_STEP, fd["mask"].device)            # every image the previous step asked for, from one launch
     try:
         return _forward_train(model, fd, decoding_randn)
     finally:
@@ -762,7 +882,8 @@ def _forward_train(model, fd, decoding_randn):
     B, N, K = E_idx.shape
     E = _RowLayerNorm.apply(y, fp.norm_edges.weight, fp.norm_edges.bias)
     V = _ln(_TableRows.apply(fp.node_embedding.weight.t(), fd["R_polymer_type"].long()), fp.norm_nodes)   # one-hot @ W^T
-    h_V, h_E = model.W_v(V), _EdgeLinear.apply(E, model.W_e.weight, model.W_e.bias)
+    h_V = _lin(V, (model.W_v.weight, model.W_v.bias))[0]
+    h_E = _EdgeLinear.apply(E, model.W_e.weight, model.W_e.bias)
     mask32 = mask.to(torch.int32).contiguous()
     maskf = mask.float().unsqueeze(-1)
     rev = ReverseAdjacency(E_idx) if torch.is_grad_enabled() else None

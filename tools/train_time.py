@@ -64,6 +64,14 @@ def main():
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
             step(); torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=70))
+        # device kernels only, all of them: name, calls, total us
+        from torch.autograd import DeviceType
+        rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_type == DeviceType.CUDA]
+        rows.sort(key=lambda r: -r[2])
+        tot = sum(r[2] for r in rows)
+        print(f"== device kernels: {len(rows)} kinds, {sum(r[1] for r in rows)} launches, {tot / 1e3:.2f} ms")
+        for k, c, t in rows:
+            print(f"{t:10.1f} us {c:5d} x  {k[:150]}")
 
 
 if __name__ == "__main__":
