@@ -1063,7 +1063,8 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   // sized for NAMP_MAX_LAYERS decoder layers (the entry point has no layer count): Pfw[L] + Pa0 on the encoder side; Pa[L-1] + Pv[L-1] +
   // h[L] on the sample-stream side
   const size_t L = NAMP_MAX_LAYERS;
-  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
+  // + the first-layer tables Z1_l = W1e_l . h_E of every edge (round 5) and one zero row
+  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + L * tbl(Ge * (size_t)K) + 512 + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
 }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
@@ -1094,7 +1095,10 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   float *Pa[NAMP_MAX_LAYERS] = {}, *Pv[NAMP_MAX_LAYERS] = {}, *hs[NAMP_MAX_LAYERS] = {};
   for (int l = 0; l + 1 < nd; ++l) { Pa[l] = c.take((size_t)Gd * NAMP_HIDDEN); Pv[l] = c.take((size_t)Gd * NAMP_HIDDEN); }
   for (int l = 0; l < nd; ++l) hs[l] = c.take((size_t)Gd * NAMP_HIDDEN);
-  if (!hs[nd - 1]) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
+  float* Z1[NAMP_MAX_LAYERS] = {};
+  for (int l = 0; l < nd; ++l) Z1[l] = c.take((size_t)Ge * K * NAMP_HIDDEN);
+  float* zero_row = c.take(NAMP_HIDDEN);
+  if (!hs[nd - 1] || !zero_row) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
   // static tables from the encoder output: Pfw_l = W1v_l . h_V^enc, Pa_0 = W1a_0 . h_V^enc + b1
   NampProj pf[NAMP_MAX_LAYERS + 1];
   int nf = 0;
@@ -1102,6 +1106,19 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   pf[nf++] = {w->dec[0].W1a_img, w->dec[0].b1, nullptr, Pa0};
   for (int q0 = 0; q0 < nf; q0 += 8)                         // (a node_linear launch takes up to 8 blocks)
     if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf + q0, nf - q0 < 8 ? nf - q0 : 8, nullptr, stream))) return rc;
+
+  // the first-layer product of every decoder layer on every edge: Z1_l = W1e_l . h_E (h_E is the encoder's output: static during the walk)
+  {
+    hipError_t ez = hipMemsetAsync(zero_row, 0, NAMP_HIDDEN * sizeof(float), (hipStream_t)stream);
+    if (ez != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample: hipMemsetAsync: %s", hipGetErrorString(ez));
+    for (int l = 0; l < nd; ++l) {
+      const NampDecLayerW* D = &w->dec[l];
+      const bool x3l = prec_of(D->flags) == PREC_X3;
+      const float* img = x3l ? D->W1e_ximg : D->W1e_img;
+      REQUIRE_PTR(img);
+      if ((rc = namp_edge_embed_prec(img, zero_row, h_E, Z1[l], x3l ? 1 : 0, B_enc, N, K, stream))) return rc;
+    }
+  }
 
   SampleArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask_true = mask; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
@@ -1119,9 +1136,9 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
     const NampDecLayerW* D = &w->dec[l];
     SampleLayer& L = a.l[l];
     const int prec = prec_of(D->flags) == PREC_X3 ? PREC_X3 : PREC_F32;       // the sampler has no bf16 mode: fp32-class only
-    L.W1e_img = pick_img(prec, D->W1e_img, nullptr, D->W1e_ximg); L.W2_img = pick_img(prec, D->W2_img, nullptr, D->W2_ximg);
+    L.Z1 = Z1[l]; L.W2_img = pick_img(prec, D->W2_img, nullptr, D->W2_ximg);
     L.W3_img = pick_img(prec, D->W3_img, nullptr, D->W3_ximg); L.b2 = D->b2; L.b3 = D->b3; L.tok = D->tok;
-    REQUIRE_PTR(L.W1e_img); REQUIRE_PTR(L.W2_img); REQUIRE_PTR(L.W3_img);
+    REQUIRE_PTR(L.W2_img); REQUIRE_PTR(L.W3_img);
     L.Pfw = Pfw[l];
     L.Pa = (l == 0) ? Pa0 : Pa[l - 1];
     L.Pv = (l == 0) ? Pfw[0] : Pv[l - 1];
@@ -1294,6 +1311,17 @@ extern "C" int namp_debug_stamps(long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(namp_stamp_acc), sizeof(z)) != hipSuccess) return -1;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(namp_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
   return 0;
+}
+#endif
+
+#ifdef NAMP_ABL_WSTAMPS
+// copies the per-wave event log of workgroup 0 out and clears it: counts[8], log[8][NAMP_WS_EVENTS][2]
+extern "C" int namp_debug_wstamps(int* counts8, long long* log, int reset) {
+  if (hipMemcpyFromSymbol(counts8, HIP_SYMBOL(namp_wstamp_n), 8 * sizeof(int)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(log, HIP_SYMBOL(namp_wstamp_log), sizeof(long long) * 8 * NAMP_WS_EVENTS * 2) != hipSuccess) return -1;
+  int z[8] = {0};
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(namp_wstamp_n), z, sizeof(z)) != hipSuccess) return -1;
+  return NAMP_WS_EVENTS;
 }
 #endif
 

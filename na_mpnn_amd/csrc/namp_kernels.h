@@ -199,9 +199,36 @@ __device__ long long namp_stamp_prev;
     __syncthreads();                                                                              \
     if (blockIdx.x == 0 && threadIdx.x == 0) namp_stamp_prev = wall_clock64();                    \
   } while (0)
+#elif defined(NAMP_ABL_WSTAMPS)
+// Per-WAVE event log of workgroup 0 (tools/build_variants.sh wstamps:-DNAMP_ABL_WSTAMPS; tools/sample_wstamps.py): lane 0 of every wave appends
+// (slot, s_memtime) — no barrier, one 16-byte store per event — so the phases' true durations AND the waits at the barriers between them can be
+// read off per wave.  (The barrier-per-stamp form above costs ~1 us per stamp and synchronises the waves: good for sums, not for a time line.)
+#define NAMP_WS_EVENTS 8192
+__device__ long long namp_wstamp_log[8][NAMP_WS_EVENTS][2];
+__device__ int namp_wstamp_n[8];                      // events logged by the LAST launch (written at its end)
+__shared__ int namp_ws_cur[8];                        // the running event count lives in LDS: a global counter would put a dependent load into every stamp
+#define NAMP_STAMP(slot)                                                                          \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {                    \
+      const int w_ = threadIdx.x >> 6;                                                            \
+      const int c_ = namp_ws_cur[w_];                                                             \
+      if ((unsigned)c_ < (unsigned)NAMP_WS_EVENTS) {                                              \
+        namp_wstamp_log[w_][c_][0] = (slot);                                                      \
+        namp_wstamp_log[w_][c_][1] = (long long)__builtin_amdgcn_s_memtime();                     \
+        namp_ws_cur[w_] = c_ + 1;                                                                 \
+      }                                                                                           \
+    }                                                                                             \
+  } while (0)
+#define NAMP_WSTAMP_INIT() do { if (threadIdx.x < 8) namp_ws_cur[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define NAMP_WSTAMP_FINI() do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 8) namp_wstamp_n[threadIdx.x] = namp_ws_cur[threadIdx.x]; } while (0)
+#define NAMP_STAMP_BEGIN() do {} while (0)
 #else
 #define NAMP_STAMP(slot) do {} while (0)
 #define NAMP_STAMP_BEGIN() do {} while (0)
+#endif
+#ifndef NAMP_WSTAMP_INIT
+#define NAMP_WSTAMP_INIT() do {} while (0)
+#define NAMP_WSTAMP_FINI() do {} while (0)
 #endif
 struct ProjDesc {
   const float* img;    // 64 KiB image of the [128x128] block
@@ -1150,21 +1177,31 @@ __device__ __forceinline__ void node_tail_x3_rows(const NodeTail& a, f4 (&x)[8],
         f4 po = (f4){0.f, 0.f, 0.f, 0.f};
         po = mfma_x3(cur[4 * q], cur[4 * q + 1], hh[0], hm[0], po);
         po = mfma_x3(cur[4 * q + 2], cur[4 * q + 3], hh[1], hm[1], po);
-        if (m < R) *(f4*)(part + ((wave * R + m) * 128 + 16 * (4 * grp + q) + 4 * g)) = po;
+        // (channel tile t of row m sits at tile position t ^ m: the R rows of one tile then fall into different LDS banks — with plain rows, 512 B
+        // apart, every read of the sums below was a 4-way conflict, and with 64 of them per lane the phase took 4.5 us per layer: profiles/r05b)
+        if (m < R) *(f4*)(part + ((wave * R + m) * 128 + 16 * ((4 * grp + q) ^ m) + 4 * g)) = po;
       }
     }
   }
+  NAMP_STAMP(22);                      // (W_out partials written; barrier wait follows)
   __syncthreads();
   NAMP_STAMP(10);                      // W_out partials
+  // ---- the eight partial products, reduce-scatter: wave w adds up channel tile w of the R rows (8 reads per lane instead of 64) and leaves the
+  // sums in lds[0 .. 128 R) (same tile swizzle); then every wave picks up its rows' full sums
+  static_assert(R <= 8, "the tile swizzle t ^ m needs m < 8");
+  {
+    f4 sv = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sv += *(const f4*)(part + ((w * R + mr) * 128 + 16 * (wave ^ mr) + 4 * g));
+    if (m < R) *(f4*)(lds + m * 128 + 16 * (wave ^ m) + 4 * g) = sv;
+  }
+  __syncthreads();
   // ---- y = LayerNorm2(x + W_out h + b_out) * mask, in the chain layout, by every wave
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    f4 v = x[t] + *(const f4*)(bout_p + 16 * t + 4 * g);
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += *(const f4*)(part + ((w * R + mr) * 128 + 16 * t + 4 * g));
-    x[t] = v;
-  }
+  for (int t = 0; t < 8; ++t) x[t] = (x[t] + *(const f4*)(bout_p + 16 * t + 4 * g)) + *(const f4*)(lds + mr * 128 + 16 * (t ^ mr) + 4 * g);
+  NAMP_STAMP(13);                      // (partial sums read)
   layernorm_row_T(x, l2g, l2b, g);
+  NAMP_STAMP(14);                      // (LayerNorm 2)
   const int orw = (m < R) ? orow(m) : -1;
   {
     const float mk = (a.mask && orw >= 0) ? (float)a.mask[orw] : 1.0f;
@@ -2210,7 +2247,8 @@ template <class T>
 __device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
 
 struct SampleLayer {
-  const float* W1e_img; const float* W2_img; const float* W3_img; const float* b2; const float* b3;
+  const float* Z1;         // [G_enc * K][128]  W1e_l . h_E[i,k]: static, so it is computed for every edge and layer BEFORE the walk (round 5)
+  const float* W2_img; const float* W3_img; const float* b2; const float* b3;
   const float* tok;        // [vocab][128]  W1s . W_s
   const float* Pfw;        // [G_enc][128]  W1v_l . h_V^enc            (static)
   float* Pa;               // layer 0: [G_enc][128] static; else [G_dec][128], written at the residue's step
@@ -2358,6 +2396,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
   const f4* w0 = (const f4*)buf0 + lane;
   const f4* w1 = (const f4*)buf1 + lane;
   const SampleRows rows = {node_lds};
+  NAMP_WSTAMP_INIT();
   float tot = 0.f;                                  // running symmetry-group logit sum (head waves)
   // every token starts "not drawn" (-1): the reference's h_S is all-zero until a residue is assigned (:264)
   // (LEVEL: the host fills S_out with -1 before the first level)
@@ -2370,8 +2409,12 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     __syncthreads();
   }
 
-  copy_to_lds<8>(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);   // the first layer's images (through registers: see copy_to_lds)
+  // The first layer's images (through registers: see copy_to_lds).  Round 5: the first-layer product W1e . h_E does not depend on the decoded state
+  // — it is a table (SampleLayer.Z1) made before the walk —, so a layer needs W2 and W3 only: both are resident when the layer starts, there is
+  // no copy and no barrier between the layer's products, and a step has one tile product per layer less.
+  copy_to_lds<8>(buf0, a.l[0].W3_img, 64, wave, nwaves, lane);
   copy_to_lds<8>(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
+  __syncthreads();
   // One step: the workgroup's <= a.slots items starting at item0 (MODE 0: streams item0 .. at visit t_seq; else work-list entries
   // item0 .. < nitems).  `more`: another step follows in this launch (its first layer's images are requested under this step's last tail).
 #ifdef NAMP_ABL_STAMPS
@@ -2497,7 +2540,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     for (int l = 0; l < a.n_layers; ++l) {
       // pointers read through the segment pointer are generic: tell the compiler they are global (flat loads otherwise)
       SampleLayer L = A->l[l];
-      L.W1e_img = as_global(L.W1e_img); L.W2_img = as_global(L.W2_img); L.W3_img = as_global(L.W3_img); L.b2 = as_global(L.b2);
+      L.Z1 = as_global(L.Z1); L.W2_img = as_global(L.W2_img); L.W3_img = as_global(L.W3_img); L.b2 = as_global(L.b2);
       L.b3 = as_global(L.b3); L.tok = as_global(L.tok); L.Pfw = as_global(L.Pfw); L.Pa = as_global(L.Pa); L.Pv = as_global(L.Pv);
       {
         NodeTail& T = L.tail;
@@ -2511,42 +2554,33 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         }
       }
       const float* b2p = L.b2; const float* b3p = L.b3;
-      f4 x[8], acc[8], pjv[8];
+      f4 x[8], acc[8];
+      NAMP_STAMP(2);                    // (the layer's argument block read)
       {
-        const float* src = a.hE + erow * NAMP_H + 4 * g;
+        // z1 = ctx * (W1e . h_E)[i,k] + Pa[i] + ctx * (Pv | Pfw)[j] (+ tok[S_j])
+        const float* src = L.Z1 + erow * NAMP_H + 4 * g;
         const float* pa = L.Pa + (long)(l == 0 ? node_enc : node) * NAMP_H + 4 * g;
         const float* pj = (bw ? L.Pv + (long)(l == 0 ? j_enc : j_dec) * NAMP_H : L.Pfw + (long)j_enc * NAMP_H) + 4 * g;
         const float* tk = L.tok + (long)(has_tok ? S_j : 0) * NAMP_H + 4 * g;
         const float tokf = has_tok ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          x[q] = *(const f4*)(src + 16 * q) * ctx;
-          acc[q] = *(const f4*)(pa + 16 * q);
-          pjv[q] = *(const f4*)(pj + 16 * q);
-          pjv[q] = (pjv[q] + *(const f4*)(tk + 16 * q) * tokf) * ctx;      // (no branch: a conditional load here cost one memory round trip per q)
+          const f4 z = *(const f4*)(src + 16 * q) * ctx;
+          const f4 pav = *(const f4*)(pa + 16 * q);
+          f4 pjv = *(const f4*)(pj + 16 * q);
+          pjv = (pjv + *(const f4*)(tk + 16 * q) * tokf) * ctx;            // (no branch: a conditional load here cost one memory round trip per q)
+          acc[q] = (z + pav) + pjv;
         }
       }
-      // W1e / W2 of this layer were requested ahead (before the walk / under the previous layer's residue tail); the
-      // rows above were requested after them, so one vmcnt(0) covers both
-      wait_dma_and_sync();
-      NAMP_STAMP(1);                    // index chain + row gather + W1e / W2 landed
-      // A wave whose slot holds no residue (a level of B = 1 has ~2.5 of 4) skips the three tile GEMMs — it would only take matrix-pipe
+      NAMP_STAMP(1);                    // index chain + row gather
+      // A wave whose slot holds no residue (a level of B = 1 has ~2.5 of 4) skips the tile products — it would only take matrix-pipe
       // and issue time from the wave it shares a SIMD with — but keeps every barrier and its share of the image copies.
-      if (wave_active) {
-        SGEMM(false, false)(acc, x, w0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += pjv[q];
-      }
-      __syncthreads();
-      NAMP_STAMP(2);                    // GEMM 1
-      copy_to_lds<8>(buf0, L.W3_img, 64, wave, nwaves, lane);
       if (wave_active) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = *(const f4*)(b2p + 16 * q + 4 * g);
         SGEMM(false, true)(x, acc, w1);
       }
-      wait_dma_and_sync();
-      NAMP_STAMP(3);                    // GEMM 2 (+ W3 landed)
+      NAMP_STAMP(3);                    // product 2 (W2 . gelu(z1))
       if (wave_active) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -2561,22 +2595,24 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         for (int q = 0; q < 8; ++q) {
           float sres = (acc[q].x * wr[0] + acc[q].y * wr[1]) + (acc[q].z * wr[2] + acc[q].w * wr[3]);
           sres = xg_sum(sres);
-          if (g == 0) dpart[wave * NAMP_H + 16 * q + m] = sres;
+          if (g == 0) dpart[wave * NAMP_H + 16 * (q ^ slot) + m] = sres;      // (tile q at position q ^ slot: the slots' rows in different banks)
         }
       } else if (lane < 32) {
         *(f4*)(dpart + wave * NAMP_H + 4 * lane) = (f4){0.f, 0.f, 0.f, 0.f};      // (read by the tail's padding rows: keep it finite)
       }
+      NAMP_STAMP(20);                   // (product 3 + K-sum done; the difference to the next stamp is this wave's barrier wait)
       __syncthreads();
-      NAMP_STAMP(4);                    // GEMM 3 + K-sum
-      // both ring slots are free: the next layer's W1e / W2 (the next step's first layer in the sequential walk) stream in
-      // under the residue tail, whose scratch lives behind the ring
+      NAMP_STAMP(4);                    // product 3 + K-sum
+      // both ring slots are free: the next layer's W3 / W2 (the next step's first layer in the sequential walk) are copied in
+      // ahead of the residue tail, whose scratch lives behind the ring
       if (l + 1 < a.n_layers) {
-        copy_to_lds<8>(buf0, as_global(A->l[l + 1].W1e_img), 64, wave, nwaves, lane);
+        copy_to_lds<8>(buf0, as_global(A->l[l + 1].W3_img), 64, wave, nwaves, lane);
         copy_to_lds<8>(buf1, as_global(A->l[l + 1].W2_img), 64, wave, nwaves, lane);
       } else if (more) {
-        copy_to_lds<8>(buf0, a.l[0].W1e_img, 64, wave, nwaves, lane);
+        copy_to_lds<8>(buf0, a.l[0].W3_img, 64, wave, nwaves, lane);
         copy_to_lds<8>(buf1, a.l[0].W2_img, 64, wave, nwaves, lane);
       }
+      NAMP_STAMP(21);                   // (next images copied)
       // residue tail over the workgroup's <= 4 streams: tile row m -> stream slot m
       {
         const int nd = (m < NAMP_SAMPLE_SLOTS) ? node_lds[m] : -1;
@@ -2591,7 +2627,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         for (int q2 = 0; q2 < a.TPN; ++q2) {
           const float* dp = dpart + (ms * a.TPN + q2) * NAMP_H + 4 * g;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * q);
+          for (int q = 0; q < 8; ++q) x[q] += *(const f4*)(dp + 16 * (q ^ ms));
         }
 #ifndef NAMP_ABL_SAMPLE_NOTAIL
         // split-bf16 mode, 8-wave workgroups: the tail as one MFMA tile on x3 images (both walks: level == sequential bit for bit);
@@ -2600,6 +2636,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         else node_tail_rows<NAMP_SAMPLE_SLOTS, SampleRows, MODE == 2, true, LEVEL && MAXW == 8>(L.tail, x, 0.f, rows, tail_lds, tid, wave, nwaves, lane);
 #endif
       }
+      NAMP_STAMP(23);                   // (tail done; barrier wait follows)
       __syncthreads();            // tail outputs (h^(l+1), next layer's Pa / Pv) visible to every wave; LDS reusable
       NAMP_STAMP(5);                    // next images requested + residue tail
     }
@@ -2651,6 +2688,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         draw(bq, t, v_first, tot);
       }
     }
+    NAMP_STAMP(24);                     // (head + draw done; barrier wait follows)
     __syncthreads();              // S of this step is published before the next step's neighbours read it
     NAMP_STAMP(6);                      // output head + draw
   };
@@ -2713,6 +2751,7 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
         a.logp_out[e] = __builtin_nanf("");
     }
   }
+  NAMP_WSTAMP_FINI();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA of a prefetched image is in flight when the workgroup's LDS is released
 }
 

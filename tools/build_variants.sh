@@ -9,7 +9,7 @@ mkdir -p tools/_variants
 build() {
   name=$1; shift
   ( timeout 1500 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c na_mpnn_amd/csrc/namp.hip -o tools/_variants/$name.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/_variants/$name.o na_mpnn_amd/lib/obj/namp_train.o na_mpnn_amd/lib/obj/namp_persist.o -o tools/_variants/$name.so &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/_variants/$name.o na_mpnn_amd/lib/obj/namp_train.o na_mpnn_amd/lib/obj/namp_train_eu.o na_mpnn_amd/lib/obj/namp_persist.o -o tools/_variants/$name.so &&
     rm -f tools/_variants/$name.o ) &
 }
 if [ $# -eq 0 ]; then

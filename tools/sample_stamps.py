@@ -7,11 +7,12 @@ from na_mpnn_amd import hip, spec, synth
 from na_mpnn_amd.model import ProteinMPNN
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
+torch.manual_seed(0)
 w = synth.make_weights(0)
 L = C.CDLL(os.environ["NAMP_LIB_PATH"])
-names = ["between steps (barrier / launch)", "index chain + rows + W1e/W2 landed", "GEMM 1", "GEMM 2 (+W3 landed)", "GEMM 3 + K-sum",
+names = ["between steps (barrier / launch)", "index chain + row gather", "layer argument block read", "product 2 (W2 . gelu(z1))", "product 3 + K-sum",
          "tail: projections (rest of the tail phase)", "head + draw", "tail: next images copied + K-sums read", "tail: LayerNorm 1", "tail: W_in + GELU",
-         "tail: W_out partials", "tail: partial sums + LayerNorm 2"]
+         "tail: W_out partials", "tail: mask, h_V' out (rest of LN2 phase)", "(12)", "tail: partial sums read", "tail: LayerNorm 2", "(15)"]
 for n, k, bs, walk in ((97, 32, 1, True), (97, 32, 1, False), (400, 32, 30, True)):
     m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=k, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
                     polytype_to_int=spec.polytype_to_int())
@@ -30,7 +31,7 @@ for n, k, bs, walk in ((97, 32, 1, True), (97, 32, 1, False), (400, 32, 30, True
     torch.cuda.synchronize()
     L.namp_debug_stamps(buf, 1)
     lv = int(out["levels"])
-    tot = sum(buf[:12])
+    tot = sum(buf[:16])
     print(f"N={n} K={k} batch_size={bs} {'persistent walk' if walk else 'launch per level'}: {lv} levels; workgroup 0, us per level (3 layers summed):")
     for i, nm in enumerate(names):
         print(f"   {nm:40s} {buf[i] * 0.01 / reps / lv:8.2f}")
