@@ -1064,7 +1064,7 @@ size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
   // h[L] on the sample-stream side
   const size_t L = NAMP_MAX_LAYERS;
   // + the first-layer tables Z1_l = W1e_l . h_E of every edge (round 5) and one zero row
-  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + L * tbl(Ge * (size_t)K) + 512 + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
+  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + L * tbl(Ge * (size_t)K) + 512 + NAMP_HIDDEN * 64 * 4 + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
 }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
@@ -1098,7 +1098,8 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
   float* Z1[NAMP_MAX_LAYERS] = {};
   for (int l = 0; l < nd; ++l) Z1[l] = c.take((size_t)Ge * K * NAMP_HIDDEN);
   float* zero_row = c.take(NAMP_HIDDEN);
-  if (!hs[nd - 1] || !zero_row) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
+  float* head_wT = c.take((size_t)NAMP_HIDDEN * 64);
+  if (!hs[nd - 1] || !zero_row || !head_wT) return fail(NAMP_EWORKSPACE, "namp_decoder_sample: workspace too small (%zu bytes)", ws_bytes);
   // static tables from the encoder output: Pfw_l = W1v_l . h_V^enc, Pa_0 = W1a_0 . h_V^enc + b1
   NampProj pf[NAMP_MAX_LAYERS + 1];
   int nf = 0;
@@ -1120,10 +1121,13 @@ static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float
     }
   }
 
+  REQUIRE_PTR(w->Wout_w); REQUIRE_PTR(w->Wout_b);
+  hipLaunchKernelGGL(head_transpose_kernel, dim3(NAMP_HIDDEN * 64 / 256), dim3(256), 0, (hipStream_t)stream, w->Wout_w, head_wT, w->vocab);
+
   SampleArgs a = {};
   a.hE = h_E; a.E_idx = E_idx; a.mask_true = mask; a.chain_mask = chain_mask; a.S_true = S_true; a.bias = bias; a.order = order; a.rank = rank;
   a.uniform = uniform; a.S_forced = S_forced; a.group_first = group_first; a.group_last = group_last;
-  a.sym_w = sym_weights; a.pair_bias = pair_bias; a.head_w = w->Wout_w; a.head_b = w->Wout_b; a.S_out = S_out;
+  a.sym_w = sym_weights; a.pair_bias = pair_bias; a.head_wT = head_wT; a.head_b = w->Wout_b; a.S_out = S_out;
   a.probs_out = probs_out; a.logp_out = logp_out; a.special = special_tokens; a.inv_T = 1.0f / temperature;
   a.B_dec = B_dec; a.B_enc = B_enc; a.N = N; a.K = K; a.TPN = (K + 15) / 16; a.n_layers = w->n_dec; a.vocab = w->vocab;
   // 8 waves per workgroup (256 VGPRs per lane: no scratch) serve 8 / TPN streams; K > 128 falls back to the 12-wave form
@@ -1299,7 +1303,8 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
   }
   if (e != hipSuccess) return fail(NAMP_ELAUNCH, "namp_decoder_sample_walk: hipMemsetAsync / hipMemcpyAsync: %s", hipGetErrorString(e));
   ProfScope prof_(NAMP_KIND_DEC_MESSAGE, s);
-  const int g2 = (nwork + a.slots - 1) / a.slots;
+  int g2 = (nwork + a.slots - 1) / a.slots;
+  if (const char* e_ = getenv("NAMP_WALK_GRID")) { const int v = atoi(e_); if (v >= 1 && v < g2) g2 = v; }      // (measurement switch)
   launch_sample(2, prec_of(w->dec[0].flags) == PREC_X3, nwaves, g2 < grid ? g2 : grid, s, a, work, work_n, nwork, level_off, sync);
   CHECK_LAUNCH();
   return NAMP_OK;

@@ -2246,6 +2246,30 @@ __global__ __launch_bounds__(768) void edge_mlp_x3_persistent_kernel(const EdgeA
 template <class T>
 __device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
 
+// Whole-wave (64-lane) reductions without LDS round trips: a butterfly inside each 16-lane DPP row (quad_perm pairs, then the row's mirrors as
+// pairings), then the four row totals through v_readlane.  __shfl_xor compiles to ds_bpermute_b32 — an LDS round trip per step, six per reduction,
+// and the sampler's head + draw is a chain of five reductions and a scan on the critical path of every level.
+template <int CTRL>
+__device__ __forceinline__ float wv_dpp(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wv_lane(const float v, const int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += wv_dpp<0xB1>(v); v += wv_dpp<0x4E>(v); v += wv_dpp<0x141>(v); v += wv_dpp<0x140>(v);      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+  return (wv_lane(v, 0) + wv_lane(v, 16)) + (wv_lane(v, 32) + wv_lane(v, 48));
+}
+__device__ __forceinline__ float wave_max64(float v) {
+  v = fmaxf(v, wv_dpp<0xB1>(v)); v = fmaxf(v, wv_dpp<0x4E>(v)); v = fmaxf(v, wv_dpp<0x141>(v)); v = fmaxf(v, wv_dpp<0x140>(v));
+  return fmaxf(fmaxf(wv_lane(v, 0), wv_lane(v, 16)), fmaxf(wv_lane(v, 32), wv_lane(v, 48)));
+}
+// inclusive prefix sum over the 64 lanes: row_shr scans inside the rows (zeros shifted in), then the totals of the rows below
+__device__ __forceinline__ float wave_scan64(float v, const int lane) {
+  v += wv_dpp<0x111>(v); v += wv_dpp<0x112>(v); v += wv_dpp<0x114>(v); v += wv_dpp<0x118>(v);
+  const float r0 = wv_lane(v, 15), r1 = wv_lane(v, 31), r2 = wv_lane(v, 47);
+  const int row = lane >> 4;
+  return v + (row == 0 ? 0.f : row == 1 ? r0 : row == 2 ? (r0 + r1) : ((r0 + r1) + r2));
+}
+
 struct SampleLayer {
   const float* Z1;         // [G_enc * K][128]  W1e_l . h_E[i,k]: static, so it is computed for every edge and layer BEFORE the walk (round 5)
   const float* W2_img; const float* W3_img; const float* b2; const float* b3;
@@ -2272,7 +2296,7 @@ struct SampleArgs {
   const int32_t* group_last;   // optional [B_dec][N]: 1 if visit v closes its group                       (null: always)
   const float* sym_w;          // optional [G_enc]: weight of a residue's logits in its group's sum        (null: 1)
   const float* pair_bias;      // optional [G_enc][vocab][N][vocab] (model_utils.py:116,170-172)
-  const float* head_w; const float* head_b;
+  const float* head_wT; const float* head_b;   // head_wT [128][64]: W_out transposed, token t of channel c at c * 64 + t (zero beyond vocab): coalesced reads
   int32_t* S_out;              // [B_dec][N]   (also the running sequence read back for decoded neighbours)
   float* probs_out;            // [B_dec][N][vocab]
   float* logp_out;             // [B_dec][N][vocab]
@@ -2309,6 +2333,14 @@ static __global__ void cvt_tables_bf16_kernel(const CvtTables c) {
   }
 }
 
+// W_out [vocab][128] -> [128][64] (token-minor, zero beyond vocab) for the sampler's head
+static __global__ void head_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int vocab) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;              // c * 64 + t
+  if (e >= NAMP_H * 64) return;
+  const int c = e >> 6, t = e & 63;
+  WT[e] = t < vocab ? W[t * NAMP_H + c] : 0.f;
+}
+
 // sample_levels_kernel: dependency level of every visit of the plain sampling branch.  One wave per stream walks its
 // decoding order once: level(i) = 1 + max level of the neighbours visited before i (0 if none) — lanes cover the K
 // neighbours, levels live in LDS.  level_out[b][t] is indexed by VISIT t.
@@ -2325,27 +2357,42 @@ static __global__ __launch_bounds__(64) void sample_levels_kernel(const int32_t*
   const int b = blockIdx.x, lane = threadIdx.x;
   const int b_enc = b % B_enc;
   const int32_t* rk = rank + (long)b * N;
+  const int32_t* ord = order + (long)b * N;
   int dg = -1;                                                   // running maximum over the open group's members
+  // The visit's residue and its first 64 neighbours are requested one visit AHEAD (they do not depend on the levels): what is left on the
+  // chain of a visit is the LDS look-up of the neighbours' levels and one wave maximum (DPP + readlane, no LDS round trips) — the walk is
+  // serial over the N visits of a stream, and at ~0.8 us per visit it was 78 us of a 97-residue design call.
+  // (the residues of 64 consecutive visits sit one per lane and are handed out by v_readlane: no load on the way to a visit's residue)
+  int ord_blk = ord[lane < N ? lane : 0];
+  int i_n = __builtin_amdgcn_readlane(ord_blk, 0);
+  int j_n = lane < K ? E_idx[((long)b_enc * N + i_n) * K + lane] : -1;
+  int rj_n = j_n >= 0 ? rk[j_n] : 0x7fffffff;
   for (int t = 0; t < N; ++t) {
-    const int i = order[(long)b * N + t];
+    const int i = i_n, j0 = j_n, rj0 = rj_n;
+    if (t + 1 < N) {
+      if (((t + 1) & 63) == 0) ord_blk = ord[t + 1 + lane < N ? t + 1 + lane : 0];
+      i_n = __builtin_amdgcn_readlane(ord_blk, (t + 1) & 63);
+      j_n = lane < K ? E_idx[((long)b_enc * N + i_n) * K + lane] : -1;
+      rj_n = j_n >= 0 ? rk[j_n] : 0x7fffffff;
+    }
     const int vf = group_first ? group_first[(long)b * N + t] : t;       // rank[i] == t; the group's first visit
     int d = -1;
-    for (int k = lane; k < K; k += 64) {
+    if (rj0 < vf) d = lv[j0];                                    // earlier groups already have their level
+    for (int k = lane + 64; k < K; k += 64) {
       const int j = E_idx[((long)b_enc * N + i) * K + k];
-      if (rk[j] < vf) d = max(d, lv[j]);                         // earlier groups already have their level
+      if (rk[j] < vf) d = max(d, lv[j]);
     }
     if (dep_idx)
       for (int k = lane; k < D; k += 64) {
         const int j = dep_idx[((long)b_enc * N + i) * D + k];
         if (j >= 0 && rk[j] < vf) d = max(d, lv[j]);
       }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) d = max(d, __shfl_xor(d, o));
+    d = (int)wave_max64((float)d);                               // (levels < 2^24: exact in fp32)
     dg = (vf == t) ? d : max(dg, d);
     const bool closes = group_last ? (group_last[(long)b * N + t] != 0) : true;
     if (closes)
-      for (int v = vf + lane; v <= t; v += 64) { lv[order[(long)b * N + v]] = dg + 1; level_out[(long)b * N + v] = dg + 1; }
-    __builtin_amdgcn_s_waitcnt(0);                               // LDS write visible to the wave's next iteration
+      for (int v = vf + lane; v <= t; v += 64) { lv[ord[v]] = dg + 1; level_out[(long)b * N + v] = dg + 1; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // LDS write visible to the wave's next iteration (the requests made ahead stay in flight)
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -2449,28 +2496,15 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
       }
       add += acc_pb;
     }
+    const float u = a.uniform[vis];                                 // (requested ahead of the reductions)
     float zt = (lane < a.vocab) ? (total + add) * a.inv_T : -INFINITY;
-    float mt = zt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
+    const float mt = wave_max64(zt);
     float p = (lane < a.vocab) ? expf(zt - mt) : 0.f;
-    float ps = p;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) ps += __shfl_xor(ps, o);
-    p = p / ps;
+    p = p / wave_sum64(p);
     if ((a.special >> lane) & 1ull) p = 0.f;
-    float pr = p;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) pr += __shfl_xor(pr, o);
-    p = p / pr;
+    p = p / wave_sum64(p);
     // inverse CDF: first token whose inclusive prefix sum exceeds u
-    float cdf = p;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const float up = __shfl_up(cdf, o);
-      if (lane >= o) cdf += up;
-    }
-    const float u = a.uniform[vis];
+    const float cdf = wave_scan64(p, lane);
     const unsigned long long hit = __ballot(p > 0.f && cdf > u);
     const unsigned long long any = __ballot(p > 0.f);
     int S_t = hit ? (int)__builtin_ctzll(hit) : (any ? 63 - (int)__builtin_clzll(any) : 0);
@@ -2645,31 +2679,28 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
     // logit sum of a symmetry group lives in its registers).  h^(n_layers) row of slot n is yT[c * R + n].
     {
       const float* yT = tail_lds + (128 + 512 + 4 * 128) * NAMP_SAMPLE_SLOTS;
-      const float* head_w = a.head_w; const float* head_b = a.head_b;
+      const float* head_wT = a.head_wT; const float* head_b = a.head_b;
       for (int n = wave; n < NAMP_SAMPLE_SLOTS; n += nwaves) {
         const int nd = node_lds[n];
         if (nd < 0) continue;
         const int bq = nd / a.N, iq = nd - bq * a.N;
         const int ne = (bq % a.B_enc) * a.N + iq;
         float z = -INFINITY;
-        if (lane < a.vocab) {
-          const float* w = head_w + (long)lane * NAMP_H;
+        {
+          // logits: token = lane, the transposed table read 256 contiguous bytes per channel (the [vocab][128] layout made every lane walk its own
+          // 512-byte row: 33 cache lines per load instruction); h_V' of the slot is broadcast from LDS.  Same four partial sums as before.
+          const float* w = head_wT + lane;
           float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
           for (int c = 0; c < NAMP_H; c += 4) {
-            const f4 wv = *(const f4*)(w + c);
-            s0 = fmaf(wv.x, yT[(c + 0) * NAMP_SAMPLE_SLOTS + n], s0); s1 = fmaf(wv.y, yT[(c + 1) * NAMP_SAMPLE_SLOTS + n], s1);
-            s2 = fmaf(wv.z, yT[(c + 2) * NAMP_SAMPLE_SLOTS + n], s2); s3 = fmaf(wv.w, yT[(c + 3) * NAMP_SAMPLE_SLOTS + n], s3);
+            s0 = fmaf(w[(c + 0) * 64], yT[(c + 0) * NAMP_SAMPLE_SLOTS + n], s0); s1 = fmaf(w[(c + 1) * 64], yT[(c + 1) * NAMP_SAMPLE_SLOTS + n], s1);
+            s2 = fmaf(w[(c + 2) * 64], yT[(c + 2) * NAMP_SAMPLE_SLOTS + n], s2); s3 = fmaf(w[(c + 3) * 64], yT[(c + 3) * NAMP_SAMPLE_SLOTS + n], s3);
           }
-          z = (s0 + s1) + (s2 + s3) + head_b[lane];
+          if (lane < a.vocab) z = (s0 + s1) + (s2 + s3) + head_b[lane];
         }
         // log_softmax(logits) of this residue                          (model_utils.py:190 / :296-297)
-        float mx = z;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float e = (lane < a.vocab) ? expf(z - mx) : 0.f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) e += __shfl_xor(e, o);
+        const float mx = wave_max64(z);
+        const float e = wave_sum64((lane < a.vocab) ? expf(z - mx) : 0.f);
         const float logp = (z - mx) - logf(e);
         if (lane < a.vocab) a.logp_out[(long)nd * a.vocab + lane] = a.chain_mask[ne] ? logp : 0.f;
         // group logit sum: total += symmetry_weight[i] * logits          (model_utils.py:298)
