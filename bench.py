@@ -314,6 +314,25 @@ def features_bench(dev):
                     "gexp_per_s": round(FEAT_EXP_ALGO * residues / max(ef, 1e-9) / 1e6, 1),
                     "knn_select_ms": round(t.get("knn_select_kernel", t.get("knn_kernel", 0.0)), 4),
                     "prep_atoms_ms": round(t.get("prep_atoms_kernel", 0.0), 4)}
+        if which == "cfg2":
+            # the GPU partner of cpu_baseline.full_forward_from_X ("features timed separately AND as full forward"): score() from
+            # coordinates — featuriser + encoder + decoder, the same synthetic complex (synth.make_complex(seed=77, n=1000, n_chains=4)) —
+            # 20 calls back to back between two device syncs after 5 warm-up calls, randn fixed
+            fd["batch_size"] = 1
+            fd["randn"] = torch.randn(1, tokens, generator=torch.Generator().manual_seed(7)).to(dev)
+            for _ in range(5):
+                sc = m.score(fd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                sc = m.score(fd)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            res["full_forward_from_X"] = {"value": round(residues / dt, 1), "unit": "residues/s", "ms_per_call": round(dt * 1e3, 4),
+                                          "sample": f"ProteinMPNN.score() from coordinates (HIP featuriser + enc + dec), the cpu_baseline complex "
+                                                    f"({tokens} residues, K=48), 20 calls after 5 warm-up calls",
+                                          "finite": bool(torch.isfinite(sc["log_probs"]).all())}
+            del sc
         del fd, out
     big = res["cfg4_batch"]
     res.update({"achieved": round(big["frac"] * PEAK_BF16_MFMA_TFLOPS, 2), "frac": big["frac"], "algorithmic_frac": big["algorithmic_frac"],
@@ -1003,6 +1022,10 @@ def compact_line(out):
         if "one_thread" in cb:
             c["cpu_baseline"]["one_thread"] = cb["one_thread"]["value"]
             c["cpu_baseline"]["full_forward_from_X"] = cb["full_forward_from_X"]["value"]
+            gf = (out.get("features") or {}).get("full_forward_from_X")
+            if gf:                                            # its GPU partner: score() from coordinates on the same complex (features_bench)
+                c["cpu_baseline"]["gpu_full_forward_from_X"] = gf["value"]
+                c["cpu_baseline"]["gpu_full_forward_ms"] = gf["ms_per_call"]
     if "parity" in out:
         pr = out["parity"]
         c["parity"] = {"max_abs_dlogp_vs_cpu": pr["max_abs_dlogp_vs_cpu"], "argmax_equal": pr["argmax_equal"],
@@ -1018,6 +1041,8 @@ def compact_line(out):
         for tag in ("cfg2_from_X", "cfg4_batch"):
             if tag in f:
                 c["features"][tag] = {k: f[tag][k] for k in ("tokens", "avg_launch_ms", "frac", "algorithmic_frac", "knn_select_ms")}
+        if "full_forward_from_X" in f:
+            c["features"]["full_forward_from_X"] = {k: f["full_forward_from_X"][k] for k in ("value", "unit", "ms_per_call")}
     if "x3" in out:
         x = out["x3"]
         c["x3"] = {"value": x["value"], "ms_per_step": x["ms_per_step"], "dtype": "bf16x3", "kernel": x["roofline"]["kernel"],
