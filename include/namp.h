@@ -487,6 +487,22 @@ int namp_train_adam_step(const int32_t* blk_tensor, const long long* blk_off, co
                          int ntensors, int nblocks, float max_norm, double beta1, double beta2, float step_size, float bias_correction2_sqrt,
                          float eps, float* ws, void* stream);
 
+/* Positional edge features of the training step (PositionalEncodings, na_model_utils.py:537-541) as two launches (round 5):
+ *   namp_train_pos_features: d_out[e] = chain_i == chain_j ? clip(R_i - R_j + 32, 0, 64) : 65 and E_pos[e][16] = pos_w[:, d] + pos_b for every edge
+ *     (pos_w = embeddings.linear.weight [16][66], j = E_idx[e] within the complex) — the input of namp_train_feat_wgrad's positional block.
+ *   namp_train_pos_grad: with gp[e][k] = sum_c g[e][c] * Wedge[c][k] (k < 16; Wedge row stride ld) per-workgroup partials part[groups][67][16]:
+ *     rows 0..65 = sum of gp over the edges of class d (-> d pos_w^T), row 66 = sum over all edges (-> d pos_b).  groups =
+ *     namp_train_pos_grad_groups(edges); add them with namp_reduce_sum.  Deterministic. */
+int namp_train_pos_features(const int32_t* R_idx, const int32_t* chain, const int32_t* E_idx, const float* pos_w, const float* pos_b,
+                            int32_t* d_out, float* E_pos, int B, int L, int K, void* stream);
+int namp_train_pos_grad_groups(long edges);
+int namp_train_pos_grad(const float* g, const float* Wedge, int ld, const int32_t* d, float* part, long edges, void* stream);
+
+/* Reverse adjacency for namp_train_scatter_rows (round 5; four small launches instead of a stock 64-bit radix sort + bincount + cumsum): offsets
+ * [B*N + 1] and edges [B*N*K] such that edges[offsets[j] .. offsets[j+1]) are the edge rows e = (b, i, k) with b*N + E_idx[b,i,k] == j in ascending
+ * order (= a stable sort of the edges by target row).  ws: 2*B*N + B*N*K int32 of scratch. */
+int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t* edges, int32_t* ws, int B, int N, int K, void* stream);
+
 /* Sums over partials, up to 16 segments in ONE launch (round 5): dst[a * Mb + b] = sum_{i < n} src[a * sa + i * sn + b] for a < A, b < Mb (element
  * strides; fp32).  Covers the reductions behind the training launches — [n][M] partials of weight gradients (A = 1, sa = 0, sn = M), per-tile rows
  * [G][T][128] -> [G][128] (A = G, sa = T * 128, sn = 128) — which were ~100 stock reduction launches per cfg5 step.  Deterministic (fixed order). */

@@ -1536,4 +1536,136 @@ static __global__ __launch_bounds__(256) void reduce_sum_kernel(const ReduceArgs
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Positional edge features of the training step (PositionalEncodings, na_model_utils.py:537-541 / 577-582) on two launches (round 5) instead of
+// ~25 stock ones (the class index as six int64 tensor expressions, a 10^6-row table gather, the data gradient as a [10^6 x 128] x [128 x 16] library
+// GEMM, the table gradient as one-hot batched GEMMs).
+//   pos_features_kernel: d[e] = same-chain ? clip(R_i - R_j + 32, 0, 64) : 65;  E_pos[e][k] = W[k][d] + b[k]  (W = embeddings.linear.weight [16][66])
+//   pos_grad_kernel:     gp[e][k] = sum_c g[e][c] * Wedge[c][k] (k < 16: the embedding's positional columns);  table[d[e]][k] += gp;  table[66][k] += gp
+//     (= d weight^T, d bias).  A wave takes one edge row at a time: lane (k, part) multiplies channels 32 part .. +31 — the row's values are
+//     broadcast loads, the 32 weights stay in registers —, the four parts meet through two cross-row shuffles and lanes of part 0 add into the
+//     wave's PRIVATE table in LDS (plain read-modify-write, fixed order: deterministic); per-workgroup partials [groups][67][16] leave the chip.
+// ------------------------------------------------------------------------------------------
+#define POS_CLASSES 66
+#define POS_DIM 16
+static __global__ __launch_bounds__(256) void pos_features_kernel(const int32_t* __restrict__ R_idx, const int32_t* __restrict__ chain,
+                                                           const int32_t* __restrict__ E_idx, const float* __restrict__ W, const float* __restrict__ b,
+                                                           int32_t* __restrict__ d_out, float* __restrict__ E_pos, long E, int L, int K) {
+  __shared__ float tab[POS_CLASSES * POS_DIM];                    // [d][k] = W[k][d] + b[k]
+  for (int q = threadIdx.x; q < POS_CLASSES * POS_DIM; q += blockDim.x) { const int d = q / POS_DIM, k = q % POS_DIM; tab[q] = W[k * POS_CLASSES + d] + b[k]; }
+  __syncthreads();
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+    const int node = (int)(e / K);
+    const int j = node - node % L + E_idx[e];
+    int off = R_idx[node] - R_idx[j] + 32;
+    off = off < 0 ? 0 : (off > 64 ? 64 : off);
+    const int d = (chain[node] == chain[j]) ? off : 65;
+    d_out[e] = d;
+    const f4* t = (const f4*)(tab + d * POS_DIM);
+    f4* o = (f4*)(E_pos + e * POS_DIM);
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  }
+}
+
+#define POS_GRAD_WAVES 8
+static __global__ __launch_bounds__(64 * POS_GRAD_WAVES) void pos_grad_kernel(const float* __restrict__ g, const float* __restrict__ Wedge, int ld,
+                                                                       const int32_t* __restrict__ d, float* __restrict__ part, long E) {
+  __shared__ float tab[POS_GRAD_WAVES][(POS_CLASSES + 1) * POS_DIM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = lane & 15, pt = lane >> 4;
+  for (int q = lane; q < (POS_CLASSES + 1) * POS_DIM; q += 64) tab[wave][q] = 0.f;
+  float w[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) w[c] = Wedge[(long)(32 * pt + c) * ld + k];
+  const long nw = (long)gridDim.x * POS_GRAD_WAVES;
+  for (long e = (long)blockIdx.x * POS_GRAD_WAVES + wave; e < E; e += nw) {
+    const f4* row = (const f4*)(g + e * NAMP_H + 32 * pt);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f4 v = row[q];
+      s0 = fmaf(v.x, w[4 * q], s0); s1 = fmaf(v.y, w[4 * q + 1], s1);
+      s0 = fmaf(v.z, w[4 * q + 2], s0); s1 = fmaf(v.w, w[4 * q + 3], s1);
+    }
+    float s = s0 + s1;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const int cls = d[e];
+    if (pt == 0) {
+      tab[wave][cls * POS_DIM + k] += s;
+      tab[wave][POS_CLASSES * POS_DIM + k] += s;
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < (POS_CLASSES + 1) * POS_DIM; q += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < POS_GRAD_WAVES; ++w_) s += tab[w_][q];
+    part[(long)blockIdx.x * (POS_CLASSES + 1) * POS_DIM + q] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Reverse adjacency of the neighbour lists (the transpose of the gather: for every table row j the edges e = (i, k) with E_idx[i, k] = j, ascending),
+// which scatter_rows_kernel streams.  A counting sort on the target row — keys < B * N — in four small launches (round 5) instead of a 64-bit
+// stable radix sort of 10^6 pairs, a bincount and a cumsum on stock kernels (~0.4 ms per step): count, scan, fill (atomic slots: any order
+// inside a row), then one wave per row puts its segment in ascending edge order by rank counting — the result is the stable sort's, bit for bit.
+// ------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void radj_count_kernel(const int32_t* __restrict__ E_idx, int32_t* __restrict__ counts, long E, int N, int K) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+    const int node = (int)(e / K);
+    atomicAdd(counts + (node - node % N + E_idx[e]), 1);
+  }
+}
+// offsets[0 .. G] = exclusive scan of counts[0 .. G); cursor[j] = offsets[j] (the fill's running slots).  One workgroup.
+static __global__ __launch_bounds__(1024) void radj_scan_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, int32_t* __restrict__ cursor,
+                                                         int G) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < G; base += 1024) {
+    const int i = base + tid;
+    const int c = i < G ? counts[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (i < G) { offsets[i] = before + incl - c; cursor[i] = before + incl - c; }
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) offsets[G] = carry;
+}
+static __global__ __launch_bounds__(256) void radj_fill_kernel(const int32_t* __restrict__ E_idx, int32_t* __restrict__ cursor, int32_t* __restrict__ tmp,
+                                                        long E, int N, int K) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+    const int node = (int)(e / K);
+    const int slot = atomicAdd(cursor + (node - node % N + E_idx[e]), 1);
+    tmp[slot] = (int32_t)e;
+  }
+}
+// one wave per row: out[off + rank(x)] = x for the row's (distinct) edge numbers x, rank = how many of the row's numbers are smaller
+static __global__ __launch_bounds__(256) void radj_sort_kernel(const int32_t* __restrict__ offsets, const int32_t* __restrict__ tmp, int32_t* __restrict__ out, int G) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= G) return;
+  const int off = offsets[row], n = offsets[row + 1] - off;
+  for (int base = 0; base < n; base += 64) {
+    const int mine = base + lane < n ? tmp[off + base + lane] : 0x7fffffff;
+    int cnt = 0;
+    for (int cb = 0; cb < n; cb += 64) {
+      const int other = cb + lane < n ? tmp[off + cb + lane] : 0x7fffffff;
+      const int m_ = n - cb < 64 ? n - cb : 64;
+      for (int t = 0; t < m_; ++t) cnt += (__builtin_amdgcn_readlane(other, t) < mine) ? 1 : 0;
+    }
+    if (base + lane < n) out[off + cnt] = mine;
+  }
+}
 #endif  // NAMP_TRAIN_EDGE_ONLY

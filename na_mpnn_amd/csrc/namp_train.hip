@@ -371,6 +371,58 @@ int namp_reduce_sum(const NampReduce* seg, int nseg, void* stream) {
   return NAMP_OK;
 }
 
+int namp_train_pos_features(const int32_t* R_idx, const int32_t* chain, const int32_t* E_idx, const float* pos_w, const float* pos_b,
+                            int32_t* d_out, float* E_pos, int B, int L, int K, void* stream) {
+  if (!R_idx || !chain || !E_idx || !d_out) return fail(NAMP_EINVAL, "namp_train_pos_features: null pointer argument");
+  REQUIRE_PTR(pos_w); REQUIRE_PTR(pos_b); REQUIRE_PTR(E_pos);
+  REQUIRE(B >= 1 && L >= 1 && K >= 1 && K <= L, "namp_train_pos_features: bad dims B=%d L=%d K=%d", B, L, K);
+  const long E = (long)B * L * K;
+  long blocks = (E + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pos_features_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, R_idx, chain, E_idx, pos_w, pos_b, d_out, E_pos,
+                     E, L, K);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_pos_grad_groups(long edges) {
+  if (edges <= 0) return 0;
+  long n = (edges + 8 * POS_GRAD_WAVES - 1) / (8 * POS_GRAD_WAVES);      // >= 8 rows per wave
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+
+int namp_train_pos_grad(const float* g, const float* Wedge, int ld, const int32_t* d, float* part, long edges, void* stream) {
+  REQUIRE_PTR(g); REQUIRE_PTR(Wedge); REQUIRE_PTR(part);
+  if (!d) return fail(NAMP_EINVAL, "namp_train_pos_grad: null class index");
+  REQUIRE(edges >= 1 && ld >= POS_DIM, "namp_train_pos_grad: edges=%ld ld=%d", edges, ld);
+  hipLaunchKernelGGL(pos_grad_kernel, dim3(namp_train_pos_grad_groups(edges)), dim3(64 * POS_GRAD_WAVES), 0, (hipStream_t)stream, g, Wedge, ld, d,
+                     part, edges);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t* edges, int32_t* ws, int B, int N, int K, void* stream) {
+  if (!E_idx || !offsets || !edges || !ws) return fail(NAMP_EINVAL, "namp_train_reverse_adjacency: null pointer argument");
+  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= N, "namp_train_reverse_adjacency: bad dims B=%d N=%d K=%d", B, N, K);
+  const long G = (long)B * N, E = G * K;
+  REQUIRE(E < (1L << 31), "namp_train_reverse_adjacency: %ld edges do not fit int32", E);
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* counts = ws;                    // [G]
+  int32_t* cursor = ws + G;                // [G]
+  int32_t* tmp = ws + 2 * G;               // [E]
+  hipError_t e_ = hipMemsetAsync(counts, 0, (size_t)G * sizeof(int32_t), s);
+  if (e_ != hipSuccess) return fail(NAMP_ELAUNCH, "namp_train_reverse_adjacency: hipMemsetAsync: %s", hipGetErrorString(e_));
+  long blocks = (E + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(radj_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, E_idx, counts, E, N, K);
+  hipLaunchKernelGGL(radj_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, cursor, (int)G);
+  hipLaunchKernelGGL(radj_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, E_idx, cursor, tmp, E, N, K);
+  hipLaunchKernelGGL(radj_sort_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, s, offsets, tmp, edges, (int)G);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
   long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 2 workgroups per CU (the split-bf16

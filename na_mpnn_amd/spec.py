@@ -16,6 +16,7 @@ VOCAB = 33         # num_letters == vocab (run.py:130-131)
 NUM_RBF = 16
 NUM_POS = 16
 MAX_REL = 32       # PositionalEncodings.max_relative_feature (model_utils.py:607)
+NUM_POS_CLASSES = 2 * MAX_REL + 2   # relative offsets -32..32 within a chain + one class for other chains
 MSG_SCALE = 30.0   # EncLayer/DecLayer ``scale`` (model_utils.py:620,660)
 LN_EPS = 1e-5
 

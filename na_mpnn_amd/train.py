@@ -251,18 +251,34 @@ def _wgrad_many(pairs, x3=None):
 
 class ReverseAdjacency:
     """Edges grouped by the table row they gather (global row b*N + E_idx[b,i,k]) — the transpose of the neighbour
-    gather, built once per step and shared by all per-edge stages' backward passes."""
+    gather, built once per step (namp_train_reverse_adjacency: a counting sort on the device) and shared by all per-edge stages'
+    backward passes."""
 
     def __init__(self, E_idx32):
         B, N, K = E_idx32.shape
         dev = E_idx32.device
-        jflat = (E_idx32.long() + (torch.arange(B, device=dev) * N)[:, None, None]).view(-1)
-        order = torch.argsort(jflat, stable=True)
-        self.edges = order.to(torch.int32).contiguous()
-        counts = torch.bincount(jflat, minlength=B * N)
-        self.offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).to(torch.int32).contiguous()
-        self.jflat = jflat
-        self.G = B * N
+        E_idx32 = E_idx32.contiguous()
+        self.G, self.K, self.N = B * N, K, N
+        self.edges = torch.empty(B * N * K, dtype=torch.int32, device=dev)
+        self.offsets = torch.empty(B * N + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(2 * B * N + B * N * K, dtype=torch.int32, device=dev)
+        hip.check(hip.lib().namp_train_reverse_adjacency(E_idx32.data_ptr(), self.offsets.data_ptr(), self.edges.data_ptr(), ws.data_ptr(),
+                                                         B, N, K, hip.current_stream()), "train_reverse_adjacency")
+        self._E_idx32 = E_idx32
+        self._sel = {}
+
+    def decoder_sel(self, rank32):
+        """uint8 per edge: 1 where the gathered neighbour comes EARLIER in the decoding order (its row was read from the first table).  The same for
+        all decoder layers of a step: computed once per rank tensor."""
+        key = (rank32.data_ptr(), rank32._version)
+        hit = self._sel.get(key)
+        if hit is None:
+            B = self.G // self.N
+            r = rank32.view(B, self.N)
+            rj = torch.gather(r, 1, self._E_idx32.view(B, -1).long()).view(B, self.N, self.K)
+            hit = (rj < r[:, :, None]).to(torch.uint8).contiguous().view(-1)
+            self._sel = {key: hit}
+        return hit
 
     def scatter(self, G1, sel=None):
         """-> sum of G1 rows per gathered table row [G,128] (two outputs when sel, uint8 per edge, is given)."""
@@ -363,9 +379,7 @@ class _EdgeMLP(torch.autograd.Function):
                                         B, N, K, hip.current_stream()), "train_edge_bwd")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
-            r = rank32.view(-1)
-            sel = (r[rev.jflat] < r.repeat_interleave(K)).to(torch.uint8).contiguous()
-            g_Pj0, g_Pj1 = rev.scatter(G1, sel)
+            g_Pj0, g_Pj1 = rev.scatter(G1, rev.decoder_sel(rank32))
         else:
             g_Pj0, g_Pj1 = rev.scatter(G1)
         if mode == ENC_EDGE:
@@ -413,9 +427,7 @@ class _EdgeMLP(torch.autograd.Function):
                                            B, N, K, hip.current_stream()), "train_edge_bwd_dw")
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         if mode == DEC_MSG:
-            r = rank32.view(-1)
-            sel = (r[rev.jflat] < r.repeat_interleave(K)).to(torch.uint8).contiguous()
-            g_Pj0, g_Pj1 = rev.scatter(G1, sel)
+            g_Pj0, g_Pj1 = rev.scatter(G1, rev.decoder_sel(rank32))
         else:
             g_Pj0, g_Pj1 = rev.scatter(G1)
         # the workgroups' partials and the per-tile dL/dPa rows: one reduction launch
@@ -628,29 +640,38 @@ def _edge_embedding_fwd(fp, W18, X, ints, top_k, ref_atom):
 
 
 class _EdgeEmbeddingGrad(torch.autograd.Function):
-    """Identity on y that routes dL/dy into edge_embedding.weight and the positional features E_pos."""
+    """Identity on y that routes dL/dy into edge_embedding.weight and the positional embedding (embeddings.linear weight / bias): the weight
+    gradient of the 5200 -> 128 embedding (namp_train_feat_wgrad) and the positional table gradient (namp_train_pos_grad: the data gradient
+    g . Wedge[:, :16] contracted per relative-position class on chip — no [E,16] tensors, no library GEMM, no one-hot products)."""
 
     @staticmethod
-    def forward(ctx, y, Wedge, E_pos, X18, M18, E_idx):
+    def forward(ctx, y, Wedge, pos_w, pos_b, E_pos, d32, X18, M18, E_idx):
         ctx.x3 = X3
-        ctx.save_for_backward(Wedge, E_pos, X18, M18, E_idx)
+        ctx.save_for_backward(Wedge, E_pos, d32, X18, M18, E_idx)
         return y.view_as(y)
 
     @staticmethod
     def backward(ctx, g_y):
-        Wedge, E_pos, X18, M18, E_idx = ctx.saved_tensors
+        Wedge, E_pos, d32, X18, M18, E_idx = ctx.saved_tensors
         L = hip.lib()
         B, Lr, K = E_idx.shape
+        E = B * Lr * K
         g = g_y.contiguous()
-        n = L.namp_train_feat_wgrad_chunks(B * Lr * K)
+        n = L.namp_train_feat_wgrad_chunks(E)
         part = torch.empty(n, H, Wedge.shape[1], device=g.device)
-        Ep = E_pos.detach().contiguous()
-        tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(B * Lr * K), dtype=torch.int32, device=g.device)
-        hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), Ep.data_ptr(), g.data_ptr(),
+        tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(E), dtype=torch.int32, device=g.device)
+        hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(),
                                           part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
-        g_Epos = (g.view(-1, H) @ Wedge.detach()[:, :spec.NUM_POS]).view_as(E_pos)
-        return None, _reduce(_seg0(part))[0].view(part.shape[1:]), g_Epos, None, None, None
+        Wc = Wedge.detach().contiguous()
+        n2 = L.namp_train_pos_grad_groups(E)
+        part2 = torch.empty(n2, spec.NUM_POS_CLASSES + 1, spec.NUM_POS, device=g.device)
+        hip.check(L.namp_train_pos_grad(g.data_ptr(), Wc.data_ptr(), Wc.stride(0), d32.data_ptr(), part2.data_ptr(), E, hip.current_stream()),
+                  "train_pos_grad")
+        dW, tab = _reduce(_seg0(part), _seg0(part2))
+        tab = tab.view(spec.NUM_POS_CLASSES + 1, spec.NUM_POS)
+        return (None, dW.view(part.shape[1:]), tab[:spec.NUM_POS_CLASSES].t().contiguous(), tab[spec.NUM_POS_CLASSES].contiguous(),
+                None, None, None, None, None)
 
 
 def edge_embedding(model, fd):
@@ -664,17 +685,16 @@ def edge_embedding(model, fd):
     W18 = model.edge_weight18()                               # differentiable expansion when include_pred_na_N = 0
     with torch.no_grad():
         y, E_idx = _edge_embedding_fwd(fp, W18, X, ints, model.k_neighbors, model.atom_dict[model.na_ref_atom])
-    # positional features as a torch expression (PositionalEncodings, na_model_utils.py:537-541) so that autograd
-    # carries dL/dE_pos into embeddings.linear
-    B, Lr, K = E_idx.shape
-    R, ch = fd["R_idx"].long(), fd["chain_labels"].long()
-    j = E_idx.long()
-    bidx = torch.arange(B, device=X.device)[:, None, None]
-    off = R[:, :, None] - R[bidx, j]
-    same = (ch[:, :, None] == ch[bidx, j]).long()
-    d = torch.clip(off + spec.MAX_REL, 0, 2 * spec.MAX_REL) * same + (1 - same) * (2 * spec.MAX_REL + 1)
-    E_pos = _TableRows.apply(fp.embeddings.linear.weight.t(), d) + fp.embeddings.linear.bias     # [B,L,K,16]
-    y = _EdgeEmbeddingGrad.apply(y, W18, E_pos, X18, M18, E_idx)
+        # positional features (PositionalEncodings, na_model_utils.py:537-541): class index and E_pos rows from one launch; their gradient
+        # reaches embeddings.linear through _EdgeEmbeddingGrad
+        B, Lr, K = E_idx.shape
+        pw, pb = fp.embeddings.linear.weight, fp.embeddings.linear.bias
+        d32 = torch.empty(B, Lr, K, dtype=torch.int32, device=X.device)
+        E_pos = torch.empty(B, Lr, K, spec.NUM_POS, device=X.device)
+        hip.check(hip.lib().namp_train_pos_features(ints[2].data_ptr(), ints[3].data_ptr(), E_idx.data_ptr(), pw.detach().contiguous().data_ptr(),
+                                                    pb.detach().contiguous().data_ptr(), d32.data_ptr(), E_pos.data_ptr(), B, Lr, K,
+                                                    hip.current_stream()), "train_pos_features")
+    y = _EdgeEmbeddingGrad.apply(y, W18, pw, pb, E_pos, d32, X18, M18, E_idx)
     return y, E_idx
 
 

@@ -259,6 +259,28 @@ def test_on_chip_backward_matches_fp64_autograd(kind, prec, monkeypatch):
         assert v < bar, (name, v, worst)
 
 
+@pytest.mark.parametrize("B,N,K", [(1, 50, 48), (3, 257, 30), (2, 1500, 48)])
+def test_reverse_adjacency_equals_the_stable_sort(B, N, K):
+    """namp_train_reverse_adjacency (counting sort + per-row rank sort on the device) against torch's stable argsort of the edges by target row;
+    hub rows (every residue lists residue 0: a row with B... N incoming edges, > 64) included."""
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    E_idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)])
+    E_idx[:, :, 0] = 0                                           # a hub
+    E32 = E_idx.to(torch.int32).to(DEV).contiguous()
+    rev = train.ReverseAdjacency(E32)
+    jflat = (E_idx + (torch.arange(B) * N)[:, None, None]).view(-1)
+    order = torch.argsort(jflat, stable=True).to(torch.int32)
+    counts = torch.bincount(jflat, minlength=B * N)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32)
+    assert torch.equal(rev.offsets.cpu(), offsets)
+    assert torch.equal(rev.edges.cpu(), order)
+    rank = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(torch.int32).to(DEV)
+    sel = rev.decoder_sel(rank).cpu()
+    r = rank.cpu().view(-1).long()
+    ref = (r[jflat] < r.repeat_interleave(K)).to(torch.uint8)
+    assert torch.equal(sel, ref)
+
+
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_edge_update_backward(p):
     """_EdgeUpdate (message + dropout3 + residual + LayerNorm3 in one launch each way).  p = 0: against fp64 autograd of the
