@@ -419,6 +419,8 @@ class _EdgeMLP(torch.autograd.Function):
         n = L.namp_train_edge_bwd_dw_groups(B, N, K)
         dWp = torch.empty(n, 2, H, H, device=dev)
         dbp = torch.empty(n, H, device=dev)
+        if mode == ENC_MSG and mask32 is None and mask_attend32 is None:
+            mask32 = torch.ones(B, N, dtype=torch.int32, device=dev)       # "no mask" = all ones (the persistent launch reads one unconditionally)
         hip.check(L.namp_train_edge_bwd_dw(mode, h_E.data_ptr(), E_idx32.data_ptr(), hip.ptr(mask32), hip.ptr(mask_attend32),
                                            hip.ptr(rank32), Pa.data_ptr(), Pj0.data_ptr(), hip.ptr(Pj1), img1.data_ptr(),
                                            img2.data_ptr(), img2t.data_ptr(), img1t.data_ptr(), b2c.data_ptr(), g.data_ptr(),
@@ -1031,7 +1033,9 @@ class FusedAdam(torch.optim.Adam):
     ONE multi-tensor HIP launch over all parameter tensors (namp_train_adam_step; three launches with clipping) instead of the
     foreach kernel chain.  The state is torch's own (`step` / `exp_avg` / `exp_avg_sq` per parameter), so `state_dict()` is the
     reference's checkpoint format (na_run.py:342) and loads into a plain torch.optim.Adam.  Plain Adam only (no amsgrad / weight decay
-    / maximize), fp32 parameters on one HIP device; anything else falls back to torch's step."""
+    / maximize), fp32 parameters on one HIP device; anything else falls back to torch's step.  The step count is read from the state's `step`
+    tensors once per set of tensors and counted on the host afterwards: REPLACE those tensors to change it (as load_state_dict does) — an
+    in-place edit of state["step"] is not seen until they are replaced."""
 
     clip_norm = 0.0            # > 0: clip the global gradient norm to this value inside the step
     last_grad_norm = None      # device tensor [2]: (gradient norm, clip coefficient) of the last clipped step
@@ -1094,9 +1098,16 @@ class FusedAdam(torch.optim.Adam):
                 ring = self._ptr_ring = [torch.empty(4, len(params), dtype=torch.int64).pin_memory() for _ in range(4)]
                 self._ptr_dev = [torch.empty(4, len(params), dtype=torch.int64, device=dev) for _ in range(4)]
                 self._ptr_i = 0
-            self._ptr_i = (self._ptr_i + 1) % 4            # (four staging buffers: a buffer is rewritten four uploads later at the earliest)
+            self._ptr_i = (self._ptr_i + 1) % 4            # (four staging buffers: a buffer is rewritten four uploads later at the earliest ...
+            ev = getattr(self, "_ptr_ev", None)
+            if ev is None or len(ev) != 4:
+                ev = self._ptr_ev = [None] * 4
+            if ev[self._ptr_i] is not None:
+                ev[self._ptr_i].synchronize()              # ... and never before the upload that last read it has completed)
             ring[self._ptr_i].copy_(torch.tensor(rows, dtype=torch.int64))
             self._ptr_dev[self._ptr_i].copy_(ring[self._ptr_i], non_blocking=True)
+            ev[self._ptr_i] = torch.cuda.Event()
+            ev[self._ptr_i].record()
             self._ptrs, self._ptr_key = self._ptr_dev[self._ptr_i], pkey
         ptrs = self._ptrs
         b1, b2 = grp["betas"]

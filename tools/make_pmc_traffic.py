@@ -38,6 +38,16 @@ def cfg5_algorithmic(kernel, prec):
     E, G = 16 * 1500 * 48, 16 * 1500
     row16 = 256 if prec == "bf16" else 512            # G1 row bytes
     base = E * 4 + E // 16 * 512 + 3 * G * 512
+    if "edge_update_bwd_a16" in kernel:                # launch A: h_E + dL/dh_E' rows in, dL/dx rows (fp32) + G2 rows (bf16) out, E_idx, tables
+        return E * (512 + 512 + 512 + 256) + E * 4 + 3 * G * 512
+    if "edge_update_bwd_b16" in kernel:                # launch B: h_E + G2 + dL/dx rows in, dL/dh_E + G1 rows out, E_idx, per-tile sums, tables
+        return E * (512 + 256 + 512 + 512 + 256) + base
+    if "feat_wgrad" in kernel:                         # g_pre rows once, atom frames, E_idx, the 128 chunks' [128 x 5200] partials
+        return E * 512 + G * 18 * 16 + E * 4 + 128 * 128 * 5200 * 4
+    if "pos_grad_kernel" in kernel:
+        return E * 512 + E * 4
+    if "scatter_rows_kernel" in kernel:                # G1 rows once, reverse adjacency, one or two [G,128] outputs
+        return E * row16 + E * 4 + 2 * G * 512
     if "edge_bwd_dw" in kernel:
         acc = "true" in kernel                         # <MODE, [PREC,] ACC, GPA>
         return E * (512 + (512 if acc else 0) + row16 + 512) + base
@@ -52,8 +62,8 @@ def cfg5_section(fetch_db, write_db, prec):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     sec = {}
     for k in sorted(set(f) | set(w)):
-        if not any(t in k for t in ("edge_bwd_dw", "edge_chain_bwd", "wgrad", "scatter_rows", "edge_mlp_x3_persistent", "edge_mlp_bf16_persistent",
-                                    "feat_wgrad", "edge_features")):
+        if not any(t in k for t in ("edge_bwd_dw", "edge_update_bwd_", "edge_chain_bwd", "wgrad", "scatter_rows", "edge_mlp_x3_persistent",
+                                    "edge_mlp_bf16_persistent", "feat_wgrad", "edge_features", "reduce_sum", "pos_grad", "ln_rows")):
             continue
         nbytes = (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024
         e = {"measured_bytes": round(nbytes)}

@@ -1,4 +1,4 @@
-# Round-4 profile: default bench line, rocprofv3 kernel-trace stats (cfg2, cfg3, cfg5 x3 / bf16, featuriser), PMC traffic (cfg2 + cfg5),
+# Round profile set (round 4 on): default bench line, rocprofv3 kernel-trace stats (cfg2, cfg3, cfg5 x3 / bf16, featuriser), PMC traffic (cfg2 + cfg5),
 # issue counters of the cfg3 launches.      gpurun --timeout 3000 -- 'bash tools/profile_round4.sh <tag, e.g. r04d> <git commit>'
 export TMPDIR=/tmp
 TAG=${1:-r04}
@@ -37,3 +37,4 @@ head -c 600 $O/bench_default.json; echo; head -12 $O/train_cfg5_bf16_kernel_stat
 import json; d=json.load(open('$O/pmc_traffic.json'))
 for k in ('cfg5_x3','cfg5_bf16'):
     print(k); [print('  ',n,v) for n,v in d.get(k,{}).items() if 'algorithmic_bytes' in v]"
+python tools/spills.py > $O/register_report.txt
