@@ -483,7 +483,7 @@ def train_bench(args, dev, rank, world, dist):
             t_us = getattr(ev, "self_cuda_time_total", 0.0)
         if t_us > 0:
             kern[ev.key] = (t_us / 1e3, ev.count)
-    ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "edge_bwd_dw", "edge_update_bwd_", "reduce_sum_kernel", "pack_multi", "table_rows", "adam_", "loss_smoothed", "wgrad_kernel", "feat_wgrad", "edge_features",
+    ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "edge_bwd_dw", "edge_update_bwd_", "reduce_sum_kernel", "pack_multi", "pos_grad", "pos_features", "radj_", "adam_", "loss_smoothed", "wgrad_kernel", "feat_wgrad", "edge_features",
                                                                   "edge_mlp_kernel", "edge_mlp_x3_persistent", "edge_mlp_bf16", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
                                                                   "prep_atoms", "wgrad_x3", "wgrad_bf16", "tail_train", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
     total_dev_ms = sum(v[0] for v in kern.values())
