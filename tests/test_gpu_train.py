@@ -281,6 +281,98 @@ def test_reverse_adjacency_equals_the_stable_sort(B, N, K):
     assert torch.equal(sel, ref)
 
 
+def test_reduce_sum_segments_match_torch():
+    """namp_reduce_sum: several segments of different shapes in one launch — [n][M] partials, per-tile rows [G][T][128] -> [G][128], a scalar
+    (Mb = 1) segment and an odd-sized one on the scalar path — against fp64 sums; deterministic (two launches bit-identical)."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(37, 128, 128, generator=g).to(DEV)                 # [n][M]
+    b = torch.randn(301, 3, 128, generator=g).to(DEV)                  # [G][T][128] over T
+    c = torch.randn(1000, 3, generator=g).to(DEV)                      # [G][T] over T, Mb = 1
+    d = torch.randn(5, 7, 33, generator=g).to(DEV)                     # [A][n][33] over n (33 % 4 != 0)
+    segs = [train._seg0(a), (b, 301, 128, 3 * 128, 128, 3), (c, 1000, 1, 3, 1, 3), train._seg1(d)]
+    o1 = train._reduce(*segs)
+    o2 = train._reduce(*segs)
+    refs = [a.double().sum(0).view(1, -1), b.double().sum(1), c.double().sum(1, keepdim=True), d.double().sum(1)]
+    for x, y, r in zip(o1, o2, refs):
+        assert torch.equal(x, y)
+        assert rel(x, r) < 1e-6
+    many = [train._seg0(torch.randn(4 + i, 64, generator=g).to(DEV)) for i in range(19)]      # > 16 segments: two launches
+    for x, (t, *_r) in zip(train._reduce(*many), many):
+        assert rel(x, t.double().sum(0).view(1, -1)) < 1e-6
+
+
+def test_pack_images_equals_the_single_image_launches():
+    """namp_pack_images (one launch over a descriptor table, transposition inside) against namp_pack_image_x3 / _bf16 / _x3_general on the same blocks,
+    byte for byte — including column-sliced views and transposed blocks."""
+    from na_mpnn_amd import hip
+    g = torch.Generator().manual_seed(9)
+    W1 = torch.randn(128, 384, generator=g).to(DEV)
+    Win = torch.randn(512, 128, generator=g).to(DEV)
+    plan = train._PackPlan()
+    blocks = [(W1[:, 128:256], 1, False), (W1[:, 128:256], 1, True), (W1[:, :128], 2, False), (W1[:, 256:], 2, True),
+              (Win, 3, False), (Win, 3, True)]
+    for blk, kind, tr in blocks:
+        plan.register(blk, kind, tr)
+    tok = object()
+    plan.begin_step(tok, torch.device(DEV))
+    L = hip.lib()
+    for blk, kind, tr in blocks:
+        got = plan.lookup(blk, kind, tr, tok)
+        assert got is not None
+        src = blk.t().contiguous() if tr else blk
+        ref = torch.empty(src.numel(), device=DEV)
+        if kind == 1:
+            hip.check(L.namp_pack_image_x3(src.data_ptr(), src.stride(0), 0, ref.data_ptr(), hip.current_stream()), "x3")
+        elif kind == 2:
+            hip.check(L.namp_pack_image_bf16(src.data_ptr(), src.stride(0), 0, ref.data_ptr(), hip.current_stream()), "bf16")
+        else:
+            hip.check(L.namp_pack_image_x3_general(src.data_ptr(), src.shape[1], 0, src.shape[0], src.shape[1], ref.data_ptr(), hip.current_stream()), "x3g")
+        nbytes = got.numel() * 4
+        assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8)[:nbytes]), (kind, tr)
+    plan.begin_step(object(), torch.device(DEV))                        # entries nobody asked for during a step are forgotten
+    plan.begin_step(object(), torch.device(DEV))
+    assert not plan.entries
+
+
+def test_positional_features_and_gradients_match_torch():
+    """namp_train_pos_features / namp_train_pos_grad against the torch expression of PositionalEncodings (na_model_utils.py:537-541) and fp64 autograd
+    of E_pos . (g Wedge[:, :16])."""
+    from na_mpnn_amd import hip
+    B, N, K = 2, 211, 30
+    g = torch.Generator().manual_seed(17)
+    R = torch.cumsum(torch.randint(1, 4, (B, N), generator=g), 1).to(torch.int32)
+    ch = (torch.arange(N)[None, :] // 60 + torch.arange(B)[:, None]).to(torch.int32)
+    E_idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)])
+    W = torch.randn(16, 66, generator=g)
+    b = torch.randn(16, generator=g)
+    Wedge = torch.randn(128, 5200, generator=g) * 0.05
+    gy = torch.randn(B, N, K, 128, generator=g)
+    bidx = torch.arange(B)[:, None, None]
+    off = R.long()[:, :, None] - R.long()[bidx, E_idx]
+    same = (ch[:, :, None] == ch[bidx, E_idx]).long()
+    d_ref = torch.clip(off + 32, 0, 64) * same + (1 - same) * 65
+    Wd, bd = W.double().requires_grad_(), b.double().requires_grad_()
+    with torch.enable_grad():
+        E_pos_ref = Wd.t()[d_ref] + bd
+        (E_pos_ref * (gy.double().view(-1, 128) @ Wedge.double()[:, :16]).view(B, N, K, 16)).sum().backward()
+    L = hip.lib()
+    dv = lambda t: t.to(DEV).contiguous()
+    d32 = torch.empty(B, N, K, dtype=torch.int32, device=DEV)
+    E_pos = torch.empty(B, N, K, 16, device=DEV)
+    Rd, cd, Ed, Wv, bv, Wev, gv = dv(R), dv(ch), dv(E_idx.to(torch.int32)), dv(W), dv(b), dv(Wedge), dv(gy)
+    hip.check(L.namp_train_pos_features(Rd.data_ptr(), cd.data_ptr(), Ed.data_ptr(), Wv.data_ptr(), bv.data_ptr(), d32.data_ptr(), E_pos.data_ptr(),
+                                        B, N, K, hip.current_stream()), "pos_features")
+    assert torch.equal(d32.cpu().long(), d_ref)
+    assert rel(E_pos, E_pos_ref) < 1e-6
+    E = B * N * K
+    n = L.namp_train_pos_grad_groups(E)
+    part = torch.empty(n, 67, 16, device=DEV)
+    hip.check(L.namp_train_pos_grad(gv.data_ptr(), Wev.data_ptr(), Wev.stride(0), d32.data_ptr(), part.data_ptr(), E, hip.current_stream()), "pos_grad")
+    tab = part.double().sum(0)
+    assert rel(tab[:66].t(), Wd.grad) < 2e-5
+    assert rel(tab[66], bd.grad) < 2e-5
+
+
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_edge_update_backward(p):
     """_EdgeUpdate (message + dropout3 + residual + LayerNorm3 in one launch each way).  p = 0: against fp64 autograd of the
