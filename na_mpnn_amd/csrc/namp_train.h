@@ -1569,32 +1569,56 @@ static __global__ __launch_bounds__(256) void pos_features_kernel(const int32_t*
 }
 
 #define POS_GRAD_WAVES 8
+// sum over the 16 lanes of a DPP row, total in lane 15 (row_shr 8, 4, 2, 1 with zeros shifted in)
+template <int CTRL>
+__device__ __forceinline__ float pos_dpp_add(const float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float pos_row_sum15(float v) {
+  v = pos_dpp_add<0x118>(v); v = pos_dpp_add<0x114>(v); v = pos_dpp_add<0x112>(v); v = pos_dpp_add<0x111>(v);
+  return v;
+}
+// A wave takes 16 edge rows at a time: the rows in the register-chain layout (coalesced 16-byte loads), gp = g . Wedge[:, :16] as 32 exact-fp32
+// v_mfma_f32_16x16x4 against fragments of the 16 positional columns held in registers — lane (m, g) ends up with gp[row m][4g .. 4g+3] —, then
+// LDS adds into the wave's PRIVATE table at the row's class (ds_add_f32; lanes of one instruction that meet at an address are served in lane
+// order, instructions in program order: deterministic) and one add per tile into the bias row after a DPP sum over the 16 rows.
+// (First form, one row per wave-iteration with broadcast loads: 362 us per cfg5 launch, 1.6 TB/s — 16 lanes fetched the same 16 bytes.)
 static __global__ __launch_bounds__(64 * POS_GRAD_WAVES) void pos_grad_kernel(const float* __restrict__ g, const float* __restrict__ Wedge, int ld,
                                                                        const int32_t* __restrict__ d, float* __restrict__ part, long E) {
   __shared__ float tab[POS_GRAD_WAVES][(POS_CLASSES + 1) * POS_DIM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = lane & 15, pt = lane >> 4;
+  const int m = lane & 15, gq = lane >> 4;
   for (int q = lane; q < (POS_CLASSES + 1) * POS_DIM; q += 64) tab[wave][q] = 0.f;
-  float w[32];
+  f4 wf[8];                                                       // A fragments: W^T[n = m][16 tk + 4 gq + r] = Wedge[16 tk + 4 gq + r][m]
 #pragma unroll
-  for (int c = 0; c < 32; ++c) w[c] = Wedge[(long)(32 * pt + c) * ld + k];
+  for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wf[tk][r] = Wedge[(long)(16 * tk + 4 * gq + r) * ld + m];
+  const long ntile = (E + 15) / 16;
   const long nw = (long)gridDim.x * POS_GRAD_WAVES;
-  for (long e = (long)blockIdx.x * POS_GRAD_WAVES + wave; e < E; e += nw) {
-    const f4* row = (const f4*)(g + e * NAMP_H + 32 * pt);
-    float s0 = 0.f, s1 = 0.f;
+  float* tw = tab[wave];
+  for (long tile = (long)blockIdx.x * POS_GRAD_WAVES + wave; tile < ntile; tile += nw) {
+    const long e_raw = tile * 16 + m;
+    const bool valid = e_raw < E;
+    const long e = valid ? e_raw : E - 1;
+    const float* row = g + e * NAMP_H + 4 * gq;
+    f4 x[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f4 v = row[q];
-      s0 = fmaf(v.x, w[4 * q], s0); s1 = fmaf(v.y, w[4 * q + 1], s1);
-      s0 = fmaf(v.z, w[4 * q + 2], s0); s1 = fmaf(v.w, w[4 * q + 3], s1);
-    }
-    float s = s0 + s1;
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    for (int tk = 0; tk < 8; ++tk) x[tk] = *(const f4*)(row + 16 * tk);
     const int cls = d[e];
-    if (pt == 0) {
-      tab[wave][cls * POS_DIM + k] += s;
-      tab[wave][POS_CLASSES * POS_DIM + k] += s;
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tk = 0; tk < 8; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma4(wf[tk][r], x[tk][r], acc);
+    if (!valid) acc = (f4){0.f, 0.f, 0.f, 0.f};
+    float* dst = tw + cls * POS_DIM + 4 * gq;
+    atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+    f4 s = acc;
+    s.x = pos_row_sum15(s.x); s.y = pos_row_sum15(s.y); s.z = pos_row_sum15(s.z); s.w = pos_row_sum15(s.w);
+    if (m == 15) {
+      float* db = tw + POS_CLASSES * POS_DIM + 4 * gq;
+      db[0] += s.x; db[1] += s.y; db[2] += s.z; db[3] += s.w;
     }
   }
   __syncthreads();
