@@ -464,6 +464,7 @@ int namp_train_wgrad_chunks(long rows);
 int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long rows, float* dW_part, float* db_part, void* stream);
 int namp_train_feat_wgrad_chunks(long edges);
 long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_ws (atom-presence words per 64-edge tile) */
+/* (round 5) M18 == NULL: X18 is the PACKED atom array [B*L][18][4] = (x, y, z, mask) — one 16-byte request per gathered atom; split-bf16 / bf16 only. */
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
                           float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream);
 

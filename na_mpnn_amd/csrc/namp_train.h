@@ -657,7 +657,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const __bf16* __restric
 // tile_presence_kernel: for every 64-edge tile, which of the 18 atoms occur on the residue side (word 0) and on the
 // neighbour side (word 1) of any of its edges.  An (a, b) block can only be non-zero on a tile that has a on one side and
 // b on the other; feat_wgrad_kernel reads these two words instead of voting across the workgroup for every tile.
-static __global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restrict__ M18, const int32_t* __restrict__ E_idx, long E,
+// (ms: element stride between consecutive atoms' mask values — 1 for M18 [G][18], 4 for the mask lane of the packed [G][18][4] array)
+static __global__ __launch_bounds__(256) void tile_presence_kernel(const float* __restrict__ M18, int ms, const int32_t* __restrict__ E_idx, long E,
                                                            int L, int K, int32_t* __restrict__ pres) {
   const int lane = threadIdx.x & 63;
   const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -668,8 +669,8 @@ static __global__ __launch_bounds__(256) void tile_presence_kernel(const float* 
     const int node = (int)(el / K);
     const int j = node - node % L + E_idx[el];
     for (int q = 0; q < 18; ++q) {
-      if (M18[(long)node * 18 + q] != 0.f) bi |= 1u << q;
-      if (M18[(long)j * 18 + q] != 0.f) bj |= 1u << q;
+      if (M18[((long)node * 18 + q) * ms] != 0.f) bi |= 1u << q;
+      if (M18[((long)j * 18 + q) * ms] != 0.f) bj |= 1u << q;
     }
   }
 #pragma unroll
@@ -810,7 +811,10 @@ static __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __r
 #define FEATW_WG_BLOCKS (4 * FEATW_NBW)
 #define FEATW_GRID_X ((FEATW_BLOCKS + FEATW_WG_BLOCKS - 1) / FEATW_WG_BLOCKS)
 
-template <bool MID>      // MID = false: hi . hi products only (mixed-precision mode)
+// PK: X18 is the PACKED atom array [G][18][4] = (x, y, z, mask) and M18 is unused: an atom of the gathered neighbour is then ONE 16-byte request per
+// lane where the separate arrays take four scattered 4-byte ones — with every lane on its own cache line, those requests (16 per lane and tile,
+// 1,024 line requests per wave) were what the launch waited for: removing them took 30 % off it, requesting them a tile ahead 2 % (profiles/r05c).
+template <bool MID, bool PK>      // MID = false: hi . hi products only (mixed-precision mode)
 __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                             const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
                                                             const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
@@ -850,13 +854,70 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
   const int sc = tid & 127, sh = tid >> 7;                     // staging: channel, edge half (32 edges) of this thread
   float* dw = &dsc[wave][0][0];
   bool staged = false;
-  for (long e0 = e_begin; e0 < e_end; e0 += FEATW_TILE) {
-    const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE)]);
-    const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane(pres[2 * (e0 / FEATW_TILE) + 1]);
-    bool any_live = false;
+  // Round 5 (profiles/r05c): what bounded this launch was neither its products, nor its exponentials, nor the staging of g_pre (each removed:
+  // +-2 %) but two dependent round trips per tile in front of everything else — the tile's presence words (a load + v_readfirstlane: the wave
+  // waits for memory before it knows whether the tile is live, 18,000 / 128 times per workgroup, skipped tiles included) and the neighbour index
+  // -> coordinates chain of the distances (removed: -30 %).  Now: the presence words of 64 tiles sit one per lane and are handed out by
+  // v_readlane; the next live tile's coordinates and the one after's neighbour index are requested a tile ahead.
+  const long t_begin = e_begin / FEATW_TILE, t_end = (e_end + FEATW_TILE - 1) / FEATW_TILE;      // (chunks are whole tiles)
+  long pw_base = -1;
+  int pw_i = 0, pw_j = 0;
+  auto presence = [&](const long t, uint32_t& pi, uint32_t& pj) {
+    if (t - pw_base >= 64 || pw_base < 0) {
+      pw_base = t;
+      const long tl = t + lane < t_end ? t + lane : t_end - 1;
+      pw_i = pres[2 * tl]; pw_j = pres[2 * tl + 1];
+    }
+    pi = (uint32_t)__builtin_amdgcn_readlane(pw_i, (int)(t - pw_base));
+    pj = (uint32_t)__builtin_amdgcn_readlane(pw_j, (int)(t - pw_base));
+  };
+  auto next_live = [&](long t, uint32_t& pi, uint32_t& pj) {        // first tile at or behind t with a live block of this workgroup (t_end: none)
+    for (; t < t_end; ++t) {
+      presence(t, pi, pj);
+      bool any_live = false;
 #pragma unroll
-    for (int q = 0; q < FEATW_WG_BLOCKS; ++q) any_live = any_live || block_live(wg_blk0 + q, pi, pj);
-    if (!any_live) continue;
+      for (int q = 0; q < FEATW_WG_BLOCKS; ++q) any_live = any_live || block_live(wg_blk0 + q, pi, pj);
+      if (any_live) break;
+    }
+    return t;
+  };
+  struct Coords { float xi[FEATW_NBW][3], xj[FEATW_NBW][3], mi[FEATW_NBW], mj[FEATW_NBW]; };
+  auto edge_of = [&](const long t) { const long el = t * FEATW_TILE + lane; return el < e_end ? el : e_begin; };
+  auto req_coords = [&](Coords& c, const long t, const int jrel) {   // (dead blocks included: no branch around the requests)
+    const long ec = edge_of(t);
+    const int node = (int)(ec / K);
+    const int j = node - node % L + jrel;
+#pragma unroll
+    for (int q = 0; q < FEATW_NBW; ++q) {
+      if constexpr (PK) {
+        const f4 vi = *(const f4*)(X18 + ((long)node * 18 + pa[q]) * 4), vj = *(const f4*)(X18 + ((long)j * 18 + pb[q]) * 4);
+        c.xi[q][0] = vi.x; c.xi[q][1] = vi.y; c.xi[q][2] = vi.z; c.mi[q] = vi.w;
+        c.xj[q][0] = vj.x; c.xj[q][1] = vj.y; c.xj[q][2] = vj.z; c.mj[q] = vj.w;
+      } else {
+        const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
+        const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) { c.xi[q][cc] = xi[cc]; c.xj[q][cc] = xj[cc]; }
+        c.mi[q] = M18[(long)node * 18 + pa[q]]; c.mj[q] = M18[(long)j * 18 + pb[q]];
+      }
+    }
+  };
+  uint32_t pi0, pj0, pi1, pj1, pi2, pj2;
+  long t0 = next_live(t_begin, pi0, pj0);
+  long t1 = t0 < t_end ? next_live(t0 + 1, pi1, pj1) : t_end;
+  long t2 = t1 < t_end ? next_live(t1 + 1, pi2, pj2) : t_end;
+  Coords c0, c1;
+  int j1 = 0, j2 = 0;
+  if (t0 < t_end) {
+    req_coords(c0, t0, E_idx[edge_of(t0)]);
+    if (t1 < t_end) j1 = E_idx[edge_of(t1)];
+  }
+  for (; t0 < t_end; ) {
+    const long e0 = t0 * FEATW_TILE;
+    const uint32_t pi = pi0, pj = pj0;
+    // a tile ahead: the next live tile's coordinates (its neighbour index was requested an iteration ago), the one after's neighbour index
+    if (t1 < t_end) req_coords(c1, t1, j1);
+    if (t2 < t_end) j2 = E_idx[edge_of(t2)];
     bool live[FEATW_NBW], wave_live = false;
 #pragma unroll
     for (int q = 0; q < FEATW_NBW; ++q) { live[q] = block_live(blk0 + q, pi, pj); wave_live = wave_live || live[q]; }
@@ -894,24 +955,11 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
     }
     // this lane's edge of the tile: scaled distances of the wave's atom pairs (masked pairs -> "infinitely far": RBF = 0)
     if (wave_live) {
-      const long el = e0 + lane;
-      const bool eok = el < e_end;
-      const long ec = eok ? el : e_begin;
-      const int node = (int)(ec / K);
-      const int j = node - node % L + E_idx[ec];
-      float xi_[FEATW_NBW][3], xj_[FEATW_NBW][3], mi_[FEATW_NBW], mj_[FEATW_NBW];
-#pragma unroll
-      for (int q = 0; q < FEATW_NBW; ++q) {                    // every block's requests first (dead blocks included), then the arithmetic
-        const float* xi = X18 + ((long)node * 18 + pa[q]) * 3;
-        const float* xj = X18 + ((long)j * 18 + pb[q]) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { xi_[q][c] = xi[c]; xj_[q][c] = xj[c]; }
-        mi_[q] = M18[(long)node * 18 + pa[q]]; mj_[q] = M18[(long)j * 18 + pb[q]];
-      }
+      const bool eok = e0 + lane < e_end;
 #pragma unroll
       for (int q = 0; q < FEATW_NBW; ++q) {
-        const float dx = xi_[q][0] - xj_[q][0], dy = xi_[q][1] - xj_[q][1], dz = xi_[q][2] - xj_[q][2];
-        dw[q * FEATW_TILE + lane] = (eok && mi_[q] * mj_[q] != 0.f) ? C * sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
+        const float dx = c0.xi[q][0] - c0.xj[q][0], dy = c0.xi[q][1] - c0.xj[q][1], dz = c0.xi[q][2] - c0.xj[q][2];
+        dw[q * FEATW_TILE + lane] = (eok && c0.mi[q] * c0.mj[q] != 0.f) ? C * sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
       }
     }
     __syncthreads();
@@ -970,6 +1018,11 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
         }
       }
     }
+    // rotate the look-ahead
+    c0 = c1; j1 = j2;
+    t0 = t1; pi0 = pi1; pj0 = pj1;
+    t1 = t2; pi1 = pi2; pj1 = pj2;
+    t2 = t1 < t_end ? next_live(t1 + 1, pi2, pj2) : t_end;
   }
   float* out = dW_part + (long)blockIdx.y * NAMP_H * FEATW_COLS;
 #pragma unroll

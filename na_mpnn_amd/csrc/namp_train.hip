@@ -486,7 +486,10 @@ long namp_train_feat_wgrad_ws_ints(long edges) { return edges <= 0 ? 0 : 2 * ((e
 int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
                           float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream) {
   if (!tile_ws) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null tile workspace (namp_train_feat_wgrad_ws_ints int32s)");
-  REQUIRE_PTR(X18); REQUIRE_PTR(M18); REQUIRE_PTR(E_pos); REQUIRE_PTR(g_pre); REQUIRE_PTR(dW_part);
+  REQUIRE_PTR(X18); REQUIRE_PTR(E_pos); REQUIRE_PTR(g_pre); REQUIRE_PTR(dW_part);
+  const bool packed = (M18 == nullptr);            // X18 = [G][18][4] (x, y, z, mask): split-bf16 / bf16 launches only
+  REQUIRE(!packed || x3 != 0, "namp_train_feat_wgrad: the exact-fp32 launch takes X18 [G][18][3] and M18 [G][18] (M18 = NULL means the packed form)");
+  REQUIRE(packed || aligned16(M18), "namp_train_feat_wgrad: 'M18' is not 16-byte aligned");
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null E_idx");
   REQUIRE(B >= 1 && L >= 1 && K >= 1 && K <= L, "namp_train_feat_wgrad: bad dims B=%d L=%d K=%d", B, L, K);
   const long E = (long)B * L * K;
@@ -494,14 +497,13 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   long per = (E + nchunk - 1) / nchunk;
   per = (per + FEATW_TILE - 1) / FEATW_TILE * FEATW_TILE;
   const long ntile = (E + FEATW_TILE - 1) / FEATW_TILE;
-  hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M18, E_idx, E, L, K,
-                     tile_ws);
-  if (x3 == 2)            // mixed precision: plain bf16 products
-    hipLaunchKernelGGL(feat_wgrad_x3_kernel<false>, dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
-                       tile_ws, E, per, L, K, dW_part);
-  else if (x3)
-    hipLaunchKernelGGL(feat_wgrad_x3_kernel<true>, dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
-                       tile_ws, E, per, L, K, dW_part);
+  hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, packed ? X18 + 3 : M18,
+                     packed ? 4 : 1, E_idx, E, L, K, tile_ws);
+#define NAMP_FEATW(MID_, PK_) hipLaunchKernelGGL((feat_wgrad_x3_kernel<MID_, PK_>), dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, \
+                                                 M18, E_idx, E_pos, g_pre, tile_ws, E, per, L, K, dW_part)
+  if (x3 == 2) { if (packed) NAMP_FEATW(false, true); else NAMP_FEATW(false, false); }        // mixed precision: plain bf16 products
+  else if (x3) { if (packed) NAMP_FEATW(true, true); else NAMP_FEATW(true, false); }
+#undef NAMP_FEATW
   else
     hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,
                        tile_ws, E, per, L, K, dW_part);

@@ -662,7 +662,12 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         n = L.namp_train_feat_wgrad_chunks(E)
         part = torch.empty(n, H, Wedge.shape[1], device=g.device)
         tws = torch.empty(L.namp_train_feat_wgrad_ws_ints(E), dtype=torch.int32, device=g.device)
-        hip.check(L.namp_train_feat_wgrad(X18.data_ptr(), M18.data_ptr(), E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(),
+        if int(ctx.x3):                                   # packed atoms (x, y, z, mask): one 16-byte request per gathered atom
+            XM = torch.cat((X18, M18.unsqueeze(-1)), -1).contiguous()
+            xp, mp = XM.data_ptr(), None
+        else:
+            xp, mp = X18.data_ptr(), M18.data_ptr()
+        hip.check(L.namp_train_feat_wgrad(xp, mp, E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(),
                                           part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
         Wc = Wedge.detach().contiguous()
