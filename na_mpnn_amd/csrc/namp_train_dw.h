@@ -39,6 +39,7 @@ struct EdgeBwdDwArgs {
 #define DW_ARR (128 * DW_ROWB)                   // one staged plane: 16 KiB
 #define DW_STAGE_BYTES (4 * DW_ARR)              // G_hi, G_mid, A_hi, A_mid (bf16 products use planes 0 and 2)
 #define DW_LDS (2 * DW_SLOT_BYTES + DW_STAGE_BYTES + 512)
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 
 // workgroup barrier that waits for LDS traffic only: vector-memory requests stay in flight across it (__syncthreads() drains them too)
 __device__ __forceinline__ void dw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -49,12 +50,17 @@ __device__ __forceinline__ void dw_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // chunk) then covers all 64 banks exactly once (tests/test_layout_sim.py).
 // Ablation switches for tools/dw_time.py (never defined in the shipped build): DW_EXP_NOSTAGE / NOCONTRACT / NOGEMM / NOGELU / NOSTORE / NOLOAD
 // drop the staging writes, the contraction, the chain products, the GELU evaluations, the row stores, the per-round row loads.
+// Split-bf16 (X3: two planes per value), round 5: rows m and m ^ 1 of a channel are neighbours in the plane (2 bytes each) and live in neighbouring
+// lanes: the even lane of a pair takes components 0, 1 of BOTH rows, the odd lane components 2, 3 (two DPP quad_perm [1,0,3,2] moves each way), so
+// that a value pair goes out as one v_cvt_pk_bf16_f32 + ds_write_b32 — half the LDS write instructions: -4 % on the ring kernels (4.54 -> 4.35 ms
+// per three cfg5 launches).  The one-plane bf16 form keeps single values: paired, it measured the same and cost edge_bwd_dw16_kernel its last registers.
 template <bool X3>
 __device__ __forceinline__ void dw_stage(char* base, const f4 (&v)[8], const int wave, const int m, const int g) {
 #ifdef DW_EXP_NOSTAGE
   return;
 #endif
   const int chunkv = 2 * wave + (m >> 3);
+  if constexpr (!X3) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int chl = 4 * g + r;
@@ -65,8 +71,26 @@ __device__ __forceinline__ void dw_stage(char* base, const f4 (&v)[8], const int
       const float val = v[t][r];
       const __bf16 hi = (__bf16)val;
       *(__bf16*)(p + t * 16 * DW_ROWB) = hi;
-      if (X3) *(__bf16*)(p + DW_ARR + t * 16 * DW_ROWB) = (__bf16)(val - (float)hi);
     }
+  }
+  } else {
+  const bool odd = (m & 1) != 0;
+  const int c0 = 4 * g + (odd ? 2 : 0);                 // this lane's two channels (within a tile) of the row pair (m & ~1, m | 1)
+  const int f = (c0 >> 1) & 7;                          // same swizzle for c0 and c0 + 1
+  char* p = base + c0 * DW_ROWB + ((chunkv ^ f) << 4) + ((m & 6) << 1);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float s0 = odd ? v[t][0] : v[t][2], s1 = odd ? v[t][1] : v[t][3];          // what the partner lane packs
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, true));
+    const float lo0 = odd ? r0 : v[t][0], hi0 = odd ? v[t][2] : r0;                  // (row m & ~1, row m | 1) of channel c0
+    const float lo1 = odd ? r1 : v[t][1], hi1 = odd ? v[t][3] : r1;                  // ... of channel c0 + 1
+    const bf2 a = (bf2){(__bf16)lo0, (__bf16)hi0}, b = (bf2){(__bf16)lo1, (__bf16)hi1};
+    *(bf2*)(p + t * 16 * DW_ROWB) = a;
+    *(bf2*)(p + DW_ROWB + t * 16 * DW_ROWB) = b;
+    *(bf2*)(p + DW_ARR + t * 16 * DW_ROWB) = (bf2){(__bf16)(lo0 - (float)a[0]), (__bf16)(hi0 - (float)a[1])};
+    *(bf2*)(p + DW_ARR + DW_ROWB + t * 16 * DW_ROWB) = (bf2){(__bf16)(lo1 - (float)b[0]), (__bf16)(hi1 - (float)b[1])};
+  }
   }
 }
 
@@ -515,7 +539,6 @@ __device__ __forceinline__ f4 dw_gelu_split4_bf16(f4& z) {
 }
 
 // dw_stage<false> from a tile kept as packed bf16 pairs: h[2t + (r >> 1)][r & 1] = bf16(v[t][r])
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dw_stage_packed(char* base, const bf2 (&h)[16], const int wave, const int m, const int g) {
 #ifdef DW_EXP_NOSTAGE
   return;
