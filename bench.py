@@ -1094,6 +1094,7 @@ def main():
                     help="timed steps (default per workload; cfg2: 500 = 0.25 s — a 20-50-step region reads 4-10 %% high: ~1 ms of fixed start / drain cost)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20 for cfg2, 5 otherwise)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--specificity", action="store_true", help="with --workload cfg1: the specificity-mode call (cfg1s: batch_size 30, T 0.6, 389 residues)")
     ap.add_argument("--precision", choices=["x3", "fp32", "bf16"], default=None,
                     help="per-edge GEMM evaluation of the headline: default fp32 for cfg2 (exact fp32 MFMA, BASELINE configs[1]; the "
                          "x3 evaluation is timed beside it), bf16 for cfg3 (BASELINE configs[2]); x3 = split-bf16 products")
@@ -1177,7 +1178,7 @@ def main():
             dist.destroy_process_group()
 
     if args.workload == "cfg1":
-        return finish(design_bench(args, dev, rank, world, dist))
+        return finish(design_bench(args, dev, rank, world, dist, specificity=bool(getattr(args, "specificity", False))))
     if args.workload == "cfg4":
         args.warmup = min(args.warmup, 1)
         return finish(split_bench(args, dev, rank, world, dist))
