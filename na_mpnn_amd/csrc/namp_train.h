@@ -1113,7 +1113,20 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   const int beg = rev_off[j], end = rev_off[j + 1];
   const int half = lane >> 5, c4 = lane & 31;                 // two edges per step, 32 lanes x float4 each
   f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int p = beg + half; p < end; p += 2) {
+  // four steps' edge numbers, then their four rows (and selectors), are requested together: the loop was two dependent round trips per step
+  int p = beg + half;
+  for (; p + 6 < end; p += 8) {
+    int e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = rev_edge[p + 2 * u];
+    f4 v[4];
+    bool first[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = ld_row4<BF>(G1, (long)e[u] * NAMP_H + 4 * c4); first[u] = !sel || sel[e[u]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { if (first[u]) s0 += v[u]; else s1 += v[u]; }
+  }
+  for (; p < end; p += 2) {
     const int e = rev_edge[p];
     const f4 v = ld_row4<BF>(G1, (long)e * NAMP_H + 4 * c4);
     if (!sel || sel[e]) s0 += v; else s1 += v;
