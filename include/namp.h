@@ -504,6 +504,14 @@ int namp_train_pos_grad(const float* g, const float* Wedge, int ld, const int32_
  * order (= a stable sort of the edges by target row).  ws: 2*B*N + B*N*K int32 of scratch. */
 int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t* edges, int32_t* ws, int B, int N, int K, void* stream);
 
+/* Two residue-level reductions of the training step (round 5; per-workgroup partials, groups = namp_train_rows_groups(rows), add with namp_reduce_sum):
+ *   namp_train_class_sums: part[groups][nclass][128] = per-class sums of the rows g [rows][128] by idx [rows] (nclass <= 64; rows with idx outside
+ *     [0, nclass) are skipped) — the gradient of a few-row embedding lookup: W_s (na_model_utils.py:626) and node_embedding (:586).
+ *   namp_train_wcolsum:    part[groups][128] = sum_rows g[row][:] * w[row] — db3 of a message stage with its third layer behind the K-sum. */
+int namp_train_rows_groups(long rows);
+int namp_train_class_sums(const float* g, const int32_t* idx, int nclass, long rows, float* part, void* stream);
+int namp_train_wcolsum(const float* g, const float* w, long rows, float* part, void* stream);
+
 /* Sums over partials, up to 16 segments in ONE launch (round 5): dst[a * Mb + b] = sum_{i < n} src[a * sa + i * sn + b] for a < A, b < Mb (element
  * strides; fp32).  Covers the reductions behind the training launches — [n][M] partials of weight gradients (A = 1, sa = 0, sn = M), per-tile rows
  * [G][T][128] -> [G][128] (A = G, sa = T * 128, sn = 128) — which were ~100 stock reduction launches per cfg5 step.  Deterministic (fixed order). */

@@ -1758,4 +1758,50 @@ static __global__ __launch_bounds__(256) void radj_sort_kernel(const int32_t* __
     if (base + lane < n) out[off + cnt] = mine;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Two small residue-level reductions of the training step that were stock launches (round 5):
+//   class_sums_kernel:  part[wg][cls][c] = sum over the workgroup's rows with idx[row] == cls of g[row][c]   (c < 128, cls < nclass <= 64)
+//     — the gradient of an embedding-table lookup with FEW rows (W_s: 33 tokens, node_embedding: 6 polymer types; na_model_utils.py:586-599);
+//     the stock embedding backward scatters 24,000 rows into those few with atomics (119 us), the one-hot GEMM form is a library launch.
+//     A wave owns a private [nclass][128] table in LDS and adds its rows in order (plain read-modify-write: deterministic).
+//   wcolsum_kernel:     part[wg][c] = sum over the workgroup's rows of g[row][c] * w[row]                    — db3 of the hoisted layer 3.
+// ------------------------------------------------------------------------------------------
+#define CLASS_SUMS_MAX 64
+static __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, int nclass, long rows,
+                                                         float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float cs_tab[];     // [4 waves][nclass][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* tw = cs_tab + (long)wave * nclass * NAMP_H;
+  for (int q = lane; q < nclass * NAMP_H; q += 64) tw[q] = 0.f;
+  const long nw = (long)gridDim.x * 4;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += nw) {
+    const int cls = __builtin_amdgcn_readfirstlane(idx[r]);
+    const float2 v = *(const float2*)(g + r * NAMP_H + 2 * lane);
+    if (cls >= 0 && cls < nclass) {
+      float2* d = (float2*)(tw + cls * NAMP_H + 2 * lane);
+      float2 o = *d; o.x += v.x; o.y += v.y; *d = o;
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < nclass * NAMP_H; q += 256) {
+    const float s_ = (cs_tab[q] + cs_tab[nclass * NAMP_H + q]) + (cs_tab[2 * nclass * NAMP_H + q] + cs_tab[3 * nclass * NAMP_H + q]);
+    part[(long)blockIdx.x * nclass * NAMP_H + q] = s_;
+  }
+}
+
+static __global__ __launch_bounds__(256) void wcolsum_kernel(const float* __restrict__ g, const float* __restrict__ w, long rows, float* __restrict__ part) {
+  __shared__ float red[4][NAMP_H];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2 acc = make_float2(0.f, 0.f);
+  const long nw = (long)gridDim.x * 4;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += nw) {
+    const float2 v = *(const float2*)(g + r * NAMP_H + 2 * lane);
+    const float wr = w[r];
+    acc.x = fmaf(v.x, wr, acc.x); acc.y = fmaf(v.y, wr, acc.y);
+  }
+  red[wave][2 * lane] = acc.x; red[wave][2 * lane + 1] = acc.y;
+  __syncthreads();
+  if (tid < NAMP_H) part[(long)blockIdx.x * NAMP_H + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
 #endif  // NAMP_TRAIN_EDGE_ONLY

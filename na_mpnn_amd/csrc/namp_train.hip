@@ -423,6 +423,36 @@ int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t
   return NAMP_OK;
 }
 
+int namp_train_rows_groups(long rows) {
+  if (rows <= 0) return 0;
+  long n = (rows + 63) / 64;               // >= 16 rows per wave
+  if (n > 256) n = 256;
+  return (int)n;
+}
+
+int namp_train_class_sums(const float* g, const int32_t* idx, int nclass, long rows, float* part, void* stream) {
+  REQUIRE_PTR(g); REQUIRE_PTR(part);
+  if (!idx) return fail(NAMP_EINVAL, "namp_train_class_sums: null class index");
+  REQUIRE(nclass >= 1 && nclass <= CLASS_SUMS_MAX && rows >= 1, "namp_train_class_sums: nclass=%d (1..%d) rows=%ld", nclass, CLASS_SUMS_MAX, rows);
+  static std::once_flag once;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [] { err = hipFuncSetAttribute((const void*)class_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CLASS_SUMS_MAX * NAMP_H * 4); });
+  if (err != hipSuccess) return fail(NAMP_ELAUNCH, "hipFuncSetAttribute(class_sums): %s", hipGetErrorString(err));
+  hipLaunchKernelGGL(class_sums_kernel, dim3(namp_train_rows_groups(rows)), dim3(256), (size_t)4 * nclass * NAMP_H * 4, (hipStream_t)stream, g, idx, nclass,
+                     rows, part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_wcolsum(const float* g, const float* w, long rows, float* part, void* stream) {
+  REQUIRE_PTR(g); REQUIRE_PTR(part);
+  if (!w) return fail(NAMP_EINVAL, "namp_train_wcolsum: null row weights");
+  REQUIRE(rows >= 1, "namp_train_wcolsum: rows=%ld", rows);
+  hipLaunchKernelGGL(wcolsum_kernel, dim3(namp_train_rows_groups(rows)), dim3(256), 0, (hipStream_t)stream, g, w, rows, part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_train_wgrad_chunks(long rows) {
   if (rows <= 0) return 0;
   long n = (rows + 511) / 512;             // >= 512 rows (32 MFMA steps) per workgroup, <= 2 workgroups per CU (the split-bf16

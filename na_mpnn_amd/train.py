@@ -120,7 +120,7 @@ class _PackPlan:
 _PLAN = _PackPlan()
 
 
-def _image(block, x3=None, transposed=False, step=None):
+def _image(block, x3=None, transposed=False, step=None, plan=True):
     """Fragment image (fp32, or x3 / bf16) of a [128 x 128] block given as a (possibly column-sliced) view of an nn.Linear
     weight (or of its transpose).  x3 None: the module-level setting (forward passes); backward passes hand in the value
     their forward saved.  Inside a training step (split-bf16 / bf16) the image comes out of the step's one packing launch (_PackPlan)."""
@@ -136,8 +136,8 @@ def _image(block, x3=None, transposed=False, step=None):
         hit = _IMG_CACHE.get(key)
         if hit is not None:
             return hit
-        if prec in (1, 2) and block.stride(1) == 1 and block.dtype == torch.float32 and tuple(block.shape) == (H, H):
-            _PLAN.register(block.detach(), prec, transposed)
+        if plan and prec in (1, 2) and block.stride(1) == 1 and block.dtype == torch.float32 and tuple(block.shape) == (H, H):
+            _PLAN.register(block.detach(), prec, transposed)      # (plan=False: a per-step temporary — its address changes every step)
     if transposed:
         block = block.detach().t().contiguous()
     assert block.shape == (H, H) and block.stride(1) == 1 and block.dtype == torch.float32
@@ -352,7 +352,12 @@ class _EdgeMLP(torch.autograd.Function):
             # dW3 = g^T . (K-sums): a 24,000-row contraction — the row-contraction kernel (the library GEMM picks a 32 x 32 x 64 tiling
             # for this [128 x 24,000] x [24,000 x 128] shape: 85 us against ~30)
             dW3 = _wgrad_many([(g2d.contiguous(), msum.contiguous(), False)], x3=ctx.x3)[0][0]
-            db3 = (g2d * wsum).sum(0)
+            g2c = g2d.contiguous()
+            n3 = L.namp_train_rows_groups(g2c.shape[0])
+            p3 = torch.empty(n3, H, device=dev)
+            hip.check(L.namp_train_wcolsum(g2c.data_ptr(), wsum.contiguous().data_ptr(), g2c.shape[0], p3.data_ptr(), hip.current_stream()),
+                      "train_wcolsum")
+            db3 = _reduce(_seg0(p3))[0].view(H)
             g = _node_linear_call(g2d.contiguous(), [W3.detach()], [None], x3=min(int(ctx.x3), 1), transposed=True, step=ctx.step)[0]
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         if mode != ENC_EDGE and int(ctx.x3) in (1, 2) and DW_ONCHIP:
@@ -544,9 +549,9 @@ _EdgeUpdate._backward_dw = staticmethod(_edge_update_backward_dw)
 
 
 class _TableRows(torch.autograd.Function):
-    """table[idx] for a table with FEW rows (the 66 relative-position classes, the 6 polymer types).  The stock
-    index backward scatters ~10^6 rows into those few with atomics (measured: 1/3 of the training step); here the
-    gradient is the per-class sum, computed as chunked one-hot GEMMs."""
+    """table[idx] for a table with FEW rows and 128 columns (the 6 polymer types of node_embedding, the 33 tokens of W_s).  The stock
+    index / embedding backward scatters the 24,000 rows into those few with atomics; here the gradient is the per-class sum on
+    namp_train_class_sums (per-wave private tables in LDS: deterministic) + one namp_reduce_sum."""
 
     @staticmethod
     def forward(ctx, table, idx):
@@ -558,15 +563,16 @@ class _TableRows(torch.autograd.Function):
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         C_ = g.shape[-1]
-        g2, i2 = g.reshape(-1, C_), idx.reshape(-1)
-        E = g2.shape[0]
-        chunk = 4096
-        S = (E + chunk - 1) // chunk
-        if S * chunk != E:
-            g2 = F.pad(g2, (0, 0, 0, S * chunk - E))
-            i2 = F.pad(i2, (0, S * chunk - E), value=0)          # padded rows carry zero gradient
-        oh = F.one_hot(i2.view(S, chunk), ctx.nrows).to(g2.dtype)
-        return torch.bmm(oh.transpose(1, 2), g2.view(S, chunk, C_)).sum(0), None
+        g2 = g.reshape(-1, C_).contiguous().float()
+        i32 = idx.reshape(-1).to(torch.int32).contiguous()
+        rows = g2.shape[0]
+        L = hip.lib()
+        if C_ != H or ctx.nrows > 64 or not g2.is_cuda:
+            return torch.zeros(ctx.nrows, C_, device=g.device, dtype=g2.dtype).index_add_(0, i32.long(), g2), None
+        n = L.namp_train_rows_groups(rows)
+        part = torch.empty(n, ctx.nrows, H, device=g.device)
+        hip.check(L.namp_train_class_sums(g2.data_ptr(), i32.data_ptr(), ctx.nrows, rows, part.data_ptr(), hip.current_stream()), "train_class_sums")
+        return _reduce(_seg0(part))[0].view(ctx.nrows, H), None
 
 
 class _EdgeLinear(torch.autograd.Function):
@@ -709,7 +715,7 @@ def _ln(x, norm):
     return F.layer_norm(x, (H,), norm.weight, norm.bias, 1e-5)
 
 
-def _node_linear_call(x2, blocks, biases, x3=None, transposed=False, step=None):
+def _node_linear_call(x2, blocks, biases, x3=None, transposed=False, step=None, plan=True):
     """y_q = x2 @ blocks[q]^T (+ biases[q]) — transposed: x2 @ blocks[q] — for up to 8 [128 x 128] blocks in ONE node_linear launch
     -> list of [G,128].  Products at the step's precision: exact fp32 MFMA (code 0), split-bf16 (1), plain bf16 (2: the hi plane of
     the x3 images)."""
@@ -719,7 +725,7 @@ def _node_linear_call(x2, blocks, biases, x3=None, transposed=False, step=None):
     if prec == 0:
         keep = [_image_f32(b_.t().contiguous() if transposed else b_) for b_ in blocks]
     else:
-        keep = [_image(b_, 1, transposed=transposed, step=step) for b_ in blocks]          # x3 images serve codes 1 and 2
+        keep = [_image(b_, 1, transposed=transposed, step=step, plan=plan) for b_ in blocks]          # x3 images serve codes 1 and 2
     bc = [None if b_ is None else b_.detach().contiguous() for b_ in biases]
     proj = (hip.NampProj * len(blocks))(*[hip.NampProj(keep[q].data_ptr(), hip.ptr(bc[q]), None, outs[q].data_ptr())
                                           for q in range(len(blocks))])
@@ -734,11 +740,13 @@ class _NodeLinears(torch.autograd.Function):
     32 x 32 tiling for these [24,000 x 128] x [128 x 128] products: 81 us each at cfg5.)"""
 
     @staticmethod
-    def forward(ctx, x, nb, *wb):
+    def forward(ctx, x, nb, prec, *wb):
         Ws, bs = wb[:nb], wb[nb:]
         x2 = x.contiguous().view(-1, H)
-        outs = _node_linear_call(x2, [w.detach() for w in Ws], bs)
-        ctx.nb, ctx.shape, ctx.has_b, ctx.x3, ctx.step = nb, x.shape, [b is not None for b in bs], X3, _STEP
+        ctx.plan = prec is None                                 # an explicit precision comes with per-step temporaries (the padded output head)
+        prec = X3 if prec is None else prec                     # (... and keeps the head fp32-equivalent under mixed precision)
+        outs = _node_linear_call(x2, [w.detach() for w in Ws], bs, x3=prec, plan=ctx.plan)
+        ctx.nb, ctx.shape, ctx.has_b, ctx.x3, ctx.step = nb, x.shape, [b is not None for b in bs], prec, _STEP
         ctx.save_for_backward(x2, *Ws)
         return tuple(o.view(*x.shape[:-1], H) for o in outs)
 
@@ -748,18 +756,18 @@ class _NodeLinears(torch.autograd.Function):
         g2 = [g.contiguous().view(-1, H) for g in gs]
         gx = None
         for q, w in enumerate(Ws):                                  # dL/dx = sum_q g_q W_q
-            t = _node_linear_call(g2[q], [w.detach()], [None], x3=ctx.x3, transposed=True, step=ctx.step)[0]
+            t = _node_linear_call(g2[q], [w.detach()], [None], x3=ctx.x3, transposed=True, step=ctx.step, plan=ctx.plan)[0]
             gx = t if gx is None else gx + t
         res = _wgrad_many([(g2[q], x2, ctx.has_b[q]) for q in range(ctx.nb)], x3=ctx.x3)      # one reduction for all blocks
         gW, gb = [r[0] for r in res], [r[1] for r in res]
-        return (gx.view(ctx.shape), None, *gW, *gb)
+        return (gx.view(ctx.shape), None, None, *gW, *gb)
 
 
 def _lin(x, *pairs):
     """_lin(x, (W_a, b_a), (W_b, None), ...) -> tuple of x W^T + b for [128 x 128] blocks; HIP kernels on a HIP device."""
     Ws = [p[0] for p in pairs]
     bs = [p[1] for p in pairs]
-    return _NodeLinears.apply(x, len(Ws), *Ws, *bs)
+    return _NodeLinears.apply(x, len(Ws), None, *Ws, *bs)
 
 
 class _RowLayerNorm(torch.autograd.Function):
@@ -930,7 +938,7 @@ def _forward_train(model, fd, decoding_randn):
     if decoding_randn is None:
         decoding_randn = torch.randn(chain_M.shape, device=mask.device)
     rank32 = model.ranks_of(model.decoding_order(chain_M, decoding_randn)).to(torch.int32).contiguous()
-    h_S = model.W_s(fd["S"].long())
+    h_S = _TableRows.apply(model.W_s.weight, fd["S"].long())
     h_V_enc = h_V
     for p in model.decoder_layers:                                                   # DecLayer on the implicit h_ESV, :610-640
         W1 = p.W1.weight
@@ -940,7 +948,10 @@ def _forward_train(model, fd, decoding_randn):
         dh, h_E = _EdgeMLP.apply(DEC_MSG, h_E, Pa, Pbw, Pfw, W1[:, H:2 * H], p.W2.weight, p.W2.bias, p.W3.weight, p.W3.bias,
                                  E_idx, None, None, rank32, rev)          # h_E: passed through to the next DecLayer
         h_V = _tail(h_V, dh, mask32, maskf, p, drop, drop_p)
-    logits = model.W_out(h_V)
+    # output head (33 rows) on the residue-level HIP launches: W_out padded to a [128 x 128] block, the extra 95 logits dropped
+    nl = model.W_out.weight.shape[0]
+    logits = _NodeLinears.apply(h_V, 1, min(int(X3), 1), F.pad(model.W_out.weight, (0, 0, 0, H - nl)),
+                                F.pad(model.W_out.bias, (0, H - nl)))[0][..., :nl]
     return F.log_softmax(logits, dim=-1), F.softmax(logits, dim=-1)
 
 

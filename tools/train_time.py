@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--K", type=int, default=48); ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--profile", action="store_true")
     ap.add_argument("--precision", default=None)
+    ap.add_argument("--shapes", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rti = spec.restype_to_int()
@@ -61,9 +62,16 @@ def main():
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if a.profile:
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes="--shapes" in sys.argv) as prof:
             step(); torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=70))
+        if "--shapes" in sys.argv:                        # stock (aten::) ops by input shape, sorted by the device time of their own kernels
+            rows = [(e.key, str(e.input_shapes)[:110], e.count, e.self_device_time_total) for e in prof.key_averages(group_by_input_shape=True)
+                    if e.key.startswith("aten::") and e.self_device_time_total > 0]
+            rows.sort(key=lambda r: -r[3])
+            print("== stock ops by input shape (self device time)")
+            for k, sh, c, t in rows[:45]:
+                print(f"{t:9.1f} us {c:4d} x  {k:28s} {sh}")
         # device kernels only, all of them: name, calls, total us
         from torch.autograd import DeviceType
         rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_type == DeviceType.CUDA]
