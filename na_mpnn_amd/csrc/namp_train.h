@@ -1559,11 +1559,11 @@ static __global__ __launch_bounds__(256) void adam_step_kernel(const AdamPlan p,
 // output per thread, i ascending.  Fixed summation order: deterministic.
 // ------------------------------------------------------------------------------------------
 #define NAMP_REDUCE_MAX 16
-struct ReduceSeg { const float* src; float* dst; long A, Mb, sa, sn; int n; int vec; };
+struct ReduceSeg { const float* src; float* dst; long A, Mb, sa, sn; int n; int vec; };      // vec: 0 scalar path, else the slice count (4 or 16)
 struct ReduceArgs { ReduceSeg seg[NAMP_REDUCE_MAX]; int first_block[NAMP_REDUCE_MAX + 1]; int nseg; };
 
 static __global__ __launch_bounds__(256) void reduce_sum_kernel(const ReduceArgs ra) {
-  __shared__ f4 red[3][64];
+  __shared__ f4 red[256];
   int s = 0;
   while (s + 1 < ra.nseg && (int)blockIdx.x >= ra.first_block[s + 1]) ++s;
   const ReduceSeg& g = ra.seg[s];
@@ -1571,24 +1571,29 @@ static __global__ __launch_bounds__(256) void reduce_sum_kernel(const ReduceArgs
   const long total = g.A * g.Mb;
   const int tid = threadIdx.x;
   if (g.vec) {
-    const int c = tid & 63, sl = tid >> 6;
-    const long o = (tile * 64 + c) * 4;
+    // S slices of i per workgroup: 4 (64 x 16-byte outputs per workgroup) for short sums, 16 (16 outputs) for long ones — with 4, the [512][128 x 128]
+    // partials of a row contraction were 192 workgroups of 128 dependent-free but serial requests per thread: 312 us for 100 MB
+    const int S = g.vec, Wd = 256 / S;
+    const int c = tid % Wd, sl = tid / Wd;
+    const long o = (tile * Wd + c) * 4;
     f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
     if (o < total) {
       const long a = o / g.Mb, b = o - a * g.Mb;
       const float* p = g.src + a * g.sa + b;
       int i = sl;
-      for (; i + 12 < g.n; i += 16) {
-        const f4 v0 = *(const f4*)(p + (long)i * g.sn), v1 = *(const f4*)(p + (long)(i + 4) * g.sn);
-        const f4 v2 = *(const f4*)(p + (long)(i + 8) * g.sn), v3 = *(const f4*)(p + (long)(i + 12) * g.sn);
-        acc += v0; acc += v1; acc += v2; acc += v3;
+      for (; i + 7 * S < g.n; i += 8 * S) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f4*)(p + (long)(i + u * S) * g.sn);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
       }
-      for (; i < g.n; i += 4) acc += *(const f4*)(p + (long)i * g.sn);
+      for (; i < g.n; i += S) acc += *(const f4*)(p + (long)i * g.sn);
     }
-    if (sl) red[sl - 1][c] = acc;
+    if (sl) red[(sl - 1) * Wd + c] = acc;
     __syncthreads();
     if (sl == 0 && o < total) {
-      acc += red[0][c]; acc += red[1][c]; acc += red[2][c];
+      for (int q = 1; q < S; ++q) acc += red[(q - 1) * Wd + c];
       *(f4*)(g.dst + o) = acc;
     }
   } else {

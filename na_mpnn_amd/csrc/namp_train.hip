@@ -360,9 +360,11 @@ int namp_reduce_sum(const NampReduce* seg, int nseg, void* stream) {
             (long)d.A, (long)d.Mb, d.n, (long)d.sa, (long)d.sn);
     ReduceSeg& g = ra.seg[s];
     g.src = d.src; g.dst = d.dst; g.A = d.A; g.Mb = d.Mb; g.sa = d.sa; g.sn = d.sn; g.n = d.n;
-    g.vec = (d.Mb % 4 == 0 && d.sa % 4 == 0 && d.sn % 4 == 0 && aligned16(d.src) && aligned16(d.dst)) ? 1 : 0;
+    const bool vec = d.Mb % 4 == 0 && d.sa % 4 == 0 && d.sn % 4 == 0 && aligned16(d.src) && aligned16(d.dst);
+    g.vec = vec ? (d.n >= 64 ? 16 : 4) : 0;
     ra.first_block[s] = (int)blocks;
-    blocks += (d.A * d.Mb + 255) / 256;
+    const long per_block = vec ? 4 * (256 / g.vec) : 256;      // outputs per workgroup
+    blocks += (d.A * d.Mb + per_block - 1) / per_block;
     REQUIRE(blocks < (1L << 30), "namp_reduce_sum: too many outputs");
   }
   ra.first_block[nseg] = (int)blocks;

@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT; timeout 1500 python -m pytest tests/test_gpu_train.py -x -q 2>&1 | tail -5
-timeout 600 python tools/train_time.py --steps 5 --precision bf16 --profile --shapes 2>&1 | grep -E "ms/step|== device|aten::" | head -12 | cut -c1-150
-timeout 600 python tools/train_time.py --steps 5 2>&1 | grep -E "ms/step"
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -k "reduce_sum or golden or on_chip" 2>&1 | tail -3
+timeout 600 python tools/train_time.py --steps 3 --profile --each reduce_sum 2>&1 | grep -E "ms/step|== reduce_sum" | cut -c1-600
+timeout 600 python tools/train_time.py --steps 5 --precision bf16 2>&1 | grep -E "ms/step"

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--profile", action="store_true")
     ap.add_argument("--precision", default=None)
     ap.add_argument("--shapes", action="store_true")
+    ap.add_argument("--each", default=None, help="print every launch duration (us) of the device kernels whose name contains this")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rti = spec.restype_to_int()
@@ -65,6 +66,7 @@ def main():
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes="--shapes" in sys.argv) as prof:
             step(); torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=70))
+        from torch.autograd import DeviceType
         if "--shapes" in sys.argv:                        # stock (aten::) ops by input shape, sorted by the device time of their own kernels
             rows = [(e.key, str(e.input_shapes)[:110], e.count, e.self_device_time_total) for e in prof.key_averages(group_by_input_shape=True)
                     if e.key.startswith("aten::") and e.self_device_time_total > 0]
@@ -72,8 +74,10 @@ def main():
             print("== stock ops by input shape (self device time)")
             for k, sh, c, t in rows[:45]:
                 print(f"{t:9.1f} us {c:4d} x  {k:28s} {sh}")
+        if a.each:
+            ds = [round(e.device_time, 1) for e in prof.events() if e.device_type == DeviceType.CUDA and a.each in e.name]
+            print(f"== {a.each}: {len(ds)} launches, us each:", ds)
         # device kernels only, all of them: name, calls, total us
-        from torch.autograd import DeviceType
         rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_type == DeviceType.CUDA]
         rows.sort(key=lambda r: -r[2])
         tot = sum(r[2] for r in rows)
