@@ -383,12 +383,13 @@ int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const 
  * the message (6 GEMMs per row: 3 recompute + 3 data gradients), differentiates LayerNorm3 and the mask in registers and
  * writes A1, A2, G1, G2, G3 (for namp_train_wgrad), g_hE (chain + residual path), the table gradients (atomics, as
  * namp_train_edge_bwd) and per-workgroup partial sums dgb_part [namp_train_edge_update_bwd_groups][2][128] of
- * d(ln weight) = sum g*xhat and d(ln bias) = sum g. */
+ * d(ln weight) = sum g*xhat and d(ln bias) = sum g.  A caller that walks the batch in slices of complexes (all pointers advanced to the slice, B =
+ * its complexes: the row tensors then hold one slice at a time) passes the slice's first edge row as drop_row0, so that the mask is the forward's. */
 int namp_train_edge_update_bwd_groups(int B, int N, int K);
 int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
                                const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
                                const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
-                               uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
+                               uint32_t drop_seed, long drop_row0, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                                float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int x3, int B, int N, int K, void* stream);
 /* The same backward as TWO persistent launches that own their weight gradients (round 5; mixed precision only: x3 & 3 == 2, bit 3 as above) — no
  * A1 / A2 / G3 rows and no row contractions behind it.  Launch A: recompute, LayerNorm3 + dropout backward (dL/dx rows parked in g_hE, d ln sums),
@@ -432,8 +433,11 @@ int namp_train_scatter_rows(const float* G1, const int32_t* rev_edge, const int3
  * (plain channel order; the float* parameters then point at bf16 storage), namp_train_wgrad takes them with bit 4 (G is
  * bf16; required) / bit 5 (A is bf16) added to its precision argument, and the table-gradient gather reads G1 here. */
 /* n <= 8 row contractions over the SAME rows in one launch (fp32 row tensors; precision code 1 or 2): G[q], A[q], dW_part[q],
- * db_part[q] (may be NULL) are host arrays of device pointers, each pair as in namp_train_wgrad. */
-int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, float* const* dW_part,
+ * db_part[q] (may be NULL) are host arrays of device pointers, each pair as in namp_train_wgrad.  Bit 6 of x3: ADD to the partials an earlier launch
+ * over other rows left there (every workgroup adds to its own chunk slot; the earlier launch must have at least as many chunks).  chunks: the
+ * number of row chunks (= partials per contraction), 0 = namp_train_wgrad_chunks(rows); a caller that walks the rows in slices picks n * chunks
+ * close to the 512 workgroups the chip holds at a time.  Rows past the last chunk's end are not read: chunks whose range is empty store zeros. */
+int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, int chunks, float* const* dW_part,
                            float* const* db_part, void* stream);
 int namp_train_scatter_rows_bf16(const void* G1, const int32_t* rev_edge, const int32_t* rev_off, const uint8_t* sel,
                                  float* out0, float* out1, int G, void* stream);

@@ -561,6 +561,16 @@ __device__ __forceinline__ float drop_factor(uint32_t row_key, int channel, uint
   return mix32(row_key + (uint32_t)channel * 0x9E3779B9U) >= thresh ? scale : 0.f;
 }
 
+// Workgroup b of a grid of n (dispatched to XCD b % 8) -> position of b in the order "all of XCD 0's workgroups, then XCD 1's, ...": a bijection
+// on [0, n) for any n.  Kernels that index their data with it give every XCD one contiguous range.
+__device__ __forceinline__ int xcd_block_index(const int b, const int n) {
+#ifdef NAMP_ABL_NOXCD
+  return b;
+#endif
+  const int x = b & 7, slot = b >> 3, q = n >> 3, r = n & 7;
+  return x * q + (x < r ? x : r) + slot;
+}
+
 // sum over the 4 lane groups g (lanes l, l^16, l^32, l^48 hold the same column)
 __device__ __forceinline__ float xg_sum(float v) {
   v += __shfl_xor(v, 16);

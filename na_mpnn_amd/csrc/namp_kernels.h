@@ -230,16 +230,6 @@ __shared__ int namp_ws_cur[8];                        // the running event count
 #define NAMP_WSTAMP_INIT() do {} while (0)
 #define NAMP_WSTAMP_FINI() do {} while (0)
 #endif
-// Workgroup b of a grid of n (dispatched to XCD b % 8) -> position of b in the order "all of XCD 0's workgroups, then XCD 1's, ...": a bijection
-// on [0, n) for any n.  Kernels that index their data with it give every XCD one contiguous range.
-__device__ __forceinline__ int xcd_block_index(const int b, const int n) {
-#ifdef NAMP_ABL_NOXCD
-  return b;
-#endif
-  const int x = b & 7, slot = b >> 3, q = n >> 3, r = n & 7;
-  return x * q + (x < r ? x : r) + slot;
-}
-
 struct ProjDesc {
   const float* img;    // 64 KiB image of the [128x128] block
   const float* bias;   // [128] or null

@@ -213,7 +213,7 @@ int namp_train_edge_update_bwd_groups(int B, int N, int K) {
 int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const float* Pa, const float* Pc, const float* W1_img,
                                const float* W2_img, const float* W3_img, const float* W3t_img, const float* W2t_img,
                                const float* W1t_img, const float* b2, const float* b3, const float* ln_g, float drop_p,
-                               uint32_t drop_seed, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
+                               uint32_t drop_seed, long drop_row0, const float* g_out, float* A1, float* A2, float* G1, float* G2, float* G3,
                                float* g_hE, float* g_Pa, float* g_Pc, float* dgb_part, int x3, int B, int N, int K, void* stream) {
   REQUIRE_PTR(h_E); REQUIRE_PTR(Pa); REQUIRE_PTR(Pc); REQUIRE_PTR(W1_img); REQUIRE_PTR(W2_img); REQUIRE_PTR(W3_img);
   REQUIRE_PTR(W3t_img); REQUIRE_PTR(W2t_img); REQUIRE_PTR(W1t_img); REQUIRE_PTR(b2); REQUIRE_PTR(b3); REQUIRE_PTR(ln_g);
@@ -222,6 +222,7 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_edge_update_bwd: null E_idx");
   REQUIRE(drop_p >= 0.f && drop_p < 1.f, "namp_train_edge_update_bwd: drop_p=%g must be in [0,1)", (double)drop_p);
   REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= NAMP_MAX_K, "namp_train_edge_update_bwd: bad dims B=%d N=%d K=%d", B, N, K);
+  REQUIRE(drop_row0 >= 0, "namp_train_edge_update_bwd: drop_row0=%ld", drop_row0);
   int rc = ensure_attributes();
   if (rc) return rc;
   EdgeBwdArgs a = {};
@@ -229,6 +230,7 @@ int namp_train_edge_update_bwd(const float* h_E, const int32_t* E_idx, const flo
   a.W1_img = W1_img; a.W2_img = W2_img; a.W3_img = W3_img; a.W3t_img = W3t_img; a.W2t_img = W2t_img; a.W1t_img = W1t_img;
   a.b2 = b2; a.b3 = b3; a.ln_g = ln_g; a.g_rows = g_out;
   if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_seed = drop_seed; a.drop_scale = 1.0f / (1.0f - drop_p); }
+  a.drop_row0 = drop_row0;
   a.A1 = A1; a.A2 = A2; a.G1 = G1; a.G2 = G2; a.G3 = G3; a.g_hE = g_hE; a.g_Pa = g_Pa; a.g_Pj0 = g_Pc; a.dgb_part = dgb_part;
   a.G = B * N; a.N = N; a.K = K; a.E = (long)a.G * K;
   a.gpa_tiles = (x3 & 8) ? 1 : 0;
@@ -484,10 +486,12 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
   return NAMP_OK;
 }
 
-int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, float* const* dW_part,
+int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, int x3, long rows, int chunks, float* const* dW_part,
                            float* const* db_part, void* stream) {
   REQUIRE(G && A && dW_part && db_part, "namp_train_wgrad_multi: null pointer table");
   REQUIRE(n >= 1 && n <= 8, "namp_train_wgrad_multi: n=%d must be in [1,8]", n);
+  const int accumulate = (x3 & 64) ? 1 : 0;          // bit 6: add to the partials of an earlier launch over other rows (same chunk count or more)
+  x3 &= ~64;
   REQUIRE(x3 == 1 || x3 == 2, "namp_train_wgrad_multi: precision code %d (1 = split-bf16, 2 = bf16 products of fp32 rows)", x3);
   REQUIRE(rows >= 1, "namp_train_wgrad_multi: rows=%ld", rows);
   WgradMulti m = {};
@@ -496,12 +500,13 @@ int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, 
     REQUIRE_PTR(G[s_]); REQUIRE_PTR(A[s_]); REQUIRE_PTR(dW_part[s_]);
     m.G[q] = G[s_]; m.A[q] = A[s_]; m.dW[q] = dW_part[s_]; m.db[q] = db_part[s_];
   }
-  const int nchunk = namp_train_wgrad_chunks(rows);
+  REQUIRE(chunks >= 0 && chunks <= 512, "namp_train_wgrad_multi: chunks=%d must be in [0,512] (0 = namp_train_wgrad_chunks(rows))", chunks);
+  const int nchunk = chunks ? chunks : namp_train_wgrad_chunks(rows);
   long per = (rows + nchunk - 1) / nchunk;
   per = (per + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
-  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per);
-  else hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per);
+  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
+  else hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

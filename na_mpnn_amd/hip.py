@@ -115,7 +115,7 @@ _PROTOTYPES = {
                                   C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),
     "namp_train_edge_fwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 10 + [C.c_float, C.c_uint32, c_fp, i32, i32, i32, i32, vp]),
     "namp_train_edge_update_bwd_groups": (i32, [i32, i32, i32]),
-    "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 10 + [i32, i32, i32, i32, vp]),
+    "namp_train_edge_update_bwd": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32, C.c_long] + [c_fp] * 10 + [i32, i32, i32, i32, vp]),
     "namp_train_edge_update_bwd_dw": (i32, [c_fp, c_ip] + [c_fp] * 11 + [C.c_float, C.c_uint32] + [c_fp] * 8 + [i32, i32, i32, i32, vp]),
     "namp_train_edge_bwd": (i32, [i32, c_fp, c_ip, c_ip, c_ip, c_ip] + [c_fp] * 22 + [i32, i32, i32, i32, vp]),
     "namp_train_edge_bwd_dw_groups": (i32, [i32, i32, i32]),
@@ -140,7 +140,7 @@ _PROTOTYPES = {
     "namp_train_ln_rows_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, vp]),
     "namp_train_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_wgrad": (i32, [c_fp, c_fp, i32, i32, C.c_long, c_fp, c_fp, vp]),
-    "namp_train_wgrad_multi": (i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, i32, C.c_long, C.POINTER(C.c_void_p),
+    "namp_train_wgrad_multi": (i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, i32, C.c_long, i32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), vp]),
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),

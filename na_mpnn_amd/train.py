@@ -36,11 +36,14 @@ X3 = 1
 PREC_CODE = {"fp32": 0, "x3": 1, "bf16": 2}
 # Message-stage backward that accumulates its weight gradients on chip (csrc/namp_train_dw.h; split-bf16 and bf16 products).
 # NAMP_TRAIN_DW=0 restores the row tensors + row-contraction launches of rounds 1-3 (A/B runs, tests of both forms).
+import itertools
 import os as _os
 DW_ONCHIP = _os.environ.get("NAMP_TRAIN_DW", "1") != "0"
 # The edge update's backward in the same form (mixed precision): two persistent launches cut at g2 = dL/dz2, all three weight gradients and the
 # LayerNorm sums on chip (csrc/namp_train_eu.h; round 5).  NAMP_TRAIN_DW_EDGE=0 restores the round-3 launch + its three row contractions.
 DW_ONCHIP_EDGE = _os.environ.get("NAMP_TRAIN_DW_EDGE", "1") != "0"
+# split-bf16 edge-update backward (fp32 row tensors): complexes per batch are walked in this many slices at most (1 = the whole batch at once)
+EDGE_UPDATE_SLICES = max(1, int(_os.environ.get("NAMP_TRAIN_EU_SLICES", "3")))
 
 
 # Fragment images made during ONE training step (forward_train and the backward pass that follows it), keyed by (storage
@@ -208,31 +211,37 @@ def _wgrad(G, A, gelu_A, want_bias, x3=None):
     return _reduce(_seg0(dW))[0].view(H, H), None
 
 
-def _wgrad_many(pairs, x3=None):
+def _wgrad_many(pairs, x3=None, more=()):
     """Several row contractions over the SAME rows in one go: pairs = [(G, A, want_bias), ...] -> [(dW, db or None), ...].
     The per-chunk partials of all of them land in one buffer and are reduced by ONE sum (a stage's three weight gradients
-    otherwise cost six small reductions)."""
+    otherwise cost six small reductions).  more: an iterable of further lists of the same pairs over OTHER rows (a batch walked in slices,
+    the row tensors of one slice alive at a time — consumed lazily, between the launches): they add to the first list's partials (fp32
+    rows, precision 1 / 2)."""
     L = hip.lib()
     rows = pairs[0][0].shape[0]
     n = L.namp_train_wgrad_chunks(rows)
     k = len(pairs)
+    if more:                                   # slices: all launches on the same chunk count, k * n workgroups = one round of the chip's 512
+        n = max(1, min(n, 512 // min(k, 8)))
     dev = pairs[0][0].device
     prec = int(X3 if x3 is None else x3)
     tmp = torch.empty(k, n, H, H, device=dev)
     tmpb = torch.empty(k, n, H, device=dev)
-    if prec in (1, 2) and all(G.dtype == torch.float32 and A.dtype == torch.float32 for G, A, _ in pairs):
+    multi = prec in (1, 2) and all(G.dtype == torch.float32 and A.dtype == torch.float32 for G, A, _ in pairs)
+    assert multi or not more, "slices are added up by namp_train_wgrad_multi only"
+    if multi:
         # fp32 row tensors, split-bf16 / bf16 products: up to 8 contractions per launch
-        for q0 in range(0, k, 8):
-            grp = pairs[q0:q0 + 8]
-            arr = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
-            hip.check(L.namp_train_wgrad_multi(arr([G.data_ptr() for G, _, _ in grp]), arr([A.data_ptr() for _, A, _ in grp]), len(grp),
-                                               prec, rows, arr([tmp[q0 + i].data_ptr() for i in range(len(grp))]),
-                                               arr([(tmpb[q0 + i].data_ptr() if grp[i][2] else None) for i in range(len(grp))]),
-                                               hip.current_stream()), "train_wgrad_multi")
-        pairs_done = True
-    else:
-        pairs_done = False
-    for q, (G, A, wb) in enumerate(() if pairs_done else pairs):
+        arr = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
+        for s, sl in enumerate(itertools.chain((pairs,), more)):     # lazily: a generator may launch the producer of slice s when asked for it
+            r = sl[0][0].shape[0]
+            assert len(sl) == k
+            for q0 in range(0, k, 8):
+                grp = sl[q0:q0 + 8]
+                hip.check(L.namp_train_wgrad_multi(arr([G.data_ptr() for G, _, _ in grp]), arr([A.data_ptr() for _, A, _ in grp]), len(grp),
+                                                   prec | (64 if s else 0), r, n, arr([tmp[q0 + i].data_ptr() for i in range(len(grp))]),
+                                                   arr([(tmpb[q0 + i].data_ptr() if grp[i][2] else None) for i in range(len(grp))]),
+                                                   hip.current_stream()), "train_wgrad_multi")
+    for q, (G, A, wb) in enumerate(() if multi else pairs):
         assert G.shape[0] == rows
         code = prec
         if G.dtype == torch.bfloat16:                       # the mixed-precision backward's bf16 row tensors
@@ -484,25 +493,43 @@ class _EdgeUpdate(torch.autograd.Function):
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         if int(ctx.x3) == 2 and DW_ONCHIP and DW_ONCHIP_EDGE:
             return _EdgeUpdate._backward_dw(ctx, g, (img1, img2, img3, img3t, img2t, img1t))
-        A1, A2, G1, G2, G3 = (torch.empty(E, H, device=dev, dtype=rdt) for _ in range(5))
+        # Row tensors A1, A2, G2, G3 exist for the contractions only.  Split-bf16 (fp32 rows, 590 MB each at cfg5): the batch is walked in up to
+        # three slices of complexes — launch, contract (adding to the first slice's partials), next slice into the same buffers — so that one
+        # slice's rows are alive at a time: 7.4 -> 5.9 GiB peak at cfg5.  G1 (the table-gradient gather reads it through the reverse adjacency
+        # of the whole batch), dL/dh_E and the per-tile dL/dPa rows are whole-batch tensors the slices fill.
+        nsl = min(B, EDGE_UPDATE_SLICES) if int(ctx.x3) == 1 else 1
+        bounds = [i * (B // nsl) + min(i, B % nsl) for i in range(nsl + 1)]        # the larger slices first (the first one sizes the partials)
+        Es = max(b1 - b0 for b0, b1 in zip(bounds, bounds[1:])) * N * K
+        A1, A2, G2, G3 = (torch.empty(Es, H, device=dev, dtype=rdt) for _ in range(4))
+        G1 = torch.empty(E, H, device=dev, dtype=rdt)
         g_hE = torch.empty(E, H, device=dev)
         gpa_tiles = K % 16 == 0
         g_Pa = torch.empty(E // 16, H, device=dev) if gpa_tiles else torch.zeros(B * N, H, device=dev)
-        part = torch.empty(L.namp_train_edge_update_bwd_groups(B, N, K), 2, H, device=dev)
+        groups = [L.namp_train_edge_update_bwd_groups(b1 - b0, N, K) for b0, b1 in zip(bounds, bounds[1:])]
+        part = torch.empty(sum(groups), 2, H, device=dev)
         b2c, b3c, lw = b2.detach().contiguous(), b3.detach().contiguous(), ln_w.detach().contiguous()
-        hip.check(L.namp_train_edge_update_bwd(h_E.data_ptr(), E_idx32.data_ptr(), Pa.data_ptr(), Pc.data_ptr(), img1.data_ptr(),
-                                               img2.data_ptr(), img3.data_ptr(), img3t.data_ptr(), img2t.data_ptr(),
-                                               img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed,
-                                               g.data_ptr(), A1.data_ptr(), A2.data_ptr(), G1.data_ptr(), G2.data_ptr(),
-                                               G3.data_ptr(), g_hE.data_ptr(), g_Pa.data_ptr(), None, part.data_ptr(),
-                                               int(ctx.x3) | (8 if gpa_tiles else 0), B, N, K, hip.current_stream()), "train_edge_update_bwd")
+        hE2, g2, Pa2, Pc2 = h_E.view(E, H), g.view(E, H), Pa.view(B * N, H), Pc.view(B * N, H)
+
+        def launch(i):
+            b0, b1 = bounds[i], bounds[i + 1]
+            e0, e1, n0 = b0 * N * K, b1 * N * K, b0 * N
+            hip.check(L.namp_train_edge_update_bwd(hE2[e0:].data_ptr(), E_idx32[b0:].data_ptr(), Pa2[n0:].data_ptr(), Pc2[n0:].data_ptr(),
+                                                   img1.data_ptr(), img2.data_ptr(), img3.data_ptr(), img3t.data_ptr(), img2t.data_ptr(),
+                                                   img1t.data_ptr(), b2c.data_ptr(), b3c.data_ptr(), lw.data_ptr(), ctx.p, ctx.seed, e0,
+                                                   g2[e0:].data_ptr(), A1.data_ptr(), A2.data_ptr(), G1[e0:].data_ptr(), G2.data_ptr(),
+                                                   G3.data_ptr(), g_hE[e0:].data_ptr(), (g_Pa[e0 // 16:] if gpa_tiles else g_Pa[n0:]).data_ptr(),
+                                                   None, part[sum(groups[:i]):].data_ptr(), int(ctx.x3) | (8 if gpa_tiles else 0), b1 - b0, N, K,
+                                                   hip.current_stream()), "train_edge_update_bwd")
+            r = e1 - e0
+            return [(G3[:r], A2[:r], True), (G2[:r], A1[:r], True), (G1[e0:e1], hE2[e0:e1], False)]
+
+        (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many(launch(0), x3=ctx.x3, more=(launch(i) for i in range(1, nsl)) if nsl > 1 else ())
         red = _reduce(*([_seg0(part)] + ([(g_Pa, B * N, H, (K // 16) * H, H, K // 16)] if gpa_tiles else [])))
         dgb = red[0].view(2, H)
         if gpa_tiles:
             g_Pa = red[1]
         rev = ctx.rev if ctx.rev is not None else ReverseAdjacency(E_idx32)
         g_Pc, _ = rev.scatter(G1)
-        (dW3, db3), (dW2, db2), (dW1b, _) = _wgrad_many([(G3, A2, True), (G2, A1, True), (G1, h_E.view(E, H), False)], x3=ctx.x3)
         return (g_hE.view_as(h_E), g_Pa.view_as(Pa), g_Pc.view_as(Pc), dW1b, dW2, db2, dW3, db3, dgb[0], dgb[1],
                 None, None, None, None)
 

@@ -374,6 +374,30 @@ def test_positional_features_and_gradients_match_torch():
 
 
 @pytest.mark.parametrize("p", [0.0, 0.25])
+def test_edge_update_backward_in_slices_equals_one_launch(p, monkeypatch):
+    """Split-bf16 mode walks the batch in slices of complexes (one slice's A1 / A2 / G2 / G3 rows alive at a time): same gradients as the
+    whole batch in one launch — the dropout mask included (drop_row0), the weight-gradient partials added up across the slices' launches."""
+    B, N, K = 5, 150, 32
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    leaves = [rn(B, N, K, 128), rn(B, N, 128), rn(B, N, 128), rn(128, 128, sc=0.08), rn(128, 128, sc=0.1), rn(128, sc=0.1), rn(128, 128, sc=0.1),
+              rn(128, sc=0.1), 1 + rn(128, sc=0.1), rn(128, sc=0.1)]
+    E32 = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(DEV).to(torch.int32).contiguous()
+    R = rn(B, N, K, 128)
+    monkeypatch.setattr(train, "X3", 1)
+    grads = {}
+    for nsl in (1, 4):
+        monkeypatch.setattr(train, "EDGE_UPDATE_SLICES", nsl)
+        with torch.enable_grad():
+            ins = [t.clone().requires_grad_(True) for t in leaves]
+            out = train._EdgeUpdate.apply(*ins, E32, p, 77)
+            (out * R).sum().backward()
+        grads[nsl] = [t.grad for t in ins]
+    for a, b in zip(grads[1], grads[4]):
+        assert rel(a, b) < 2e-6, rel(a, b)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
 def test_edge_update_backward(p):
     """_EdgeUpdate (message + dropout3 + residual + LayerNorm3 in one launch each way).  p = 0: against fp64 autograd of the
     dense formula.  p > 0: the hash mask is regenerated by the backward launch — checked by (i) the mask statistics and the

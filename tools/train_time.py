@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1); ap.add_argument("--profile", action="store_true")
     ap.add_argument("--precision", default=None)
     ap.add_argument("--shapes", action="store_true")
+    ap.add_argument("--mem", action="store_true", help="allocated / peak bytes around every autograd Function of the step")
     ap.add_argument("--each", default=None, help="print every launch duration (us) of the device kernels whose name contains this")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -61,6 +62,28 @@ def main():
     print("host enqueue / step total (ms), device idle at the start of each:", ", ".join(f"{x * 1e3:.1f} / {y * 1e3:.1f}" for x, y in th))
     print(f"B={a.B} N={a.N} K={a.K}: {dt * 1e3:.1f} ms/step, {a.B * a.N / dt:.0f} residues/s trained, loss {float(loss):.4f}, "
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if a.mem:
+        log = []
+
+        def wrap(cls, which):
+            fn = getattr(cls, which)
+
+            def w(*args, **kw):
+                before = torch.cuda.memory_allocated(); torch.cuda.reset_peak_memory_stats()
+                out = fn(*args, **kw)
+                log.append((f"{cls.__name__}.{which}", before, torch.cuda.max_memory_allocated(), torch.cuda.memory_allocated()))
+                return out
+            setattr(cls, which, staticmethod(w))
+        for cls in vars(train).values():
+            if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+                wrap(cls, "forward"); wrap(cls, "backward")
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        step(); torch.cuda.synchronize()
+        G = 2.0 ** 30
+        print("== memory around every autograd Function (GiB): allocated before, peak inside, allocated after")
+        for name, b, pk, af in log:
+            print(f"{name:34s} {b / G:6.2f} {pk / G:6.2f} {af / G:6.2f}")
+        print("max peak:", max(log, key=lambda r: r[2]))
     if a.profile:
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes="--shapes" in sys.argv) as prof:
