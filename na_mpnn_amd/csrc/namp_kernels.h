@@ -3638,7 +3638,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   need = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(need >> 32)) << 32) |
          __builtin_amdgcn_readfirstlane((uint32_t)need);
   const float* img1 = a.Wedge_img + 8 * 64 * 4;                    // k-tile 1 onwards
-  const int chunk_kb = FEAT_CHUNK_BYTES / 1024;
+  const int chunk_kb = (X3 == 2 ? FEAT_CHUNK_BYTES / 2 : FEAT_CHUNK_BYTES) / 1024;     // plain bf16 products read the hi half of a chunk only
   __syncthreads();                                                  // votes consumed before the ring overwrites... (slot tail is not DMA'd, but keep order simple)
   int slot = 0;
   if (need) dma_to_lds(smem, img1 + (long)__builtin_ctzll(need) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
