@@ -455,6 +455,7 @@ def train_bench(args, dev, rank, world, dist):
         torch.cuda.synchronize()
 
     quiet_gc.collect()
+    torch.cuda.reset_peak_memory_stats()                 # peak_mem_gib is this workload's own peak (the secondary runs share the process)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -509,8 +510,10 @@ def train_bench(args, dev, rank, world, dist):
     x3 = mp != "fp32"                                       # bf16 pipe; "x3": 3 bf16 MFMAs per algorithmic product, "bf16": 1
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
     gemm_flop = 2 * 128 * 128 * edges
-    exec_flop = sum(gemms_of(k)[0] * v[1] for k, v in bwd) * gemm_flop * (3 if mp == "x3" else 1)
-    algo_flop = sum(gemms_of(k)[1] * v[1] for k, v in bwd) * gemm_flop
+    # (split-bf16: the edge update's backward walks the batch in train.EDGE_UPDATE_SLICES slices — a launch covers that fraction of the edges)
+    cover = lambda k: 1.0 / min(B, train.EDGE_UPDATE_SLICES) if ("edge_chain_bwd_kernel<3" in k and mp == "x3") else 1.0
+    exec_flop = sum(gemms_of(k)[0] * v[1] * cover(k) for k, v in bwd) * gemm_flop * (3 if mp == "x3" else 1)
+    algo_flop = sum(gemms_of(k)[1] * v[1] * cover(k) for k, v in bwd) * gemm_flop
     exec_tf = exec_flop / max(bwd_ms, 1e-9) / 1e9
     algo_tf = algo_flop / max(bwd_ms, 1e-9) / 1e9
     dom_b = max(bwd, key=lambda kv: kv[1][0])[0] if bwd else "edge_chain_bwd_kernel"
@@ -951,6 +954,7 @@ def secondary_runs(args, dev):
                 o2 = train_bench(a2, dev, 0, 1, None)            # the mixed-precision mode of the same step
                 o["mixed_precision_bf16"] = {k: o2[k] for k in ("value", "ms_per_step", "dtype", "hip_kernel_share", "roofline")}
                 o["mixed_precision_bf16"]["final_loss"] = o2["whole_step"]["final_loss"]
+                o["mixed_precision_bf16"]["peak_mem_gib"] = o2["whole_step"]["peak_mem_gib"]
             elif wl == "cfg4":
                 a.min_seconds = 0.0                              # one pass over the split (BASELINE configs[3] at N = 1)
                 o = split_bench(a, dev, 0, 1, None)
@@ -997,7 +1001,8 @@ def compact_secondary(o):
         c["final_loss"] = o["whole_step"]["final_loss"]
     if "mixed_precision_bf16" in o:
         m = o["mixed_precision_bf16"]
-        c["mixed_precision_bf16"] = {"value": m["value"], "ms_per_step": m["ms_per_step"], "hip_kernel_share": m.get("hip_kernel_share")}
+        c["mixed_precision_bf16"] = {"value": m["value"], "ms_per_step": m["ms_per_step"], "hip_kernel_share": m.get("hip_kernel_share"),
+                                     "peak_mem_gib": m.get("peak_mem_gib")}
     if "shard" in o:
         c["batches"] = o["shard"]["rank0_batches"]
         c["residues"] = o["collation"]["residues_collated"]

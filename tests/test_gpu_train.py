@@ -334,6 +334,50 @@ def test_pack_images_equals_the_single_image_launches():
     assert not plan.entries
 
 
+def test_class_sums_and_weighted_column_sums_match_torch():
+    """namp_train_class_sums (gradient of a few-row embedding lookup: per-class sums of [rows][128] by an index, out-of-range rows skipped) and
+    namp_train_wcolsum (sum_rows g[row] * w[row]) against fp64; both deterministic."""
+    from na_mpnn_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(9)
+    for rows, ncls in ((1, 6), (1000, 6), (24001, 33), (70003, 64)):
+        x = torch.randn(rows, 128, generator=g).to(DEV)
+        idx = torch.randint(-1, ncls + 1, (rows,), generator=g).to(torch.int32).to(DEV)        # -1 and ncls: skipped
+        w = torch.randn(rows, generator=g).to(DEV)
+        n = L.namp_train_rows_groups(rows)
+        outs = []
+        for _ in range(2):
+            part = torch.empty(n, ncls, 128, device=DEV)
+            hip.check(L.namp_train_class_sums(x.data_ptr(), idx.data_ptr(), ncls, rows, part.data_ptr(), hip.current_stream()), "class_sums")
+            pw = torch.empty(n, 128, device=DEV)
+            hip.check(L.namp_train_wcolsum(x.data_ptr(), w.data_ptr(), rows, pw.data_ptr(), hip.current_stream()), "wcolsum")
+            outs.append((train._reduce(train._seg0(part))[0].view(ncls, 128), train._reduce(train._seg0(pw))[0].view(128)))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ok = (idx >= 0) & (idx < ncls)
+        ref = torch.zeros(ncls, 128, dtype=torch.float64, device=DEV).index_add_(0, idx[ok].long(), x[ok].double())
+        assert rel(outs[0][0], ref) < 1e-6
+        assert rel(outs[0][1], (x.double() * w.double()[:, None]).sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+def test_row_contraction_in_slices_adds_up(prec):
+    """namp_train_wgrad_multi with bit 6 (add to the partials of an earlier launch) and an explicit chunk count: three launches over three row
+    slices = one launch over all rows; against fp64 within the product precision."""
+    g = torch.Generator().manual_seed(21)
+    rows = 50000
+    G1, A1, G2, A2 = (torch.randn(rows, 128, generator=g).to(DEV) for _ in range(4))
+    cuts = [0, 20000, 37000, rows]
+    sl = [[(G1[a:b], A1[a:b], True), (G2[a:b], A2[a:b], False)] for a, b in zip(cuts, cuts[1:])]
+    whole = train._wgrad_many([(G1, A1, True), (G2, A2, False)], x3=prec)
+    parts = train._wgrad_many(sl[0], x3=prec, more=iter(sl[1:]))
+    tol = 3e-5 if prec == 1 else 2e-2             # split-bf16 products drop the mid x mid term (2^-16 relative per product); plain bf16: 2^-8
+    for (dw, db), (dw2, db2), (G, A) in zip(whole, parts, ((G1, A1), (G2, A2))):
+        assert rel(dw, dw2) < 1e-5, rel(dw, dw2)                           # same products, another order of the fp32 additions
+        assert rel(dw, G.double().t() @ A.double()) < tol, rel(dw, G.double().t() @ A.double())
+        if db is not None:
+            assert rel(db, db2) < 1e-5 and rel(db, G.double().sum(0)) < 1e-5
+
+
 def test_positional_features_and_gradients_match_torch():
     """namp_train_pos_features / namp_train_pos_grad against the torch expression of PositionalEncodings (na_model_utils.py:537-541) and fp64 autograd
     of E_pos . (g Wedge[:, :16])."""

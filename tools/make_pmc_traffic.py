@@ -67,6 +67,10 @@ def cfg5_section(fetch_db, write_db, prec):
             continue
         nbytes = (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024
         e = {"measured_bytes": round(nbytes)}
+        if "edge_chain_bwd_kernel<3" in k and prec == "x3":
+            # split-bf16: train.EDGE_UPDATE_SLICES (3) launches walk the batch; bytes per STAGE = the per-launch average x 3
+            nbytes *= 3
+            e = {"measured_bytes": round(nbytes), "launches_per_stage": 3}
         alg = cfg5_algorithmic(k, prec)
         if alg:
             e["algorithmic_bytes"] = alg
