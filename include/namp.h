@@ -508,6 +508,20 @@ int namp_train_pos_grad(const float* g, const float* Wedge, int ld, const int32_
  * order (= a stable sort of the edges by target row).  ws: 2*B*N + B*N*K int32 of scratch. */
 int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t* edges, int32_t* ws, int B, int N, int K, void* stream);
 
+/* norm_edges + W_e of the training copy (na_model_utils.py:509,598) without the normalised rows in memory (round 5):
+ *   namp_edge_embed_ln:       h_E = W_e . LayerNorm(Y) + b_e over the [B*N*K][128] PRE-LayerNorm rows Y (one launch; precision code as namp_edge_embed_prec);
+ *   namp_train_embed_ln_bwd:  g_pre = dL/dY from g = dL/dh_E: the W_e^T product and the LayerNorm backward in one pass (Wt_img = image of W_e^T at the
+ *                             precision code, 1 or 2); leaves (mean, rstd) per row in ln_stats [rows][2] and per-workgroup sums
+ *                             dgb_part [namp_train_embed_ln_bwd_groups(rows)][2][128] of d(ln weight) = sum g_E xhat and d(ln bias) = sum g_E;
+ *   namp_train_wgrad_ln:      dW_e = sum_rows g^T LayerNorm(Y) (+ db_e = sum g) as namp_train_wgrad, LayerNorm(Y) re-derived from Y and ln_stats. */
+int namp_edge_embed_ln(const float* We_img, const float* We_b, const float* ln_g, const float* ln_b, const float* Y, float* h_E, int prec,
+                       int B, int N, int K, void* stream);
+int namp_train_embed_ln_bwd_groups(long rows);
+int namp_train_embed_ln_bwd(const float* g, const float* Y, const float* Wt_img, const float* ln_g, float* g_pre, float* ln_stats,
+                            float* dgb_part, int x3, long rows, void* stream);
+int namp_train_wgrad_ln(const float* G, const float* Y, const float* ln_stats, const float* ln_g, const float* ln_b, int x3, long rows,
+                        float* dW_part, float* db_part, void* stream);
+
 /* Two residue-level reductions of the training step (round 5; per-workgroup partials, groups = namp_train_rows_groups(rows), add with namp_reduce_sum):
  *   namp_train_class_sums: part[groups][nclass][128] = per-class sums of the rows g [rows][128] by idx [rows] (nclass <= 64; rows with idx outside
  *     [0, nclass) are skipped) — the gradient of a few-row embedding lookup: W_s (na_model_utils.py:626) and node_embedding (:586).

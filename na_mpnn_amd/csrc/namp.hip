@@ -658,6 +658,24 @@ int namp_edge_embed_prec(const float* We_img, const float* We_b, const float* E,
   return NAMP_OK;
 }
 
+int namp_edge_embed_ln(const float* We_img, const float* We_b, const float* ln_g, const float* ln_b, const float* Y, float* h_E, int prec,
+                       int B, int N, int K, void* stream) {
+  REQUIRE_PTR(We_img); REQUIRE_PTR(We_b); REQUIRE_PTR(ln_g); REQUIRE_PTR(ln_b); REQUIRE_PTR(Y); REQUIRE_PTR(h_E);
+  REQUIRE(prec >= 0 && prec <= 2, "namp_edge_embed_ln: precision code %d (0 fp32, 1 split-bf16, 2 bf16)", prec);
+  int rc = check_dims(__func__, B, N, K);
+  if (rc) return rc;
+  EdgeArgs a = {};
+  a.hE = Y; a.hE_out = h_E; a.W1_img = We_img; a.b1 = We_b; a.ln_g = ln_g; a.ln_b = ln_b;
+  a.G = a.G_enc = B * N; a.N = N; a.K = K;
+  ProfScope prof_(NAMP_KIND_EDGE_EMBED, (hipStream_t)stream);
+  if (prec == 1) rc = launch_edge<MODE_EMBED, 0, PREC_X3>(a, (hipStream_t)stream);
+  else if (prec == 2) rc = launch_edge<MODE_EMBED, 0, PREC_BF16>(a, (hipStream_t)stream);
+  else rc = launch_edge<MODE_EMBED>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 // namp_node_linear with split-bf16 (1) or plain bf16 (2) products: every image is then an x3 image (namp_pack_image_x3; the bf16
 // evaluation reads its hi plane only).  No pre-stage, no token tables (the training path's hoisted first-layer tables and their data
 // gradients: [B*N,128] x [128,128] products that ran as exact fp32 MFMA).

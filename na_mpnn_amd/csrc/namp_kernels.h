@@ -1397,6 +1397,9 @@ __device__ __forceinline__ void edge_stage(const Args& a, f4 (&x)[8], char* smem
   }
   if (MODE == MODE_EMBED) {
 #endif
+    // training (namp_edge_embed_ln): the rows are PRE-LayerNorm (norm_edges, na_model_utils.py:509) — normalised here, so that the
+    // normalised rows never exist in memory (the backward launch and the weight-gradient contraction re-derive them from the same rows)
+    if (a.ln_g) layernorm_row_T(x, a.ln_g, a.ln_b, g);
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc[t] = *(const f4*)(a.b1 + 16 * t + 4 * g); pjv[t] = (f4){0.f, 0.f, 0.f, 0.f}; }
   } else if (PRE == PRE_EMBED) {

@@ -473,10 +473,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& mid) {
 }
 
 // MID = false: plain bf16 products (hi . hi only) — the mixed-precision mode
-template <bool MID>
+// LN: the A rows are PRE-LayerNorm rows y and the operand is LayerNorm(y) = (y - mean) * rstd * gamma + beta, re-derived per loaded value from
+// the row statistics the backward launch left in ln_stats [rows][2] (embed_ln_bwd_kernel) — the normalised rows are never stored.
+template <bool MID, bool LN = false>
 __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const float* __restrict__ A, long rows,
                                               long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part,
-                                              const bool accumulate = false) {
+                                              const bool accumulate = false, const float* __restrict__ ln_stats = nullptr,
+                                              const float* __restrict__ ln_g = nullptr, const float* __restrict__ ln_b = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -491,6 +494,8 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
     for (int t = 0; t < 4; ++t) acc[q][t] = (f4){0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   float gv[4][8], av[4][8], gn[4][8], an[4][8];
+  f4 ln_ga = (f4){1.f, 1.f, 1.f, 1.f}, ln_be = (f4){0.f, 0.f, 0.f, 0.f};
+  if (LN) { ln_ga = *(const f4*)(ln_g + 16 * tc0 + 4 * n); ln_be = *(const f4*)(ln_b + 16 * tc0 + 4 * n); }
   auto load = [&](long r0, float (&go)[4][8], float (&ao)[4][8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -501,7 +506,12 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
       // holds column 4n + q (not 16q + n) — a permutation of the output channels that the final store undoes.  256 contiguous
       // bytes per row and instruction instead of four 64-byte pieces.
       const f4 gq = *(const f4*)(G + rr * NAMP_H + 16 * to0 + 4 * n);
-      const f4 aq = *(const f4*)(A + rr * NAMP_H + 16 * tc0 + 4 * n);
+      f4 aq = *(const f4*)(A + rr * NAMP_H + 16 * tc0 + 4 * n);
+      if (LN) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 st = *(const f2*)(ln_stats + 2 * rr);
+        aq = (aq - st.x) * st.y * ln_ga + ln_be;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) go[q][j] = ok ? gq[q] : 0.f;
 #pragma unroll
@@ -562,6 +572,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
                                                        long rows_per_chunk, float* __restrict__ dW_part,
                                                        float* __restrict__ db_part) {
   wgrad_x3_body<MID>(G, A, rows, rows_per_chunk, dW_part, db_part);
+}
+template <bool MID>
+__global__ __launch_bounds__(256) void wgrad_x3_ln_kernel(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ ln_stats,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b, long rows,
+                                                          long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part) {
+  wgrad_x3_body<MID, true>(G, Y, rows, rows_per_chunk, dW_part, db_part, false, ln_stats, ln_g, ln_b);
 }
 
 // Up to 8 contractions over the SAME rows in one launch (blockIdx.y = which): a residue tail's eight [24,000-row] weight-gradient
@@ -1073,6 +1089,99 @@ static __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __
     *(f4*)(out + r * NAMP_H + 4 * c4) = v * rstd * ga + be;
   }
 }
+
+// embed_ln_bwd_kernel: backward of h_E = W_e . LayerNorm(y) + b_e (norm_edges + W_e, na_model_utils.py:509,598) through BOTH steps in one pass over the
+// rows: g_E = W_e^T g (tile GEMM at the step's precision), then the LayerNorm backward against the statistics re-derived from the y row —
+//     g_pre = rstd * (g_E gamma - mean(g_E gamma) - xhat mean(g_E gamma xhat)),   d gamma = sum g_E xhat,   d beta = sum g_E
+// — where two launches (the W_e^T product writing g_E rows, ln_rows_bwd reading them back with y) moved 2.95 GB per cfg5 step, this one moves
+// 1.77 GB (g and y in, g_pre out).  It also leaves (mean, rstd) per row for the weight-gradient contraction, which re-derives LayerNorm(y) from y
+// (wgrad_x3_ln_kernel): the normalised rows E are never written — 590 MB less traffic in the forward pass and 0.55 GiB less alive through backward.
+// Persistent workgroups of 8 waves, the W_e^T image resident in LDS; a wave walks 16-row tiles in the register-chain layout (lane (m, g): channels
+// 16 t + 4 g + r of row m) and keeps its d gamma / d beta sums per (row slot, channel) in 64 registers until the end.
+struct EmbedLnBwdArgs {
+  const float* g;          // [E][128] dL/dh_E rows
+  const float* y;          // [E][128] pre-LayerNorm rows
+  const float* Wt_img;     // image of W_e^T at the launch's precision
+  const float* ln_g;       // LayerNorm weight
+  float* g_pre;            // [E][128] dL/dy
+  float* stats;            // [E][2] mean, rstd
+  float* dgb_part;         // [gridDim.x][2][128]: sum g_E xhat, sum g_E
+  long E;
+};
+template <int PREC>
+__global__ __launch_bounds__(512) void embed_ln_bwd_kernel(const EmbedLnBwdArgs a) {
+  constexpr int IMG_KB = (PREC == 2) ? 32 : 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float colsum[2 * NAMP_H];
+  __shared__ __attribute__((aligned(16))) float gam[NAMP_H];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  if (tid < 2 * NAMP_H) colsum[tid] = 0.f;
+  if (tid < NAMP_H) gam[tid] = a.ln_g[tid];
+  dma_to_lds(smem, a.Wt_img, IMG_KB, wave, 8, lane);
+  wait_dma_and_sync();
+  const f4* w = (const f4*)smem + lane;
+  f4 dga[8], dbe[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { dga[t] = (f4){0.f, 0.f, 0.f, 0.f}; dbe[t] = dga[t]; }
+  const long ntile = (a.E + 15) / 16;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < ntile; tile += (long)gridDim.x * 8) {
+    asm volatile("" ::: "memory");                           // the image fragments are loop-invariant LDS reads: keep them out of registers
+    const long e_raw = tile * 16 + m;
+    const bool valid = e_raw < a.E;
+    const long e = valid ? e_raw : (a.E - 1);
+    f4 x[8], yv[8], acc[8];
+    {
+      const float* gs = a.g + e * NAMP_H + 4 * g;
+      const float* ys = a.y + e * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { x[t] = *(const f4*)(gs + 16 * t); yv[t] = *(const f4*)(ys + 16 * t); }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { if (!valid) x[t] = (f4){0.f, 0.f, 0.f, 0.f}; acc[t] = (f4){0.f, 0.f, 0.f, 0.f}; }
+    gemm128p<PREC, false>(acc, x, w);                        // acc = g_E = W_e^T g
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s1 += (yv[t].x + yv[t].y) + (yv[t].z + yv[t].w);
+    const float mean = xg_sum(s1) * (1.0f / 128.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { yv[t] -= mean; s2 += (yv[t].x * yv[t].x + yv[t].y * yv[t].y) + (yv[t].z * yv[t].z + yv[t].w * yv[t].w); }
+    const float rstd = rsqrtf(xg_sum(s2) * (1.0f / 128.0f) + 1e-5f);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      yv[t] *= rstd;                                         // xhat
+      dga[t] += acc[t] * yv[t];
+      dbe[t] += acc[t];
+      acc[t] *= *(const f4*)(gam + 16 * t + 4 * g);          // g_E gamma
+      m1 += (acc[t].x + acc[t].y) + (acc[t].z + acc[t].w);
+      m2 += (acc[t].x * yv[t].x + acc[t].y * yv[t].y) + (acc[t].z * yv[t].z + acc[t].w * yv[t].w);
+    }
+    m1 = xg_sum(m1) * (1.0f / 128.0f);
+    m2 = xg_sum(m2) * (1.0f / 128.0f);
+    if (valid) {
+      float* dst = a.g_pre + e * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = (acc[t] - m1 - yv[t] * m2) * rstd;
+      if (g == 0) { a.stats[2 * e] = mean; a.stats[2 * e + 1] = rstd; }
+    }
+  }
+  // ---- the wave's sums over its row slots m, then over the workgroup's waves (LDS atomics: 128 values per wave, once per launch)
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float cw = dga[t][r], cb = dbe[t][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { cw += __shfl_xor(cw, o); cb += __shfl_xor(cb, o); }
+      if (m == 0) { atomicAdd(&colsum[16 * t + 4 * g + r], cw); atomicAdd(&colsum[NAMP_H + 16 * t + 4 * g + r], cb); }
+    }
+  __syncthreads();
+  if (tid < 2 * NAMP_H) a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + tid] = colsum[tid];
+}
+
 
 static __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ gamma, float* __restrict__ gx,

@@ -49,6 +49,7 @@ int ensure_attributes() {
 #define NAMP_SET3(M, ...) set((const void*)(edge_chain_bwd_kernel<M, 0 __VA_ARGS__>)); set((const void*)(edge_chain_bwd_kernel<M, 1 __VA_ARGS__>)); \
                           set((const void*)(edge_chain_bwd_kernel<M, 2 __VA_ARGS__>))
     NAMP_SET3(BWD_ENC_MSG); NAMP_SET3(BWD_DEC_MSG); NAMP_SET3(BWD_ROWS); NAMP_SET3(BWD_EDGE_LN);
+    set((const void*)(embed_ln_bwd_kernel<1>)); set((const void*)(embed_ln_bwd_kernel<2>));
     auto set_dw = [](const void* f) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
       if (e != hipSuccess) g_attr_err = e;
@@ -482,6 +483,47 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
   else if (x3) hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else if (gelu_A) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, A, rows, per, dW_part, db_part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_wgrad_ln(const float* G, const float* Y, const float* ln_stats, const float* ln_g, const float* ln_b, int x3, long rows,
+                        float* dW_part, float* db_part, void* stream) {
+  REQUIRE_PTR(G); REQUIRE_PTR(Y); REQUIRE_PTR(ln_g); REQUIRE_PTR(ln_b); REQUIRE_PTR(dW_part);
+  if (!ln_stats || ((uintptr_t)ln_stats & 7)) return fail(NAMP_EINVAL, "namp_train_wgrad_ln: ln_stats is null or not 8-byte aligned");
+  REQUIRE(x3 == 1 || x3 == 2, "namp_train_wgrad_ln: precision code %d (1 = split-bf16, 2 = bf16 products)", x3);
+  REQUIRE(rows >= 1, "namp_train_wgrad_ln: rows=%ld", rows);
+  const int nchunk = namp_train_wgrad_chunks(rows);
+  long per = (rows + nchunk - 1) / nchunk;
+  per = (per + 31) / 32 * 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_ln_kernel<false>, dim3(nchunk), dim3(256), 0, s, G, Y, ln_stats, ln_g, ln_b, rows, per, dW_part, db_part);
+  else hipLaunchKernelGGL(wgrad_x3_ln_kernel<true>, dim3(nchunk), dim3(256), 0, s, G, Y, ln_stats, ln_g, ln_b, rows, per, dW_part, db_part);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_train_embed_ln_bwd_groups(long rows) {
+  if (rows <= 0) return 0;
+  const long tiles = (rows + 15) / 16, wgs = (tiles + 7) / 8;
+  const int cus = dw_cus();
+  return (int)(wgs < cus ? wgs : cus);
+}
+
+int namp_train_embed_ln_bwd(const float* g, const float* Y, const float* Wt_img, const float* ln_g, float* g_pre, float* ln_stats,
+                            float* dgb_part, int x3, long rows, void* stream) {
+  REQUIRE_PTR(g); REQUIRE_PTR(Y); REQUIRE_PTR(Wt_img); REQUIRE_PTR(ln_g); REQUIRE_PTR(g_pre); REQUIRE_PTR(dgb_part);
+  if (!ln_stats || ((uintptr_t)ln_stats & 7)) return fail(NAMP_EINVAL, "namp_train_embed_ln_bwd: ln_stats is null or not 8-byte aligned");
+  REQUIRE(x3 == 1 || x3 == 2, "namp_train_embed_ln_bwd: precision code %d (1 = split-bf16, 2 = bf16 products)", x3);
+  REQUIRE(rows >= 1, "namp_train_embed_ln_bwd: rows=%ld", rows);
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  EmbedLnBwdArgs a = {};
+  a.g = g; a.y = Y; a.Wt_img = Wt_img; a.ln_g = ln_g; a.g_pre = g_pre; a.stats = ln_stats; a.dgb_part = dgb_part; a.E = rows;
+  const int grid = namp_train_embed_ln_bwd_groups(rows);
+  hipStream_t s = (hipStream_t)stream;
+  if (x3 == 2) hipLaunchKernelGGL(embed_ln_bwd_kernel<2>, dim3(grid), dim3(512), NAMP_BIMG_BYTES, s, a);
+  else hipLaunchKernelGGL(embed_ln_bwd_kernel<1>, dim3(grid), dim3(512), NAMP_IMG_BYTES, s, a);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

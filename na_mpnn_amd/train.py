@@ -42,8 +42,10 @@ DW_ONCHIP = _os.environ.get("NAMP_TRAIN_DW", "1") != "0"
 # The edge update's backward in the same form (mixed precision): two persistent launches cut at g2 = dL/dz2, all three weight gradients and the
 # LayerNorm sums on chip (csrc/namp_train_eu.h; round 5).  NAMP_TRAIN_DW_EDGE=0 restores the round-3 launch + its three row contractions.
 DW_ONCHIP_EDGE = _os.environ.get("NAMP_TRAIN_DW_EDGE", "1") != "0"
+# norm_edges + W_e as one forward / one backward launch without the normalised rows in memory (split-bf16 / mixed precision; 0 = the round-4 pair)
+EMBED_LN_FUSED = _os.environ.get("NAMP_TRAIN_EMBED_LN", "1") != "0"
 # split-bf16 edge-update backward (fp32 row tensors): complexes per batch are walked in this many slices at most (1 = the whole batch at once)
-EDGE_UPDATE_SLICES = max(1, int(_os.environ.get("NAMP_TRAIN_EU_SLICES", "3")))
+EDGE_UPDATE_SLICES = max(1, int(_os.environ.get("NAMP_TRAIN_EU_SLICES", "2")))
 
 
 # Fragment images made during ONE training step (forward_train and the backward pass that follows it), keyed by (storage
@@ -493,9 +495,9 @@ class _EdgeUpdate(torch.autograd.Function):
         rdt = torch.bfloat16 if int(ctx.x3) == 2 else torch.float32          # mixed precision: bf16 row tensors
         if int(ctx.x3) == 2 and DW_ONCHIP and DW_ONCHIP_EDGE:
             return _EdgeUpdate._backward_dw(ctx, g, (img1, img2, img3, img3t, img2t, img1t))
-        # Row tensors A1, A2, G2, G3 exist for the contractions only.  Split-bf16 (fp32 rows, 590 MB each at cfg5): the batch is walked in up to
-        # three slices of complexes — launch, contract (adding to the first slice's partials), next slice into the same buffers — so that one
-        # slice's rows are alive at a time: 7.4 -> 5.9 GiB peak at cfg5.  G1 (the table-gradient gather reads it through the reverse adjacency
+        # Row tensors A1, A2, G2, G3 exist for the contractions only.  Split-bf16 (fp32 rows, 590 MB each at cfg5): the batch is walked in
+        # two slices of complexes — launch, contract (adding to the first slice's partials), next slice into the same buffers — so that one
+        # slice's rows are alive at a time: 6.7 -> 5.6 GiB peak at cfg5 (+0.2 ms).  G1 (the table-gradient gather reads it through the reverse adjacency
         # of the whole batch), dL/dh_E and the per-tile dL/dPa rows are whole-batch tensors the slices fill.
         nsl = min(B, EDGE_UPDATE_SLICES) if int(ctx.x3) == 1 else 1
         bounds = [i * (B // nsl) + min(i, B % nsl) for i in range(nsl + 1)]        # the larger slices first (the first one sizes the partials)
@@ -594,7 +596,9 @@ class _TableRows(torch.autograd.Function):
         i32 = idx.reshape(-1).to(torch.int32).contiguous()
         rows = g2.shape[0]
         L = hip.lib()
-        if C_ != H or ctx.nrows > 64 or not g2.is_cuda:
+        if not g2.is_cuda:
+            raise RuntimeError("na_mpnn_amd.train: tensors must be on a HIP device (no CPU fallback)")
+        if C_ != H or ctx.nrows > 64:                         # not a table of this model: the stock scatter
             return torch.zeros(ctx.nrows, C_, device=g.device, dtype=g2.dtype).index_add_(0, i32.long(), g2), None
         n = L.namp_train_rows_groups(rows)
         part = torch.empty(n, ctx.nrows, H, device=g.device)
@@ -842,6 +846,46 @@ class _RowLayerNorm(torch.autograd.Function):
         return gx, s[0], s[1]
 
 
+class _EdgeEmbedTail(torch.autograd.Function):
+    """h_E = W_e LayerNorm(y) + b_e (norm_edges + W_e, na_model_utils.py:509,598) with the normalised rows never in memory (split-bf16 / mixed
+    precision): forward = one launch on the pre-LayerNorm rows (namp_edge_embed_ln); backward = one launch for dL/dy (W_e^T product + LayerNorm
+    backward, namp_train_embed_ln_bwd) that also leaves the rows' (mean, rstd), and the row contraction dW_e = g^T LayerNorm(y) re-deriving its
+    operand from y (namp_train_wgrad_ln).  Against _RowLayerNorm + _EdgeLinear: 1.2 GB less traffic forward, 1.2 GB less backward, one [E,128]
+    tensor less alive from forward to backward."""
+
+    @staticmethod
+    def forward(ctx, y, ln_w, ln_b, W, b):
+        B, N, K, _ = y.shape
+        y = y.contiguous()
+        out = torch.empty_like(y)
+        lw, lb = ln_w.detach().contiguous(), ln_b.detach().contiguous()
+        hip.check(hip.lib().namp_edge_embed_ln(_image(W.detach()).data_ptr(), b.detach().contiguous().data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                               y.data_ptr(), out.data_ptr(), int(X3), B, N, K, hip.current_stream()), "edge_embed_ln")
+        ctx.x3, ctx.step = X3, _STEP
+        ctx.save_for_backward(y, lw, lb, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, lw, lb, W = ctx.saved_tensors
+        L = hip.lib()
+        g = g.contiguous()
+        rows = y.numel() // H
+        dev = y.device
+        g_pre = torch.empty_like(y)
+        stats = torch.empty(rows, 2, device=dev)
+        part = torch.empty(L.namp_train_embed_ln_bwd_groups(rows), 2, H, device=dev)
+        hip.check(L.namp_train_embed_ln_bwd(g.data_ptr(), y.data_ptr(), _image_t(W, ctx.x3, ctx.step).data_ptr(), lw.data_ptr(), g_pre.data_ptr(),
+                                            stats.data_ptr(), part.data_ptr(), int(ctx.x3), rows, hip.current_stream()), "train_embed_ln_bwd")
+        n = L.namp_train_wgrad_chunks(rows)
+        dWp, dbp = torch.empty(n, H, H, device=dev), torch.empty(n, H, device=dev)
+        hip.check(L.namp_train_wgrad_ln(g.data_ptr(), y.data_ptr(), stats.data_ptr(), lw.data_ptr(), lb.data_ptr(), int(ctx.x3), rows,
+                                        dWp.data_ptr(), dbp.data_ptr(), hip.current_stream()), "train_wgrad_ln")
+        dgb, dW, db = _reduce(_seg0(part), _seg0(dWp), _seg0(dbp))
+        dgb = dgb.view(2, H)
+        return g_pre, dgb[0], dgb[1], dW.view(H, H), db.view(H)
+
+
 def _ximage_general(W, transposed=False, step=None):
     """x3 image of a general [out_f x in_f] block (residue-level FFN weights; namp_pack_image_x3_general), cached per step."""
     step = _STEP if step is None else step
@@ -958,10 +1002,12 @@ def _forward_train(model, fd, decoding_randn):
     fp = model.features
     y, E_idx = edge_embedding(model, fd)
     B, N, K = E_idx.shape
-    E = _RowLayerNorm.apply(y, fp.norm_edges.weight, fp.norm_edges.bias)
     V = _ln(_TableRows.apply(fp.node_embedding.weight.t(), fd["R_polymer_type"].long()), fp.norm_nodes)   # one-hot @ W^T
     h_V = _lin(V, (model.W_v.weight, model.W_v.bias))[0]
-    h_E = _EdgeLinear.apply(E, model.W_e.weight, model.W_e.bias)
+    if X3 and EMBED_LN_FUSED:
+        h_E = _EdgeEmbedTail.apply(y, fp.norm_edges.weight, fp.norm_edges.bias, model.W_e.weight, model.W_e.bias)
+    else:
+        h_E = _EdgeLinear.apply(_RowLayerNorm.apply(y, fp.norm_edges.weight, fp.norm_edges.bias), model.W_e.weight, model.W_e.bias)
     mask32 = mask.to(torch.int32).contiguous()
     maskf = mask.float().unsqueeze(-1)
     rev = ReverseAdjacency(E_idx) if torch.is_grad_enabled() else None

@@ -334,6 +334,34 @@ def test_pack_images_equals_the_single_image_launches():
     assert not plan.entries
 
 
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,N,K", [(1, 40, 16), (2, 700, 48), (1, 333, 30)])
+def test_edge_embed_tail_matches_fp64_autograd(B, N, K, prec, monkeypatch):
+    """_EdgeEmbedTail: h_E = W_e LayerNorm(y) + b_e in one forward launch on the pre-LayerNorm rows, backward without the normalised rows in
+    memory (W_e^T product + LayerNorm backward in one pass; dW_e from y and the rows' statistics) — against fp64 autograd of the dense formula
+    at sizes where every persistent workgroup walks several tiles, and against the unfused pair of launches."""
+    g = torch.Generator(device="cpu").manual_seed(17)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    leaves = [rn(B, N, K, 128, sc=2.0) + 0.5, 1 + rn(128, sc=0.2), rn(128, sc=0.2), rn(128, 128, sc=0.1), rn(128, sc=0.1)]
+    R = rn(B, N, K, 128)
+    monkeypatch.setattr(train, "X3", prec)
+    with torch.enable_grad():
+        ins = [t.clone().requires_grad_(True) for t in leaves]
+        out = train._EdgeEmbedTail.apply(*ins)
+        (out * R).sum().backward()
+        ref_in = [t.double().requires_grad_(True) for t in leaves]
+        ref = F.linear(F.layer_norm(ref_in[0], (128,), ref_in[1], ref_in[2], 1e-5), ref_in[3], ref_in[4])
+        (ref * R.double()).sum().backward()
+        old_in = [t.clone().requires_grad_(True) for t in leaves]
+        old = train._EdgeLinear.apply(train._RowLayerNorm.apply(old_in[0], old_in[1], old_in[2]), old_in[3], old_in[4])
+        (old * R).sum().backward()
+    tol = 3e-5 if prec == 1 else 2e-2
+    assert rel(out, ref) < tol, rel(out, ref)
+    for name, a, b, c in zip(("y", "ln_w", "ln_b", "W_e", "b_e"), ins, ref_in, old_in):
+        assert rel(a.grad, b.grad) < (1e-4 if prec == 1 else 3e-2), (name, rel(a.grad, b.grad))
+        assert rel(a.grad, c.grad) < (2e-5 if prec == 1 else 2e-2), (name, rel(a.grad, c.grad))
+
+
 def test_class_sums_and_weighted_column_sums_match_torch():
     """namp_train_class_sums (gradient of a few-row embedding lookup: per-class sums of [rows][128] by an index, out-of-range rows skipped) and
     namp_train_wcolsum (sum_rows g[row] * w[row]) against fp64; both deterministic."""
