@@ -475,17 +475,23 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf8& hi, bf8& mid) {
 // MID = false: plain bf16 products (hi . hi only) — the mixed-precision mode
 // LN: the A rows are PRE-LayerNorm rows y and the operand is LayerNorm(y) = (y - mean) * rstd * gamma + beta, re-derived per loaded value from
 // the row statistics the backward launch left in ln_stats [rows][2] (embed_ln_bwd_kernel) — the normalised rows are never stored.
-template <bool MID, bool LN = false>
+// KS = 2: eight waves — two groups of four, each taking every other 32-row step of the chunk; the second group hands its accumulators to the first
+// through LDS at the end.  A 24,000-row contraction is 47 chunks of 16 dependent steps (load, split, 16-48 MFMAs): its duration is one workgroup's
+// latency chain, and halving the chain halves the launch.
+template <bool MID, bool LN = false, int KS = 1>
 __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const float* __restrict__ A, long rows,
                                               long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part,
                                               const bool accumulate = false, const float* __restrict__ ln_stats = nullptr,
                                               const float* __restrict__ ln_g = nullptr, const float* __restrict__ ln_b = nullptr) {
+  __shared__ __attribute__((aligned(16))) float ks_red[KS == 2 ? 4 * 8 * 64 * 4 + 4 * 4 * 64 : 4];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave8 & 3, grp = wave8 >> 2;
   const int n = lane & 15, g = lane >> 4;
   const int to0 = 4 * (wave >> 1), tc0 = 4 * (wave & 1);
-  const long r_begin = (long)blockIdx.x * rows_per_chunk;
-  long r_end = r_begin + rows_per_chunk;
+  const long r_chunk = (long)blockIdx.x * rows_per_chunk;
+  const long r_begin = r_chunk + 32 * grp;
+  long r_end = r_chunk + rows_per_chunk;
   if (r_end > rows) r_end = rows;
   f4 acc[4][4];
 #pragma unroll
@@ -501,7 +507,7 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
     for (int j = 0; j < 8; ++j) {
       const long row = r0 + 8 * g + j;
       const bool ok = row < r_end;
-      const long rr = ok ? row : r_begin;
+      const long rr = ok ? row : r_chunk;
       // one 16-byte load per row and operand: lane n takes columns 4n .. 4n+3 of the wave's 64-column half, i.e. MFMA tile q
       // holds column 4n + q (not 16q + n) — a permutation of the output channels that the final store undoes.  256 contiguous
       // bytes per row and instruction instead of four 64-byte pieces.
@@ -519,9 +525,9 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
     }
   };
   if (r_begin < r_end) load(r_begin, gv, av);
-  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
-    const bool more = r0 + 32 < r_end;
-    if (more) load(r0 + 32, gn, an);
+  for (long r0 = r_begin; r0 < r_end; r0 += 32 * KS) {
+    const bool more = r0 + 32 * KS < r_end;
+    if (more) load(r0 + 32 * KS, gn, an);
     bf8 gh[4], gm[4], ah[4], am[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -546,6 +552,36 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
         for (int j = 0; j < 8; ++j) { gv[q][j] = gn[q][j]; av[q][j] = an[q][j]; }
     }
   }
+  if (KS == 2) {
+    f4* rd = (f4*)ks_red + wave * 8 * 64 + lane;                    // [wave][8 tiles][64 lanes] x 16 B = 32 KiB, used twice
+    float* rb = ks_red + 4 * 8 * 64 * 4 + wave * 4 * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (grp == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) rd[(4 * q + t) * 64] = acc[2 * h + q][t];
+        if (h == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rb[q * 64] = bsum[q];
+        }
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[2 * h + q][t] += rd[(4 * q + t) * 64];
+        if (h == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bsum[q] += rb[q * 64];
+        }
+      }
+      if (h == 0) __syncthreads();
+    }
+    if (grp == 1) return;
+  }
   float* out = dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -567,30 +603,30 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ G, const
   }
 }
 
-template <bool MID>
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
-                                                       long rows_per_chunk, float* __restrict__ dW_part,
-                                                       float* __restrict__ db_part) {
-  wgrad_x3_body<MID>(G, A, rows, rows_per_chunk, dW_part, db_part);
+template <bool MID, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void wgrad_x3_kernel(const float* __restrict__ G, const float* __restrict__ A, long rows,
+                                                            long rows_per_chunk, float* __restrict__ dW_part,
+                                                            float* __restrict__ db_part) {
+  wgrad_x3_body<MID, false, KS>(G, A, rows, rows_per_chunk, dW_part, db_part);
 }
-template <bool MID>
-__global__ __launch_bounds__(256) void wgrad_x3_ln_kernel(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ ln_stats,
+template <bool MID, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void wgrad_x3_ln_kernel(const float* __restrict__ G, const float* __restrict__ Y, const float* __restrict__ ln_stats,
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b, long rows,
                                                           long rows_per_chunk, float* __restrict__ dW_part, float* __restrict__ db_part) {
-  wgrad_x3_body<MID, true>(G, Y, rows, rows_per_chunk, dW_part, db_part, false, ln_stats, ln_g, ln_b);
+  wgrad_x3_body<MID, true, KS>(G, Y, rows, rows_per_chunk, dW_part, db_part, false, ln_stats, ln_g, ln_b);
 }
 
 // Up to 8 contractions over the SAME rows in one launch (blockIdx.y = which): a residue tail's eight [24,000-row] weight-gradient
 // blocks would otherwise be eight launches of 47 workgroups each.
 struct WgradMulti { const float* G[8]; const float* A[8]; float* dW[8]; float* db[8]; };
-template <bool MID>
-__global__ __launch_bounds__(256) void wgrad_x3_multi_kernel(const WgradMulti m, long rows, long rows_per_chunk, int accumulate) {
+template <bool MID, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void wgrad_x3_multi_kernel(const WgradMulti m, long rows, long rows_per_chunk, int accumulate) {
   // (accumulate: a launch over another slice of the rows already left its partials in dW / db)
   const float* G = m.G[0]; const float* A = m.A[0]; float* dW = m.dW[0]; float* db = m.db[0];
 #pragma unroll
   for (int q = 1; q < 8; ++q)
     if ((int)blockIdx.y == q) { G = m.G[q]; A = m.A[q]; dW = m.dW[q]; db = m.db[q]; }     // static indices: no kernarg spill
-  wgrad_x3_body<MID>(G, A, rows, rows_per_chunk, dW, db, accumulate != 0);
+  wgrad_x3_body<MID, false, KS>(G, A, rows, rows_per_chunk, dW, db, accumulate != 0);
 }
 
 // wgrad_bf16_kernel: the row contraction of the mixed-precision mode on bf16 row tensors (G always bf16; A bf16 — A1 / A2 —

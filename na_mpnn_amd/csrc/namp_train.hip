@@ -547,8 +547,15 @@ int namp_train_wgrad_multi(const float* const* G, const float* const* A, int n, 
   long per = (rows + nchunk - 1) / nchunk;
   per = (per + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
-  if (x3 == 2) hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
-  else hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
+  // few workgroups (residue-level contractions: 47 chunks x <= 8): the launch lasts as long as one workgroup's chain of dependent steps — two
+  // groups of four waves split the chain (KS = 2).  Chip-filling launches keep four waves, two workgroups per CU.
+  const bool ks2 = (long)nchunk * n <= 1024;            // cfg5: 984 -> 650 us per step over the 28 residue-level launches (36 -> 23 us each)
+  per = (per + 63) / 64 * 64;
+  if (ks2) {
+    if (x3 == 2) hipLaunchKernelGGL((wgrad_x3_multi_kernel<false, 2>), dim3(nchunk, n), dim3(512), 0, s, m, rows, per, accumulate);
+    else hipLaunchKernelGGL((wgrad_x3_multi_kernel<true, 2>), dim3(nchunk, n), dim3(512), 0, s, m, rows, per, accumulate);
+  } else if (x3 == 2) hipLaunchKernelGGL((wgrad_x3_multi_kernel<false, 1>), dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
+  else hipLaunchKernelGGL((wgrad_x3_multi_kernel<true, 1>), dim3(nchunk, n), dim3(256), 0, s, m, rows, per, accumulate);
   CHECK_LAUNCH();
   return NAMP_OK;
 }
