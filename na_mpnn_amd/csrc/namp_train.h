@@ -1325,7 +1325,9 @@ struct TailTrainArgs {
 #ifndef FFN_LD
 #define FFN_LD 132             // padded row stride (floats) of the LDS tiles (as in namp_kernels.h)
 #endif
-#define TAIL_T 2
+#ifndef TAIL_T
+#define TAIL_T 3             // 48 rows per pass over the 1 MB of FFN images a workgroup pulls from L2 (2: 0.89 ms per cfg5 step in the six fwd + bwd launches; 3: 0.81; 4 spills)
+#endif
 #define TAIL_LDS (((2 * TAIL_T * 16) + 8 * 16) * FFN_LD * 4)
 
 // per-wave GEMM "A": out[q][4 tiles of this wave's 64 hidden units] = W (512 x 128 image) . rows of tile q (from LDS, fp32)
