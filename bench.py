@@ -486,7 +486,8 @@ def train_bench(args, dev, rank, world, dist):
             kern[ev.key] = (t_us / 1e3, ev.count)
     ours = {k: v for k, v in kern.items() if any(s in k for s in ("edge_chain_bwd", "edge_bwd_dw", "edge_update_bwd_", "reduce_sum_kernel", "pack_multi", "pos_grad", "pos_features", "radj_", "adam_", "loss_smoothed", "wgrad_kernel", "feat_wgrad", "edge_features",
                                                                   "edge_mlp_kernel", "edge_mlp_x3_persistent", "edge_mlp_bf16", "knn_kernel", "knn_select", "pack_image", "pack_feat", "scatter_rows",
-                                                                  "prep_atoms", "wgrad_x3", "wgrad_bf16", "tail_train", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear"))}
+                                                                  "prep_atoms", "wgrad_x3", "wgrad_bf16", "tail_train", "tile_presence", "cvt_tables", "ln_rows", "node_update", "node_linear",
+                                                                  "embed_ln_bwd", "class_sums", "wcolsum"))}
     total_dev_ms = sum(v[0] for v in kern.values())
     # the per-edge backward launches.  128 x 128 GEMM-equivalents per edge row — (executed, algorithmic = data + weight gradients):
     #   edge_bwd_dw*           message stage owning its weight gradients: 2 recompute + 2 data-gradient + 2 weight-gradient  (6, 4)

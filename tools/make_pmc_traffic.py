@@ -27,6 +27,7 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+EU_SLICES = int(__import__("os").environ.get("NAMP_TRAIN_EU_SLICES", "2"))
 KIND = {(0, 1): "enc_message", (0, 3): "enc_edge_message", (1, 3): "enc_edge_dec_message", (1, 0): "dec_message"}
 
 
@@ -68,9 +69,9 @@ def cfg5_section(fetch_db, write_db, prec):
         nbytes = (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024
         e = {"measured_bytes": round(nbytes)}
         if "edge_chain_bwd_kernel<3" in k and prec == "x3":
-            # split-bf16: train.EDGE_UPDATE_SLICES (3) launches walk the batch; bytes per STAGE = the per-launch average x 3
-            nbytes *= 3
-            e = {"measured_bytes": round(nbytes), "launches_per_stage": 3}
+            # split-bf16: train.EDGE_UPDATE_SLICES (default 2) launches walk the batch; bytes per STAGE = the per-launch average x slices
+            nbytes *= EU_SLICES
+            e = {"measured_bytes": round(nbytes), "launches_per_stage": EU_SLICES}
         alg = cfg5_algorithmic(k, prec)
         if alg:
             e["algorithmic_bytes"] = alg
