@@ -1,5 +1,5 @@
 # Round profile set (round 4 on): default bench line, rocprofv3 kernel-trace stats (cfg2, cfg3, cfg5 x3 / bf16, featuriser), PMC traffic (cfg2 + cfg5),
-# issue counters of the cfg3 launches.      gpurun --timeout 3000 -- 'bash tools/profile_round4.sh <tag, e.g. r04d> <git commit>'
+# issue counters of the cfg3 launches.      gpurun --timeout 3000 -- 'bash tools/profile_round5.sh <tag, e.g. r05f> <git commit>'
 export TMPDIR=/tmp
 TAG=${1:-r04}
 COMMIT=${2:-unknown}
