@@ -469,7 +469,11 @@ int namp_train_wgrad(const float* G, const float* A, int gelu_A, int x3, long ro
 int namp_train_feat_wgrad_chunks(long edges);
 long namp_train_feat_wgrad_ws_ints(long edges);       /* int32 elements of tile_ws (atom-presence words per 64-edge tile) */
 /* (round 5) M18 == NULL: X18 is the PACKED atom array [B*L][18][4] = (x, y, z, mask) — one 16-byte request per gathered atom; split-bf16 / bf16 only. */
-int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
+/* g16 (optional, with the packed atoms and precision code 1 / 2): g_pre once more as bf16 tiles [ceil(E / 64)][128 channels][64 edges] — split-bf16: the
+ * remainders in a second array namp_train_g16_elems(E) elements behind — as namp_train_embed_ln_bwd writes them: the launch then stages its tiles by
+ * 16-byte copies instead of converting and transposing the fp32 rows in every column group (half of its time at cfg5). */
+long namp_train_g16_elems(long rows);
+int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre, const void* g16,
                           float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream);
 
 /* ---- training: loss and optimiser step (round 3) ----------------------------------------------
@@ -513,12 +517,14 @@ int namp_train_reverse_adjacency(const int32_t* E_idx, int32_t* offsets, int32_t
  *   namp_train_embed_ln_bwd:  g_pre = dL/dY from g = dL/dh_E: the W_e^T product and the LayerNorm backward in one pass (Wt_img = image of W_e^T at the
  *                             precision code, 1 or 2); leaves (mean, rstd) per row in ln_stats [rows][2] and per-workgroup sums
  *                             dgb_part [namp_train_embed_ln_bwd_groups(rows)][2][128] of d(ln weight) = sum g_E xhat and d(ln bias) = sum g_E;
+ *                             g16 (optional; the tail tile zeroed by the caller when rows % 64 != 0): g_pre also as the bf16 tiles of
+ *                             namp_train_feat_wgrad (1 or 2 arrays of namp_train_g16_elems(rows) bf16 by the precision code);
  *   namp_train_wgrad_ln:      dW_e = sum_rows g^T LayerNorm(Y) (+ db_e = sum g) as namp_train_wgrad, LayerNorm(Y) re-derived from Y and ln_stats. */
 int namp_edge_embed_ln(const float* We_img, const float* We_b, const float* ln_g, const float* ln_b, const float* Y, float* h_E, int prec,
                        int B, int N, int K, void* stream);
 int namp_train_embed_ln_bwd_groups(long rows);
 int namp_train_embed_ln_bwd(const float* g, const float* Y, const float* Wt_img, const float* ln_g, float* g_pre, float* ln_stats,
-                            float* dgb_part, int x3, long rows, void* stream);
+                            float* dgb_part, void* g16, int x3, long rows, void* stream);
 int namp_train_wgrad_ln(const float* G, const float* Y, const float* ln_stats, const float* ln_g, const float* ln_b, int x3, long rows,
                         float* dW_part, float* db_part, void* stream);
 

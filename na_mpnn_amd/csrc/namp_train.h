@@ -110,8 +110,9 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   // and dL/da2 of row k is just w_k * g_node — no W3^T product, no A2 / G3 rows, four GEMMs (W1, W2, W2^T, W1^T + dh_E).
   constexpr bool MSG = (MODE == BWD_ENC_MSG || MODE == BWD_DEC_MSG);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float colsum[2 * NAMP_H];        // BWD_EDGE_LN: workgroup sums for d(ln weight), d(ln bias)
-  if (MODE == BWD_EDGE_LN) { if (threadIdx.x < 2 * NAMP_H) colsum[threadIdx.x] = 0.f; }
+  // BWD_EDGE_LN: the waves' column sums for d(ln weight), d(ln bias) — one slot per wave, added in wave order at the end (LDS float atomics here
+  // made the sum's order, hence its last bits, vary from run to run)
+  __shared__ float colsum[MODE == BWD_EDGE_LN ? 8 : 1][2 * NAMP_H];
   // b2 (| b3 | LayerNorm-3 weight) staged once per workgroup: as 16-byte loads per lane they are 8 KiB per wave and vector through the
   // CU's 64 B/clk vector-memory path (profiles/r02k_bf16s_ablation.md, last table)
   __shared__ __attribute__((aligned(16))) float cstb[3 * NAMP_H];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
         float cw = gy[r] * z3[t][r], cb = gy[r];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { cw += __shfl_xor(cw, o); cb += __shfl_xor(cb, o); }
-        if (m == 0) { atomicAdd(&colsum[16 * t + 4 * g + r], cw); atomicAdd(&colsum[NAMP_H + 16 * t + 4 * g + r], cb); }
+        if (m == 0) { colsum[wave][16 * t + 4 * g + r] = cw; colsum[wave][NAMP_H + 16 * t + 4 * g + r] = cb; }
       }
     }
     m1 = xg_sum(m1) * (1.0f / 128.0f);
@@ -372,7 +373,12 @@ __global__ __launch_bounds__(512) void edge_chain_bwd_kernel(const EdgeBwdArgs a
   }
   if (MODE == BWD_EDGE_LN) {
     __syncthreads();
-    if (threadIdx.x < 2 * NAMP_H) a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + threadIdx.x] = colsum[threadIdx.x];
+    if (threadIdx.x < 2 * NAMP_H) {
+      float s_ = colsum[0][threadIdx.x];
+#pragma unroll
+      for (int w2 = 1; w2 < 8; ++w2) s_ += colsum[w2][threadIdx.x];
+      a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + threadIdx.x] = s_;
+    }
   }
 }
 
@@ -873,12 +879,17 @@ static __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __r
 // PK: X18 is the PACKED atom array [G][18][4] = (x, y, z, mask) and M18 is unused: an atom of the gathered neighbour is then ONE 16-byte request per
 // lane where the separate arrays take four scattered 4-byte ones — with every lane on its own cache line, those requests (16 per lane and tile,
 // 1,024 line requests per wave) were what the launch waited for: removing them took 30 % off it, requesting them a tile ahead 2 % (profiles/r05c).
-template <bool MID, bool PK>      // MID = false: hi . hi products only (mixed-precision mode)
+// S16: g_pre arrives as bf16 tiles in the operand order of the staged planes — g16 [tile][128 channels][64 edges] (split-bf16: a second array of
+// the remainders behind it, g16_plane elements further) — written by the launch that produced g_pre (embed_ln_bwd_kernel).  Staging a tile is then four
+// (eight) 16-byte copies per thread; from the fp32 rows it is 32 four-byte loads, 32 conversions and the transposition, repeated by each of the 41 column
+// groups — HALF of this launch once its L2 misses and coordinate gathers were gone (ablation: 2.17 -> 1.06 ms without the staging; profiles/r05g).
+template <bool MID, bool PK, bool S16 = false>      // MID = false: hi . hi products only (mixed-precision mode)
 __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
                                                             const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
                                                             const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
                                                             long E, long edges_per_chunk, int L, int K,
-                                                            float* __restrict__ dW_part) {
+                                                            float* __restrict__ dW_part, const __bf16* __restrict__ g16 = nullptr,
+                                                            long g16_plane = 0) {
   __shared__ __attribute__((aligned(16))) __bf16 gh[NAMP_H * FEATW_LDT];
   __shared__ __attribute__((aligned(16))) __bf16 gm[MID ? NAMP_H * FEATW_LDT : 8];
   __shared__ __attribute__((aligned(16))) float dsc[4][FEATW_NBW][FEATW_TILE];      // c * distance per (wave, block, edge of the tile)
@@ -988,7 +999,15 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
     if (staged) __syncthreads();
     staged = true;
     // stage + split + transpose g_pre rows e0 .. e0+63: this thread's channel, 4 groups of 8 edges
-    if constexpr (MID) {
+    if constexpr (S16) {
+      const bf8* srcp = (const bf8*)(g16 + t0 * (long)(NAMP_H * FEATW_TILE));        // 1,024 pieces of 16 bytes: piece p = (channel p / 8, edges 8 (p % 8) ..)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        *(bf8*)(gh + (p >> 3) * FEATW_LDT + 8 * (p & 7)) = srcp[p];
+        if constexpr (MID) *(bf8*)(gm + (p >> 3) * FEATW_LDT + 8 * (p & 7)) = ((const bf8*)(g16 + g16_plane + t0 * (long)(NAMP_H * FEATW_TILE)))[p];
+      }
+    } else if constexpr (MID) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[8];
@@ -1140,6 +1159,8 @@ struct EmbedLnBwdArgs {
   const float* Wt_img;     // image of W_e^T at the launch's precision
   const float* ln_g;       // LayerNorm weight
   float* g_pre;            // [E][128] dL/dy
+  __bf16* g16;             // optional: dL/dy once more as bf16 tiles [ceil(E / 64)][128][64] in the operand order of feat_wgrad_x3_kernel's staged planes
+  long g16_plane;          //           (split-bf16: the remainders g - bf16(g) in a second array, g16_plane elements behind the first)
   float* stats;            // [E][2] mean, rstd
   float* dgb_part;         // [gridDim.x][2][128]: sum g_E xhat, sum g_E
   long E;
@@ -1148,12 +1169,11 @@ template <int PREC>
 __global__ __launch_bounds__(512) void embed_ln_bwd_kernel(const EmbedLnBwdArgs a) {
   constexpr int IMG_KB = (PREC == 2) ? 32 : 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float colsum[2 * NAMP_H];
+  __shared__ float colsum[8][2 * NAMP_H];           // one slot per wave, added in wave order at the end: deterministic
   __shared__ __attribute__((aligned(16))) float gam[NAMP_H];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
-  if (tid < 2 * NAMP_H) colsum[tid] = 0.f;
   if (tid < NAMP_H) gam[tid] = a.ln_g[tid];
   dma_to_lds(smem, a.Wt_img, IMG_KB, wave, 8, lane);
   wait_dma_and_sync();
@@ -1199,12 +1219,25 @@ __global__ __launch_bounds__(512) void embed_ln_bwd_kernel(const EmbedLnBwdArgs 
     m2 = xg_sum(m2) * (1.0f / 128.0f);
     if (valid) {
       float* dst = a.g_pre + e * NAMP_H + 4 * g;
+      // the 16 edges of this wave are a quarter of a 64-edge tile of g16: channel c of edge m at [(tile / 4) * 128 + c][16 (tile % 4) + m]
+      __bf16* d16 = a.g16 ? a.g16 + ((tile >> 2) * NAMP_H + 4 * g) * 64 + 16 * (tile & 3) + m : nullptr;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = (acc[t] - m1 - yv[t] * m2) * rstd;
+      for (int t = 0; t < 8; ++t) {
+        const f4 v = (acc[t] - m1 - yv[t] * m2) * rstd;
+        *(f4*)(dst + 16 * t) = v;
+        if (d16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const __bf16 hi = (__bf16)v[r];
+            d16[(16 * t + r) * 64] = hi;
+            if (PREC == 1) d16[a.g16_plane + (16 * t + r) * 64] = (__bf16)(v[r] - (float)hi);
+          }
+        }
+      }
       if (g == 0) { a.stats[2 * e] = mean; a.stats[2 * e + 1] = rstd; }
     }
   }
-  // ---- the wave's sums over its row slots m, then over the workgroup's waves (LDS atomics: 128 values per wave, once per launch)
+  // ---- the wave's sums over its row slots m (butterfly), then over the workgroup's waves in wave order
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -1212,10 +1245,15 @@ __global__ __launch_bounds__(512) void embed_ln_bwd_kernel(const EmbedLnBwdArgs 
       float cw = dga[t][r], cb = dbe[t][r];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { cw += __shfl_xor(cw, o); cb += __shfl_xor(cb, o); }
-      if (m == 0) { atomicAdd(&colsum[16 * t + 4 * g + r], cw); atomicAdd(&colsum[NAMP_H + 16 * t + 4 * g + r], cb); }
+      if (m == 0) { colsum[wave][16 * t + 4 * g + r] = cw; colsum[wave][NAMP_H + 16 * t + 4 * g + r] = cb; }
     }
   __syncthreads();
-  if (tid < 2 * NAMP_H) a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + tid] = colsum[tid];
+  if (tid < 2 * NAMP_H) {
+    float s_ = colsum[0][tid];
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) s_ += colsum[w2][tid];
+    a.dgb_part[(long)blockIdx.x * 2 * NAMP_H + tid] = s_;
+  }
 }
 
 

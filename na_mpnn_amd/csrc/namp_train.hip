@@ -510,8 +510,10 @@ int namp_train_embed_ln_bwd_groups(long rows) {
   return (int)(wgs < cus ? wgs : cus);
 }
 
+long namp_train_g16_elems(long rows) { return rows <= 0 ? 0 : (rows + FEATW_TILE - 1) / FEATW_TILE * (long)(NAMP_H * FEATW_TILE); }
+
 int namp_train_embed_ln_bwd(const float* g, const float* Y, const float* Wt_img, const float* ln_g, float* g_pre, float* ln_stats,
-                            float* dgb_part, int x3, long rows, void* stream) {
+                            float* dgb_part, void* g16, int x3, long rows, void* stream) {
   REQUIRE_PTR(g); REQUIRE_PTR(Y); REQUIRE_PTR(Wt_img); REQUIRE_PTR(ln_g); REQUIRE_PTR(g_pre); REQUIRE_PTR(dgb_part);
   if (!ln_stats || ((uintptr_t)ln_stats & 7)) return fail(NAMP_EINVAL, "namp_train_embed_ln_bwd: ln_stats is null or not 8-byte aligned");
   REQUIRE(x3 == 1 || x3 == 2, "namp_train_embed_ln_bwd: precision code %d (1 = split-bf16, 2 = bf16 products)", x3);
@@ -520,6 +522,8 @@ int namp_train_embed_ln_bwd(const float* g, const float* Y, const float* Wt_img,
   if (rc) return rc;
   EmbedLnBwdArgs a = {};
   a.g = g; a.y = Y; a.Wt_img = Wt_img; a.ln_g = ln_g; a.g_pre = g_pre; a.stats = ln_stats; a.dgb_part = dgb_part; a.E = rows;
+  if (g16 && ((uintptr_t)g16 & 15)) return fail(NAMP_EINVAL, "namp_train_embed_ln_bwd: g16 is not 16-byte aligned");
+  a.g16 = (__bf16*)g16; a.g16_plane = namp_train_g16_elems(rows);
   const int grid = namp_train_embed_ln_bwd_groups(rows);
   hipStream_t s = (hipStream_t)stream;
   if (x3 == 2) hipLaunchKernelGGL(embed_ln_bwd_kernel<2>, dim3(grid), dim3(512), NAMP_BIMG_BYTES, s, a);
@@ -569,7 +573,7 @@ int namp_train_feat_wgrad_chunks(long edges) {
 
 long namp_train_feat_wgrad_ws_ints(long edges) { return edges <= 0 ? 0 : 2 * ((edges + FEATW_TILE - 1) / FEATW_TILE); }
 
-int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre,
+int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_idx, const float* E_pos, const float* g_pre, const void* g16,
                           float* dW_part, int32_t* tile_ws, int x3, int B, int L, int K, void* stream) {
   if (!tile_ws) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null tile workspace (namp_train_feat_wgrad_ws_ints int32s)");
   REQUIRE_PTR(X18); REQUIRE_PTR(E_pos); REQUIRE_PTR(g_pre); REQUIRE_PTR(dW_part);
@@ -585,10 +589,13 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   const long ntile = (E + FEATW_TILE - 1) / FEATW_TILE;
   hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, packed ? X18 + 3 : M18,
                      packed ? 4 : 1, E_idx, E, L, K, tile_ws);
-#define NAMP_FEATW(MID_, PK_) hipLaunchKernelGGL((feat_wgrad_x3_kernel<MID_, PK_>), dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, \
-                                                 M18, E_idx, E_pos, g_pre, tile_ws, E, per, L, K, dW_part)
-  if (x3 == 2) { if (packed) NAMP_FEATW(false, true); else NAMP_FEATW(false, false); }        // mixed precision: plain bf16 products
-  else if (x3) { if (packed) NAMP_FEATW(true, true); else NAMP_FEATW(true, false); }
+  REQUIRE(!g16 || (packed && x3 != 0 && aligned16(g16)), "namp_train_feat_wgrad: g16 (bf16 tiles of g_pre) goes with the packed atoms and precision code 1 / 2");
+  const __bf16* g16p = (const __bf16*)g16;
+  const long g16_plane = namp_train_g16_elems(E);
+#define NAMP_FEATW(MID_, PK_, S16_) hipLaunchKernelGGL((feat_wgrad_x3_kernel<MID_, PK_, S16_>), dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, \
+                                                       X18, M18, E_idx, E_pos, g_pre, tile_ws, E, per, L, K, dW_part, g16p, g16_plane)
+  if (x3 == 2) { if (g16p) NAMP_FEATW(false, true, true); else if (packed) NAMP_FEATW(false, true, false); else NAMP_FEATW(false, false, false); }   // mixed precision
+  else if (x3) { if (g16p) NAMP_FEATW(true, true, true); else if (packed) NAMP_FEATW(true, true, false); else NAMP_FEATW(true, false, false); }
 #undef NAMP_FEATW
   else
     hipLaunchKernelGGL(feat_wgrad_kernel, dim3(41, nchunk), dim3(256), 0, (hipStream_t)stream, X18, M18, E_idx, E_pos, g_pre,

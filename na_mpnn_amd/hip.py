@@ -129,7 +129,7 @@ _PROTOTYPES = {
     "namp_reduce_sum": (i32, [C.POINTER(NampReduce), i32, vp]),
     "namp_edge_embed_ln": (i32, [c_fp] * 6 + [i32, i32, i32, i32, vp]),
     "namp_train_embed_ln_bwd_groups": (i32, [C.c_long]),
-    "namp_train_embed_ln_bwd": (i32, [c_fp] * 7 + [i32, C.c_long, vp]),
+    "namp_train_embed_ln_bwd": (i32, [c_fp] * 7 + [vp, i32, C.c_long, vp]),
     "namp_train_wgrad_ln": (i32, [c_fp] * 5 + [i32, C.c_long, c_fp, c_fp, vp]),
     "namp_train_rows_groups": (i32, [C.c_long]),
     "namp_train_class_sums": (i32, [c_fp, c_ip, i32, C.c_long, c_fp, vp]),
@@ -148,7 +148,8 @@ _PROTOTYPES = {
                                       C.POINTER(C.c_void_p), vp]),
     "namp_train_feat_wgrad_chunks": (i32, [C.c_long]),
     "namp_train_feat_wgrad_ws_ints": (C.c_long, [C.c_long]),
-    "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_ip, i32, i32, i32, i32, vp]),
+    "namp_train_feat_wgrad": (i32, [c_fp, c_fp, c_ip, c_fp, c_fp, vp, c_fp, c_ip, i32, i32, i32, i32, vp]),
+    "namp_train_g16_elems": (C.c_long, [C.c_long]),
     "namp_train_loss_smoothed": (i32, [i32, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(C.c_float), C.c_double, c_ip, vp,
                                        vp, vp, c_fp, C.c_long, i32, vp]),
     "namp_train_adam_chunk": (i32, []),

@@ -44,6 +44,7 @@ DW_ONCHIP = _os.environ.get("NAMP_TRAIN_DW", "1") != "0"
 DW_ONCHIP_EDGE = _os.environ.get("NAMP_TRAIN_DW_EDGE", "1") != "0"
 # norm_edges + W_e as one forward / one backward launch without the normalised rows in memory (split-bf16 / mixed precision; 0 = the round-4 pair)
 EMBED_LN_FUSED = _os.environ.get("NAMP_TRAIN_EMBED_LN", "1") != "0"
+G16_SPLIT = _os.environ.get("NAMP_TRAIN_G16_SPLIT", "0") == "1"      # bf16 operand tiles of dL/dy in the split-bf16 mode too (measured: a loss)
 # split-bf16 edge-update backward (fp32 row tensors): complexes per batch are walked in this many slices at most (1 = the whole batch at once)
 EDGE_UPDATE_SLICES = max(1, int(_os.environ.get("NAMP_TRAIN_EU_SLICES", "2")))
 
@@ -704,9 +705,13 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
             xp, mp = XM.data_ptr(), None
         else:
             xp, mp = X18.data_ptr(), M18.data_ptr()
-        hip.check(L.namp_train_feat_wgrad(xp, mp, E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(),
+        g16 = _G16.pop(g.data_ptr(), None)                     # bf16 operand tiles of this very tensor, left by _EdgeEmbedTail.backward
+        if g16 is not None and (g16[1] != E or g16[2] != int(ctx.x3)):
+            g16 = None
+        hip.check(L.namp_train_feat_wgrad(xp, mp, E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(), g16[0].data_ptr() if g16 else None,
                                           part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
                   "train_feat_wgrad")
+        _G16.clear()
         Wc = Wedge.detach().contiguous()
         n2 = L.namp_train_pos_grad_groups(E)
         part2 = torch.empty(n2, spec.NUM_POS_CLASSES + 1, spec.NUM_POS, device=g.device)
@@ -846,6 +851,11 @@ class _RowLayerNorm(torch.autograd.Function):
         return gx, s[0], s[1]
 
 
+# dL/dy of the edge embedding as bf16 operand tiles (namp_train_embed_ln_bwd writes them beside the fp32 rows): keyed by the fp32 tensor's address so
+# that the gradient launch of the embedding weight (_EdgeEmbeddingGrad.backward, the next autograd node) finds them IF it is handed that very tensor
+_G16 = {}
+
+
 class _EdgeEmbedTail(torch.autograd.Function):
     """h_E = W_e LayerNorm(y) + b_e (norm_edges + W_e, na_model_utils.py:509,598) with the normalised rows never in memory (split-bf16 / mixed
     precision): forward = one launch on the pre-LayerNorm rows (namp_edge_embed_ln); backward = one launch for dL/dy (W_e^T product + LayerNorm
@@ -875,8 +885,20 @@ class _EdgeEmbedTail(torch.autograd.Function):
         g_pre = torch.empty_like(y)
         stats = torch.empty(rows, 2, device=dev)
         part = torch.empty(L.namp_train_embed_ln_bwd_groups(rows), 2, H, device=dev)
+        # Mixed precision: dL/dy also as bf16 operand tiles for the embedding-weight gradient (feat_wgrad 2.17 -> 1.29 ms at cfg5 for +0.16 ms here).
+        # Split-bf16 (hi + remainder tiles, G16_SPLIT): the gradient launch gains 0.05 ms and this one loses 0.35 — off.
+        g16 = None
+        if int(ctx.x3) == 2 or G16_SPLIT:
+            ne = L.namp_train_g16_elems(rows)
+            g16 = torch.empty(2 if int(ctx.x3) == 1 else 1, ne, device=dev, dtype=torch.bfloat16)      # [ceil(rows / 64)][128][64] (x 2)
+            if rows % 64:
+                g16[:, ne - 64 * H:].zero_()                  # rows past the end of the last tile
         hip.check(L.namp_train_embed_ln_bwd(g.data_ptr(), y.data_ptr(), _image_t(W, ctx.x3, ctx.step).data_ptr(), lw.data_ptr(), g_pre.data_ptr(),
-                                            stats.data_ptr(), part.data_ptr(), int(ctx.x3), rows, hip.current_stream()), "train_embed_ln_bwd")
+                                            stats.data_ptr(), part.data_ptr(), hip.ptr(g16), int(ctx.x3), rows, hip.current_stream()),
+                  "train_embed_ln_bwd")
+        _G16.clear()
+        if g16 is not None:
+            _G16[g_pre.data_ptr()] = (g16, rows, int(ctx.x3))
         n = L.namp_train_wgrad_chunks(rows)
         dWp, dbp = torch.empty(n, H, H, device=dev), torch.empty(n, H, device=dev)
         hip.check(L.namp_train_wgrad_ln(g.data_ptr(), y.data_ptr(), stats.data_ptr(), lw.data_ptr(), lb.data_ptr(), int(ctx.x3), rows,
@@ -985,6 +1007,7 @@ def forward_train(model, fd, decoding_randn=None):
     X3 = PREC_CODE[getattr(model, "message_precision", "x3")]
     _STEP = _CACHE_STEP = object()                           # a new step: its own (empty) image cache
     _IMG_CACHE.clear()
+    _G16.clear()
     if X3 and fd["mask"].is_cuda and torch.is_grad_enabled():
         _PLAN.begin_step(_STEP, fd["mask"].device)            # every image the previous step asked for, from one launch
     try:

@@ -537,6 +537,42 @@ def test_edge_update_backward(p):
         assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (name, fd, an)
 
 
+@pytest.mark.parametrize("prec", ["x3", "bf16"])
+def test_feature_weight_gradient_from_bf16_tiles(weights_np, prec, monkeypatch):
+    """The backward launch of norm_edges + W_e leaves dL/dy a second time as bf16 operand tiles [tile][channel][64 edges] (hi | remainder); the
+    embedding-weight gradient stages those by 16-byte copies instead of converting / transposing the fp32 rows.  Same operands, same products:
+    the gradients are bit-identical to the fp32-row path (here: the tiles withheld), at a size with a partial last tile (46 x 14 = 644 edges)."""
+    n, k = 46, 14
+    cx = synth.make_complex(seed=31, n=n, n_chains=2, missing_atom_frac=0.05, masked_frac=0.04)
+    fd = {k_: torch.from_numpy(np.ascontiguousarray(v))[None].to(DEV) for k_, v in cx.items()}
+    m = make_model(weights_np, k)
+    m.message_precision = prec
+    monkeypatch.setattr(train, "X3", train.PREC_CODE[prec])
+    monkeypatch.setattr(train, "G16_SPLIT", True)             # (split-bf16: the hi + remainder tiles are off by default)
+    fp = m.features
+    R = None
+    grads = []
+
+    class NoTiles(dict):
+        def __setitem__(self, key, value):
+            pass
+
+    for tiles in (True, False):
+        if not tiles:
+            monkeypatch.setattr(train, "_G16", NoTiles())
+        m.zero_grad()
+        with torch.enable_grad():
+            y, E_idx = train.edge_embedding(m, fd)
+            h = train._EdgeEmbedTail.apply(y, fp.norm_edges.weight, fp.norm_edges.bias, m.W_e.weight, m.W_e.bias)
+            if R is None:
+                R = torch.randn(h.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+            (h * R).sum().backward()
+        grads.append({n_: p.grad.clone() for n_, p in fp.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and "edge_embedding.weight" in grads[0]
+    for n_ in grads[0]:
+        assert torch.equal(grads[0][n_], grads[1][n_]), n_
+
+
 def test_feature_weight_gradient(weights_np):
     """namp_train_feat_wgrad (+ the positional path) vs torch autograd through the dense RBF featurisation."""
     n, k = 46, 14

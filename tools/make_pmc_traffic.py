@@ -43,8 +43,10 @@ def cfg5_algorithmic(kernel, prec):
         return E * (512 + 512 + 512 + 256) + E * 4 + 3 * G * 512
     if "edge_update_bwd_b16" in kernel:                # launch B: h_E + G2 + dL/dx rows in, dL/dh_E + G1 rows out, E_idx, per-tile sums, tables
         return E * (512 + 256 + 512 + 512 + 256) + base
-    if "feat_wgrad" in kernel:                         # g_pre rows once, atom frames, E_idx, the 128 chunks' [128 x 5200] partials
-        return E * 512 + G * 18 * 16 + E * 4 + 128 * 128 * 5200 * 4
+    if "feat_wgrad" in kernel:                         # g_pre rows once (bf16 operand tiles in the mixed-precision mode), atom frames, E_idx, the 128 chunks' [128 x 5200] partials
+        return E * (256 if prec == "bf16" else 512) + G * 18 * 16 + E * 4 + 128 * 128 * 5200 * 4
+    if "embed_ln_bwd" in kernel:                       # g and y rows in, g_pre rows out (+ its bf16 tiles in the mixed-precision mode), row statistics
+        return E * (512 * 3 + (256 if prec == "bf16" else 0) + 8)
     if "pos_grad_kernel" in kernel:
         return E * 512 + E * 4
     if "scatter_rows_kernel" in kernel:                # G1 rows once, reverse adjacency, one or two [G,128] outputs
@@ -64,7 +66,7 @@ def cfg5_section(fetch_db, write_db, prec):
     sec = {}
     for k in sorted(set(f) | set(w)):
         if not any(t in k for t in ("edge_bwd_dw", "edge_update_bwd_", "edge_chain_bwd", "wgrad", "scatter_rows", "edge_mlp_x3_persistent",
-                                    "edge_mlp_bf16_persistent", "feat_wgrad", "edge_features", "reduce_sum", "pos_grad", "ln_rows")):
+                                    "edge_mlp_bf16_persistent", "feat_wgrad", "edge_features", "reduce_sum", "pos_grad", "ln_rows", "embed_ln_bwd")):
             continue
         nbytes = (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024
         e = {"measured_bytes": round(nbytes)}
