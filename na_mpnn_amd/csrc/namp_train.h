@@ -884,12 +884,11 @@ static __global__ __launch_bounds__(256) void feat_wgrad_kernel(const float* __r
 // (eight) 16-byte copies per thread; from the fp32 rows it is 32 four-byte loads, 32 conversions and the transposition, repeated by each of the 41 column
 // groups — HALF of this launch once its L2 misses and coordinate gathers were gone (ablation: 2.17 -> 1.06 ms without the staging; profiles/r05g).
 template <bool MID, bool PK, bool S16 = false>      // MID = false: hi . hi products only (mixed-precision mode)
-__global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
-                                                            const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
-                                                            const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
-                                                            long E, long edges_per_chunk, int L, int K,
-                                                            float* __restrict__ dW_part, const __bf16* __restrict__ g16 = nullptr,
-                                                            long g16_plane = 0) {
+__device__ __forceinline__ void feat_wgrad_x3_body(const float* __restrict__ X18, const float* __restrict__ M18,
+                                                   const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
+                                                   const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
+                                                   long E, long edges_per_chunk, int L, int K,
+                                                   float* __restrict__ dW_part, const __bf16* __restrict__ g16, long g16_plane) {
   __shared__ __attribute__((aligned(16))) __bf16 gh[NAMP_H * FEATW_LDT];
   __shared__ __attribute__((aligned(16))) __bf16 gm[MID ? NAMP_H * FEATW_LDT : 8];
   __shared__ __attribute__((aligned(16))) float dsc[4][FEATW_NBW][FEATW_TILE];      // c * distance per (wave, block, edge of the tile)
@@ -1116,6 +1115,28 @@ __global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(long)(16 * t + 4 * g + r) * FEATW_COLS + 16 * (blk0 + q) + n] = acc[q][t][r];
   }
+}
+
+template <bool MID, bool PK, bool S16 = false>
+__global__ __launch_bounds__(256) void feat_wgrad_x3_kernel(const float* __restrict__ X18, const float* __restrict__ M18,
+                                                            const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
+                                                            const float* __restrict__ g_pre, const int32_t* __restrict__ pres,
+                                                            long E, long edges_per_chunk, int L, int K,
+                                                            float* __restrict__ dW_part, const __bf16* __restrict__ g16 = nullptr,
+                                                            long g16_plane = 0) {
+  feat_wgrad_x3_body<MID, PK, S16>(X18, M18, E_idx, E_pos, g_pre, pres, E, edges_per_chunk, L, K, dW_part, g16, g16_plane);
+}
+#ifndef FEATW_T16_WAVES
+#define FEATW_T16_WAVES 3
+#endif
+// The mixed-precision launch on bf16 operand tiles at three workgroups per CU (156 registers; at four — 128 registers — it spills 47 and runs 2.5 ms):
+// the waves of the other workgroups cover the per-tile round trips (coordinates, LDS, two barriers) that are what is left of a tile visit once the
+// staging is four copies.
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FEATW_T16_WAVES, FEATW_T16_WAVES)))
+void feat_wgrad_t16_kernel(const float* __restrict__ X18, const int32_t* __restrict__ E_idx, const float* __restrict__ E_pos,
+                           const int32_t* __restrict__ pres, long E, long edges_per_chunk, int L, int K, float* __restrict__ dW_part,
+                           const __bf16* __restrict__ g16) {
+  feat_wgrad_x3_body<false, true, true>(X18, nullptr, E_idx, E_pos, nullptr, pres, E, edges_per_chunk, L, K, dW_part, g16, 0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -594,7 +594,9 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   const long g16_plane = namp_train_g16_elems(E);
 #define NAMP_FEATW(MID_, PK_, S16_) hipLaunchKernelGGL((feat_wgrad_x3_kernel<MID_, PK_, S16_>), dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, \
                                                        X18, M18, E_idx, E_pos, g_pre, tile_ws, E, per, L, K, dW_part, g16p, g16_plane)
-  if (x3 == 2) { if (g16p) NAMP_FEATW(false, true, true); else if (packed) NAMP_FEATW(false, true, false); else NAMP_FEATW(false, false, false); }   // mixed precision
+  if (x3 == 2) { if (g16p) hipLaunchKernelGGL(feat_wgrad_t16_kernel, dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, X18, E_idx, E_pos, tile_ws,
+                                               E, per, L, K, dW_part, g16p);
+                 else if (packed) NAMP_FEATW(false, true, false); else NAMP_FEATW(false, false, false); }   // mixed precision
   else if (x3) { if (g16p) NAMP_FEATW(true, true, true); else if (packed) NAMP_FEATW(true, true, false); else NAMP_FEATW(true, false, false); }
 #undef NAMP_FEATW
   else
