@@ -58,6 +58,33 @@ template <bool BF> __device__ __forceinline__ f4 ld_row4(const float* base, cons
   return *(const f4*)(base + off);
 }
 
+// A wave's 16-row tile (register-chain layout: lane (m, g) holds channels 16t + 4g + r of row m) as bf16 rows: the 8-byte piece (t, g) of a row sits at
+// piece index 4t + g, so a lane's own pieces are 32 bytes apart and a store instruction moves 16 x 32 bytes.  v_permlane16_swap_b32 (gfx950: the odd
+// 16-lane rows of one register against the even rows of another) hands lane group g the piece of g ^ 1: even groups then store pieces (4t + g, 4t + g + 1),
+// odd ones (4(t+1) + g - 1, 4(t+1) + g) — four 16-byte stores per lane and tile instead of eight 8-byte ones.
+#ifndef NAMP_ABL_NOPAIRST
+__device__ __forceinline__ void st_tile_bf16(float* base, const long row_off, const f4 (&v)[8], const int g) {
+  __bf16* dst = (__bf16*)base + row_off;
+  typedef int i4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int t = 0; t < 8; t += 2) {
+    const bf4 x = to_bf4(v[t]), y = to_bf4(v[t + 1]);
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    const i2v xi = __builtin_bit_cast(i2v, x), yi = __builtin_bit_cast(i2v, y);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(xi[0], yi[0], false, false);      // [0]: x with its odd rows replaced by y's even rows; [1]: y with its
+    const auto s1 = __builtin_amdgcn_permlane16_swap(xi[1], yi[1], false, false);      //      even rows replaced by x's odd rows
+    const i4v o = (i4v){(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+    const int col = (g & 1) ? 16 * (t + 1) + 4 * (g - 1) : 16 * t + 4 * g;
+    *(i4v*)(dst + col) = o;
+  }
+}
+#else
+__device__ __forceinline__ void st_tile_bf16(float* base, const long row_off, const f4 (&v)[8], const int g) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) st_row4<true>(base, row_off + 4 * g + 16 * t, v[t]);
+}
+#endif
+
 enum { BWD_ENC_MSG = 0, BWD_DEC_MSG = 1, BWD_ROWS = 2, BWD_EDGE_LN = 3 };
 
 struct EdgeBwdArgs {
@@ -906,7 +933,7 @@ __device__ __forceinline__ void feat_wgrad_x3_body(const float* __restrict__ X18
   long e_end = e_begin + edges_per_chunk;
   if (e_end > E) e_end = E;
   constexpr float C = 0.9608979270291599f;                     // 0.8 * sqrt(log2 e)
-  const float cmu = (2.0f + (float)n * (20.0f / 15.0f)) * C;
+  const float cmu = fmaf((float)n, 20.0f / 15.0f, 2.0f) * C;
   int pa[FEATW_NBW], pb[FEATW_NBW];
 #pragma unroll
   for (int q = 0; q < FEATW_NBW; ++q) {
@@ -1041,7 +1068,8 @@ __device__ __forceinline__ void feat_wgrad_x3_body(const float* __restrict__ X18
 #pragma unroll
       for (int q = 0; q < FEATW_NBW; ++q) {
         const float dx = c0.xi[q][0] - c0.xj[q][0], dy = c0.xi[q][1] - c0.xj[q][1], dz = c0.xi[q][2] - c0.xj[q][2];
-        dw[q * FEATW_TILE + lane] = (eok && c0.mi[q] * c0.mj[q] != 0.f) ? C * sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f) : 1e30f;
+        // (explicit fused chain: the instantiations of this body must agree to the bit, whatever each one's register budget makes of a * b + c)
+        dw[q * FEATW_TILE + lane] = (eok && c0.mi[q] * c0.mj[q] != 0.f) ? C * sqrtf(fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, 1e-6f)))) : 1e30f;
       }
     }
     __syncthreads();

@@ -763,8 +763,7 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_bwd_dw16_kernel(const Edge
     DW_STAMP(14);
 #ifndef DW_EXP_NOSTORE
     const long e_st = (round * DW_WAVES + wave) * 16 + m;           // unclamped: rows past E go to the buffers' padding
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.G1, e_st * NAMP_H + 4 * g + 16 * t, gr[t]);
+    st_tile_bf16(a.G1, e_st * NAMP_H, gr, g);
     if constexpr (GPA == 1) {
       // per-tile sums of G1 over the tile's 16 rows: a rotate all-reduce inside each DPP row (every lane ends with the 32 sums of its channel
       // group), then lane m keeps channel tile m & 7 — ONE unconditional 16-byte store per lane (lanes m and m + 8 write the same bytes)

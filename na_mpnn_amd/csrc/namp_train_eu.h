@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_update_bwd_a16_kernel(cons
     for (int t = 0; t < 8; ++t) y[t] = (f4){0.f, 0.f, 0.f, 0.f};
     dw_gemm16_ahead(y, gr, w3t);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.G2, e_raw * NAMP_H + 4 * g + 16 * t, y[t] * eu_unpack(e16[2 * t], e16[2 * t + 1]));
+    for (int t = 0; t < 8; ++t) y[t] *= eu_unpack(e16[2 * t], e16[2 * t + 1]);
+    st_tile_bf16(a.G2, e_raw * NAMP_H, y, g);
   }
   // ---- the workgroup's partials
   float* o3 = aa.dW_part + (long)blockIdx.x * NAMP_H * NAMP_H;
@@ -390,8 +391,7 @@ __global__ __launch_bounds__(64 * DW_WAVES) void edge_update_bwd_b16_kernel(cons
     dw_stage<false>(SG, gr, wave, m, g);
     dw_stage_packed(SA, h16, wave, m, g);
     dw_lds_barrier();
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st_row4<true>(a.G1, e_raw * NAMP_H + 4 * g + 16 * t, gr[t]);
+    st_tile_bf16(a.G1, e_raw * NAMP_H, gr, g);
     if constexpr (GPA == 1) {
       const long tile = round * DW_WAVES + wave;
       f4 keep = (f4){0.f, 0.f, 0.f, 0.f};
