@@ -2,4 +2,4 @@
 R=$GRAFT_REPO_ROOT; cd $R
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/profile_round5.sh r05f 7e788b2 > gpurun_out/r05f.log 2>&1; tail -25 gpurun_out/r05f.log
+bash tools/profile_round5.sh r05h a815814 > gpurun_out/r05h.log 2>&1; tail -25 gpurun_out/r05h.log
