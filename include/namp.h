@@ -371,6 +371,9 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
  * data gradients inside the training step. */
 int namp_edge_embed_prec(const float* We_img, const float* We_b, const float* E, float* h_E, int prec, int B, int N, int K,
                          void* stream);
+/* out[n] = sum_{q < n} W_q . X_q[n] over [G][128] rows: the data gradient of several residue-level linear maps of one input in one launch (images as
+ * namp_node_linear_prec takes them: fp32 fragment images for precision code 0, x3 images for 1 / 2). */
+int namp_node_linear_sum(const float* const* X, const float* const* img, int n, float* out, int G, int prec, void* stream);
 int namp_node_linear_prec(const float* X, int G, const NampProj* proj, int nproj, int prec, void* stream);
 int namp_train_edge_fwd(int mode, const float* h_E, const int32_t* E_idx, const int32_t* mask, const int32_t* mask_attend,
                         const int32_t* rank, const float* Pa, const float* Pj0, const float* Pj1, const float* W1_img,

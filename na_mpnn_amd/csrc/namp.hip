@@ -697,6 +697,28 @@ int namp_node_linear_prec(const float* X, int G, const NampProj* proj, int nproj
   return NAMP_OK;
 }
 
+int namp_node_linear_sum(const float* const* X, const float* const* img, int n, float* out, int G, int prec, void* stream) {
+  REQUIRE(X && img, "namp_node_linear_sum: null pointer table");
+  REQUIRE(n >= 1 && n <= 8, "namp_node_linear_sum: n=%d must be in [1,8]", n);
+  REQUIRE(G >= 1, "namp_node_linear_sum: G=%d", G);
+  REQUIRE(prec >= 0 && prec <= 2, "namp_node_linear_sum: precision code %d (0 fp32, 1 split-bf16, 2 bf16)", prec);
+  REQUIRE_PTR(out);
+  NodeLinearSumArgs a = {};
+  for (int q = 0; q < 8; ++q) {
+    const int s_ = q < n ? q : 0;
+    REQUIRE_PTR(X[s_]); REQUIRE_PTR(img[s_]);
+    a.X[q] = X[s_]; a.img[q] = img[s_];
+  }
+  a.out = out; a.G = G; a.n = n;
+  ProfScope prof_(NAMP_KIND_NODE_LINEAR, (hipStream_t)stream);
+  const dim3 grid(((G + 15) / 16 + 3) / 4);
+  if (prec == 2) hipLaunchKernelGGL(node_linear_sum_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (prec == 1) hipLaunchKernelGGL(node_linear_sum_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(node_linear_sum_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_enc_message(const NampEncLayerW* w, const float* h_E, const int32_t* E_idx, const int32_t* mask,
                      const int32_t* mask_attend, const float* Pa, const float* Pc, float* partial, int B, int N,
                      int K, void* stream) {

@@ -2795,6 +2795,41 @@ __global__ __launch_bounds__(MAXW * 64) void dec_sample_kernel(const SampleArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// node_linear_sum_kernel — out[n] = sum_q W_q . X_q[n]: the data gradient of several residue-level linear maps of one input (dL/dx = sum_q g_q W_q,
+// train._NodeLinears.backward) in ONE launch — one wave per 16-row tile runs the n products into the same accumulators; as n node_linear launches
+// the sum cost n - 1 stock additions of [G,128] tensors besides.  Images as node_linear_kernel's (x3 images for X3 = 1 / 2).
+// ------------------------------------------------------------------------------------------
+struct NodeLinearSumArgs { const float* X[8]; const float* img[8]; float* out; int G, n; };
+template <int X3>
+__global__ __launch_bounds__(256) void node_linear_sum_kernel(const NodeLinearSumArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile * 16 >= a.G) return;
+  const int m = lane & 15, g = lane >> 4;
+  const int row = tile * 16 + m;
+  const bool valid = row < a.G;
+  const long off = (long)(valid ? row : 0) * NAMP_H + 4 * g;
+  f4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {                                // static indices into the argument block
+    if (q >= a.n) break;
+    f4 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = *(const f4*)(a.X[q] + off + 16 * t);
+    if constexpr (X3) chain_gemm_global_x3<X3 == 2>(acc, x, (const bf8*)a.img[q] + lane);
+    else chain_gemm_global<8, 8, false>(acc, x, (const f4*)a.img[q] + lane, 8);
+  }
+  if (valid) {
+    float* dst = a.out + (long)row * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // node_linear_kernel — residue-level projections  out_p[n] = W_p . X[src(n)] + bias_p (+ tok_p[S[n]])
 // for up to 8 weight blocks p at once.  One wave per (16-residue tile, p); weights stream
 // straight from L2 as coalesced fragment loads (each element is used once per wave, so LDS

@@ -127,6 +127,7 @@ _PROTOTYPES = {
     "namp_train_tail_fwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 8 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 4 + [i32, vp]),
     "namp_train_tail_bwd": (i32, [c_fp, c_fp, c_ip] + [c_fp] * 4 + [C.c_float, C.c_uint32, C.c_uint32] + [c_fp] * 10 + [i32, vp]),
     "namp_reduce_sum": (i32, [C.POINTER(NampReduce), i32, vp]),
+    "namp_node_linear_sum": (i32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, c_fp, i32, i32, vp]),
     "namp_edge_embed_ln": (i32, [c_fp] * 6 + [i32, i32, i32, i32, vp]),
     "namp_train_embed_ln_bwd_groups": (i32, [C.c_long]),
     "namp_train_embed_ln_bwd": (i32, [c_fp] * 7 + [vp, i32, C.c_long, vp]),

@@ -769,6 +769,26 @@ def _node_linear_call(x2, blocks, biases, x3=None, transposed=False, step=None, 
     return outs
 
 
+def _node_linear_sum(xs, blocks, x3=None, step=None, plan=True):
+    """sum_q xs[q] @ blocks[q] over [G,128] rows in ONE launch (namp_node_linear_sum): the data gradient of _NodeLinears — as one node_linear launch per
+    block the sum cost a stock addition per further block besides."""
+    G = xs[0].shape[0]
+    prec = int(X3 if x3 is None else x3)
+    out = torch.empty(G, H, device=xs[0].device)
+    if prec == 0:
+        keep = [_image_f32(b_.t().contiguous()) for b_ in blocks]
+    else:
+        keep = [_image(b_, 1, transposed=True, step=step, plan=plan) for b_ in blocks]
+    arr = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
+    for q0 in range(0, len(xs), 8):                              # (more than 8 blocks: the launches' results are added)
+        o = out if q0 == 0 else torch.empty_like(out)
+        hip.check(hip.lib().namp_node_linear_sum(arr([x.data_ptr() for x in xs[q0:q0 + 8]]), arr([k.data_ptr() for k in keep[q0:q0 + 8]]),
+                                                 len(xs[q0:q0 + 8]), o.data_ptr(), G, prec, hip.current_stream()), "node_linear_sum")
+        if q0:
+            out = out + o
+    return out
+
+
 class _NodeLinears(torch.autograd.Function):
     """Several residue-level linear maps of the same input, y_q = x W_q^T + b_q with W_q [128 x 128] column blocks of the layers'
     first-layer weights (the hoisted tables Pa / Pc / Pbw / Pfw, na_model_utils.py:218-236, 610-636, and W_v): one
@@ -790,10 +810,7 @@ class _NodeLinears(torch.autograd.Function):
     def backward(ctx, *gs):
         x2, *Ws = ctx.saved_tensors
         g2 = [g.contiguous().view(-1, H) for g in gs]
-        gx = None
-        for q, w in enumerate(Ws):                                  # dL/dx = sum_q g_q W_q
-            t = _node_linear_call(g2[q], [w.detach()], [None], x3=ctx.x3, transposed=True, step=ctx.step, plan=ctx.plan)[0]
-            gx = t if gx is None else gx + t
+        gx = _node_linear_sum(g2, [w.detach() for w in Ws], x3=ctx.x3, step=ctx.step, plan=ctx.plan)      # dL/dx = sum_q g_q W_q
         res = _wgrad_many([(g2[q], x2, ctx.has_b[q]) for q in range(ctx.nb)], x3=ctx.x3)      # one reduction for all blocks
         gW, gb = [r[0] for r in res], [r[1] for r in res]
         return (gx.view(ctx.shape), None, None, *gW, *gb)
