@@ -1086,8 +1086,13 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     a.Wedge_img = x3 ? w->feat.Wedge_ximg : w->feat.Wedge_img; a.pos_w = w->feat.pos_w; a.pos_b = w->feat.pos_b; a.ln_g = w->feat.ln_g; a.ln_b = w->feat.ln_b;
     a.We_img = h_E ? (x3 ? w->We_ximg : w->We_img) : nullptr; a.We_b = h_E ? w->We_b : nullptr; a.E_out = E; a.hE_out = h_E;
     a.G = G; a.L = L; a.K = K;
-    const EdgeGeom e = edge_geom(G, K);
+    EdgeGeom e = edge_geom(G, K);
     a.TPN = e.tpn;
+    // A chain of up to ~250 residues (the design call of the README demos: cfg1, 97 residues): at 12 waves per workgroup the launch is a handful of
+    // workgroups that each walk the UNION of their 4-6 residues' atom-pair chunks (a protein residue needs 10 of the 54, a nucleotide 39): 169 us at
+    // 97 residues.  One residue per workgroup — its own chunks only, every workgroup on a CU of its own — 115 us.  Beyond one round of the chip it loses
+    // (1,000 residues: 177 -> 281 us: a workgroup's 140 KB of LDS allow one per CU).
+    if (G <= device_cus()) { e.npw = 1; e.nwaves = e.tpn; e.grid = G; }
     // NampModelW.reserved == 2 with an x3 image: plain bf16 products on its hi half (mixed-precision training)
     if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
     else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
