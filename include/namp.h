@@ -259,6 +259,11 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
  * namp_persistent_status: synchronous read-back of the barrier state of the last persistent launch that used `ws`
  * (0 = every grid barrier completed; otherwise the code of the barrier that gave up — the outputs are then invalid). */
 int namp_set_persistent(int on);
+/* The bf16-storage edge launches of namp_encdec_fwd (large batches of the bf16 throughput mode) exist in two instruction sequencings
+ * with bit-identical results: edge_mlp_bf16s32_kernel (round 3) and edge_mlp_bf16p_kernel (round 6; default mask 3: its embedding variant is the slower one).  mask: bit 0 the two
+ * message launches, bit 1 the edge update, bit 2 the first encoder message with the fused edge embedding; returns the previous mask.
+ * Environment: NAMP_BF16P.  For A/B timing and for the bit-equality test only. */
+int namp_set_bf16p(int mask);
 int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K, int32_t* code);
 
 /* ---- a11: graph construction + edge features ------------------------------------------------

@@ -3,7 +3,9 @@
 // launches on the caller's stream; it owns no device memory and never synchronises.
 #include "../../include/namp.h"
 #include "namp_kernels.h"
+#include <atomic>
 #include "namp_bf16s32.h"
+#include "namp_bf16p.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -143,6 +145,10 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s32_kernel<MODE_DEC_MSG>, BF16S32_LDS);
   set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_EDGE>, BF16S32_LDS);
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
+  set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
+  set((const void*)edge_mlp_bf16p_kernel<MODE_DEC_MSG>, BF16P_LDS);
+  set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_EDGE>, BF16P_LDS);
+  set((const void*)(edge_mlp_bf16p_kernel<MODE_ENC_MSG, true>), BF16P_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_X3>), NAMP_IMG_BYTES);
@@ -241,6 +247,8 @@ int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
   return NAMP_OK;
 }
 
+// which bf16-storage edge launches run in the round-6 sequencing (namp_bf16p.h): bit 0 messages, 1 edge update, 2 message + embedding
+static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 3; }()};
 // bf16 STORAGE variant (h_E and the gathered tables as bf16 rows in fragment order B): large batches of the bf16 throughput mode, on
 // v_mfma_f32_32x32x16_bf16 (namp_bf16s32.h; images from namp_pack_image_bf16_32)
 template <int MODE>
@@ -251,6 +259,18 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   a.TPN = e.tpn;
   if ((long)a.G * e.tpn >= (1L << 31)) return fail(NAMP_EINVAL, "edge launch: %ld row tiles exceed 2^31", (long)a.G * e.tpn);
   // 8 waves per CU (up to 256 VGPRs each), one 32-row pair of tiles per wave and step
+  // NAMP_BF16P (A/B switch, bit mask over 1 = messages, 2 = edge update, 4 = message + embedding): the round-6 sequencing (namp_bf16p.h)
+  const int bf16p = g_bf16p.load(std::memory_order_relaxed);
+  if constexpr (MODE == MODE_ENC_MSG) {
+    if (a.eW1_img && (bf16p & 4)) {
+      hipLaunchKernelGGL((edge_mlp_bf16p_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(512), BF16P_LDS, s, a);
+      return NAMP_OK;
+    }
+  }
+  if (!(MODE == MODE_ENC_MSG && a.eW1_img) && (bf16p & (MODE == MODE_ENC_EDGE ? 2 : 1))) {
+    hipLaunchKernelGGL((edge_mlp_bf16p_kernel<MODE>), dim3(device_cus()), dim3(512), BF16P_LDS, s, a);
+    return NAMP_OK;
+  }
   if constexpr (MODE == MODE_ENC_MSG) {
     if (a.eW1_img) {                     // fused edge embedding: a.hE = fp32 E, a.hE16_out = the bf16 rows
       hipLaunchKernelGGL((edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(512), BF16S32_LDS, s, a);
@@ -1374,6 +1394,8 @@ extern "C" int namp_debug_wstamps(int* counts8, long long* log, int reset) {
   return NAMP_WS_EVENTS;
 }
 #endif
+
+int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 7); }
 
 int namp_set_persistent(int on) {
   std::lock_guard<std::mutex> lk(g_persist_mutex);

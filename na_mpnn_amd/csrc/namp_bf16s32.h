@@ -28,6 +28,23 @@ static __global__ void pack_image_bf16_32_kernel(const float* __restrict__ W, in
 
 // GELU (bf16-mode polynomial) of eight accumulators -> the bf16 operand of one K-step
 __device__ __forceinline__ bf8 gelu_pack8(const f16v& v, const int u) {
+#ifdef B32_SCALAR
+  // eight independent scalar Horner chains (no packed-fp32 forms: a v_pk_fma_f32 costs more than two v_fma_f32 beside MFMAs, profiles/r03c)
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = v[8 * u + i], t = x * x;
+    float q = fmaf(NAMP_GELU4_Q4, t, NAMP_GELU4_Q3);
+    q = fmaf(q, t, NAMP_GELU4_Q2); q = fmaf(q, t, NAMP_GELU4_Q1); q = fmaf(q, t, NAMP_GELU4_Q0);
+    float p;
+    asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(p) : "v"(x), "v"(q));
+    y[i] = x * p;
+  }
+  bf8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (__bf16)y[i];
+  return o;
+#endif
   const f4 lo = (f4){v[8 * u + 0], v[8 * u + 1], v[8 * u + 2], v[8 * u + 3]};
   const f4 hi = (f4){v[8 * u + 4], v[8 * u + 5], v[8 * u + 6], v[8 * u + 7]};
   return pack_bf16<true>(lo, hi);
@@ -55,6 +72,15 @@ __device__ __forceinline__ void gemm32(f16v (&out)[4], const bf8* w, Op op) {
     }
     if constexpr (PIN) __builtin_amdgcn_sched_barrier(2);
     const bf8 ab = op(s);
+#ifdef B32_NOLDSW
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) { wf[s & 1][tn] = ab; wf[s & 1][tn][0] = (__bf16)(float)(s * 4 + tn); }
+#endif
+#ifdef B32_NOMFMA
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) asm volatile("" :: "v"(wf[s & 1][tn]), "v"(ab));
+    continue;
+#endif
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
       out[tn] = FLIP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, wf[s & 1][tn], out[tn], 0, 0, 0)

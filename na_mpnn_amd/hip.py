@@ -171,6 +171,7 @@ _PROTOTYPES = {
     "namp_enc_layer_fwd": (i32, [C.POINTER(NampEncLayerW), c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp,
                                  vp, sz, i32, i32, i32, vp]),
     "namp_set_persistent": (i32, [i32]),
+    "namp_set_bf16p": (i32, [i32]),
     "namp_persistent_status": (i32, [vp, sz, i32, i32, i32, C.POINTER(C.c_int32)]),
     "namp_dec_layer_fwd": (i32, [C.POINTER(NampDecLayerW), c_fp, c_fp, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, vp]),
     "namp_encoder_fwd": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_fp, c_fp,

@@ -659,6 +659,28 @@ def test_bf16_throughput_mode(L, dev, wt, golden_dir):
             assert float((lp_x.argmax(-1) == lp_f.argmax(-1))[valid].float().mean()) >= 0.97, (b, n, k)
 
 
+@pytest.mark.parametrize("b,n,k,mf", [(5, 900, 48, 0.0), (6, 700, 30, 0.1), (3, 901, 16, 0.1), (1, 2600, 128, 0.0), (9, 520, 20, 0.0)])
+def test_bf16p_equals_bf16s32(L, dev, wt, b, n, k, mf):
+    """The round-6 sequencing of the bf16-storage edge launches (edge_mlp_bf16p_kernel: accumulator-major blocks, every MFMA slot carrying
+    a slice of the previous block's epilogue) against the round-3 kernels it replaces (edge_mlp_bf16s32_kernel), through namp_encdec_fwd:
+    same accumulation order, same rounding points, so h_V and the log-probabilities must agree to the BIT — incl. K % 16 != 0 (padding
+    rows), an odd number of row tiles (a trailing half pair), masked residues, one and eight tiles per residue."""
+    t, d = graph(dev, seed=70 + k, batch=b, n=n, k=k, masked_frac=mf)
+    P = PackedWeights({k_: v.to(dev) for k_, v in wt.items()}, 3, 3, 33, dev)
+    P.set_precision("bf16")
+    prev = L.namp_set_bf16p(0)
+    try:
+        hV0, _, lp0, _ = run_encdec(L, dev, P, d, b, n, k, joint=True)
+        for mask in (1, 2, 4, 7):
+            L.namp_set_bf16p(mask)
+            hV1, _, lp1, _ = run_encdec(L, dev, P, d, b, n, k, joint=True)
+            assert torch.isfinite(lp1).all()
+            assert torch.equal(hV0, hV1), (mask, float((hV0 - hV1).abs().max()))
+            assert torch.equal(lp0, lp1), (mask, float((lp0 - lp1).abs().max()))
+    finally:
+        L.namp_set_bf16p(prev)
+
+
 @pytest.mark.parametrize("B,N,K", [(3, 333, 48), (2, 257, 30), (1, 75, 16), (5, 201, 70)])
 def test_bf16_storage_message_kernel(dev, B, N, K):
     """namp_bf16s_message (edge_mlp_bf16s32_kernel, v_mfma_f32_32x32x16_bf16 on rows stored in fragment order B) against a torch
