@@ -261,8 +261,9 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
 int namp_set_persistent(int on);
 /* The bf16-storage edge launches of namp_encdec_fwd (large batches of the bf16 throughput mode) exist in two instruction sequencings
  * with bit-identical results: edge_mlp_bf16s32_kernel (round 3) and edge_mlp_bf16p_kernel (round 6; default mask 3: its embedding variant is the slower one).  mask: bit 0 the two
- * message launches, bit 1 the edge update, bit 2 the first encoder message with the fused edge embedding; returns the previous mask.
- * Environment: NAMP_BF16P.  For A/B timing and for the bit-equality test only. */
+ * message launches, bit 1 the edge update, bit 2 the first encoder message with the fused edge embedding; bit 3 selects the round-6
+ * residue update of that path (node_update_w_kernel: same rounding points, another summation order in the FFN's second product);
+ * returns the previous mask.  Environment: NAMP_BF16P (default 11).  For A/B timing and for the equality tests only. */
 int namp_set_bf16p(int mask);
 int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K, int32_t* code);
 

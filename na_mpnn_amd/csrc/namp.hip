@@ -6,6 +6,7 @@
 #include <atomic>
 #include "namp_bf16s32.h"
 #include "namp_bf16p.h"
+#include "namp_node_w.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -35,6 +36,10 @@ __attribute__((visibility("hidden"))) int namp_internal_launch_persistent(const 
 __attribute__((visibility("hidden"))) int namp_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 
 namespace {
+
+// which launches of the bf16-storage path run in their round-6 form: bit 0 messages, 1 edge update, 2 message + embedding (namp_bf16p.h),
+// 3 residue update (namp_node_w.h)
+static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 11; }()};
 
 // ---- optional per-kernel timing (bench.py): thread-local, off by default --------------------
 struct ProfRec { int kind; hipEvent_t a, b; };
@@ -145,6 +150,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s32_kernel<MODE_DEC_MSG>, BF16S32_LDS);
   set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_EDGE>, BF16S32_LDS);
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
+  set((const void*)node_update_w_kernel, NODEW_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_DEC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_EDGE>, BF16P_LDS);
@@ -247,8 +253,6 @@ int launch_edge_x3_persistent(EdgeArgs a, hipStream_t s) {
   return NAMP_OK;
 }
 
-// which bf16-storage edge launches run in the round-6 sequencing (namp_bf16p.h): bit 0 messages, 1 edge update, 2 message + embedding
-static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 3; }()};
 // bf16 STORAGE variant (h_E and the gathered tables as bf16 rows in fragment order B): large batches of the bf16 throughput mode, on
 // v_mfma_f32_32x32x16_bf16 (namp_bf16s32.h; images from namp_pack_image_bf16_32)
 template <int MODE>
@@ -406,7 +410,10 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   if (multi && g_out16) g_out16->honoured = true;
   // large batches: 2 tiles per workgroup share every weight fragment (the one-tile form re-streams 768 KiB per 16 rows;
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
-  if (x3 && g_residue_x1)      // bf16 throughput mode: hi . hi products out of the same x3 images
+  if (x3 && g_residue_x1 && a.t.m3_img && !a.t.head_w && nproj <= 4 && G >= 2048 && (g_bf16p.load(std::memory_order_relaxed) & 8))
+    // bf16 throughput mode, large batch: one tile per wave end to end, weight blocks through an LDS ring (namp_node_w.h)
+    hipLaunchKernelGGL(node_update_w_kernel, dim3((G + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
+  else if (x3 && g_residue_x1)      // bf16 throughput mode: hi . hi products out of the same x3 images
     hipLaunchKernelGGL((node_update_multi_kernel<2, 2>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
   else if (x3)                 // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only
     hipLaunchKernelGGL((node_update_multi_kernel<2, 1>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
@@ -1395,7 +1402,7 @@ extern "C" int namp_debug_wstamps(int* counts8, long long* log, int reset) {
 }
 #endif
 
-int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 7); }
+int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 15); }
 
 int namp_set_persistent(int on) {
   std::lock_guard<std::mutex> lk(g_persist_mutex);
