@@ -282,7 +282,8 @@ def features_bench(dev):
     """The `features` object of the default line: edge_features_kernel — the dominant launch of the fused featuriser
     (model_utils.py:489-593; 27 % of a cfg4 pass) — timed from the device trace of one featurise call at cfg2-from-coordinates and at a
     32,000-token cfg4 batch; `frac` prices the FLOPs it executes against the bf16 dense MFMA peak (its products run as split-bf16),
-    `algorithmic_frac` the dense formulation of SURVEY 8(d) (63.9 MFLOP + 248,832 exp per residue)."""
+    `algorithmic_frac` the dense formulation of SURVEY 8(d) (63.9 MFLOP + 248,832 exp per TOKEN: the launch walks every token of the padded batch;
+    `algorithmic_frac_unmasked_residues` prices the unmasked residues only)."""
     from torch.profiler import profile, ProfilerActivity
     m = _feat_model(dev)
     res = {"kernel": "edge_features_kernel", "bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "basis": "executed FLOPs",
@@ -310,7 +311,8 @@ def features_bench(dev):
         tag = "cfg2_from_X" if which == "cfg2" else "cfg4_batch"
         res[tag] = {"tokens": tokens, "residues": residues, "avg_launch_ms": round(ef, 4),
                     "frac": round(ex / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
-                    "algorithmic_frac": round(FEAT_FLOP_ALGO * residues / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "algorithmic_frac": round(FEAT_FLOP_ALGO * tokens / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "algorithmic_frac_unmasked_residues": round(FEAT_FLOP_ALGO * residues / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "gexp_per_s": round(FEAT_EXP_ALGO * residues / max(ef, 1e-9) / 1e6, 1),
                     "knn_select_ms": round(t.get("knn_select_kernel", t.get("knn_kernel", 0.0)), 4),
                     "prep_atoms_ms": round(t.get("prep_atoms_kernel", 0.0), 4)}
@@ -329,6 +331,8 @@ def features_bench(dev):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
             res["full_forward_from_X"] = {"value": round(residues / dt, 1), "unit": "residues/s", "ms_per_call": round(dt * 1e3, 4),
+                                          "dtype": "bf16x3 (the product default: split-bf16 products, fp32-equivalent to 2^-16 — the headline beside it is exact fp32)"
+                                                   if getattr(m, "message_precision", "x3") == "x3" else "f32",
                                           "sample": f"ProteinMPNN.score() from coordinates (HIP featuriser + enc + dec), the cpu_baseline complex "
                                                     f"({tokens} residues, K=48), 20 calls after 5 warm-up calls",
                                           "finite": bool(torch.isfinite(sc["log_probs"]).all())}
@@ -695,7 +699,19 @@ def design_bench(args, dev, rank, world, dist, specificity=False):
         t = torch.tensor([elapsed], device=coll_device(dev, dist), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # latency of ONE synchronised design call (the timed region above issues the calls back to back: pipelined throughput — the host enqueues
+    # call i + 1 while call i runs): median of 20 calls, each bracketed by device syncs
+    lat = []
+    with quiet_gc():
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+    lat.sort()
     res = {"metric": "sampled residues/sec (design: featurise + encode + autoregressive sample), " + ("1am9-sized complex, specificity mode" if specificity else "4oqu-sized complex"),
+           "latency_ms": round(lat[len(lat) // 2] * 1e3, 3), "latency_ms_min": round(lat[0] * 1e3, 3),
            "value": round(world * bs * n * args.steps / elapsed, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16x3 (GEMMs as split-bf16 products, fp32 accumulate: fp32-equivalent to 2^-16; fp32 elsewhere)" if getattr(m, "message_precision", "x3") == "x3" else "f32", "data": "synthetic",
@@ -986,6 +1002,8 @@ def compact_secondary(o):
     wl = o.get("config", {}).get("workload", "")
     c = {"workload": wl.split(":")[0], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
          "dtype": short_dtype(o["dtype"])}
+    if "latency_ms" in o:                                     # design calls: one synchronised call (ms_per_step is pipelined throughput)
+        c["latency_ms"] = o["latency_ms"]
     if "roofline" in o:
         r = o["roofline"]
         c["roofline"] = {"kernel": r["kernel"], "frac": r["frac"], "algorithmic_frac": r.get("algorithmic_frac"),
@@ -1014,7 +1032,7 @@ def compact_secondary(o):
 def compact_line(out):
     """The one JSON line rank 0 prints: contract keys first, then roofline / cpu_baseline / parity / gather / x3, then the
     secondaries — all short; per-kernel tables and sample descriptions stay in the detail file."""
-    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "latency_ms", "higher_is_better", "scaling",
                              "vs_baseline", "dtype", "data", "config") if k in out}
     c["dtype"] = short_dtype(c["dtype"])
     if "roofline" in out:
@@ -1032,6 +1050,7 @@ def compact_line(out):
             if gf:                                            # its GPU partner: score() from coordinates on the same complex (features_bench)
                 c["cpu_baseline"]["gpu_full_forward_from_X"] = gf["value"]
                 c["cpu_baseline"]["gpu_full_forward_ms"] = gf["ms_per_call"]
+                c["cpu_baseline"]["gpu_full_forward_dtype"] = short_dtype(gf.get("dtype", "bf16x3"))
     if "parity" in out:
         pr = out["parity"]
         c["parity"] = {"max_abs_dlogp_vs_cpu": pr["max_abs_dlogp_vs_cpu"], "argmax_equal": pr["argmax_equal"],
@@ -1049,6 +1068,7 @@ def compact_line(out):
                 c["features"][tag] = {k: f[tag][k] for k in ("tokens", "avg_launch_ms", "frac", "algorithmic_frac", "knn_select_ms")}
         if "full_forward_from_X" in f:
             c["features"]["full_forward_from_X"] = {k: f["full_forward_from_X"][k] for k in ("value", "unit", "ms_per_call")}
+            c["features"]["full_forward_from_X"]["dtype"] = short_dtype(f["full_forward_from_X"].get("dtype", "bf16x3"))
     if "x3" in out:
         x = out["x3"]
         c["x3"] = {"value": x["value"], "ms_per_step": x["ms_per_step"], "dtype": "bf16x3", "kernel": x["roofline"]["kernel"],

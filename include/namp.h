@@ -327,7 +327,23 @@ int namp_encdec_fwd(const NampModelW* w, const float* V, const float* E, const i
  *   special_tokens  bit t set = token t is never drawn (UNK, DX, RX, MAS, PAD: model_utils.py:199-203)
  * Outputs: S_out int32 [B_dec,N]; probs_out / logp_out [B_dec,N,vocab] = chain_mask * (sampling
  * distribution / log_softmax(logits)) as model_utils.py:211-212. */
+/* Work lists of namp_decoder_sample_walk for the plain branch (every visit its own work item), built on the device from the levels of
+ * namp_sample_levels_dep: work [B_dec * N][2] int32 = (stream, visit) grouped by level (the order inside a level is not defined: its items
+ * are independent), level_off [N + 2] int32 = items of a level below l, n_levels[0] = number of non-empty levels.  N <= 16000. */
+int namp_sample_work_lists(const int32_t* level, int32_t* work, int32_t* level_off, int32_t* n_levels, int B_dec, int N, void* stream);
+
+/* Decoding order on the device: order[b] = argsort((mask[b % B_mask] * chain_mask[b % B_mask] + 1e-4) * |randn[b]|) (ascending; ties by
+ * index; NaN keys last) and rank = its inverse permutation (model_utils.py:389-390, na_model_utils.py:623 — the reference's
+ * torch.argsort + one-hot einsum), one launch.  mask / chain_mask [B_mask, L] float (chain_mask NULL = ones), randn [B, L] float; outputs
+ * order64 [B, L] int64 and / or order32 [B, L] int32 (either may be NULL), rank32 [B, L] int32.  L <= 8192. */
+int namp_decoding_order(const float* mask, const float* chain_mask, const float* randn, int64_t* order64, int32_t* order32, int32_t* rank32,
+                        int B, int B_mask, int L, void* stream);
+
 size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K);
+/* The same for a model of n_dec decoder layers (1 .. NAMP_MAX_LAYERS; 0 on bad arguments).  namp_sample_workspace_bytes sizes for
+ * NAMP_MAX_LAYERS layers — n_dec h_E-sized first-layer tables are what a call carves, so a three-layer model needs well under half of it.
+ * The level walk keeps its grid-barrier words in the last 4 KiB of the n_dec-sized region; a larger workspace is accepted. */
+size_t namp_sample_workspace_bytes_n(int B_enc, int B_dec, int N, int K, int n_dec);
 int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                         const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
                         const int32_t* order, const int32_t* rank, const float* uniform, const int32_t* S_forced,

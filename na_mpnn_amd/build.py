@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libnamp_hip.so")
 INC = os.path.join("..", "..", "include", "namp.h")
 # translation unit -> files it depends on (each unit is compiled to its own object, in parallel, then linked)
-UNITS = {"namp.hip": ["namp.hip", "namp_kernels.h", "namp_bf16s32.h", "namp_device.h", INC],
+UNITS = {"namp.hip": ["namp.hip", "namp_kernels.h", "namp_bf16s32.h", "namp_bf16p.h", "namp_node_w.h", "namp_order.h", "namp_device.h", INC],
          "namp_persist.hip": ["namp_persist.hip", "namp_kernels.h", "namp_device.h"],
          "namp_train.hip": ["namp_train.hip", "namp_train.h", "namp_train_dw.h", "namp_device.h", INC],
          "namp_train_eu.hip": ["namp_train_eu.hip", "namp_train_eu.h", "namp_train_dw.h", "namp_train.h", "namp_device.h", INC]}

@@ -7,6 +7,7 @@
 #include "namp_bf16s32.h"
 #include "namp_bf16p.h"
 #include "namp_node_w.h"
+#include "namp_order.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -151,6 +152,8 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_EDGE>, BF16S32_LDS);
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
   set((const void*)node_update_w_kernel, NODEW_LDS);
+  set((const void*)decoding_order_kernel, 65536);
+  set((const void*)work_lists_kernel, 65536);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_DEC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_EDGE>, BF16P_LDS);
@@ -1129,15 +1132,17 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
   return NAMP_OK;
 }
 
-size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) {
-  if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1) return 0;
+// Sampler workspace for a model of n_dec decoder layers: Pfw[L] + Pa0 on the encoder side; Pa[L-1] + Pv[L-1] + h[L] on the sample-stream
+// side; the first-layer tables Z1_l = W1e_l . h_E of every edge (round 5) and one zero row; the 4 KiB tail holds the level walk's grid-barrier
+// words.  (Round 5 sized every workspace for NAMP_MAX_LAYERS = 8 layers: 8 h_E-sized tables where the shipped model carves 3.)
+static size_t sample_ws_bytes(int B_enc, int B_dec, int N, int K, int n_dec) {
+  if (B_enc < 1 || B_dec < 1 || N < 1 || K < 1 || n_dec < 1 || n_dec > NAMP_MAX_LAYERS) return 0;
   const size_t Ge = (size_t)B_enc * N, Gd = (size_t)B_dec * N;
-  // sized for NAMP_MAX_LAYERS decoder layers (the entry point has no layer count): Pfw[L] + Pa0 on the encoder side; Pa[L-1] + Pv[L-1] +
-  // h[L] on the sample-stream side
-  const size_t L = NAMP_MAX_LAYERS;
-  // + the first-layer tables Z1_l = W1e_l . h_E of every edge (round 5) and one zero row
-  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + L * tbl(Ge * (size_t)K) + 512 + NAMP_HIDDEN * 64 * 4 + 4096;       // (the 4 KiB tail holds the level walk's grid-barrier words)
+  const size_t L = (size_t)n_dec;
+  return (L + 1) * tbl(Ge) + (3 * L - 2) * tbl(Gd) + L * tbl(Ge * (size_t)K) + 512 + NAMP_HIDDEN * 64 * 4 + 4096;
 }
+size_t namp_sample_workspace_bytes_n(int B_enc, int B_dec, int N, int K, int n_dec) { return sample_ws_bytes(B_enc, B_dec, N, K, n_dec); }
+size_t namp_sample_workspace_bytes(int B_enc, int B_dec, int N, int K) { return sample_ws_bytes(B_enc, B_dec, N, K, NAMP_MAX_LAYERS); }
 
 static int sample_prepare(const NampModelW* w, const float* h_V_enc, const float* h_E, const int32_t* E_idx,
                           const int32_t* mask, const int32_t* mask_dec, const int32_t* chain_mask, const int32_t* S_true, const float* bias,
@@ -1276,6 +1281,31 @@ int namp_decoder_sample(const NampModelW* w, const float* h_V_enc, const float* 
   return NAMP_OK;
 }
 
+
+int namp_decoding_order(const float* mask, const float* chain_mask, const float* randn, int64_t* order64, int32_t* order32, int32_t* rank32,
+                        int B, int B_mask, int L, void* stream) {
+  if (!mask || !randn || !rank32) return fail(NAMP_EINVAL, "namp_decoding_order: null mask / randn / rank");      // (4-byte accesses: any alignment)
+  REQUIRE(B >= 1 && B_mask >= 1 && B % B_mask == 0 && L >= 1 && L <= 8192, "namp_decoding_order: bad dims B=%d B_mask=%d L=%d (L <= 8192)", B, B_mask, L);
+  int P2 = 2;
+  while (P2 < L) P2 <<= 1;
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  hipLaunchKernelGGL(decoding_order_kernel, dim3(B), dim3(P2 >= 1024 ? 512 : 256), (size_t)P2 * 8, (hipStream_t)stream, mask, chain_mask, randn,
+                     B_mask, L, P2, order64, order32, rank32);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
+int namp_sample_work_lists(const int32_t* level, int32_t* work, int32_t* level_off, int32_t* n_levels, int B_dec, int N, void* stream) {
+  if (!level || !work || !level_off || !n_levels) return fail(NAMP_EINVAL, "namp_sample_work_lists: null pointer argument");
+  REQUIRE(B_dec >= 1 && N >= 1 && N <= 16000 && (long)B_dec * N < (1L << 31), "namp_sample_work_lists: bad dims B_dec=%d N=%d", B_dec, N);
+  int rc = ensure_attributes();
+  if (rc) return rc;
+  hipLaunchKernelGGL(work_lists_kernel, dim3(1), dim3(1024), (size_t)(N + 2) * 4, (hipStream_t)stream, level, B_dec * N, N, work, level_off, n_levels);
+  CHECK_LAUNCH();
+  return NAMP_OK;
+}
+
 int namp_sample_levels_dep(const int32_t* E_idx, const int32_t* order, const int32_t* rank, const int32_t* dep_idx, int D,
                            const int32_t* group_first, const int32_t* group_last, int32_t* level,
                            int B_dec, int B_enc, int N, int K, void* stream) {
@@ -1364,8 +1394,8 @@ int namp_decoder_sample_walk(const NampModelW* w, const float* h_V_enc, const fl
   if (rc) return rc;
   REQUIRE(nwaves <= 8, "namp_decoder_sample_walk: needs the 8-wave workgroup form (K <= 128)");
   // grid-barrier words: the last 4 KiB of the workspace (namp_sample_workspace_bytes reserves them behind the tables)
-  REQUIRE(ws_bytes >= namp_sample_workspace_bytes(B_enc, B_dec, N, K), "namp_decoder_sample_walk: workspace too small");
-  unsigned* sync = (unsigned*)((char*)ws + namp_sample_workspace_bytes(B_enc, B_dec, N, K) - 4096);
+  REQUIRE(ws_bytes >= sample_ws_bytes(B_enc, B_dec, N, K, w->n_dec), "namp_decoder_sample_walk: workspace too small");
+  unsigned* sync = (unsigned*)((char*)ws + sample_ws_bytes(B_enc, B_dec, N, K, w->n_dec) - 4096);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(S_out, 0xFF, (size_t)B_dec * N * sizeof(int32_t), s);          // every token "not drawn" (-1)
   if (e == hipSuccess) e = hipMemsetAsync(sync, 0, NAMP_SYNC_WORDS * sizeof(unsigned), s);

@@ -99,15 +99,22 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
     const bool valid = row < a.G;
     const int rr = valid ? row : (a.G - 1);
     __syncthreads();                                             // (a later pass: every wave is done with the ring)
-    stage_load(0); stage_store(0);
-    stage_load(1); stage_store(1);
-    stage_load(2);
-    // ---- K-sums of the layer-2 activations and their weight sums (up to three row tiles per request round — K = 48; a tile past the residue's
-    // last re-reads that one with weight 0); the residue's own row
-    f4 x[8];
+    // ---- every request of the pass's opening in one round trip: the first two weight blocks, the K-sums of the layer-2 activations with
+    // their weight sums (three row tiles per round — K = 48; a tile past the residue's last re-reads that one with weight 0), the residue's row
+    f4 sreg2[8];
+    stage_load(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sreg2[k] = sreg[k];
+    stage_load(1);
+    f4 x[8], hv[8];
     float ws = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) x[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* src = t.hV + (long)rr * NAMP_H + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) hv[c] = *(const f4*)(src + 16 * c);
+    }
 #ifndef NW_NOIN
     for (int p0 = 0; p0 < a.TPN; p0 += 3) {
       f4 v[3][8];
@@ -120,6 +127,15 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
         for (int c = 0; c < 8; ++c) v[q][c] = *(const f4*)(ps_ + 16 * c);
         wv[q] = a.partial[(long)a.G * a.TPN * NAMP_H + (long)rr * a.TPN + p];
       }
+      if (p0 == 0) {
+#ifndef NW_NOSTAGE
+        char* d0 = smem + tid * 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { *(f4*)(d0 + 8192 * k) = sreg2[2 * k]; *(f4*)(d0 + 8192 * k + 4096) = sreg2[2 * k + 1]; }
+#endif
+        stage_store(1);
+        stage_load(2);
+      }
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         if (p0 + q < a.TPN) {
@@ -129,13 +145,9 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
         }
       }
     }
+#else
+    stage_store(0); stage_store(1); stage_load(2);
 #endif
-    f4 hv[8];
-    {
-      const float* src = t.hV + (long)rr * NAMP_H + 4 * g;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) hv[c] = *(const f4*)(src + 16 * c);
-    }
     bf8 xb[4];
     pack_rows(xb, x);
     __syncthreads();                                             // blocks 0, 1 in LDS

@@ -582,6 +582,7 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   REQUIRE(packed || aligned16(M18), "namp_train_feat_wgrad: 'M18' is not 16-byte aligned");
   if (!E_idx) return fail(NAMP_EINVAL, "namp_train_feat_wgrad: null E_idx");
   REQUIRE(B >= 1 && L >= 1 && K >= 1 && K <= L, "namp_train_feat_wgrad: bad dims B=%d L=%d K=%d", B, L, K);
+  REQUIRE(!g16 || (packed && x3 != 0 && aligned16(g16)), "namp_train_feat_wgrad: g16 (bf16 tiles of g_pre) goes with the packed atoms and precision code 1 / 2");
   const long E = (long)B * L * K;
   const int nchunk = namp_train_feat_wgrad_chunks(E);
   long per = (E + nchunk - 1) / nchunk;
@@ -589,7 +590,6 @@ int namp_train_feat_wgrad(const float* X18, const float* M18, const int32_t* E_i
   const long ntile = (E + FEATW_TILE - 1) / FEATW_TILE;
   hipLaunchKernelGGL(tile_presence_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, packed ? X18 + 3 : M18,
                      packed ? 4 : 1, E_idx, E, L, K, tile_ws);
-  REQUIRE(!g16 || (packed && x3 != 0 && aligned16(g16)), "namp_train_feat_wgrad: g16 (bf16 tiles of g_pre) goes with the packed atoms and precision code 1 / 2");
   const __bf16* g16p = (const __bf16*)g16;
   const long g16_plane = namp_train_g16_elems(E);
 #define NAMP_FEATW(MID_, PK_, S16_) hipLaunchKernelGGL((feat_wgrad_x3_kernel<MID_, PK_, S16_>), dim3(FEATW_GRID_X, nchunk), dim3(256), 0, (hipStream_t)stream, \

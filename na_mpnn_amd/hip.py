@@ -106,7 +106,10 @@ _PROTOTYPES = {
     "namp_fused_tail_max_residues": (i32, []),
     "namp_logits_log_softmax": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, vp]),
     "namp_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_sample_work_lists": (i32, [c_ip, c_ip, c_ip, c_ip, i32, i32, vp]),
+    "namp_decoding_order": (i32, [c_fp, c_fp, c_fp, vp, c_ip, c_ip, i32, i32, i32, vp]),
     "namp_sample_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "namp_sample_workspace_bytes_n": (sz, [i32, i32, i32, i32, i32]),
     "namp_featurize_workspace_bytes": (sz, [i32, i32]),
     "namp_featurize": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
                              vp, sz, i32, i32, vp]),

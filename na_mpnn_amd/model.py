@@ -188,6 +188,9 @@ class ProteinMPNN(nn.Module):
         self._packed_sig = None
         self._ws = None
         self._tokens_ok = {}          # argument name -> (weakref to the validated tensor, its version)
+        self._conv = {}               # (id(tensor), kind) -> (weakref, version, converted): see _as
+        self._zeros = {}              # (shape, device) -> int32 zeros (the N_na masks of a model built without include_pred_na_N)
+        self._v_cache = None          # (weakref to R_polymer_type, version, weights signature, V)
         # per-edge message / edge-update GEMMs: "x3" (default, parity mode) = three bf16 products of split operands with fp32
         # accumulation, fp32-equivalent to ~2^-16 (3e-5 on log-probs, arg-max unchanged) at 3/16 of the fp32 MFMA cost;
         # "fp32" = exact fp32 MFMA; "bf16" = plain bf16 inputs, BASELINE configs[2]'s throughput mode (~1e-2 on log-probs).
@@ -210,7 +213,13 @@ class ProteinMPNN(nn.Module):
         """(dna_mask, rna_mask) as the featuriser kernels see them: they only decide the presence of the virtual N_na atom."""
         if self.include_pred_na_N:
             return fd["dna_mask"], fd["rna_mask"]
-        return torch.zeros_like(fd["dna_mask"]), torch.zeros_like(fd["rna_mask"])
+        key = (tuple(fd["dna_mask"].shape), fd["dna_mask"].device)
+        z = self._zeros.get(key)
+        if z is None:
+            if len(self._zeros) > 64:
+                self._zeros.clear()
+            z = self._zeros[key] = torch.zeros(key[0], dtype=torch.int32, device=key[1])
+        return z, z
 
     def _weights(self):
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -241,6 +250,43 @@ class ProteinMPNN(nn.Module):
         if int(lo) < 0 or int(hi) >= self.vocab:
             raise IndexError(f"na_mpnn_amd: token ids in '{what}' must lie in [0, {self.vocab}); got [{int(lo)}, {int(hi)}]")
         self._tokens_ok[what] = (weakref.ref(S), S._version)
+
+    def _as(self, t, kind):
+        """`t` in the dtype / layout the kernels read ("i32": int32, "f32": float32; contiguous), converted ONCE per tensor object: a
+        feature_dict that stays resident (run.py scores / samples the same parsed complex many times; bench.py's shards) costs its ~12
+        cast launches on the first call only.  Keyed on the tensor's identity through a weak reference and on its version counter — never on
+        its address (the caching allocator hands a new tensor the block of a freed one) — so an in-place edit or a new tensor converts afresh;
+        the converted copy lives as long as its source."""
+        dt = torch.int32 if kind == "i32" else torch.float32
+        if t.dtype == dt and t.is_contiguous():
+            return t
+        key = (id(t), kind)
+        e = self._conv.get(key)
+        if e is not None and e[0]() is t and e[1] == t._version:
+            return e[2]
+        c = t.to(dt).contiguous()
+        if len(self._conv) > 8192:                            # (dead entries normally leave through their weak references' callbacks)
+            self._conv.clear()
+        conv = self._conv
+        self._conv[key] = (weakref.ref(t, lambda _r, k=key: conv.pop(k, None)), t._version, c)
+        return c
+
+    def order_and_rank(self, mask, chain_mask, randn):
+        """Decoding order argsort((mask * chain_mask + 1e-4) * |randn|) (model_utils.py:389; na_model_utils.py:623) and its inverse permutation
+        in one HIP launch (namp_decoding_order): order int64 [B', L], rank int32 [B', L], B' = rows of randn; mask / chain_mask [B, L] with
+        B' % B == 0 (chain_mask None = ones).  Shapes the kernel does not take (L > 8192, mismatched rows) run the stock ops."""
+        Bm, L = mask.shape
+        Br = randn.shape[0]
+        if mask.is_cuda and L <= 8192 and Br % Bm == 0 and tuple(randn.shape) == (Br, L) and (chain_mask is None or chain_mask.shape == mask.shape):
+            m, r = self._as(mask, "f32"), self._as(randn, "f32")
+            cm = self._as(chain_mask, "f32") if chain_mask is not None else None
+            order = torch.empty(Br, L, dtype=torch.int64, device=mask.device)
+            rank = torch.empty(Br, L, dtype=torch.int32, device=mask.device)
+            hip.check(hip.lib().namp_decoding_order(m.data_ptr(), hip.ptr(cm), r.data_ptr(), order.data_ptr(), None, rank.data_ptr(),
+                                                    Br, Bm, L, hip.current_stream()), "decoding_order")
+            return order, rank
+        order = self.decoding_order(mask if chain_mask is None else mask * chain_mask, randn)
+        return order, self.ranks_of(order).to(torch.int32)
 
     def _workspace(self, B_enc, B_dec, N, K, device):
         need = hip.lib().namp_workspace_bytes(B_enc, B_dec, N, K)
@@ -274,14 +320,24 @@ class ProteinMPNN(nn.Module):
 
     def _node_features(self, fd):
         fp = self.features
-        V = fp.node_embedding.weight.t()[fd["R_polymer_type"].long()]      # one-hot @ W^T == row select (6 rows)
-        return nn.functional.layer_norm(V, (self.node_features,), fp.norm_nodes.weight, fp.norm_nodes.bias, 1e-5)
+        rp = fd["R_polymer_type"]
+        if not torch.is_grad_enabled():                      # inference: V depends on the polymer types and three small parameters only
+            c = self._v_cache
+            sig = tuple((p.data_ptr(), p._version) for p in (fp.node_embedding.weight, fp.norm_nodes.weight, fp.norm_nodes.bias))
+            if c is not None and c[0]() is rp and c[1] == rp._version and c[2] == sig:
+                return c[3]
+        V = fp.node_embedding.weight.t()[rp.long()]      # one-hot @ W^T == row select (6 rows)
+        V = nn.functional.layer_norm(V, (self.node_features,), fp.norm_nodes.weight, fp.norm_nodes.bias, 1e-5)
+        if not torch.is_grad_enabled():
+            self._v_cache = (weakref.ref(rp), rp._version, sig, V)
+        return V
 
     @torch.no_grad()
     def _featurize_hip(self, fd, want_E=True, want_hE=False):
         """a11 on the HIP kernels (prep_atoms, knn, edge_features): returns V, E (or None), h_E0 (or None), E_idx."""
         self._require_reference_atom_order()
-        X = self._noised_X(fd).float().contiguous()
+        X = self._noised_X(fd)
+        X = self._as(X, "f32") if X is fd["X"] else X.float().contiguous()
         _require_device(X, "X")
         W = self._weights()
         Lb = hip.lib()
@@ -293,7 +349,7 @@ class ProteinMPNN(nn.Module):
         hE = torch.empty(B, L, K, self.hidden_dim, device=dev) if want_hE else None
         ws = torch.empty(Lb.namp_featurize_workspace_bytes(B, L), dtype=torch.uint8, device=dev)
         dna_m, rna_m = self._na_masks(fd)
-        t = [_i32(fd[k]) for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + [_i32(dna_m), _i32(rna_m)]
+        t = [self._as(fd[k], "i32") for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + [self._as(dna_m, "i32"), self._as(rna_m, "i32")]
         hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
                                     int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
                                     ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
@@ -371,16 +427,17 @@ class ProteinMPNN(nn.Module):
         return (log_probs, logits) if want_logits else log_probs
 
     @torch.no_grad()
-    def encode_decode(self, feature_dict, S, rank, want_logits=False):
+    def encode_decode(self, feature_dict, S, rank, want_logits=False, idx_long=True):
         """encode() + decode_graph() for one decoder batch per complex, as ONE library call (namp_encdec_fwd): lets the
-        kernels fuse across the encoder/decoder boundary.  Returns h_V, h_E, E_idx, log_probs(, logits)."""
+        kernels fuse across the encoder/decoder boundary.  Returns h_V, h_E, E_idx, log_probs(, logits); E_idx is int64 like the
+        reference's unless idx_long=False (score() does not return it: no cast launch)."""
         mask = feature_dict["mask"]
         self._check_tokens(S)
         V, E, h_E, E_idx = self._featurize_hip(feature_dict, want_E=False, want_hE=True)
         W = self._weights()
         B, N, K = E_idx.shape
         V = V.float().contiguous()
-        E32, S32, m32, r32 = _i32(E_idx), _i32(S), _i32(mask), _i32(rank)
+        E32, S32, m32, r32 = E_idx, self._as(S, "i32"), self._as(mask, "i32"), self._as(rank, "i32")
         h_V = torch.empty(B, N, H, device=V.device)
         log_probs = torch.empty(B, N, self.num_letters, device=V.device)
         logits = torch.empty_like(log_probs) if want_logits else None
@@ -391,7 +448,7 @@ class ProteinMPNN(nn.Module):
                                             E32.data_ptr(), m32.data_ptr(), S32.data_ptr(), r32.data_ptr(), h_V.data_ptr(),
                                             h_E.data_ptr(), log_probs.data_ptr(), hip.ptr(logits), self._ws.data_ptr(),
                                             self._ws.numel(), B, N, K, hip.current_stream()), "encdec_fwd")
-        return h_V, h_E, E_idx.long(), log_probs, logits
+        return h_V, h_E, (E_idx.long() if idx_long else E_idx), log_probs, logits
 
     @torch.no_grad()
     def score(self, feature_dict):
@@ -399,11 +456,10 @@ class ProteinMPNN(nn.Module):
         bs = feature_dict["batch_size"]
         S_true, mask = feature_dict["S"], feature_dict["mask"]
         B, L = S_true.shape
-        chain_mask = mask * feature_dict["chain_mask"]
-        order = self.decoding_order(chain_mask, feature_dict["randn"])
-        rank = self.ranks_of(order)[:B]          # the reference's gather keeps only E_idx's batch rows (:393)
+        order, rank = self.order_and_rank(mask, feature_dict["chain_mask"], feature_dict["randn"])
+        rank = rank[:B]                          # the reference's gather keeps only E_idx's batch rows (:393)
         if bs == 1:
-            log_probs = self.encode_decode(feature_dict, S_true, rank)[3]
+            log_probs = self.encode_decode(feature_dict, S_true, rank, idx_long=False)[3]
             return {"S": S_true, "log_probs": log_probs, "decoding_order": order[0]}
         h_V, h_E, E_idx = self.encode(feature_dict)
         rep = lambda t: t.repeat(bs, *([1] * (t.dim() - 1)))
@@ -435,8 +491,8 @@ class ProteinMPNN(nn.Module):
                 chain_M = chain_M.masked_fill(feature_dict["protein_mask"].to(torch.bool), 0.0)
             if decoding_randn is None:
                 decoding_randn = torch.randn(chain_M.shape, device=mask.device)
-            rank = self.ranks_of(self.decoding_order(chain_M, decoding_randn))
-            _, _, _, log_probs, logits = self.encode_decode(feature_dict, feature_dict["S"], rank, want_logits=True)
+            rank = self.order_and_rank(chain_M, None, decoding_randn)[1]
+            _, _, _, log_probs, logits = self.encode_decode(feature_dict, feature_dict["S"], rank, want_logits=True, idx_long=False)
             return log_probs, torch.softmax(logits, dim=-1)
 
     # reference quirk (model_utils.py:186): DecLayer receives mask_t of shape [B], which broadcasts so that
@@ -471,10 +527,11 @@ class ProteinMPNN(nn.Module):
         self._check_tokens(S_true)
         if fd.get("S_forced") is not None:
             self._check_tokens(fd["S_forced"], "S_forced")
-        h_V, h_E, E_idx = self.encode(fd)
+        V, _, h_E, E_idx = self._featurize_hip(fd, want_E=False, want_hE=True)       # (E_idx stays int32: the kernels' dtype)
+        h_V, h_E = self.encode_graph(V, None, E_idx, mask, h_E_embedded=h_E)
         K = E_idx.shape[-1]
         chain_mask = mask * fd["chain_mask"]
-        order = self.decoding_order(chain_mask, fd["randn"])                  # [max(B, bs), L]
+        order, rank = self.order_and_rank(mask, fd["chain_mask"], fd["randn"])       # [max(B, bs), L]
         B_dec = B * bs
         group_first = group_last = sym_w = None
         if symmetric:
@@ -507,10 +564,10 @@ class ProteinMPNN(nn.Module):
             group_first = torch.tensor(gf, dtype=torch.int32, device=dev).repeat(B_dec, 1).contiguous()
             group_last = torch.tensor(gl, dtype=torch.int32, device=dev).repeat(B_dec, 1).contiguous()
             sym_w = weights.to(dev).contiguous()
+            rank = self.ranks_of(order)
         if order.shape[0] != B_dec:
             raise ValueError(f"randn has {fd['randn'].shape[0]} rows; expected batch_size*B = {B_dec}")
-        rank = self.ranks_of(order)
-        mask_dec = mask.repeat(bs, 1)
+        mask_dec = mask if bs == 1 else mask.repeat(bs, 1)
         if self.reference_sample_mask_quirk and B == 1 and bs > 1 and not symmetric:   # :186 vs :292
             m0 = mask[0][order[0]]                                             # stream 0's mask along the steps
             mask_dec = torch.empty_like(mask_dec).scatter_(1, order, m0.expand(B_dec, L).contiguous())
@@ -524,9 +581,11 @@ class ProteinMPNN(nn.Module):
         S_out = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
         probs = torch.empty(B_dec, L, self.num_letters, device=dev)
         logp = torch.empty_like(probs)
-        ws = torch.empty(Lb.namp_sample_workspace_bytes(B, B_dec, L, K), dtype=torch.uint8, device=dev)
-        E32, cm32, St32 = _i32(E_idx), _i32(chain_mask), _i32(S_true)
-        md32, o32, r32, m32 = _i32(mask_dec), _i32(order), _i32(rank), _i32(mask)
+        ws_bytes = Lb.namp_sample_workspace_bytes_n(B, B_dec, L, K, len(self.decoder_layers))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        E32, cm32, St32 = _i32(E_idx), _i32(chain_mask), self._as(S_true, "i32")
+        m32 = self._as(mask, "i32")
+        md32, o32, r32 = (m32 if mask_dec is mask else _i32(mask_dec)), _i32(order), _i32(rank)
         bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
         forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
@@ -562,8 +621,38 @@ class ProteinMPNN(nn.Module):
                                                 B_dec, B, L, K, hip.current_stream()), "sample_levels")
             walk = self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0
             zbuf = None
+            if walk and not symmetric and L <= 16000:
+                # plain branch: the walk's work lists are built on the device as well (one launch instead of a stable argsort, gathers,
+                # divisions, a histogram and its prefix sums) — the whole design is enqueued with ~a dozen launches
+                nwork = B_dec * L
+                work = torch.empty(nwork, 2, dtype=torch.int32, device=dev)
+                level_off = torch.empty(L + 2, dtype=torch.int32, device=dev)
+                n_levels = torch.empty(1, dtype=torch.int32, device=dev)
+                hip.check(Lb.namp_sample_work_lists(level.data_ptr(), work.data_ptr(), level_off.data_ptr(), n_levels.data_ptr(), B_dec, L,
+                                                    hip.current_stream()), "sample_work_lists")
+                hip.check(Lb.namp_decoder_sample_walk(
+                    W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),
+                    St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced),
+                    None, None, None, hip.ptr(pair_bias), work.data_ptr(), None, nwork, level_off.data_ptr(), None, None, None,
+                    float(fd["temperature"]), special, S_out.data_ptr(), probs.data_ptr(), logp.data_ptr(), ws.data_ptr(), ws.numel(),
+                    B_dec, B, L, K, hip.current_stream()), "decoder_sample_walk")
+                self._walk_sync = ws[ws_bytes - 4096:][:256].view(torch.int32).clone()
+                out = {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
+                       "uniform": uniform, "levels": n_levels[0], "work_items": nwork}
+                if self.sample_check_walk and self.sample_walk_status() != 0:
+                    import warnings
+                    warnings.warn(f"persistent level walk timed out (code {self.sample_walk_status():#x}); re-running with per-level launches")
+                    prev, self.sample_level_walk = self.sample_level_walk, False
+                    try:
+                        fd2 = dict(feature_dict)
+                        fd2["S_forced"] = fd.get("S_forced")
+                        fd2["_uniform"] = uniform
+                        out = self.sample(fd2)
+                    finally:
+                        self.sample_level_walk = prev
+                return out
             sel, flat, work_n, close, close_off = level_work_lists(
-                level, group_first if symmetric else None, group_last if symmetric else None, order[0], E_idx[0],
+                level, group_first if symmetric else None, group_last if symmetric else None, order[0], E_idx[0].long(),
                 split=bool(symmetric and walk and self.sample_split_groups))
             if close is not None:
                 zbuf = torch.empty(B_dec, L, self.num_letters, device=dev)
@@ -582,7 +671,7 @@ class ProteinMPNN(nn.Module):
                 hip.check(Lb.namp_decoder_sample_walk(*common, nwork, level_off.data_ptr(), hip.ptr(close), hip.ptr(close_off), hip.ptr(zbuf),
                                                       *tail), "decoder_sample_walk")
                 # the 64 barrier words, copied out of the per-call workspace (a view would keep the whole workspace alive on the model)
-                self._walk_sync = ws[Lb.namp_sample_workspace_bytes(B, B_dec, L, K) - 4096:][:256].view(torch.int32).clone()
+                self._walk_sync = ws[ws_bytes - 4096:][:256].view(torch.int32).clone()
                 out = {"S": S_out.long(), "sampling_probs": probs, "log_probs": logp, "decoding_order": order,
                        "uniform": uniform, "levels": (hist > 0).sum(), "work_items": nwork}   # "levels": a device scalar (no read-back here)
                 if self.sample_check_walk and self.sample_walk_status() != 0:

@@ -89,6 +89,8 @@ class _PackPlan:
         if e is None or e["img"] is None:
             return None
         e["used"] = True
+        if e.get("version") != block._version:            # edited in place since begin_step packed it (weight tying, clamping, an EMA swap
+            return None                                   # inside the step): the caller packs this block on its own
         return e["img"]
 
     def begin_step(self, step, dev):
@@ -119,6 +121,7 @@ class _PackPlan:
             self.nblocks, self.dirty = blocks, False
         for e in self.entries.values():
             e["used"] = False
+            e["version"] = e["src"]._version
         hip.check(hip.lib().namp_pack_images(self.table.data_ptr(), len(self.entries), self.nblocks, hip.current_stream()), "pack_images")
         self.valid_step = step
 
@@ -706,7 +709,9 @@ class _EdgeEmbeddingGrad(torch.autograd.Function):
         else:
             xp, mp = X18.data_ptr(), M18.data_ptr()
         g16 = _G16.pop(g.data_ptr(), None)                     # bf16 operand tiles of this very tensor, left by _EdgeEmbedTail.backward
-        if g16 is not None and (g16[1] != E or g16[2] != int(ctx.x3)):
+        # (same tensor, UNEDITED: a hook that scales or clips dL/dy in place between the two nodes bumps its version counter, and the
+        # tiles would then describe the old values while pos_grad below reads the new ones — fall back to the fp32 rows)
+        if g16 is not None and (g16[1] != E or g16[2] != int(ctx.x3) or g16[3] != g._version):
             g16 = None
         hip.check(L.namp_train_feat_wgrad(xp, mp, E_idx.data_ptr(), E_pos.data_ptr(), g.data_ptr(), g16[0].data_ptr() if g16 else None,
                                           part.data_ptr(), tws.data_ptr(), int(ctx.x3), B, Lr, K, hip.current_stream()),
@@ -915,7 +920,7 @@ class _EdgeEmbedTail(torch.autograd.Function):
                   "train_embed_ln_bwd")
         _G16.clear()
         if g16 is not None:
-            _G16[g_pre.data_ptr()] = (g16, rows, int(ctx.x3))
+            _G16[g_pre.data_ptr()] = (g16, rows, int(ctx.x3), g_pre._version)
         n = L.namp_train_wgrad_chunks(rows)
         dWp, dbp = torch.empty(n, H, H, device=dev), torch.empty(n, H, device=dev)
         hip.check(L.namp_train_wgrad_ln(g.data_ptr(), y.data_ptr(), stats.data_ptr(), lw.data_ptr(), lb.data_ptr(), int(ctx.x3), rows,

@@ -103,6 +103,29 @@ def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw, prec):
     assert torch.equal(lp2, out["log_probs"])
 
 
+def test_score_from_coordinates_at_the_headline_size(weights_np):
+    """score() FROM COORDINATES at the size the metric is quoted on (BASELINE configs[1]: N = 1000, K = 48; the complex behind bench.py's
+    `gpu_full_forward_from_X`: synth.make_complex(seed=77, n=1000, n_chains=4)) against the CPU oracle's score() on the same feature dict —
+    featuriser, encoder and decoder in one comparison, in the product default (split-bf16 products) and in exact fp32: log-probs within 1e-3,
+    decoding order and arg-max sequence identical on every unmasked residue."""
+    dev = torch.device("cuda:0")
+    cx = synth.make_complex(seed=77, n=1000, n_chains=4)
+    fd = fd_of(cx, dev)
+    m = make_model(weights_np, 48, dev)
+    w = {k_: torch.from_numpy(v) for k_, v in weights_np.items()}
+    fdc = {k_: (v.cpu() if isinstance(v, torch.Tensor) else v) for k_, v in fd.items()}
+    ref = cpu_ref.score(w, fdc, 48)
+    valid = torch.from_numpy(cx["mask"].astype(bool))
+    for prec in ("x3", "fp32"):
+        m.message_precision = prec
+        sc = m.score(fd)
+        assert torch.equal(sc["decoding_order"].cpu(), ref["decoding_order"])
+        d = maxdiff(sc["log_probs"][0][valid], ref["log_probs"][0][valid])
+        print(f"score() from coordinates, N = 1000, {prec}: max|dlogp| vs the CPU oracle = {d:.2e}")
+        assert d < 1e-3, (prec, d)
+        assert torch.equal(sc["log_probs"][0].argmax(-1).cpu()[valid], ref["log_probs"][0].argmax(-1)[valid]), prec
+
+
 @pytest.mark.parametrize("prec", ["x3", "fp32"])
 def test_ctor_variants_decode_protein_first_and_ref_atom(golden_dir, weights_np, prec):
     """Golden G4c (reference training copy built with decode_protein_first=1, na_model_utils.py:620-621, and with
