@@ -157,6 +157,7 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_DEC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_EDGE>, BF16P_LDS);
+  set((const void*)(edge_mlp_bf16p_kernel<MODE_ENC_EDGE, false, true>), BF16P_LDS);
   set((const void*)(edge_mlp_bf16p_kernel<MODE_ENC_MSG, true>), BF16P_LDS);
   set((const void*)edge_mlp_kernel<MODE_EMBED, 0>, NAMP_IMG_BYTES);
   set((const void*)(edge_mlp_kernel<MODE_EMBED, 0, PREC_BF16>), NAMP_IMG_BYTES);
@@ -271,6 +272,12 @@ int launch_edge_bf16s(EdgeArgs a, hipStream_t s) {
   if constexpr (MODE == MODE_ENC_MSG) {
     if (a.eW1_img && (bf16p & 4)) {
       hipLaunchKernelGGL((edge_mlp_bf16p_kernel<MODE_ENC_MSG, true>), dim3(device_cus()), dim3(512), BF16P_LDS, s, a);
+      return NAMP_OK;
+    }
+  }
+  if constexpr (MODE == MODE_ENC_EDGE) {
+    if ((bf16p & 2) && (bf16p & 16)) {        // bit 4: LayerNorm 3 with the round-3 kernel's two-pass variance (the bit-equality test)
+      hipLaunchKernelGGL((edge_mlp_bf16p_kernel<MODE_ENC_EDGE, false, true>), dim3(device_cus()), dim3(512), BF16P_LDS, s, a);
       return NAMP_OK;
     }
   }
@@ -1432,7 +1439,7 @@ extern "C" int namp_debug_wstamps(int* counts8, long long* log, int reset) {
 }
 #endif
 
-int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 15); }
+int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 31); }
 
 int namp_set_persistent(int on) {
   std::lock_guard<std::mutex> lk(g_persist_mutex);

@@ -64,9 +64,13 @@ __device__ unsigned long long g_p32_stamps[4][8][12];
 // LDS: W1 | W2 | W3 or W_e (32 KiB each) | constants (2 KiB) | per wave: 32 row weights (128 B)
 #define BF16P_LDS (3 * NAMP_BIMG_BYTES + 2048 + 8 * 128)
 
-template <int MODE, bool EMB = false>
+// LN2P (edge update only): LayerNorm 3 with the two-pass variance of edge_mlp_bf16s32_kernel (bit-identical results: the equality test's
+// instantiation).  The product's instantiation accumulates sum and sum of squares inside the layer-3 slots (var = E[x^2] - mean^2: rows of
+// O(1) magnitude, 128 channels — 1e-6 relative in fp32) and normalises with two fused multiply-adds per value.
+template <int MODE, bool EMB = false, bool LN2P = false>
 __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
   static_assert(!EMB || MODE == MODE_ENC_MSG, "EMB: first encoder message only");
+  static_assert(!LN2P || MODE == MODE_ENC_EDGE, "LN2P: edge update only");
   constexpr bool EDGE = MODE == MODE_ENC_EDGE;
   constexpr int NL = EDGE ? 3 : EMB ? 3 : 2;               // layers of the chain (EMB: the embedding product in front)
   constexpr int NB = 4 * NL, NSLOT = 8 * NB;
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
     f2 wp[8];
     float ksx = 0.f, ktx = 0.f, ksy = 0.f, kty = 0.f;
     f2 sA = (f2){0.f, 0.f}, sB = (f2){0.f, 0.f};             // edge update: LayerNorm sums
+    f2 sQA = (f2){0.f, 0.f}, sQB = (f2){0.f, 0.f};           // ... and sums of squares (one-pass form)
     float* kdst = nullptr;
     const bool okB = 2 * pair + 1 < ntiles;
     int nodeA = 0, ktA = 0, nodeB = 0, ktB = 0;
@@ -312,6 +317,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
         z += bf8_quad(xb[2 * tn + u], h);
         A[b][4 * q] = z.x; A[b][4 * q + 1] = z.y; A[b][4 * q + 2] = z.z; A[b][4 * q + 3] = z.w;
         sA += (f2){z.x, z.y}; sB += (f2){z.z, z.w};
+        if constexpr (!LN2P) {
+          sQA = __builtin_elementwise_fma((f2){z.x, z.y}, (f2){z.x, z.y}, sQA);
+          sQB = __builtin_elementwise_fma((f2){z.z, z.w}, (f2){z.z, z.w}, sQB);
+        }
       }
     };
     // ---- the slots
@@ -388,30 +397,50 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
     if constexpr (EMB) raw_pack();
     P32_STAMP(7);
     if constexpr (EDGE) {
-      float sum = (sA.x + sA.y) + (sB.x + sB.y);
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum * (1.0f / 128.0f);
-      const f2 m2 = (f2){mean, mean};
-      f2 qA = (f2){0.f, 0.f}, qB = (f2){0.f, 0.f};
       f16v* acc = &A[4 * L3];
+      float sum = (sA.x + sA.y) + (sB.x + sB.y);
+      if constexpr (LN2P) {
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 128.0f);
+        const f2 m2 = (f2){mean, mean};
+        f2 qA = (f2){0.f, 0.f}, qB = (f2){0.f, 0.f};
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int v = 0; v < 16; v += 4) {
-          const f2 d0 = (f2){acc[tn][v], acc[tn][v + 1]} - m2, d1 = (f2){acc[tn][v + 2], acc[tn][v + 3]} - m2;
-          acc[tn][v] = d0.x; acc[tn][v + 1] = d0.y; acc[tn][v + 2] = d1.x; acc[tn][v + 3] = d1.y;
-          qA = __builtin_elementwise_fma(d0, d0, qA); qB = __builtin_elementwise_fma(d1, d1, qB);
+          for (int v = 0; v < 16; v += 4) {
+            const f2 d0 = (f2){acc[tn][v], acc[tn][v + 1]} - m2, d1 = (f2){acc[tn][v + 2], acc[tn][v + 3]} - m2;
+            acc[tn][v] = d0.x; acc[tn][v + 1] = d0.y; acc[tn][v + 2] = d1.x; acc[tn][v + 3] = d1.y;
+            qA = __builtin_elementwise_fma(d0, d0, qA); qB = __builtin_elementwise_fma(d1, d1, qB);
+          }
+        float sq = (qA.x + qA.y) + (qB.x + qB.y);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          const f16v ga = vec16(cst + 256, tn), be = vec16(cst + 384, tn);
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const f2 o = __builtin_elementwise_fma((f2){acc[tn][v], acc[tn][v + 1]} * (f2){rstd, rstd}, (f2){ga[v], ga[v + 1]}, (f2){be[v], be[v + 1]});
+            acc[tn][v] = o.x; acc[tn][v + 1] = o.y;
+          }
         }
-      float sq = (qA.x + qA.y) + (qB.x + qB.y);
-      sq += __shfl_xor(sq, 32);
-      const float rstd = rsqrtf(sq * (1.0f / 128.0f) + 1e-5f);
+      } else {
+        float sq = (sQA.x + sQA.y) + (sQB.x + sQB.y);
+        sum += __shfl_xor(sum, 32);
+        sq += __shfl_xor(sq, 32);
+        const float mean = sum * (1.0f / 128.0f);
+        const float var = fmaxf(fmaf(-mean, mean, sq * (1.0f / 128.0f)), 0.f);
+        const float rstd = rsqrtf(var + 1e-5f);
+        const f2 r2 = (f2){rstd, rstd}, n2 = (f2){-mean * rstd, -mean * rstd};
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const f16v ga = vec16(cst + 256, tn), be = vec16(cst + 384, tn);
+        for (int tn = 0; tn < 4; ++tn) {
+          const f16v ga = vec16(cst + 256, tn), be = vec16(cst + 384, tn);
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) {
-          const f2 o = __builtin_elementwise_fma((f2){acc[tn][v], acc[tn][v + 1]} * (f2){rstd, rstd}, (f2){ga[v], ga[v + 1]}, (f2){be[v], be[v + 1]});
-          acc[tn][v] = o.x; acc[tn][v + 1] = o.y;
+          for (int v = 0; v < 16; v += 2) {
+            const f2 t_ = __builtin_elementwise_fma((f2){acc[tn][v], acc[tn][v + 1]}, r2, n2);
+            const f2 o = __builtin_elementwise_fma(t_, (f2){ga[v], ga[v + 1]}, (f2){be[v], be[v + 1]});
+            acc[tn][v] = o.x; acc[tn][v + 1] = o.y;
+          }
         }
       }
       P32_STAMP(8);
