@@ -39,7 +39,7 @@ __attribute__((visibility("hidden"))) int namp_internal_fail(int code, const cha
 namespace {
 
 // which launches of the bf16-storage path run in their round-6 form: bit 0 messages, 1 edge update, 2 message + embedding (namp_bf16p.h),
-// 3 residue update (namp_node_w.h)
+// 3 residue update (namp_node_w.h), 4 the edge update's two-pass LayerNorm (equality test)
 static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 11; }()};
 
 // ---- optional per-kernel timing (bench.py): thread-local, off by default --------------------
@@ -1130,6 +1130,9 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     // 97 residues.  One residue per workgroup — its own chunks only, every workgroup on a CU of its own — 115 us.  Beyond one round of the chip it loses
     // (1,000 residues: 177 -> 281 us: a workgroup's 140 KB of LDS allow one per CU).
     if (G <= device_cus()) { e.npw = 1; e.nwaves = e.tpn; e.grid = G; }
+    // (Round 6 tried two row tiles per wave beyond that — every weight fragment read from LDS feeding both, six waves per workgroup, bit-identical
+    // rows: 159 -> 212 us at 1,000 residues, 2.42 -> 3.18 ms at a 31,100-token batch (profiles/r06b): the launch is not bound by its LDS reads
+    // either; with half the waves it hides less of everything else.  Removed.)
     // NampModelW.reserved == 2 with an x3 image: plain bf16 products on its hi half (mixed-precision training)
     if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
     else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);

@@ -1,6 +1,6 @@
 """A/B of the bf16-storage edge launches inside the cfg3 step (B=64 x N=1000, K=48, bf16 mode): per-launch HIP-event times by launch kind for
 each value of the namp_set_bf16p mask (0 = round-3 kernels, 7 = round-6 sequencing), alternating, in ONE process on one box.
-    python tools/cfg3_ab.py [--masks 0,7] [--reps 3] [--steps 20]        (NAMP_LIB_PATH selects a variant build)"""
+    python tools/cfg3_ab.py [--masks 0,11] [--reps 3] [--steps 20]        (NAMP_LIB_PATH selects a variant build)"""
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
