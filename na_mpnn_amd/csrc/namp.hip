@@ -1555,7 +1555,16 @@ int namp_encoder_fwd(const NampModelW* w, const float* V, const float* E, const 
   const NampEncLayerW* L0 = &w->enc[0];
   NampProj pre = {w->Wv_img, w->Wv_b, nullptr, hv[0]};
   NampProj p0[2] = {{L0->W1a_img, L0->b1, nullptr, P[0]}, {L0->W1c_img, nullptr, nullptr, P[1]}};
-  if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
+  if (!fused && prec_of(L0->flags) == PREC_X3 && w->Wv_ximg && L0->W1a_ximg && L0->W1c_ximg && aligned16(w->Wv_ximg) && aligned16(L0->W1a_ximg) &&
+      aligned16(L0->W1c_ximg) && w->Wv_b && L0->b1) {
+    // large batch, split-bf16 mode: the two chained residue-level products as split-bf16 products too (exact fp32 MFMA runs at 1/16 of the
+    // bf16 rate: 70 us per launch at 32,000 residues, profiles/r05h_bench_cfg4_kernel_stats.md)
+    const NampProj prex = {w->Wv_ximg, w->Wv_b, nullptr, hv[0]};
+    const NampProj px[2] = {{L0->W1a_ximg, L0->b1, nullptr, P[0]}, {L0->W1c_ximg, nullptr, nullptr, P[1]}};
+    ProfScope prof_(NAMP_KIND_NODE_LINEAR, (hipStream_t)stream);
+    if ((rc = launch_node_linear(V, nullptr, G, G, N, px, 2, &prex, (hipStream_t)stream, true))) return rc;
+    CHECK_LAUNCH();
+  } else if ((rc = namp_node_linear(V, nullptr, B, B, N, p0, 2, &pre, stream))) return rc;
   if (E && (rc = namp_edge_embed(w->We_img, w->We_b, E, h_E, B, N, K, stream))) return rc;   // E == NULL: h_E already = W_e.E + b
   int cur = 0;     // hv[cur] holds the layer input
   for (int l = 0; l < w->n_enc; ++l) {
@@ -2074,7 +2083,18 @@ int namp_decoder_fwd(const NampModelW* w, const float* h_V_enc, const float* h_E
   NampProj p0[2] = {{D0->W1a_img, D0->b1, nullptr, Pa}, {D0->W1v_img, nullptr, D0->tok, Pbw}};
   if (B_dec == B_enc && nf + 2 <= 8) {
     pf[nf++] = p0[0]; pf[nf++] = p0[1];
-    if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, pf, nf, nullptr, stream))) return rc;
+    bool xok = !fused && prec_of(D0->flags) == PREC_X3 && D0->W1a_ximg && D0->W1v_ximg && aligned16(D0->W1a_ximg) && aligned16(D0->W1v_ximg);
+    for (int l = 0; l < w->n_dec && xok; ++l) xok = w->dec[l].W1v_ximg && aligned16(w->dec[l].W1v_ximg);
+    if (xok) {                                             // large batch, split-bf16 mode: see namp_encoder_fwd
+      NampProj pfx[8];
+      for (int i = 0; i < nf; ++i) pfx[i] = pf[i];
+      for (int l = 0; l < w->n_dec; ++l) pfx[l].img = w->dec[l].W1v_ximg;
+      pfx[nf - 2].img = D0->W1a_ximg; pfx[nf - 1].img = D0->W1v_ximg;
+      ProfScope prof_(NAMP_KIND_NODE_LINEAR, s);
+      if ((rc = check_proj(__func__, pf, nf, S))) return rc;
+      if ((rc = launch_node_linear(h_V_enc, S, Gd, Ge, N, pfx, nf, nullptr, s, true))) return rc;
+      CHECK_LAUNCH();
+    } else if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, pf, nf, nullptr, stream))) return rc;
   } else {
     if ((rc = namp_node_linear(h_V_enc, nullptr, B_enc, B_enc, N, pf, nf, nullptr, stream))) return rc;
     if ((rc = namp_node_linear(h_V_enc, S, B_dec, B_enc, N, p0, 2, nullptr, stream))) return rc;
