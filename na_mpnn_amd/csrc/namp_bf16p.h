@@ -155,21 +155,21 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
     idx_n1 = idx_of(pair + stride);
   }
   bf8 xn[8];
-  // EMB: the next pair's fp32 E rows are requested when the message product starts (the gathered rows and the embedded rows are dead by then:
-  // 64 registers) and rounded to bf16 at the end of the tile
-  f4 xraw[16];
-  auto raw_fetch = [&](const TileMeta& mt) {
-    const float* src = a.hE + mt.erow * NAMP_H + 4 * hk;
+  // EMB: the next pair's fp32 E rows are requested in two halves while the message product runs (the gathered rows and the embedded rows are
+  // dead by then) and rounded to bf16 two blocks later: 32 registers of raw rows in flight at a time
+  f4 xraw[8];
+  auto raw_fetch = [&](const TileMeta& mt, const int h) {
+    const float* src = a.hE + mt.erow * NAMP_H + 4 * hk + 64 * h;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { xraw[2 * s] = *(const f4*)(src + 16 * s); xraw[2 * s + 1] = *(const f4*)(src + 16 * s + 8); }
+    for (int s = 0; s < 4; ++s) { xraw[2 * s] = *(const f4*)(src + 16 * s); xraw[2 * s + 1] = *(const f4*)(src + 16 * s + 8); }
   };
-  auto raw_pack = [&]() {
+  auto raw_pack = [&](const int h) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) xn[s] = pack_bf16<false>(xraw[2 * s], xraw[2 * s + 1]);
+    for (int s = 0; s < 4; ++s) xn[4 * h + s] = pack_bf16<false>(xraw[2 * s], xraw[2 * s + 1]);
   };
   auto row_fetch = [&](const TileMeta& mt) {
     if constexpr (EMB) {
-      raw_fetch(mt); raw_pack();             // (prologue only)
+      raw_fetch(mt, 0); raw_pack(0); raw_fetch(mt, 1); raw_pack(1);             // (prologue only)
     } else {
 #ifdef P32_NOMEM
       const bf8* src = (const bf8*)(a.hE16 + (mt.erow & 1023) * NAMP_H) + hk;
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
       if constexpr (s == 6 && b == NB - 1) meta_finish(nxt, nraw, nok, idx_cur);
       if constexpr (!EMB && s == 6 && b == (EDGE ? 8 : 4)) row_fetch(nxt);
       if constexpr (EMB && s == 6 && b == 3) gather_fetch();
-      if constexpr (EMB && s == 6 && b == 8) raw_fetch(nxt);
+      if constexpr (EMB && s == 6 && b == 7) raw_fetch(nxt, 0);
+      if constexpr (EMB && s == 6 && b == 9) { raw_pack(0); raw_fetch(nxt, 1); }
       if constexpr (!EDGE && b == 4 * L2 && s == 0) {
         // message modes: row weights of the two 16-row tiles as (first, second) pairs; where the K-sums go
 #pragma unroll
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16p_kernel(const EdgeArgs a) {
     // the last block's epilogue has no MFMAs left to ride
     P32_STAMP(6);
     static_for<0, 4>([&](auto Qc) { epilogue(std::integral_constant<int, NB - 1>{}, Qc); });
-    if constexpr (EMB) raw_pack();
+    if constexpr (EMB) raw_pack(1);
     P32_STAMP(7);
     if constexpr (EDGE) {
       f16v* acc = &A[4 * L3];
