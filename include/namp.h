@@ -262,7 +262,8 @@ int namp_set_persistent(int on);
 /* The bf16-storage edge launches of namp_encdec_fwd (large batches of the bf16 throughput mode) exist in two instruction sequencings
  * with bit-identical results: edge_mlp_bf16s32_kernel (round 3) and edge_mlp_bf16p_kernel (round 6; default mask 3: its embedding variant is the slower one).  mask: bit 0 the two
  * message launches, bit 1 the edge update, bit 2 the first encoder message with the fused edge embedding; bit 3 selects the round-6
- * residue update of that path (node_update_w_kernel: same rounding points, another summation order in the FFN's second product);
+ * residue update of that path and of the split-bf16 large-batch path (node_update_w_kernel<false / true>: same rounding points, another
+ * summation order in the FFN's second product / of the three split products);
  * bit 4 (with bit 1) runs the edge update's LayerNorm with the round-3 kernel's two-pass variance instead of the one-pass sums (the
  * bit-equality test's form).  Returns the previous mask.  Environment: NAMP_BF16P (default 11).  For A/B timing and the equality tests. */
 int namp_set_bf16p(int mask);

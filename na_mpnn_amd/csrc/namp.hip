@@ -151,7 +151,8 @@ void set_lds_attributes() {
   set((const void*)edge_mlp_bf16s32_kernel<MODE_DEC_MSG>, BF16S32_LDS);
   set((const void*)edge_mlp_bf16s32_kernel<MODE_ENC_EDGE>, BF16S32_LDS);
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
-  set((const void*)node_update_w_kernel, NODEW_LDS);
+  set((const void*)node_update_w_kernel<false>, NODEW_LDS);
+  set((const void*)node_update_w_kernel<true>, NODEW_LDS);
   set((const void*)decoding_order_kernel, 65536);
   set((const void*)work_lists_kernel, 65536);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
@@ -422,7 +423,10 @@ int launch_node_update(const float* ln1_g, const float* ln1_b, const float* Win_
   // 4 tiles would halve the stream again but spill — measured in the split-bf16 form too: 87 spilled VGPRs, 224 vs 165 us)
   if (x3 && g_residue_x1 && a.t.m3_img && !a.t.head_w && nproj <= 4 && G >= 2048 && (g_bf16p.load(std::memory_order_relaxed) & 8))
     // bf16 throughput mode, large batch: one tile per wave end to end, weight blocks through an LDS ring (namp_node_w.h)
-    hipLaunchKernelGGL(node_update_w_kernel, dim3((G + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
+    hipLaunchKernelGGL(node_update_w_kernel<false>, dim3((G + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
+  else if (x3 && !g_residue_x1 && a.t.m3_img && !a.t.head_w && nproj <= 4 && G >= 2048 && (g_bf16p.load(std::memory_order_relaxed) & 8))
+    // split-bf16 (parity) mode, large batch: the same structure with hi / mid planes as separate ring entries
+    hipLaunchKernelGGL(node_update_w_kernel<true>, dim3((G + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
   else if (x3 && g_residue_x1)      // bf16 throughput mode: hi . hi products out of the same x3 images
     hipLaunchKernelGGL((node_update_multi_kernel<2, 2>), dim3((G + 31) / 32), dim3(512), NODE_MULTI_LDS_X3(2), s, a);
   else if (x3)                 // every image is an x3 image (node_update_x3_ok below): the multi-tile kernel only

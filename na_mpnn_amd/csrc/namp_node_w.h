@@ -16,6 +16,8 @@
 // per block.  Weight traffic out of L2 per residue: 6.5 KB (13 KB before).
 // Arithmetic: that of node_update_multi_kernel<2, 2> (operands rounded to bf16, fp32 accumulation, exact-erf GELU, fp32 LayerNorms and
 // residuals); the FFN's second product accumulates its four hidden blocks in one chain instead of eight per-wave partial sums.
+// X3 = true: the split-bf16 (fp32-equivalent) products of the parity mode on large batches (node_update_multi_kernel<2, 1>): every matrix
+// block travels as two ring entries, its hi plane (products W_hi . x_mid, W_hi . x_hi) and its mid plane (W_mid . x_hi).
 #pragma once
 #include "namp_kernels.h"
 
@@ -39,11 +41,32 @@ __device__ __forceinline__ void gemm16(f4 (&acc)[8], const bf8 (&xb)[4], const b
     for (int tn = 0; tn < 8; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xb[s], acc[tn], 0, 0, 0);
   }
 }
+// ... the hi-plane pass of a split-bf16 product: W_hi . x_mid, then W_hi . x_hi, out of one read of each fragment
+__device__ __forceinline__ void gemm16_hi2(f4 (&acc)[8], const bf8 (&xh)[4], const bf8 (&xm)[4], const bf8* w) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf8 wf[8];
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) wf[tn] = w[(s * 8 + tn) * 64];
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xm[s], acc[tn], 0, 0, 0);
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xh[s], acc[tn], 0, 0, 0);
+  }
+}
 __device__ __forceinline__ void pack_rows(bf8 (&xb)[4], const f4 (&x)[8]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) xb[s] = pack_bf16<false>(x[2 * s], x[2 * s + 1]);
 }
+template <bool X3>
+__device__ __forceinline__ void split_rows(bf8 (&xh)[4], bf8 (&xm)[4], const f4 (&x)[8]) {
+  if constexpr (X3) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_x3(x[2 * s], x[2 * s + 1], xh[s], xm[s]);
+  } else pack_rows(xh, x);
+}
 
+template <bool X3>
 static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(const NodeUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tid = threadIdx.x;
@@ -52,19 +75,34 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
   const int m = lane & 15;
   int g = lane >> 4;
   const NodeTail& t = a.t;
-  const int nblk = 9 + t.nproj;
-  // block i of the layer: four 8-KiB chunks `stride` bytes apart (W_in's hidden block h is 8 of its 32 channel tiles in each of its four K-steps);
-  // blocks past the layer's last re-read that one (never used: the requests of the step loop stay free of control flow)
+  constexpr int PL = X3 ? 2 : 1;                              // ring entries per matrix block (hi plane, mid plane)
+  const int nblk = PL * (9 + t.nproj);
+  // ring entry i = plane i % PL of matrix block i / PL: four 8-KiB chunks `stride` bytes apart (W_in's hidden block h is 8 of its 32 channel
+  // tiles in each of its four K-steps); the mid plane of an image follows its hi plane (128 KiB for W_in / W_out, 32 KiB for the square ones);
+  // entries past the layer's last re-read that one (never used: the requests of the step loop stay free of control flow)
   auto block_base = [&](const int i_) -> const char* {
-    const int i = i_ < nblk ? i_ : nblk - 1;
-    if (i == 0) return (const char*)t.m3_img;
+    const int ic = i_ < nblk ? i_ : nblk - 1;
+    const int i = ic / PL, pl = ic - i * PL;
+    if (i == 0) return (const char*)t.m3_img + pl * NAMP_BIMG_BYTES;
     if (i <= 8) {
       const int h = (i - 1) >> 1;
-      return ((i - 1) & 1) ? (const char*)t.Wout_img + h * 32768 : (const char*)t.Win_img + h * 8192;
+      return ((i - 1) & 1) ? (const char*)t.Wout_img + pl * 131072 + h * 32768 : (const char*)t.Win_img + pl * 131072 + h * 8192;
     }
-    return (const char*)t.p[i - 9].img;
+    return (const char*)t.p[i - 9].img + pl * NAMP_BIMG_BYTES;
   };
-  auto block_stride = [&](const int i) -> long { return (i >= 1 && i <= 8 && !((i - 1) & 1)) ? 32768 : 8192; };
+  auto block_stride = [&](const int i_) -> long { const int i = i_ / PL; return (i >= 1 && i <= 8 && !((i - 1) & 1)) ? 32768 : 8192; };
+  // acc += W_k . x for matrix block k (ring entries PL k ..): the hi pass (and the mid pass), each closed by the ring's advance
+  auto product = [&](f4 (&acc)[8], const bf8 (&xh)[4], const bf8 (&xm)[4], const int k, auto&& adv, auto&& slot_) {
+    if constexpr (X3) {
+      gemm16_hi2(acc, xh, xm, slot_(2 * k));
+      adv(2 * k);
+      gemm16(acc, xh, slot_(2 * k + 1));
+      adv(2 * k + 1);
+    } else {
+      gemm16(acc, xh, slot_(k));
+      adv(k);
+    }
+  };
   f4 sreg[8];
   auto stage_load = [&](const int i) {
 #ifdef NW_NOSTAGE
@@ -148,44 +186,41 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
 #else
     stage_store(0); stage_store(1); stage_load(2);
 #endif
-    bf8 xb[4];
-    pack_rows(xb, x);
-    __syncthreads();                                             // blocks 0, 1 in LDS
+    bf8 xb[4], xm[X3 ? 4 : 1];
+    split_rows<X3>(xb, (bf8(&)[4])xm, x);
+    __syncthreads();                                             // ring entries 0, 1 in LDS
     // ---- block 0: hoisted layer 3, residual, LayerNorm 1
     {
       f4 acc[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[c] = *(const f4*)(t.m3_b + 16 * c + 4 * g) * ws;
-      gemm16(acc, xb, slot(0));
+      product(acc, xb, (bf8(&)[4])xm, 0, advance, slot);
 #pragma unroll
       for (int c = 0; c < 8; ++c) x[c] = hv[c] + acc[c];
     }
-    advance(0);
     layernorm_row_T(x, t.ln1_g, t.ln1_b, g);
-    pack_rows(xb, x);                                            // x = LayerNorm-1 rows: kept for the second residual
+    split_rows<X3>(xb, (bf8(&)[4])xm, x);                        // x = LayerNorm-1 rows: kept for the second residual
     f4 oacc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) oacc[c] = (f4){0.f, 0.f, 0.f, 0.f};
     // ---- blocks 1..8: the FFN, hidden block by hidden block
 #pragma unroll 1
     for (int h = 0; h < 4; ++h) {
-      bf8 hb[4];
+      bf8 hb[4], hm[X3 ? 4 : 1];
       {
         f4 hacc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) hacc[c] = *(const f4*)(t.b_in + 128 * h + 16 * c + 4 * g);
-        gemm16(hacc, xb, slot(2 * h + 1));
-        advance(2 * h + 1);
+        product(hacc, xb, (bf8(&)[4])xm, 2 * h + 1, advance, slot);
 #pragma unroll
 #ifndef NW_NOGELU
         for (int c = 0; c < 8; ++c) hacc[c] = gelu4(hacc[c]);
 #else
         for (int c = 0; c < 8; ++c) hacc[c] *= 0.5f;
 #endif
-        pack_rows(hb, hacc);
+        split_rows<X3>(hb, (bf8(&)[4])hm, hacc);
       }
-      gemm16(oacc, hb, slot(2 * h + 2));
-      advance(2 * h + 2);
+      product(oacc, hb, (bf8(&)[4])hm, 2 * h + 2, advance, slot);
     }
     // ---- residual, LayerNorm 2, mask; the new rows
 #pragma unroll
@@ -201,7 +236,7 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
         for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = x[c];
       }
     }
-    pack_rows(xb, x);
+    split_rows<X3>(xb, (bf8(&)[4])xm, x);
     // ---- blocks 9..: the tables the next launches gather
 #pragma unroll 1
     for (int pi = 0; pi < t.nproj; ++pi) {
@@ -212,8 +247,7 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
         acc[c] = d.bias ? *(const f4*)(d.bias + 16 * c + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
         if (d.tok) acc[c] += *(const f4*)(d.tok + (long)t.S[rr] * NAMP_H + 16 * c + 4 * g);
       }
-      gemm16(acc, xb, slot(pi + 9));
-      advance(pi + 9);
+      product(acc, xb, (bf8(&)[4])xm, pi + 9, advance, slot);
       if (valid && d.out) {
         float* dst = d.out + (long)row * NAMP_H + 4 * g;
 #pragma unroll

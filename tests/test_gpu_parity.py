@@ -725,6 +725,36 @@ def test_node_update_w_matches_multi(L, dev, wt, b, n, k, mf):
     assert torch.equal(hV1[~valid], hV0[~valid])              # masked residues: zero rows in both
 
 
+@pytest.mark.parametrize("b,n,k,mf", [(5, 900, 48, 0.0), (3, 901, 30, 0.1), (40, 75, 16, 0.05)])
+def test_node_update_w_split_bf16(L, dev, wt, b, n, k, mf):
+    """node_update_w_kernel<true> — the residue update of the split-bf16 (parity) mode on large batches, hi and mid planes of every weight block
+    as separate LDS ring entries — against the exact-fp32 evaluation of the same launches and against node_update_multi_kernel<2, 1>, the kernel it
+    replaces there: log-probs within 2e-4 of fp32 (the mode is fp32-equivalent to ~2^-16 per product; parity bar 1e-3), arg-max identical except
+    at near-ties, and within 1e-4 of the kernel it replaces (another order of the three split products)."""
+    t, d = graph(dev, seed=270 + k, batch=b, n=n, k=k, masked_frac=mf)
+    P = PackedWeights({k_: v.to(dev) for k_, v in wt.items()}, 3, 3, 33, dev)
+    P.set_precision("fp32")
+    _, _, lpf, _ = run_encdec(L, dev, P, d, b, n, k, joint=True)
+    P.set_precision("x3")
+    prev = L.namp_set_bf16p(3)
+    try:
+        hV0, _, lp0, _ = run_encdec(L, dev, P, d, b, n, k, joint=True)
+        L.namp_set_bf16p(11)
+        hV1, _, lp1, _ = run_encdec(L, dev, P, d, b, n, k, joint=True)
+    finally:
+        L.namp_set_bf16p(prev)
+    valid = t["mask"].bool().to(dev)
+    e0, e1, e01 = (float((x - y)[valid].abs().max()) for x, y in ((lp0, lpf), (lp1, lpf), (lp0, lp1)))
+    print(f"split-bf16 residue update: multi vs fp32 {e0:.2e}, node_update_w vs fp32 {e1:.2e}, w vs multi {e01:.2e}")
+    assert torch.isfinite(lp1).all()
+    assert e1 < 2e-4 and e01 < 1e-4
+    flips = (lp1.argmax(-1) != lpf.argmax(-1)) & valid
+    for bi, i in torch.nonzero(flips).tolist():
+        top2 = lpf[bi, i].topk(2).values
+        assert float(top2[0] - top2[1]) < 2e-3, (bi, i)
+    assert torch.equal(hV1[~valid], hV0[~valid])
+
+
 @pytest.mark.parametrize("B,N,K", [(3, 333, 48), (2, 257, 30), (1, 75, 16), (5, 201, 70)])
 def test_bf16_storage_message_kernel(dev, B, N, K):
     """namp_bf16s_message (edge_mlp_bf16s32_kernel, v_mfma_f32_32x32x16_bf16 on rows stored in fragment order B) against a torch
