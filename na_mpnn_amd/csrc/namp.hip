@@ -155,6 +155,7 @@ void set_lds_attributes() {
   set((const void*)node_update_w_kernel<true>, NODEW_LDS);
   set((const void*)decoding_order_kernel, 65536);
   set((const void*)work_lists_kernel, 65536);
+  set((const void*)logits_mfma_kernel, LOGITS_MFMA_LDS(48));
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_DEC_MSG>, BF16P_LDS);
   set((const void*)edge_mlp_bf16p_kernel<MODE_ENC_EDGE>, BF16P_LDS);
@@ -1045,6 +1046,18 @@ int namp_logits_log_softmax(const float* Wout_w, const float* Wout_b, const floa
   if (!Wout_b || !log_probs) return fail(NAMP_EINVAL, "namp_logits_log_softmax: null pointer");
   REQUIRE(G >= 1 && vocab >= 1 && vocab <= 64, "namp_logits_log_softmax: vocab=%d must be in [1,64]", vocab);
   ProfScope prof_(NAMP_KIND_LOGITS, (hipStream_t)stream);
+  if (G >= 4096 && vocab <= 48 && aligned16(Wout_w) && aligned16(h_V) && aligned16(log_probs) && (!logits || aligned16(logits))) {
+    // large batches: 16-row tiles on the exact-fp32 matrix pipe (namp_order.h: logits_mfma_kernel)
+    int rc = ensure_attributes();
+    if (rc) return rc;
+    const int ntile = (G + 15) / 16;
+    int grid = (ntile + 3) / 4;
+    if (grid > 4 * device_cus()) grid = 4 * device_cus();
+    hipLaunchKernelGGL(logits_mfma_kernel, dim3(grid), dim3(256), LOGITS_MFMA_LDS(vocab), (hipStream_t)stream, h_V, Wout_w, Wout_b, log_probs,
+                       logits, G, vocab);
+    CHECK_LAUNCH();
+    return NAMP_OK;
+  }
   int per_wg = (G + 2 * device_cus() - 1) / (2 * device_cus());            // ~2 workgroups per CU; W_out is staged once per workgroup
   per_wg = (per_wg + 15) / 16 * 16;                                         // 4 waves x 4 residues per pass
   hipLaunchKernelGGL(logits_kernel, dim3((G + per_wg - 1) / per_wg), dim3(256), (size_t)32 * vocab * 16, (hipStream_t)stream, h_V,

@@ -725,6 +725,28 @@ def test_node_update_w_matches_multi(L, dev, wt, b, n, k, mf):
     assert torch.equal(hV1[~valid], hV0[~valid])              # masked residues: zero rows in both
 
 
+@pytest.mark.parametrize("G,V,want_logits", [(5000, 33, True), (4099, 33, False), (64000, 33, False), (4100, 21, True), (100, 33, True)])
+def test_logits_head_matches_torch(L, dev, G, V, want_logits):
+    """namp_logits_log_softmax — the small-batch kernel (one token per lane) and, from 4,096 residues, logits_mfma_kernel (16-row tiles on the
+    exact-fp32 matrix pipe, W_out as a fragment image built in LDS, the tile's [16][V] block written through LDS) — against torch in fp64:
+    log-probs and logits within 2e-5, rows normalised; G not a multiple of 16 and a vocabulary of 21 (V * rows not a multiple of 4) included."""
+    g = torch.Generator().manual_seed(G + V)
+    h = torch.randn(G, 128, generator=g).to(dev)
+    W = (torch.randn(V, 128, generator=g) * 0.2).to(dev).contiguous()
+    b = (torch.randn(V, generator=g) * 0.1).to(dev)
+    lp = torch.full((G, V), float("nan"), device=dev)
+    lg = torch.full((G, V), float("nan"), device=dev) if want_logits else None
+    hip.check(L.namp_logits_log_softmax(W.data_ptr(), b.data_ptr(), h.data_ptr(), lp.data_ptr(), hip.ptr(lg), G, V, stream()))
+    torch.cuda.synchronize()
+    z = h.double() @ W.double().t() + b.double()
+    ref = torch.log_softmax(z, -1)
+    assert torch.isfinite(lp).all()
+    assert float((lp.double() - ref).abs().max()) < 2e-5
+    if want_logits:
+        assert float((lg.double() - z).abs().max()) < 2e-5
+    assert float((torch.logsumexp(lp.double(), -1)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("b,n,k,mf", [(5, 900, 48, 0.0), (3, 901, 30, 0.1), (40, 75, 16, 0.05)])
 def test_node_update_w_split_bf16(L, dev, wt, b, n, k, mf):
     """node_update_w_kernel<true> — the residue update of the split-bf16 (parity) mode on large batches, hi and mid planes of every weight block
