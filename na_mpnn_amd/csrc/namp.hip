@@ -153,6 +153,8 @@ void set_lds_attributes() {
   set((const void*)(edge_mlp_bf16s32_kernel<MODE_ENC_MSG, true>), BF16S32_LDS);
   set((const void*)node_update_w_kernel<false>, NODEW_LDS);
   set((const void*)node_update_w_kernel<true>, NODEW_LDS);
+  set((const void*)node_linear_w_kernel<1>, NODEW_LDS);
+  set((const void*)node_linear_w_kernel<2>, NODEW_LDS);
   set((const void*)decoding_order_kernel, 65536);
   set((const void*)work_lists_kernel, 65536);
   set((const void*)logits_mfma_kernel, LOGITS_MFMA_LDS(48));
@@ -397,6 +399,12 @@ int launch_node_linear(const float* X, const int32_t* S, int G_out, int G_src, i
   }
   if (g_out16) g_out16->honoured = true;
   const int units = ((G_out + 15) / 16) * nproj;
+  if (x3 && G_out >= 4096 && (g_bf16p.load(std::memory_order_relaxed) & 8) && ensure_attributes() == NAMP_OK) {
+    // large batches: one tile per wave through all blocks, weights through an LDS ring (namp_node_w.h: node_linear_w_kernel)
+    if (g_residue_x1) hipLaunchKernelGGL(node_linear_w_kernel<2>, dim3((G_out + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
+    else hipLaunchKernelGGL(node_linear_w_kernel<1>, dim3((G_out + NODEW_ROWS - 1) / NODEW_ROWS), dim3(NODEW_THREADS), NODEW_LDS, s, a);
+    return NAMP_OK;
+  }
   if (x3 && g_residue_x1) hipLaunchKernelGGL(node_linear_kernel<2>, dim3((units + 3) / 4), dim3(256), 0, s, a);
   else if (x3) hipLaunchKernelGGL(node_linear_kernel<1>, dim3((units + 3) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(node_linear_kernel<0>, dim3((units + 3) / 4), dim3(256), 0, s, a);

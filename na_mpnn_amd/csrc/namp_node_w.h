@@ -261,3 +261,125 @@ static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_update_w_kernel(
     }
   }
 }
+
+// node_linear_w_kernel — the residue-level table projections of large batches (node_linear_kernel: h = W_pre . x + b stored and fed on,
+// then up to eight 128 x 128 projections with bias / per-token rows; model_utils.py:88,406-418,636-646) in the same form: one 16-row tile per
+// wave through ALL blocks, weight blocks through the 2-slot LDS ring.  node_linear_kernel gives every (tile, projection) pair a wave of its
+// own that pulls its 32-64 KiB image out of L2 and repeats the pre-stage product per projection: 62 us per launch at 64,000 residues for
+// ~110 MB of rows (2 KB of weight traffic per row and projection).  X3: 1 split-bf16 products, 2 plain bf16 (hi . hi) — as node_linear_kernel<X3>.
+template <int X3>
+static __global__ __launch_bounds__(NODEW_THREADS, 2) void node_linear_w_kernel(const NodeLinearArgs a) {
+  static_assert(X3 == 1 || X3 == 2, "split-bf16 / bf16 forms");
+  constexpr bool SPLIT = X3 == 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15;
+  int g = lane >> 4;
+  if (a.zero && blockIdx.x == 0 && threadIdx.x < 64) a.zero[threadIdx.x] = 0u;
+  constexpr int PL = SPLIT ? 2 : 1;
+  const int has_pre = a.pre.img ? 1 : 0;
+  const int nblk = PL * (has_pre + a.nproj);
+  auto block_base = [&](const int i_) -> const char* {
+    const int ic = i_ < nblk ? i_ : nblk - 1;
+    const int k = ic / PL, pl = ic - k * PL;
+    const float* img = (has_pre && k == 0) ? a.pre.img : a.p[k - has_pre].img;
+    return (const char*)img + pl * NAMP_BIMG_BYTES;
+  };
+  f4 sreg[8];
+  auto stage_load = [&](const int i) {
+    const char* b = block_base(i) + tid * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sreg[k] = *(const f4*)(b + k * 4096);
+  };
+  auto stage_store = [&](const int i) {
+    char* d = smem + (i & 1) * NODEW_SLOT + tid * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(f4*)(d + 4096 * k) = sreg[k];
+  };
+  auto slot = [&](const int i) { return (const bf8*)(smem + (i & 1) * NODEW_SLOT) + lane; };
+  auto advance = [&](const int i) {
+    __syncthreads();
+    stage_store(i + 2);
+    stage_load(i + 3);
+  };
+  auto product = [&](f4 (&acc)[8], const bf8 (&xh)[4], const bf8 (&xm)[4], const int k) {
+    if constexpr (SPLIT) {
+      gemm16_hi2(acc, xh, xm, slot(2 * k));
+      advance(2 * k);
+      gemm16(acc, xh, slot(2 * k + 1));
+      advance(2 * k + 1);
+    } else {
+      gemm16(acc, xh, slot(k));
+      advance(k);
+    }
+  };
+  const int ntile = (a.G_out + 15) >> 4;
+  for (int tile0 = blockIdx.x * 4; tile0 < ntile; tile0 += gridDim.x * 4) {
+    asm volatile("" : "+v"(tid), "+v"(g));
+    const int tile = tile0 + wave;
+    const int row = 16 * tile + m;
+    const bool valid = row < a.G_out;
+    const int rr = valid ? row : (a.G_out - 1);
+    const int b = rr / a.N;
+    const int src_row = (b % (a.G_src / a.N)) * a.N + (rr - b * a.N);
+    __syncthreads();
+    f4 sreg2[8];
+    stage_load(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sreg2[k] = sreg[k];
+    stage_load(1);
+    f4 x[8];
+    {
+      const float* src = a.X + (long)src_row * NAMP_H + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = *(const f4*)(src + 16 * c);
+    }
+    {
+      char* d0 = smem + tid * 16;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *(f4*)(d0 + 4096 * k) = sreg2[k];
+    }
+    stage_store(1);
+    stage_load(2);
+    bf8 xb[4], xm[SPLIT ? 4 : 1];
+    split_rows<SPLIT>(xb, (bf8(&)[4])xm, x);
+    __syncthreads();
+    if (has_pre) {
+      f4 acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = a.pre.bias ? *(const f4*)(a.pre.bias + 16 * c + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+      product(acc, xb, (bf8(&)[4])xm, 0);
+      if (valid && a.pre.out) {
+        float* dst = a.pre.out + (long)row * NAMP_H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = acc[c];
+      }
+      split_rows<SPLIT>(xb, (bf8(&)[4])xm, acc);
+    }
+#pragma unroll 1
+    for (int pi = 0; pi < a.nproj; ++pi) {
+      const ProjDesc d = a.p[pi];
+      f4 acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = d.bias ? *(const f4*)(d.bias + 16 * c + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+      product(acc, xb, (bf8(&)[4])xm, has_pre + pi);
+      if (d.tok) {
+        const float* tk = d.tok + (long)a.S[rr] * NAMP_H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += *(const f4*)(tk + 16 * c);
+      }
+      if (valid && d.out) {
+        float* dst = d.out + (long)row * NAMP_H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *(f4*)(dst + 16 * c) = acc[c];
+      }
+      __bf16* o16 = a.out16[pi];
+      if (valid && o16) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) st_frag4(o16 + (long)row * NAMP_H, c, g, acc[c]);
+      }
+    }
+  }
+}
