@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import sys
 
+import os
 import weakref
 
 import numpy as np
@@ -271,7 +272,7 @@ class ProteinMPNN(nn.Module):
         self._conv[key] = (weakref.ref(t, lambda _r, k=key: conv.pop(k, None)), t._version, c)
         return c
 
-    def order_and_rank(self, mask, chain_mask, randn):
+    def order_and_rank(self, mask, chain_mask, randn, defer=False):
         """Decoding order argsort((mask * chain_mask + 1e-4) * |randn|) (model_utils.py:389; na_model_utils.py:623) and its inverse permutation
         in one HIP launch (namp_decoding_order): order int64 [B', L], rank int32 [B', L], B' = rows of randn; mask / chain_mask [B, L] with
         B' % B == 0 (chain_mask None = ones).  Shapes the kernel does not take (L > 8192, mismatched rows) run the stock ops."""
@@ -282,11 +283,41 @@ class ProteinMPNN(nn.Module):
             cm = self._as(chain_mask, "f32") if chain_mask is not None else None
             order = torch.empty(Br, L, dtype=torch.int64, device=mask.device)
             rank = torch.empty(Br, L, dtype=torch.int32, device=mask.device)
+            # The sort depends on (mask, chain_mask, randn) only and its first consumer is the decoder: it runs on a side stream beside the
+            # featuriser / encoder launches enqueued after this call (one workgroup per stream: 20-80 us that would otherwise sit in front of
+            # them).  The calling stream waits for it at once — a wait in the stream, not on the host —, so everything enqueued later is ordered
+            # behind it... which would serialise again: the wait is therefore deferred to `wait_order()` (score / sample / forward call it
+            # right before their decoder launch).
+            main = torch.cuda.current_stream(mask.device)
+            side = self._side_stream(mask.device) if (defer and self.order_side_stream) else main
+            if side is not main:
+                side.wait_stream(main)                              # the inputs' producers
             hip.check(hip.lib().namp_decoding_order(m.data_ptr(), hip.ptr(cm), r.data_ptr(), order.data_ptr(), None, rank.data_ptr(),
-                                                    Br, Bm, L, hip.current_stream()), "decoding_order")
+                                                    Br, Bm, L, side.cuda_stream), "decoding_order")
+            ev = torch.cuda.Event()
+            ev.record(side)
+            self._order_event = ev
+            for t_ in (m, r, cm, order, rank):                      # the caching allocator must not recycle these before the side stream is done
+                if t_ is not None:
+                    t_.record_stream(side)
+            if not defer:
+                self.wait_order()
             return order, rank
         order = self.decoding_order(mask if chain_mask is None else mask * chain_mask, randn)
         return order, self.ranks_of(order).to(torch.int32)
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = self._side = torch.cuda.Stream(device=device)
+        return st
+
+    def wait_order(self):
+        """Order the calling stream behind the decoding-order launch of the last `order_and_rank` (no host synchronisation)."""
+        ev = getattr(self, "_order_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._order_event = None
 
     def _workspace(self, B_enc, B_dec, N, K, device):
         need = hip.lib().namp_workspace_bytes(B_enc, B_dec, N, K)
@@ -420,6 +451,7 @@ class ProteinMPNN(nn.Module):
         log_probs = torch.empty(B_dec, N, self.num_letters, device=h_V.device)
         logits = torch.empty_like(log_probs) if want_logits else None
         ws = self._workspace(B_enc, B_dec, N, K, h_V.device)
+        self.wait_order()
         hip.check(hip.lib().namp_decoder_fwd(W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), S32.data_ptr(),
                                              m32.data_ptr(), r32.data_ptr(), log_probs.data_ptr(), hip.ptr(logits), None,
                                              ws.data_ptr(), ws.numel(), B_dec, B_enc, N, K, hip.current_stream()),
@@ -444,6 +476,7 @@ class ProteinMPNN(nn.Module):
         need = 2 * hip.lib().namp_workspace_bytes(B, B, N, K)
         if self._ws is None or self._ws.numel() < need or self._ws.device != V.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=V.device)
+        self.wait_order()                               # (rank: behind the side-stream sort, see order_and_rank)
         hip.check(hip.lib().namp_encdec_fwd(W.model(), V.data_ptr(), hip.ptr(E.float().contiguous() if E is not None else None),
                                             E32.data_ptr(), m32.data_ptr(), S32.data_ptr(), r32.data_ptr(), h_V.data_ptr(),
                                             h_E.data_ptr(), log_probs.data_ptr(), hip.ptr(logits), self._ws.data_ptr(),
@@ -456,12 +489,13 @@ class ProteinMPNN(nn.Module):
         bs = feature_dict["batch_size"]
         S_true, mask = feature_dict["S"], feature_dict["mask"]
         B, L = S_true.shape
-        order, rank = self.order_and_rank(mask, feature_dict["chain_mask"], feature_dict["randn"])
+        order, rank = self.order_and_rank(mask, feature_dict["chain_mask"], feature_dict["randn"], defer=True)
         rank = rank[:B]                          # the reference's gather keeps only E_idx's batch rows (:393)
         if bs == 1:
             log_probs = self.encode_decode(feature_dict, S_true, rank, idx_long=False)[3]
             return {"S": S_true, "log_probs": log_probs, "decoding_order": order[0]}
         h_V, h_E, E_idx = self.encode(feature_dict)
+        self.wait_order()
         rep = lambda t: t.repeat(bs, *([1] * (t.dim() - 1)))
         log_probs = self.decode_graph(h_V, h_E, E_idx, rep(S_true), rep(mask), rep(rank))
         return {"S": rep(S_true), "log_probs": log_probs, "decoding_order": order[0]}
@@ -491,7 +525,7 @@ class ProteinMPNN(nn.Module):
                 chain_M = chain_M.masked_fill(feature_dict["protein_mask"].to(torch.bool), 0.0)
             if decoding_randn is None:
                 decoding_randn = torch.randn(chain_M.shape, device=mask.device)
-            rank = self.order_and_rank(chain_M, None, decoding_randn)[1]
+            rank = self.order_and_rank(chain_M, None, decoding_randn, defer=True)[1]
             _, _, _, log_probs, logits = self.encode_decode(feature_dict, feature_dict["S"], rank, want_logits=True, idx_long=False)
             return log_probs, torch.softmax(logits, dim=-1)
 
@@ -499,6 +533,8 @@ class ProteinMPNN(nn.Module):
     # every stream is masked with STREAM 0's mask at that step.  True reproduces it; it only matters when
     # batch_size > 1 and masked residues coexist with fixed (chain_mask = 0) ones.
     reference_sample_mask_quirk = True
+    # the decoding-order sort on a side stream beside the featuriser launches (False: in the calling stream; A/B switch)
+    order_side_stream = os.environ.get("NAMP_ORDER_SIDE", "1") != "0"
     # decode the plain sampling branch by dependency level (False: the one-launch sequential walk; same results)
     sample_level_parallel = True
     # ... as ONE persistent launch walking the levels (no host read-back, warm L2); False: one launch per level
@@ -527,11 +563,12 @@ class ProteinMPNN(nn.Module):
         self._check_tokens(S_true)
         if fd.get("S_forced") is not None:
             self._check_tokens(fd["S_forced"], "S_forced")
+        order, rank = self.order_and_rank(mask, fd["chain_mask"], fd["randn"], defer=True)       # [max(B, bs), L]; beside the launches below
         V, _, h_E, E_idx = self._featurize_hip(fd, want_E=False, want_hE=True)       # (E_idx stays int32: the kernels' dtype)
         h_V, h_E = self.encode_graph(V, None, E_idx, mask, h_E_embedded=h_E)
+        self.wait_order()
         K = E_idx.shape[-1]
         chain_mask = mask * fd["chain_mask"]
-        order, rank = self.order_and_rank(mask, fd["chain_mask"], fd["randn"])       # [max(B, bs), L]
         B_dec = B * bs
         group_first = group_last = sym_w = None
         if symmetric:
