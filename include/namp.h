@@ -260,12 +260,13 @@ int namp_dec_layer_fwd(const NampDecLayerW* w, const float* h_V, const float* h_
  * (0 = every grid barrier completed; otherwise the code of the barrier that gave up — the outputs are then invalid). */
 int namp_set_persistent(int on);
 /* The bf16-storage edge launches of namp_encdec_fwd (large batches of the bf16 throughput mode) exist in two instruction sequencings
- * with bit-identical results: edge_mlp_bf16s32_kernel (round 3) and edge_mlp_bf16p_kernel (round 6; default mask 3: its embedding variant is the slower one).  mask: bit 0 the two
+ * with bit-identical results: edge_mlp_bf16s32_kernel (round 3) and edge_mlp_bf16p_kernel (round 6; its embedding variant, bit 2, is the slower one and off by default).  mask: bit 0 the two
  * message launches, bit 1 the edge update, bit 2 the first encoder message with the fused edge embedding; bit 3 selects the round-6
  * residue update of that path and of the split-bf16 large-batch path (node_update_w_kernel<false / true>: same rounding points, another
  * summation order in the FFN's second product / of the three split products);
  * bit 4 (with bit 1) runs the edge update's LayerNorm with the round-3 kernel's two-pass variance instead of the one-pass sums (the
- * bit-equality test's form).  Returns the previous mask.  Environment: NAMP_BF16P (default 11).  For A/B timing and the equality tests. */
+ * bit-equality test's form).  Bit 5 (independent of the precision mode): the edge-feature launch of namp_featurize in parts (see
+ * namp_featurize_split_bytes); bits 6-7: one or two parts more than two (measured slower; A/B only).  Returns the previous mask.  Environment: NAMP_BF16P (default 43).  For A/B timing and the equality tests. */
 int namp_set_bf16p(int mask);
 int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K, int32_t* code);
 
@@ -276,6 +277,13 @@ int namp_persistent_status(const void* ws, size_t ws_bytes, int B, int N, int K,
  * X [B,L,16,3] f32, X_m / masks / R_idx / chain_labels int32 [B,L(,16)]; atom order of run.py:15-19; ref_atom =
  * index of na_ref_atom (15 = C1').  E and/or h_E = W_e.E + b_e [B,L,K,128] are written (pass NULL to skip one). */
 size_t namp_featurize_workspace_bytes(int B, int L);
+/* Optional extra: with namp_featurize_workspace_bytes(B, L) + namp_featurize_split_bytes(B, L, top_k) bytes of workspace a batch of at most one
+ * round of the chip (one complex of up to ~1,000 residues) runs its edge-feature launch in parts: the residue blocks that hold nucleotides
+ * (39-54 atom-pair chunks against ~10 of a protein block: the launch lasts as long as its longest workgroup there) are walked by two
+ * workgroups each, every second chunk, longest blocks first, and a finishing launch adds the partial rows, normalises and embeds.  Results
+ * equal to ~1e-5 after the LayerNorm (another order of fp32 sums).  0 when the split does not apply.  When both E and h_E are requested the
+ * two-part form needs no extra (partial rows go to the output buffers). */
+size_t namp_featurize_split_bytes(int B, int L, int top_k);
 int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
                    const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
                    const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E,

@@ -39,8 +39,8 @@ __attribute__((visibility("hidden"))) int namp_internal_fail(int code, const cha
 namespace {
 
 // which launches of the bf16-storage path run in their round-6 form: bit 0 messages, 1 edge update, 2 message + embedding (namp_bf16p.h),
-// 3 residue update (namp_node_w.h), 4 the edge update's two-pass LayerNorm (equality test)
-static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 11; }()};
+// 3 residue update (namp_node_w.h), 4 the edge update's two-pass LayerNorm (equality test), 5 (any precision) the two-part edge-feature launch of small batches
+static std::atomic<int> g_bf16p{[] { const char* e = getenv("NAMP_BF16P"); return e ? atoi(e) : 43; }()};
 
 // ---- optional per-kernel timing (bench.py): thread-local, off by default --------------------
 struct ProfRec { int kind; hipEvent_t a, b; };
@@ -186,6 +186,8 @@ void set_lds_attributes() {
   set((const void*)edge_features_kernel<0>, FEAT_LDS);
   set((const void*)edge_features_kernel<1>, FEAT_LDS);
   set((const void*)edge_features_kernel<2>, FEAT_LDS);
+  set((const void*)feat_finish_kernel<0>, NAMP_IMG_BYTES);
+  set((const void*)feat_finish_kernel<1>, NAMP_IMG_BYTES);
   set((const void*)knn_kernel, 8192 * 8 + 64);
   set((const void*)knn_select_kernel, (8192 + 4096) * 8 + 1024 + 64);
 }
@@ -1101,6 +1103,18 @@ size_t namp_featurize_workspace_bytes(int B, int L) {
   return ((G * 54 * 4 + 255) & ~size_t(255)) + ((G * 4 + 255) & ~size_t(255)) + ((G * 3 * 4 + 255) & ~size_t(255)) + 4096;
 }
 
+// extra workspace bytes with which namp_featurize can split its edge-feature launch in two parts when only one of E / h_E is requested
+// (0 when the batch is too large for the split to apply)
+size_t namp_featurize_split_bytes(int B, int L, int top_k) {
+  if (B < 1 || L < 1 || top_k < 1) return 0;
+  const int K = top_k < L ? top_k : L;
+  const int G = B * L;
+  EdgeGeom e = edge_geom(G, K);
+  if (G <= device_cus()) e.grid = G;
+  if (e.grid > device_cus()) return 0;
+  return 3 * ((((size_t)G * K * NAMP_HIDDEN * 4 + 255) & ~size_t(255)) + 256) + 2048;
+}
+
 int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
                    const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
                    const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
@@ -1135,13 +1149,6 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     ProfScope prof_(NAMP_KIND_FEATURES, s);
     hipLaunchKernelGGL(prep_atoms_kernel, dim3((G + 255) / 256), dim3(256), 0, s, X, X_m, protein_mask, dna_mask, rna_mask,
                        X18, M18, P, G, ref_atom);
-    int Lp2 = 1; while (Lp2 < L) Lp2 <<= 1;
-    int Kp2 = 64; while (Kp2 < K) Kp2 <<= 1;
-    const bool full_sort = getenv("NAMP_KNN_FULL_SORT") != nullptr;      // debugging / test switch: sort whole rows
-    if (2 * Kp2 <= Lp2 && !full_sort)      // selection pays when the final sort is at most half a row
-      hipLaunchKernelGGL(knn_select_kernel, dim3(G), dim3(256), ((size_t)L + Kp2) * 8 + 1024 + 64, s, P, mask, E_idx, L, K, Kp2);
-    else
-      hipLaunchKernelGGL(knn_kernel, dim3(G), dim3(256), (size_t)Lp2 * 8 + 64, s, P, mask, E_idx, L, Lp2, K);
     FeatArgs a = {};
     a.X18 = X18; a.M18 = M18; a.E_idx = E_idx; a.R_idx = R_idx; a.chain = chain_labels;
     const bool x3 = w->feat.Wedge_ximg != nullptr;
@@ -1158,10 +1165,46 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
     // (Round 6 tried two row tiles per wave beyond that — every weight fragment read from LDS feeding both, six waves per workgroup, bit-identical
     // rows: 159 -> 212 us at 1,000 residues, 2.42 -> 3.18 ms at a 31,100-token batch (profiles/r06b): the launch is not bound by its LDS reads
     // either; with half the waves it hides less of everything else.  Removed.)
+    // At most one round of the chip (one complex of up to ~1,000 residues): the launch lasts as long as its longest chain of atom-pair chunks —
+    // 39-54 for a workgroup that holds a nucleotide, ~10 for protein residues, ~2.5 us each — while the protein workgroups' CUs idle.  In parts:
+    // the long blocks (feat_rank_blocks, an extra workgroup of the neighbour-search launch) become 2-4 items each, every n-th chunk, leaving
+    // pre-LayerNorm partial rows that feat_finish_kernel adds, normalises and embeds; the short ones stay one item; longest first in dispatch
+    // order.  Partial rows go to the output buffers themselves (E and h_E both asked for: two parts without workspace), the
+    // others to the workspace's tail when the caller sized it with namp_featurize_split_bytes.  Bit 5 of the namp_set_bf16p mask (A/B switch).
+    dim3 grid(e.grid);
+    FeatRank fr = {};
+    if ((g_bf16p.load(std::memory_order_relaxed) & 32) && e.grid <= device_cus() && e.grid <= 256 && w->feat.ln_g) {
+      int np = 2 + ((g_bf16p.load(std::memory_order_relaxed) >> 6) & 3);          // bits 6-7: one or two parts more
+      if (np > 4) np = 4;
+      const size_t rows = (size_t)G * K * NAMP_HIDDEN;
+      int32_t* order = (int32_t*)c.take(260);
+      float* bufs[4] = {h_E ? h_E : E, (E && h_E) ? E : nullptr, nullptr, nullptr};
+      int have = bufs[1] ? 2 : 1;
+      while (order && have < np) { float* t = c.take(rows); if (!t) break; bufs[have++] = t; }
+      if (order && have >= 2) {
+        a.nparts = have; a.order = order;
+        for (int q = 0; q < have; ++q) a.pbuf[q] = bufs[q];
+        grid = dim3(e.grid * have);                                    // sized for every block being long; the surplus exits at once
+        fr.M18 = M18; fr.order = order; fr.G = G; fr.npw = e.npw; fr.nblk = e.grid;
+      }
+    }
+    // neighbour lists (one workgroup per residue; one more ranks the residue blocks for a launch in parts)
+    int Lp2 = 1; while (Lp2 < L) Lp2 <<= 1;
+    int Kp2 = 64; while (Kp2 < K) Kp2 <<= 1;
+    const bool full_sort = getenv("NAMP_KNN_FULL_SORT") != nullptr;      // debugging / test switch: sort whole rows
+    const dim3 knn_grid(G + (fr.order ? 1 : 0));
+    if (2 * Kp2 <= Lp2 && !full_sort)      // selection pays when the final sort is at most half a row
+      hipLaunchKernelGGL(knn_select_kernel, knn_grid, dim3(256), ((size_t)L + Kp2) * 8 + 1024 + 64, s, P, mask, E_idx, L, K, Kp2, fr);
+    else
+      hipLaunchKernelGGL(knn_kernel, knn_grid, dim3(256), std::max((size_t)Lp2 * 8 + 64, (size_t)1024), s, P, mask, E_idx, L, Lp2, K, fr);
     // NampModelW.reserved == 2 with an x3 image: plain bf16 products on its hi half (mixed-precision training)
-    if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
-    else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
-    else hipLaunchKernelGGL(edge_features_kernel<0>, dim3(e.grid), dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, grid, dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, grid, dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    else hipLaunchKernelGGL(edge_features_kernel<0>, grid, dim3(e.nwaves * 64), FEAT_LDS, s, a);
+    if (a.nparts >= 2) {
+      if (x3) hipLaunchKernelGGL(feat_finish_kernel<1>, dim3(e.grid), dim3(e.nwaves * 64), NAMP_IMG_BYTES, s, a);
+      else hipLaunchKernelGGL(feat_finish_kernel<0>, dim3(e.grid), dim3(e.nwaves * 64), NAMP_IMG_BYTES, s, a);
+    }
   }
   CHECK_LAUNCH();
   return NAMP_OK;
@@ -1467,7 +1510,7 @@ extern "C" int namp_debug_wstamps(int* counts8, long long* log, int reset) {
 }
 #endif
 
-int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 31); }
+int namp_set_bf16p(int mask) { return g_bf16p.exchange(mask & 255); }
 
 int namp_set_persistent(int on) {
   std::lock_guard<std::mutex> lk(g_persist_mutex);

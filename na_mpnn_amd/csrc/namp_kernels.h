@@ -3399,14 +3399,47 @@ static __global__ void prep_atoms_kernel(const float* __restrict__ X, const int3
   P[3 * n] = x[3] + x[3 * ref_atom]; P[3 * n + 1] = x[4] + x[3 * ref_atom + 1]; P[3 * n + 2] = x[5] + x[3 * ref_atom + 2];
 }
 
+// Round 6 — the edge-feature launch of one complex in parts (edge_features_kernel below): its residue blocks (npw consecutive residues, one
+// workgroup's worth; at most 256 of them) ranked longest first by the number of the 18 atoms present in their residues, ties by index.
+// order[r] = block of rank r, order[256] = number of long blocks (FEAT_LONG_ATOMS or more atoms: a protein residue has 5, a nucleotide
+// 12-13).  Runs as one extra workgroup of the neighbour-search launch (blockIdx.x == gridDim.x - 1), beside it.
+#define FEAT_LONG_ATOMS 8
+struct FeatRank { const uint32_t* M18; int32_t* order; int G, npw, nblk; };
+
+static __device__ __forceinline__ void feat_rank_blocks(const FeatRank r, char* smem) {
+  const int tid = threadIdx.x;                                       // 256 threads
+  uint16_t* ck = (uint16_t*)smem;                                    // composite = atoms << 8 | 255 - block: unique, 0 for no block
+  int* cnt = (int*)(smem + 512);
+  if (tid == 0) cnt[0] = 0;
+  uint32_t u = 0;
+  if (tid < r.nblk)
+    for (int q = 0; q < r.npw; ++q) { const int nd = tid * r.npw + q; if (nd < r.G) u |= r.M18[nd]; }
+  const uint32_t cb = tid < r.nblk ? (uint32_t)((__popc(u) << 8) | (255 - tid)) : 0u;
+  ck[tid] = (uint16_t)cb;
+  __syncthreads();
+  const unsigned long long longs = __ballot(cb >= (uint32_t)(FEAT_LONG_ATOMS << 8));
+  if ((tid & 63) == 0) atomicAdd(cnt, __popcll(longs));
+  int rank = 0;
+  for (int i = 0; i < 32; ++i) {
+    const uint4 q = ((const uint4*)smem)[i];
+    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int z = 0; z < 4; ++z) rank += ((wd[z] & 0xffffu) > cb ? 1 : 0) + ((wd[z] >> 16) > cb ? 1 : 0);
+  }
+  if (tid < r.nblk) r.order[rank] = tid;
+  __syncthreads();
+  if (tid == 0) r.order[256] = cnt[0];
+}
+
 // knn_kernel: _dist (model_utils.py:489-497).  One workgroup per residue row: masked distances to all L
 // residues, row maximum, then a bitonic sort of 64-bit keys (distance bits << 32 | index) in LDS and the K
 // smallest are written in ascending order (ties: unmasked before masked, then by index; torch.topk leaves them unspecified).
 // The distance uses the reference's operation order with contraction off so that near-ties round identically.
 static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
-                                                  int32_t* __restrict__ E_idx, int L, int Lp2, int K) {
+                                                  int32_t* __restrict__ E_idx, int L, int Lp2, int K, const FeatRank fr) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (fr.order && blockIdx.x == gridDim.x - 1) { feat_rank_blocks(fr, smem); return; }
   unsigned long long* keys = (unsigned long long*)smem;            // [Lp2]
   float* red = (float*)(keys + Lp2);                               // [4]
   const int row = blockIdx.x, tid = threadIdx.x;
@@ -3466,9 +3499,10 @@ static __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict
 // network in LDS otherwise) and the first K written.  Keys are unique (index in the low bits), so the result is the
 // sorted row's prefix exactly.  O(L) per pass instead of O(L log^2 L): 13x fewer LDS passes at L = 3000.
 static __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ P, const int32_t* __restrict__ mask,
-                                                         int32_t* __restrict__ E_idx, int L, int K, int Kp2) {
+                                                         int32_t* __restrict__ E_idx, int L, int K, int Kp2, const FeatRank fr) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (fr.order && blockIdx.x == gridDim.x - 1) { feat_rank_blocks(fr, smem); return; }
   unsigned long long* keys = (unsigned long long*)smem;            // [L]
   unsigned long long* sel = keys + L;                              // [Kp2]
   uint32_t* hist = (uint32_t*)(sel + Kp2);                         // [256]
@@ -3572,6 +3606,16 @@ static __global__ __launch_bounds__(256) void knn_select_kernel(const float* __r
   for (int k = tid; k < K; k += 256) E_idx[(long)row * K + k] = (int32_t)(sel[k] & 0x7fffffffu);
 }
 
+#ifdef FEAT_STAMPS
+// -DFEAT_STAMPS (tools/feat_stamps.py): per workgroup of the last edge_features launch: s_memtime at entry, behind the set-up, at the end; residue
+// block, part, chunks walked, HW_ID
+#define GETREG_IMMED(SZ, OFF, REG) (((SZ) << 11) | ((OFF) << 6) | (REG))
+__device__ unsigned long long g_feat_stamps[1024][8];
+extern "C" int namp_debug_feat_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_feat_stamps), sizeof(g_feat_stamps), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // edge_features_kernel: RBF + positional features -> edge_embedding (5200 -> 128, no bias) -> LayerNorm
 // (model_utils.py:499-519, 577-585), optionally followed by W_e (model_utils.py:89).  Same tiling as
 // edge_mlp_kernel (one wave = 16 neighbours of one residue, activations in registers); the GEMM's 5200-long
@@ -3590,6 +3634,12 @@ struct FeatArgs {
   float* E_out;                                   // [G][K][128] or null
   float* hE_out;                                  // [G][K][128] or null (needs We_img)
   int G, L, K, TPN;
+  // nparts = 2..4 (round 6; gridDim.x = nparts x residue blocks): workgroup (block, part) walks every nparts-th of the atom-pair chunks its
+  // residues need and stores its pre-LayerNorm partial rows to pbuf[part]; feat_finish_kernel adds the parts, normalises and embeds.
+  // 0 / 1: the whole row here.
+  int nparts;
+  float* pbuf[4];
+  const int32_t* order;                           // feat_rank_blocks' output (nparts > 1)
 };
 
 #define FEAT_CHUNK_BYTES (6 * 8 * 64 * 16)        // 6 k-tiles x 8 tn x 1 KiB
@@ -3606,7 +3656,31 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   const int m = lane & 15, g = lane >> 4;
   const int npw = nwaves / a.TPN;
   const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
-  int node = blockIdx.x * npw + node_l;
+#ifdef FEAT_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+  int blk = blockIdx.x, part = 0, myparts = 1;
+  if (a.nparts > 1) {
+    // One complex, at most a round of the chip unsplit: the launch lasts as long as its longest workgroup — a block of residues that holds a
+    // nucleotide walks 39-54 atom-pair chunks, a protein block ~10.  Long blocks (feat_rank_blocks) are taken by nparts workgroups, each
+    // walking every nparts-th chunk and leaving partial rows for feat_finish_kernel; the others by one workgroup that finishes its rows
+    // itself.  Dispatch order is longest first, parts of a block next to each other: a long workgroup must not start behind short ones.
+    // The grid is sized for every block being long; the surplus exits here.  (Tried: one workgroup per CU popping the same items from a
+    // counter — no surplus, greedy packing: the same 151 us per call at 1,000 residues, with spilled scalars around the item loop.)
+    const int P = a.nparts, nblk = (int)gridDim.x / P, bx = blockIdx.x;
+    const int n_long = a.order[256];
+    int slot_i = bx / P;
+    if (bx < n_long * P) { part = bx - slot_i * P; myparts = P; }
+    else { slot_i = n_long + bx - n_long * P; if (slot_i >= nblk) return; }
+    blk = a.order[slot_i];
+  }
+  // RBF centres of this lane: mu = 2 + (4g + r) * 20/15, sigma = 1.25  (model_utils.py:499-507)
+  const float mu0 = 2.0f + (4 * g + 0) * (20.0f / 15.0f), mu1 = 2.0f + (4 * g + 1) * (20.0f / 15.0f);
+  const float mu2 = 2.0f + (4 * g + 2) * (20.0f / 15.0f), mu3 = 2.0f + (4 * g + 3) * (20.0f / 15.0f);
+  const float* img1 = a.Wedge_img + 8 * 64 * 4;                    // k-tile 1 onwards
+  const int chunk_kb = (X3 == 2 ? FEAT_CHUNK_BYTES / 2 : FEAT_CHUNK_BYTES) / 1024;     // plain bf16 products read the hi half of a chunk only
+  uint32_t* vote = (uint32_t*)(smem + 2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES);   // [2][16]
+  int node = blk * npw + node_l;
   const bool wave_active = (node_l < npw) && (node < a.G);
   if (!wave_active) node = 0;
   const int bq = node / a.L;
@@ -3634,8 +3708,47 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- chunk 0: positional k-tile (weights: first 8 KiB of the image, read straight from L2)
-  {
+  // ---- RBF chunks: c = 3a + bg, 6 k-tiles each, through the LDS ring.  An RBF feature is exactly zero when either atom is
+  // absent (M18), and absence is structured: a protein residue has 5 of the 18 atoms (N, CA, C, O, Cb), a nucleotide the
+  // other 13.  Zero k-tiles are skipped — for the whole workgroup (no DMA, no barrier) when no row of the workgroup needs
+  // the chunk, per wave (no distance / exp / MFMA work) when none of the wave's 16 neighbours has atom b or its own residue
+  // lacks atom a.  Adding exact zeros changes nothing, so the result is bit-identical to the dense evaluation; on
+  // protein-protein neighbourhoods 25 of the 324 atom pairs remain.
+  const uint32_t mi_s = __builtin_amdgcn_readfirstlane(wave_active ? mi : 0u);
+  uint32_t mj_w = valid ? mj : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mj_w |= __shfl_xor(mj_w, o);
+  const uint32_t mj_s = __builtin_amdgcn_readfirstlane(mj_w);
+  if (lane == 0) { vote[wave] = mi_s; vote[16 + wave] = mj_s; }
+  __syncthreads();
+  uint32_t wg_mi = 0, wg_mj = 0;
+  for (int q = 0; q < nwaves; ++q) { wg_mi |= vote[q]; wg_mj |= vote[16 + q]; }
+  unsigned long long need = 0;
+  for (int aa = 0; aa < 18; ++aa)
+    if ((wg_mi >> aa) & 1u)
+      for (int bg = 0; bg < 3; ++bg)
+        if ((wg_mj >> (6 * bg)) & 63u) need |= 1ull << (3 * aa + bg);
+  need = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(need >> 32)) << 32) |
+         __builtin_amdgcn_readfirstlane((uint32_t)need);
+  if (myparts > 1) {                                                // this part's share: every myparts-th needed chunk
+    unsigned long long mine = 0, rest = need;
+    int ord = 0;
+    while (rest) {
+      const unsigned long long low = rest & (0ull - rest);
+      if (ord == part) mine |= low;
+      rest ^= low; ord = ord + 1 == myparts ? 0 : ord + 1;
+    }
+    need = mine;
+  }
+  __syncthreads();                                                  // votes consumed before the ring overwrites... (slot tail is not DMA'd, but keep order simple)
+#ifdef FEAT_STAMPS
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+  const int st_chunks = __popcll(need);
+#endif
+  int slot = 0;
+  if (need) dma_to_lds(smem, img1 + (long)__builtin_ctzll(need) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
+  // ---- chunk 0: positional k-tile (weights: first 8 KiB of the image, read straight from L2), under the first chunk's DMA
+  if (part == 0) {
     const int off = a.R_idx[node] - a.R_idx[j];
     const int same = (a.chain[node] == a.chain[j]) ? 1 : 0;
     int d = off + 32; d = d < 0 ? 0 : (d > 64 ? 64 : d);
@@ -3651,38 +3764,6 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #pragma unroll
       for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(w[tn * 64][r], xk[r], acc[tn]);
   }
-
-  // ---- RBF chunks: c = 3a + bg, 6 k-tiles each, through the LDS ring.  An RBF feature is exactly zero when either atom is
-  // absent (M18), and absence is structured: a protein residue has 5 of the 18 atoms (N, CA, C, O, Cb), a nucleotide the
-  // other 13.  Zero k-tiles are skipped — for the whole workgroup (no DMA, no barrier) when no row of the workgroup needs
-  // the chunk, per wave (no distance / exp / MFMA work) when none of the wave's 16 neighbours has atom b or its own residue
-  // lacks atom a.  Adding exact zeros changes nothing, so the result is bit-identical to the dense evaluation; on
-  // protein-protein neighbourhoods 25 of the 324 atom pairs remain.
-  const uint32_t mi_s = __builtin_amdgcn_readfirstlane(wave_active ? mi : 0u);
-  uint32_t mj_w = valid ? mj : 0u;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) mj_w |= __shfl_xor(mj_w, o);
-  const uint32_t mj_s = __builtin_amdgcn_readfirstlane(mj_w);
-  uint32_t* vote = (uint32_t*)(smem + 2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES);   // [2][16]
-  if (lane == 0) { vote[wave] = mi_s; vote[16 + wave] = mj_s; }
-  __syncthreads();
-  uint32_t wg_mi = 0, wg_mj = 0;
-  for (int q = 0; q < nwaves; ++q) { wg_mi |= vote[q]; wg_mj |= vote[16 + q]; }
-  unsigned long long need = 0;
-  for (int aa = 0; aa < 18; ++aa)
-    if ((wg_mi >> aa) & 1u)
-      for (int bg = 0; bg < 3; ++bg)
-        if ((wg_mj >> (6 * bg)) & 63u) need |= 1ull << (3 * aa + bg);
-  need = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(need >> 32)) << 32) |
-         __builtin_amdgcn_readfirstlane((uint32_t)need);
-  const float* img1 = a.Wedge_img + 8 * 64 * 4;                    // k-tile 1 onwards
-  const int chunk_kb = (X3 == 2 ? FEAT_CHUNK_BYTES / 2 : FEAT_CHUNK_BYTES) / 1024;     // plain bf16 products read the hi half of a chunk only
-  __syncthreads();                                                  // votes consumed before the ring overwrites... (slot tail is not DMA'd, but keep order simple)
-  int slot = 0;
-  if (need) dma_to_lds(smem, img1 + (long)__builtin_ctzll(need) * (FEAT_CHUNK_BYTES / 4), chunk_kb, wave, nwaves, lane);
-  // RBF centres of this lane: mu = 2 + (4g + r) * 20/15, sigma = 1.25  (model_utils.py:499-507)
-  const float mu0 = 2.0f + (4 * g + 0) * (20.0f / 15.0f), mu1 = 2.0f + (4 * g + 1) * (20.0f / 15.0f);
-  const float mu2 = 2.0f + (4 * g + 2) * (20.0f / 15.0f), mu3 = 2.0f + (4 * g + 3) * (20.0f / 15.0f);
 #pragma unroll 1
   for (int aa = 0; aa < 18; ++aa) {
     if (!((need >> (3 * aa)) & 7ull)) continue;                      // workgroup-uniform: no chunk of atom a is needed
@@ -3781,6 +3862,21 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
       }
     }
   }
+#ifdef FEAT_STAMPS
+  if (tid == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = g_feat_stamps[blockIdx.x];
+    o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = blk; o[4] = part | (myparts << 8); o[5] = st_chunks;
+    o[6] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, 4)); o[7] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));
+  }
+#endif
+  if (myparts > 1) {                                               // partial rows out; feat_finish_kernel does the rest
+    if (valid) {
+      float* dst = a.pbuf[part] + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+    }
+    return;
+  }
   // ---- LayerNorm (norm_edges) -> E; optional W_e embed -> h_E
   if (a.ln_g) layernorm_row_T(acc, a.ln_g, a.ln_b, g);             // null: E_out receives the pre-LayerNorm rows
   if (a.E_out && valid) {
@@ -3791,6 +3887,62 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   if (a.hE_out) {
     __syncthreads();                                                 // ring free
     dma_to_lds(smem, a.We_img, 64, wave, nwaves, lane);
+    f4 out[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[t] = *(const f4*)(a.We_b + 16 * t + 4 * g);
+    wait_dma_and_sync();
+    gemm128<X3 != 0, false, false>(out, acc, (const f4*)smem + lane);
+    if (valid) {
+      float* dst = a.hE_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = out[t];
+    }
+  }
+}
+
+// feat_finish_kernel — behind an edge_features launch in parts: row = part 0 + part 1 (+ ...), LayerNorm (norm_edges) -> E, optional W_e embed -> h_E
+// (the epilogue of edge_features_kernel).  One wave per 16-row tile; pbuf[0] / pbuf[1] may be the output buffers themselves (a wave reads its
+// tile's rows before it writes them).
+template <int X3>
+__global__ __launch_bounds__(768) void feat_finish_kernel(const FeatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int npw = nwaves / a.TPN;
+  const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
+  int node = blockIdx.x * npw + node_l;
+  const bool wave_active = (node_l < npw) && (node < a.G);
+  if (!wave_active) node = 0;
+  const int k = 16 * kt + m;
+  const bool valid = wave_active && (k < a.K);
+  const long erow = (long)node * a.K + (valid ? k : 0);
+  {                                                                  // blocks edge_features_kernel did not split are finished already
+    uint32_t u = 0;
+    for (int q = 0; q < npw; ++q) { const int nd = (int)blockIdx.x * npw + q; if (nd < a.G) u |= a.M18[nd]; }
+    if (__popc(u) < FEAT_LONG_ATOMS) return;
+  }
+  if (a.hE_out) dma_to_lds(smem, a.We_img, 64, wave, nwaves, lane);
+  f4 acc[8];
+  {
+    const float* p0 = a.pbuf[0] + erow * NAMP_H + 4 * g;
+    const float* p1 = a.pbuf[1] + erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = *(const f4*)(p0 + 16 * t) + *(const f4*)(p1 + 16 * t);
+    for (int q = 2; q < a.nparts; ++q) {
+      const float* pq = a.pbuf[q] + erow * NAMP_H + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = acc[t] + *(const f4*)(pq + 16 * t);
+    }
+  }
+  if (a.ln_g) layernorm_row_T(acc, a.ln_g, a.ln_b, g);
+  if (a.E_out && valid) {
+    float* dst = a.E_out + erow * NAMP_H + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(f4*)(dst + 16 * t) = acc[t];
+  }
+  if (a.hE_out) {
     f4 out[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) out[t] = *(const f4*)(a.We_b + 16 * t + 4 * g);

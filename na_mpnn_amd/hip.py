@@ -111,6 +111,7 @@ _PROTOTYPES = {
     "namp_sample_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "namp_sample_workspace_bytes_n": (sz, [i32, i32, i32, i32, i32]),
     "namp_featurize_workspace_bytes": (sz, [i32, i32]),
+    "namp_featurize_split_bytes": (sz, [i32, i32, i32]),
     "namp_featurize": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
                              vp, sz, i32, i32, vp]),
     "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,

@@ -378,7 +378,8 @@ class ProteinMPNN(nn.Module):
         E_idx = torch.empty(B, L, K, dtype=torch.int32, device=dev)
         E = torch.empty(B, L, K, self.edge_features, device=dev) if want_E else None
         hE = torch.empty(B, L, K, self.hidden_dim, device=dev) if want_hE else None
-        ws = torch.empty(Lb.namp_featurize_workspace_bytes(B, L), dtype=torch.uint8, device=dev)
+        ws = torch.empty(Lb.namp_featurize_workspace_bytes(B, L) + Lb.namp_featurize_split_bytes(B, L, int(self.k_neighbors)),
+                         dtype=torch.uint8, device=dev)
         dna_m, rna_m = self._na_masks(fd)
         t = [self._as(fd[k], "i32") for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + [self._as(dna_m, "i32"), self._as(rna_m, "i32")]
         hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),

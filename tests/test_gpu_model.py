@@ -103,6 +103,43 @@ def test_score_from_coordinates(golden_dir, weights_np, n, k, tag, kw, prec):
     assert torch.equal(lp2, out["log_probs"])
 
 
+@pytest.mark.parametrize("prec", ["x3", "fp32"])
+@pytest.mark.parametrize("n,k,bs,kw", [(97, 32, 1, dict(frac_protein=0.0, frac_dna=0.0, n_chains=1)), (1000, 48, 1, dict(n_chains=4)),
+                                       (300, 30, 3, dict(missing_atom_frac=0.05, masked_frac=0.05)), (257, 70, 1, dict(n_chains=5))])
+def test_two_part_featuriser_matches_the_single_launch(weights_np, n, k, bs, kw, prec):
+    """namp_featurize with its edge-feature launch split in two parts (each walks every second atom-pair chunk; feat_finish_kernel adds the partial
+    rows, normalises and embeds — batches of at most one round of the chip; two to four parts) against the single launch: E and h_E within
+    2e-5 / 5e-5 (another order of fp32 sums in front of the LayerNorm), neighbour lists identical; with E and h_E both requested (partial rows in the output
+    buffers themselves) and with h_E only (part 1 in the workspace's tail); one-residue workgroups (97 residues), K % 16 != 0, a padded batch."""
+    from na_mpnn_amd import hip, shard
+    dev = torch.device("cuda:0")
+    cxs = [synth.make_complex(seed=9100 + n + i, n=n - 37 * i, **kw) for i in range(bs)]
+    fd = fd_of(cxs[0], dev) if bs == 1 else dict(shard.pad_batch(cxs, device=dev), batch_size=1)
+    m = make_model(weights_np, k, dev)
+    m.message_precision = prec
+    L = hip.lib()
+    prev = L.namp_set_bf16p(11)                   # single launch
+    try:
+        _, E0, hE0, I0 = m._featurize_hip(fd, want_E=True, want_hE=True)
+        E0, hE0 = E0.clone(), hE0.clone()
+        diffs = []
+        for parts in (2, 3, 4):
+            L.namp_set_bf16p(11 | 32 | ((parts - 2) << 6))
+            _, E1, hE1, I1 = m._featurize_hip(fd, want_E=True, want_hE=True)
+            E1, hE1 = E1.clone(), hE1.clone()
+            _, _, hE2, I2 = m._featurize_hip(fd, want_E=False, want_hE=True)
+            assert torch.equal(I0, I1) and torch.equal(I0, I2)
+            assert torch.isfinite(E1).all() and torch.isfinite(hE1).all() and torch.isfinite(hE2).all()
+            valid = fd["mask"].bool()
+            diffs.append(tuple(float((x - y)[valid].abs().max()) for x, y in ((E0, E1), (hE0, hE1), (hE0, hE2))))
+    finally:
+        L.namp_set_bf16p(prev)
+    for parts, (d_e, d_h, d_h2) in zip((2, 3, 4), diffs):
+        print(f"featuriser in {parts} parts: max|dE| = {d_e:.1e}, max|dh_E| = {d_h:.1e} / {d_h2:.1e}")
+        # measured 5e-6 / 1.2e-5: fp32 rounding of a 5,200-term sum taken in another order, in front of a LayerNorm; the parity bars are 2e-4 / 1e-3
+        assert d_e < 2e-5 and d_h < 5e-5 and d_h2 < 5e-5, (parts, d_e, d_h, d_h2)
+
+
 def test_score_from_coordinates_at_the_headline_size(weights_np):
     """score() FROM COORDINATES at the size the metric is quoted on (BASELINE configs[1]: N = 1000, K = 48; the complex behind bench.py's
     `gpu_full_forward_from_X`: synth.make_complex(seed=77, n=1000, n_chains=4)) against the CPU oracle's score() on the same feature dict —
