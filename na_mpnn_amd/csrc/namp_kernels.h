@@ -3607,7 +3607,7 @@ static __global__ __launch_bounds__(256) void knn_select_kernel(const float* __r
 }
 
 #ifdef FEAT_STAMPS
-// -DFEAT_STAMPS (tools/feat_stamps.py): per workgroup of the last edge_features launch: s_memtime at entry, behind the set-up, at the end; residue
+// -DFEAT_STAMPS (tools/feat_stamps.py): per workgroup of the last edge_features launch: s_memrealtime (100 MHz, one clock for the chip) at entry, behind the set-up, at the end; residue
 // block, part, chunks walked, HW_ID
 #define GETREG_IMMED(SZ, OFF, REG) (((SZ) << 11) | ((OFF) << 6) | (REG))
 __device__ unsigned long long g_feat_stamps[1024][8];
@@ -3657,7 +3657,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   const int npw = nwaves / a.TPN;
   const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
 #ifdef FEAT_STAMPS
-  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int blk = blockIdx.x, part = 0, myparts = 1;
   if (a.nparts > 1) {
@@ -3665,7 +3665,11 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
     // nucleotide walks 39-54 atom-pair chunks, a protein block ~10.  Long blocks (feat_rank_blocks) are taken by nparts workgroups, each
     // walking every nparts-th chunk and leaving partial rows for feat_finish_kernel; the others by one workgroup that finishes its rows
     // itself.  Dispatch order is longest first, parts of a block next to each other: a long workgroup must not start behind short ones.
-    // The grid is sized for every block being long; the surplus exits here.  (Tried: one workgroup per CU popping the same items from a
+    // The grid is sized for every block being long; the surplus exits here.  (Tried, profiles/r06f: one workgroup per CU popping the same
+    // items from a counter — no surplus, greedy packing: the same 151 us per call at 1,000 residues, with scalar spills around the item loop;
+    // ranking by the exact chunk counts, neighbours' atoms included, by the neighbour-search workgroup that finishes last: launch 113 -> 111
+    // us, but +22 us in the neighbour search for its per-row device-scope fences; three / four parts: 116-120 us.  The launch's sum of
+    // workgroup durations / 256 CUs is 70 us unsplit and 79 us in two parts: second-round workgroups of ~35 us behind 86 us parts.)  (Tried: one workgroup per CU popping the same items from a
     // counter — no surplus, greedy packing: the same 151 us per call at 1,000 residues, with spilled scalars around the item loop.)
     const int P = a.nparts, nblk = (int)gridDim.x / P, bx = blockIdx.x;
     const int n_long = a.order[256];
@@ -3742,7 +3746,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   }
   __syncthreads();                                                  // votes consumed before the ring overwrites... (slot tail is not DMA'd, but keep order simple)
 #ifdef FEAT_STAMPS
-  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
   const int st_chunks = __popcll(need);
 #endif
   int slot = 0;
@@ -3865,7 +3869,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #ifdef FEAT_STAMPS
   if (tid == 0 && blockIdx.x < 1024) {
     unsigned long long* o = g_feat_stamps[blockIdx.x];
-    o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = blk; o[4] = part | (myparts << 8); o[5] = st_chunks;
+    o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = blk; o[4] = part | (myparts << 8); o[5] = st_chunks;
     o[6] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, 4)); o[7] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));
   }
 #endif
