@@ -3768,6 +3768,99 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #pragma unroll
       for (int tn = 0; tn < 8; ++tn) acc[tn] = mfma4(w[tn * 64][r], xk[r], acc[tn]);
   }
+#ifndef FEAT_NOPIPE
+  if constexpr (X3 != 0) {
+    // Round 6 — split-bf16 / bf16 products: a step (K = 32: the RBFs of two atom pairs) as compact run-time loops over (b-group, step) instead
+    // of nine unrolled copies with a branch per atom (an absent atom's RBFs are G * 0 = 0 as before: its coordinates are stored zeros, D is
+    // capped), and the distance through the bare v_sqrt_f32 (1 ulp; sqrtf expands to ~13 more instructions per value for the last half ulp
+    // and denormal inputs — D^2 >= 1e-6 here): 2.75 -> 2.49 -> see NOTEBOOK ms at a 31,100-token batch.  The launch is bound by its VALU
+    // issue (~80 instructions per step against 24 MFMAs of 16 cycles; generating a step's operands between the previous step's MFMAs, also
+    // across the chunk's barrier, measured the same: profiles/r06g).  Rows equal to the previous form's to fp32 rounding (7.5e-6 after the
+    // LayerNorm; both 2.5e-5 from the exact-fp32 instantiation).
+    auto gen = [&](const float xi0, const float xi1, const float xi2, const float mia, const int b0, bf8& hi, bf8& mid) {
+      f4 xk[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int bb = b0 + h;
+        const float* xb = xj + (3 * bb) * 16;
+        const float dx = xi0 - xb[0], dy = xi1 - xb[16], dz = xi2 - xb[32];
+#ifdef FEAT_PRECISE_SQRT
+        const float D = fminf(sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
+#else
+        const float D = fminf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
+#endif
+        // this lane's four RBFs have equidistant centres mu0 + r * 4/3: with v_r = (D - mu_r) * 0.8 * sqrt(log2 e) = v_0 - r d,
+        //   G_r = exp(-((D - mu_r)/1.25)^2) = 2^(-v_r^2),   G_{r+1} / G_r = 2^(2 d v_r - d^2) =: q_r,   q_{r+1} = q_r * 2^(-2 d^2)
+        // — two v_exp_f32 and six multiplications instead of four exponentials with their argument arithmetic.  D is capped at 40 A (every
+        // RBF is exactly 0 in fp32 beyond 34 A) so that q_0 stays finite; relative error of G_3 ~1e-6, far below the split-bf16 products.
+        const float mk = mia * (float)((mj >> bb) & 1u);
+        const float v0 = (D - mu0) * 0.9608979270291599f;
+        const float G0 = __builtin_amdgcn_exp2f(-(v0 * v0)) * mk;
+        const float q0 = __builtin_amdgcn_exp2f(fmaf(v0, 2.5623944720777594f, -1.6414663576336648f));
+        const float G1 = G0 * q0, q1 = q0 * 0.10273981490249438f;
+        const float G2 = G1 * q1, q2 = q1 * 0.10273981490249438f;
+        xk[h].x = G0; xk[h].y = G1; xk[h].z = G2; xk[h].w = G2 * q2;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hi[4 * h + r] = (__bf16)xk[h][r];
+          mid[4 * h + r] = (__bf16)(xk[h][r] - (float)hi[4 * h + r]);
+        }
+    };
+    auto mul = [&](const bf8& hi, const bf8& mid, const bf8* wb) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                                  // product-major over four tiles, as chain_gemm_x3
+        bf8 wh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wh[q] = wb[(4 * h + q) * 64];
+        if (X3 == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], mid, acc[4 * h + q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bf8 wm = wb[(FEAT_CHUNK_BYTES / 32) + (4 * h + q) * 64];
+            acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, hi, acc[4 * h + q], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], hi, acc[4 * h + q], 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int aa = 0; aa < 18; ++aa) {
+      if (!((need >> (3 * aa)) & 7ull)) continue;                    // workgroup-uniform: no chunk of atom a is needed
+      const float xi0 = xi_base[3 * aa], xi1 = xi_base[3 * aa + 1], xi2 = xi_base[3 * aa + 2];
+      const float mia = (float)((mi >> aa) & 1u);
+      const bool wave_a = (mi_s >> aa) & 1u;
+#pragma unroll 1
+      for (int bg = 0; bg < 3; ++bg) {
+        const int c = 3 * aa + bg;
+        if (!((need >> c) & 1ull)) continue;                         // workgroup-uniform
+        // this wave's steps of the chunk: bit st set when a neighbour of the tile has one of the step's two atoms and the residue has atom a
+        const uint32_t pres = wave_a ? ((mj_s >> (6 * bg)) & 63u) : 0u;
+        uint32_t steps = ((pres & 3u) ? 1u : 0u) | ((pres & 12u) ? 2u : 0u) | ((pres & 48u) ? 4u : 0u);
+        const bf8* wc = (const bf8*)(smem + slot * NAMP_IMG_BYTES) + lane;
+        wait_dma_and_sync();                                         // chunk c has landed; everyone is done with the previous one
+        {
+          const unsigned long long rest = (c + 1 < 64) ? (need >> (c + 1)) : 0ull;
+          if (rest) dma_to_lds(smem + (slot ^ 1) * NAMP_IMG_BYTES, img1 + (long)(c + 1 + __builtin_ctzll(rest)) * (FEAT_CHUNK_BYTES / 4),
+                               chunk_kb, wave, nwaves, lane);
+        }
+        slot ^= 1;
+#pragma unroll 1
+        while (steps) {
+          const int st = __builtin_ctz(steps);
+          bf8 hi, mid;
+          gen(xi0, xi1, xi2, mia, 6 * bg + 2 * st, hi, mid);
+          mul(hi, mid, wc + st * 8 * 64);
+          steps &= steps - 1u;
+        }
+      }
+    }
+  } else
+#endif
 #pragma unroll 1
   for (int aa = 0; aa < 18; ++aa) {
     if (!((need >> (3 * aa)) & 7ull)) continue;                      // workgroup-uniform: no chunk of atom a is needed

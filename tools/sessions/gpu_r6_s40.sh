@@ -1,0 +1,5 @@
+R=$GRAFT_REPO_ROOT; cd $R
+for rep in 1 2; do
+echo "== pipelined"; timeout 600 python tools/feat_pipe_ab.py 2>&1 | grep -v amdgpu | grep x3
+echo "== not pipelined"; NAMP_LIB_PATH=$R/tools/_variants/feat_nopipe.so timeout 600 python tools/feat_pipe_ab.py 2>&1 | grep -v amdgpu | grep x3
+done
