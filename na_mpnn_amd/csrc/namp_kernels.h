@@ -3644,7 +3644,8 @@ struct FeatArgs {
 
 #define FEAT_CHUNK_BYTES (6 * 8 * 64 * 16)        // 6 k-tiles x 8 tn x 1 KiB
 #define FEAT_XJ_BYTES (54 * 16 * 4)               // one wave's 16 neighbour frames
-#define FEAT_LDS (2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES + 256)
+#define FEAT_DBUF_BYTES (6 * 16 * 4)               // one wave's distances to the six atoms of a b-group
+#define FEAT_LDS (2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES + 256 + 12 * FEAT_DBUF_BYTES)
 
 // X3: 0 exact fp32 MFMA; 1 split-bf16 products; 2 plain bf16 products on the x3 image's hi half (mixed-precision training)
 template <int X3>
@@ -3771,31 +3772,45 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #ifndef FEAT_NOPIPE
   if constexpr (X3 != 0) {
     // Round 6 — split-bf16 / bf16 products: a step (K = 32: the RBFs of two atom pairs) as compact run-time loops over (b-group, step) instead
-    // of nine unrolled copies with a branch per atom (an absent atom's RBFs are G * 0 = 0 as before: its coordinates are stored zeros, D is
-    // capped), and the distance through the bare v_sqrt_f32 (1 ulp; sqrtf expands to ~13 more instructions per value for the last half ulp
-    // and denormal inputs — D^2 >= 1e-6 here): 2.75 -> 2.49 -> see NOTEBOOK ms at a 31,100-token batch.  The launch is bound by its VALU
-    // issue (~80 instructions per step against 24 MFMAs of 16 cycles; generating a step's operands between the previous step's MFMAs, also
-    // across the chunk's barrier, measured the same: profiles/r06g).  Rows equal to the previous form's to fp32 rounding (7.5e-6 after the
-    // LayerNorm; both 2.5e-5 from the exact-fp32 instantiation).
-    auto gen = [&](const float xi0, const float xi1, const float xi2, const float mia, const int b0, bf8& hi, bf8& mid) {
+    // of nine unrolled copies with a branch per atom; the distance through the bare v_sqrt_f32 (1 ulp; sqrtf expands to ~13 more instructions
+    // per value for the last half ulp and denormal inputs — D^2 >= 1e-6 here); the distances of a chunk computed once per tile instead of by
+    // each of the four lane groups, the atom masks folded into them.  2.75 -> 2.31 ms at a 31,100-token batch, 149 -> 130 us per featurize
+    // call of one 1,000-residue complex.  Generating a step's operands between the previous step's MFMAs (also across the chunk's barrier)
+    // measured the same as this plain order (profiles/r06g).  Rows equal to the round-5 form's to fp32 rounding (9e-6 after the LayerNorm;
+    // both 2.5e-5 from the exact-fp32 instantiation, which is unchanged).
+    // the tile's distances to the six atoms of the chunk's b-group, once per chunk: lane (m, g) takes atoms g and g + 4 of row m (the four
+    // lane groups used to repeat every distance); an absent atom's distance is the cap — every RBF of D = 40 A is exactly 0 in fp32, which
+    // is what the mask multiplication produced.  Written and read by this wave only (LDS operations of a wave complete in order).
+    float* dbuf = (float*)(smem + 2 * NAMP_IMG_BYTES + 4 * FEAT_XJ_BYTES + 256 + wave * FEAT_DBUF_BYTES) + m;
+    auto dist = [&](const float xi0, const float xi1, const float xi2, const int bg, const uint32_t pres) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (!((pres >> (4 * r)) & (r ? 3u : 15u))) continue;         // wave-uniform: none of these atoms among the tile's neighbours
+        const int sl = g + 4 * r;
+        if (sl < 6) {
+          const int bb = 6 * bg + sl;
+          const float* xb = xj + (3 * bb) * 16;
+          const float dx = xi0 - xb[0], dy = xi1 - xb[16], dz = xi2 - xb[32];
+#ifdef FEAT_PRECISE_SQRT
+          const float D = fminf(sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
+#else
+          const float D = fminf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
+#endif
+          dbuf[sl * 16] = ((mj >> bb) & 1u) ? D : 40.0f;
+        }
+      }
+    };
+    auto gen = [&](const int st, const uint32_t pres, bf8& hi, bf8& mid) {
       f4 xk[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int bb = b0 + h;
-        const float* xb = xj + (3 * bb) * 16;
-        const float dx = xi0 - xb[0], dy = xi1 - xb[16], dz = xi2 - xb[32];
-#ifdef FEAT_PRECISE_SQRT
-        const float D = fminf(sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
-#else
-        const float D = fminf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f), 40.0f);
-#endif
         // this lane's four RBFs have equidistant centres mu0 + r * 4/3: with v_r = (D - mu_r) * 0.8 * sqrt(log2 e) = v_0 - r d,
         //   G_r = exp(-((D - mu_r)/1.25)^2) = 2^(-v_r^2),   G_{r+1} / G_r = 2^(2 d v_r - d^2) =: q_r,   q_{r+1} = q_r * 2^(-2 d^2)
-        // — two v_exp_f32 and six multiplications instead of four exponentials with their argument arithmetic.  D is capped at 40 A (every
+        // — two v_exp_f32 and five multiplications instead of four exponentials with their argument arithmetic.  D is capped at 40 A (every
         // RBF is exactly 0 in fp32 beyond 34 A) so that q_0 stays finite; relative error of G_3 ~1e-6, far below the split-bf16 products.
-        const float mk = mia * (float)((mj >> bb) & 1u);
+        const float D = ((pres >> (2 * st + h)) & 1u) ? dbuf[(2 * st + h) * 16] : 40.0f;    // (wave-uniform: the slot was not written)
         const float v0 = (D - mu0) * 0.9608979270291599f;
-        const float G0 = __builtin_amdgcn_exp2f(-(v0 * v0)) * mk;
+        const float G0 = __builtin_amdgcn_exp2f(-(v0 * v0));
         const float q0 = __builtin_amdgcn_exp2f(fmaf(v0, 2.5623944720777594f, -1.6414663576336648f));
         const float G1 = G0 * q0, q1 = q0 * 0.10273981490249438f;
         const float G2 = G1 * q1, q2 = q1 * 0.10273981490249438f;
@@ -3828,12 +3843,14 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
         for (int q = 0; q < 4; ++q) acc[4 * h + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], hi, acc[4 * h + q], 0, 0, 0);
       }
     };
+    // (Measured at this point, profiles/r06g: a chunk takes 2.1 us against 1.4 us of MFMAs; the distances shared across the lane groups —
+    // 40 % fewer VALU instructions per step — moved it 0.7 %; the next chunk through registers instead of LDS-DMA +4 %; 16 waves -1 % at a
+    // batch and +17 % at one complex.  What is left is the chain barrier -> fragment reads -> products of a step with three waves per SIMD.)
 #pragma unroll 1
     for (int aa = 0; aa < 18; ++aa) {
       if (!((need >> (3 * aa)) & 7ull)) continue;                    // workgroup-uniform: no chunk of atom a is needed
       const float xi0 = xi_base[3 * aa], xi1 = xi_base[3 * aa + 1], xi2 = xi_base[3 * aa + 2];
-      const float mia = (float)((mi >> aa) & 1u);
-      const bool wave_a = (mi_s >> aa) & 1u;
+      const bool wave_a = (mi_s >> aa) & 1u;                         // (the wave's rows share their residue: its mask is wave-uniform)
 #pragma unroll 1
       for (int bg = 0; bg < 3; ++bg) {
         const int c = 3 * aa + bg;
@@ -3842,6 +3859,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
         const uint32_t pres = wave_a ? ((mj_s >> (6 * bg)) & 63u) : 0u;
         uint32_t steps = ((pres & 3u) ? 1u : 0u) | ((pres & 12u) ? 2u : 0u) | ((pres & 48u) ? 4u : 0u);
         const bf8* wc = (const bf8*)(smem + slot * NAMP_IMG_BYTES) + lane;
+        if (steps) dist(xi0, xi1, xi2, bg, pres);                    // (in front of the barrier: under the chunk's DMA)
         wait_dma_and_sync();                                         // chunk c has landed; everyone is done with the previous one
         {
           const unsigned long long rest = (c + 1 < 64) ? (need >> (c + 1)) : 0ull;
@@ -3853,7 +3871,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
         while (steps) {
           const int st = __builtin_ctz(steps);
           bf8 hi, mid;
-          gen(xi0, xi1, xi2, mia, 6 * bg + 2 * st, hi, mid);
+          gen(st, pres, hi, mid);
           mul(hi, mid, wc + st * 8 * 64);
           steps &= steps - 1u;
         }
