@@ -3859,8 +3859,12 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
         const uint32_t pres = wave_a ? ((mj_s >> (6 * bg)) & 63u) : 0u;
         uint32_t steps = ((pres & 3u) ? 1u : 0u) | ((pres & 12u) ? 2u : 0u) | ((pres & 48u) ? 4u : 0u);
         const bf8* wc = (const bf8*)(smem + slot * NAMP_IMG_BYTES) + lane;
+#ifndef FEAT_ABL_NOGEN
         if (steps) dist(xi0, xi1, xi2, bg, pres);                    // (in front of the barrier: under the chunk's DMA)
+#endif
+#ifndef FEAT_ABL_NOBARRIER
         wait_dma_and_sync();                                         // chunk c has landed; everyone is done with the previous one
+#endif
         {
           const unsigned long long rest = (c + 1 < 64) ? (need >> (c + 1)) : 0ull;
           if (rest) dma_to_lds(smem + (slot ^ 1) * NAMP_IMG_BYTES, img1 + (long)(c + 1 + __builtin_ctzll(rest)) * (FEAT_CHUNK_BYTES / 4),
@@ -3871,8 +3875,16 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
         while (steps) {
           const int st = __builtin_ctz(steps);
           bf8 hi, mid;
+#ifdef FEAT_ABL_NOGEN
+          hi = (bf8){(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f}; mid = hi;
+#else
           gen(st, pres, hi, mid);
+#endif
+#ifdef FEAT_ABL_NOMUL
+          acc[st & 7][0] += (float)hi[0] + (float)mid[3];
+#else
           mul(hi, mid, wc + st * 8 * 64);
+#endif
           steps &= steps - 1u;
         }
       }
