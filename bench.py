@@ -301,10 +301,11 @@ def features_bench(dev):
             us = getattr(ev, "self_device_time_total", None)
             if us is None:
                 us = getattr(ev, "self_cuda_time_total", 0.0)
-            for name in ("edge_features_kernel", "knn_select_kernel", "knn_kernel", "prep_atoms_kernel"):
+            for name in ("edge_features_kernel", "feat_finish_kernel", "knn_select_kernel", "knn_kernel", "prep_atoms_kernel"):
                 if name in ev.key:
                     t[name] = t.get(name, 0.0) + us / 1e3
-        ef = t.get("edge_features_kernel", 0.0)
+        # one complex runs its edge-feature launch in parts (round 6): the finishing launch (sum of the partial rows, LayerNorm, W_e) is priced with it
+        ef = t.get("edge_features_kernel", 0.0) + t.get("feat_finish_kernel", 0.0)
         residues = int((fd["mask"] > 0).sum())
         tokens = int(fd["mask"].numel())
         ex = _feat_executed_flop(fd, out[3])
@@ -314,6 +315,7 @@ def features_bench(dev):
                     "algorithmic_frac": round(FEAT_FLOP_ALGO * tokens / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "algorithmic_frac_unmasked_residues": round(FEAT_FLOP_ALGO * residues / max(ef, 1e-9) / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "gexp_per_s": round(FEAT_EXP_ALGO * residues / max(ef, 1e-9) / 1e6, 1),
+                    "finish_launch_ms": round(t.get("feat_finish_kernel", 0.0), 4),
                     "knn_select_ms": round(t.get("knn_select_kernel", t.get("knn_kernel", 0.0)), 4),
                     "prep_atoms_ms": round(t.get("prep_atoms_kernel", 0.0), 4)}
         if which == "cfg2":
@@ -1010,6 +1012,8 @@ def compact_secondary(o):
                          "avg_launch_ms": r.get("avg_launch_ms")}
         if "clock_mhz" in r:
             c["roofline"]["clock_mhz"] = r["clock_mhz"]
+            if "frac_at_measured_clock" in r:                     # (the chip runs the bf16 batch at ~1.94 GHz: the peak it is priced on assumes 2.4)
+                c["roofline"]["frac_at_measured_clock"] = r["frac_at_measured_clock"]
     if "cpu_baseline" in o:
         c["cpu_baseline"] = o["cpu_baseline"]["value"]
     for k in ("hip_kernel_share", "checks", "levels"):
@@ -1065,7 +1069,7 @@ def compact_line(out):
                                            "traffic_algorithmic") if k in f}
         for tag in ("cfg2_from_X", "cfg4_batch"):
             if tag in f:
-                c["features"][tag] = {k: f[tag][k] for k in ("tokens", "avg_launch_ms", "frac", "algorithmic_frac", "knn_select_ms")}
+                c["features"][tag] = {k: f[tag][k] for k in ("tokens", "avg_launch_ms", "finish_launch_ms", "frac", "algorithmic_frac", "knn_select_ms") if k in f[tag]}
         if "full_forward_from_X" in f:
             c["features"]["full_forward_from_X"] = {k: f["full_forward_from_X"][k] for k in ("value", "unit", "ms_per_call")}
             c["features"]["full_forward_from_X"]["dtype"] = short_dtype(f["full_forward_from_X"].get("dtype", "bf16x3"))
