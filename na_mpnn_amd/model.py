@@ -282,6 +282,7 @@ class ProteinMPNN(nn.Module):
             m, r = self._as(mask, "f32"), self._as(randn, "f32")
             cm = self._as(chain_mask, "f32") if chain_mask is not None else None
             order = torch.empty(Br, L, dtype=torch.int64, device=mask.device)
+            order32 = torch.empty(Br, L, dtype=torch.int32, device=mask.device)        # (what the sampler's launches read: no cast launch)
             rank = torch.empty(Br, L, dtype=torch.int32, device=mask.device)
             # The sort depends on (mask, chain_mask, randn) only and its first consumer is the decoder: it runs on a side stream beside the
             # featuriser / encoder launches enqueued after this call (one workgroup per stream: 20-80 us that would otherwise sit in front of
@@ -292,12 +293,13 @@ class ProteinMPNN(nn.Module):
             side = self._side_stream(mask.device) if (defer and self.order_side_stream) else main
             if side is not main:
                 side.wait_stream(main)                              # the inputs' producers
-            hip.check(hip.lib().namp_decoding_order(m.data_ptr(), hip.ptr(cm), r.data_ptr(), order.data_ptr(), None, rank.data_ptr(),
+            hip.check(hip.lib().namp_decoding_order(m.data_ptr(), hip.ptr(cm), r.data_ptr(), order.data_ptr(), order32.data_ptr(), rank.data_ptr(),
                                                     Br, Bm, L, side.cuda_stream), "decoding_order")
+            self._order32 = (order, order32)
             ev = torch.cuda.Event()
             ev.record(side)
             self._order_event = ev
-            for t_ in (m, r, cm, order, rank):                      # the caching allocator must not recycle these before the side stream is done
+            for t_ in (m, r, cm, order, order32, rank):             # the caching allocator must not recycle these before the side stream is done
                 if t_ is not None:
                     t_.record_stream(side)
             if not defer:
@@ -566,11 +568,37 @@ class ProteinMPNN(nn.Module):
             self._check_tokens(fd["S_forced"], "S_forced")
         order, rank = self.order_and_rank(mask, fd["chain_mask"], fd["randn"], defer=True)       # [max(B, bs), L]; beside the launches below
         V, _, h_E, E_idx = self._featurize_hip(fd, want_E=False, want_hE=True)       # (E_idx stays int32: the kernels' dtype)
+        K = E_idx.shape[-1]
+        B_dec = B * bs
+        # Plain branch: the dependency levels and the walk's work lists need the neighbour lists and the decoding order only — enqueued on
+        # the side stream behind the sort, beside the encoder launches (sample_levels_kernel is a serial walk of one wave per stream: 62 us at
+        # 97 residues in front of the walk otherwise).
+        early = None
+        o32_pair = getattr(self, "_order32", None)
+        if (not symmetric and "pair_bias" not in fd and self.sample_level_parallel and self.sample_level_walk and self.order_side_stream
+                and getattr(self, "_order_event", None) is not None and o32_pair is not None and o32_pair[0] is order
+                and order.shape[0] == B_dec and L <= 16000 and E_idx.dtype == torch.int32 and E_idx.is_contiguous()
+                and hip.lib().namp_decoder_sample_walk_grid(B_dec, L, K) > 0):
+            Lb_ = hip.lib()
+            main_, side_ = torch.cuda.current_stream(dev), self._side_stream(dev)
+            level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
+            work = torch.empty(B_dec * L, 2, dtype=torch.int32, device=dev)
+            level_off = torch.empty(L + 2, dtype=torch.int32, device=dev)
+            n_levels = torch.empty(1, dtype=torch.int32, device=dev)
+            ev_ = torch.cuda.Event(); ev_.record(main_)                              # the neighbour lists are out
+            side_.wait_event(ev_)
+            hip.check(Lb_.namp_sample_levels_dep(E_idx.data_ptr(), o32_pair[1].data_ptr(), rank.data_ptr(), None, 0, None, None, level.data_ptr(),
+                                                 B_dec, B, L, K, side_.cuda_stream), "sample_levels")
+            hip.check(Lb_.namp_sample_work_lists(level.data_ptr(), work.data_ptr(), level_off.data_ptr(), n_levels.data_ptr(), B_dec, L,
+                                                 side_.cuda_stream), "sample_work_lists")
+            ev2_ = torch.cuda.Event(); ev2_.record(side_)
+            self._order_event = ev2_                                                 # wait_order() now orders behind all three launches
+            for t_ in (E_idx, level, work, level_off, n_levels):
+                t_.record_stream(side_)
+            early = (level, work, level_off, n_levels, o32_pair[1])
         h_V, h_E = self.encode_graph(V, None, E_idx, mask, h_E_embedded=h_E)
         self.wait_order()
-        K = E_idx.shape[-1]
         chain_mask = mask * fd["chain_mask"]
-        B_dec = B * bs
         group_first = group_last = sym_w = None
         if symmetric:
             # model_utils.py:220-235: tied residues are visited together, in the order stream 0 reaches their first
@@ -623,7 +651,7 @@ class ProteinMPNN(nn.Module):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         E32, cm32, St32 = _i32(E_idx), _i32(chain_mask), self._as(S_true, "i32")
         m32 = self._as(mask, "i32")
-        md32, o32, r32 = (m32 if mask_dec is mask else _i32(mask_dec)), _i32(order), _i32(rank)
+        md32, o32, r32 = (m32 if mask_dec is mask else _i32(mask_dec)), (early[4] if early is not None else _i32(order)), _i32(rank)
         bias_f = bias.float().expand(B, L, self.num_letters).contiguous()
         forced = _i32(fd["S_forced"]) if fd.get("S_forced") is not None else None
         h_V, h_E = h_V.float().contiguous(), h_E.float().contiguous()
@@ -653,21 +681,27 @@ class ProteinMPNN(nn.Module):
             # residue i depends only on the neighbours decoded before it -> decode by dependency level (one launch per level over all
             # streams, ~64 levels at L = 1000 instead of 1000 sequential steps).  Symmetry-tied: the unit of work is a GROUP (its members
             # run one after the other in the group's workgroup slot and share one draw); its level follows its members' dependencies
-            level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
-            hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep,
-                                                hip.ptr(group_first), hip.ptr(group_last), level.data_ptr(),
-                                                B_dec, B, L, K, hip.current_stream()), "sample_levels")
+            if early is not None:
+                level = early[0]
+            else:
+                level = torch.empty(B_dec, L, dtype=torch.int32, device=dev)
+                hip.check(Lb.namp_sample_levels_dep(E32.data_ptr(), o32.data_ptr(), r32.data_ptr(), hip.ptr(dep_idx), n_dep,
+                                                    hip.ptr(group_first), hip.ptr(group_last), level.data_ptr(),
+                                                    B_dec, B, L, K, hip.current_stream()), "sample_levels")
             walk = self.sample_level_walk and Lb.namp_decoder_sample_walk_grid(B_dec, L, K) > 0
             zbuf = None
             if walk and not symmetric and L <= 16000:
                 # plain branch: the walk's work lists are built on the device as well (one launch instead of a stable argsort, gathers,
                 # divisions, a histogram and its prefix sums) — the whole design is enqueued with ~a dozen launches
                 nwork = B_dec * L
-                work = torch.empty(nwork, 2, dtype=torch.int32, device=dev)
-                level_off = torch.empty(L + 2, dtype=torch.int32, device=dev)
-                n_levels = torch.empty(1, dtype=torch.int32, device=dev)
-                hip.check(Lb.namp_sample_work_lists(level.data_ptr(), work.data_ptr(), level_off.data_ptr(), n_levels.data_ptr(), B_dec, L,
-                                                    hip.current_stream()), "sample_work_lists")
+                if early is not None:
+                    _, work, level_off, n_levels, _ = early
+                else:
+                    work = torch.empty(nwork, 2, dtype=torch.int32, device=dev)
+                    level_off = torch.empty(L + 2, dtype=torch.int32, device=dev)
+                    n_levels = torch.empty(1, dtype=torch.int32, device=dev)
+                    hip.check(Lb.namp_sample_work_lists(level.data_ptr(), work.data_ptr(), level_off.data_ptr(), n_levels.data_ptr(), B_dec, L,
+                                                        hip.current_stream()), "sample_work_lists")
                 hip.check(Lb.namp_decoder_sample_walk(
                     W.model(), h_V.data_ptr(), h_E.data_ptr(), E32.data_ptr(), m32.data_ptr(), md32.data_ptr(), cm32.data_ptr(),
                     St32.data_ptr(), bias_f.data_ptr(), o32.data_ptr(), r32.data_ptr(), uniform.data_ptr(), hip.ptr(forced),
