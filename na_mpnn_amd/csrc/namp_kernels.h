@@ -3883,7 +3883,9 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
 #ifdef FEAT_ABL_NOMUL
           acc[st & 7][0] += (float)hi[0] + (float)mid[3];
 #else
-          mul(hi, mid, wc + st * 8 * 64);
+          __builtin_amdgcn_s_setprio(1);                             // the products ahead of the other waves' VALU work: -0.8 % (the same hint in
+          mul(hi, mid, wc + st * 8 * 64);                            // chain_gemm_x3 cost the split-bf16 edge launches 4.7 %: profiles/r06g)
+          __builtin_amdgcn_s_setprio(0);
 #endif
           steps &= steps - 1u;
         }
