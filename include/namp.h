@@ -288,6 +288,15 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
                    const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
                    const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E,
                    void* ws, size_t ws_bytes, int B, int L, void* stream);
+/* namp_featurize and namp_decoding_order (below) in the same launches — what score() / forward() / sample() from coordinates call
+ * (model_utils.py:389 next to :528-593): the B_order = B * batch_size sorts of (order_mask * order_chain_mask + 1e-4) * |randn| depend on
+ * none of the features, so they run as the first workgroups of the edge-feature launch instead of a launch (or a side stream) of their
+ * own.  order_mask / order_chain_mask [B, L] float (chain mask NULL = ones), randn [B_order, L]; outputs as namp_decoding_order. */
+int namp_featurize_ordered(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                           const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                           const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E,
+                           void* ws, size_t ws_bytes, int B, int L, const float* order_mask, const float* order_chain_mask,
+                           const float* randn, int64_t* order64, int32_t* order32, int32_t* rank32, int B_order, void* stream);
 
 /* ProteinMPNN.encode after featurisation (model_utils.py:88-94): (V, E, E_idx, mask) -> h_V, h_E.
  * E may be NULL when h_E already holds W_e.E + b_e (written by namp_featurize). */

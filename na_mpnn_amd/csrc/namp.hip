@@ -1115,10 +1115,10 @@ size_t namp_featurize_split_bytes(int B, int L, int top_k) {
   return 3 * ((((size_t)G * K * NAMP_HIDDEN * 4 + 255) & ~size_t(255)) + 256) + 2048;
 }
 
-int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
-                   const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
-                   const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
-                   size_t ws_bytes, int B, int L, void* stream) {
+static int featurize_impl(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                          const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                          const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
+                          size_t ws_bytes, int B, int L, const OrderJob* job, void* stream) {
   REQUIRE(w != nullptr, "namp_featurize: null weights");
   REQUIRE_PTR(X); REQUIRE_PTR(ws); OPTIONAL_PTR(E); OPTIONAL_PTR(h_E);
   OPTIONAL_PTR(w->feat.Wedge_ximg);
@@ -1197,6 +1197,7 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
       hipLaunchKernelGGL(knn_select_kernel, knn_grid, dim3(256), ((size_t)L + Kp2) * 8 + 1024 + 64, s, P, mask, E_idx, L, K, Kp2, fr);
     else
       hipLaunchKernelGGL(knn_kernel, knn_grid, dim3(256), std::max((size_t)Lp2 * 8 + 64, (size_t)1024), s, P, mask, E_idx, L, Lp2, K, fr);
+    if (job) { a.ord = *job; grid.x += job->B; }                       // the decoding orders: the launch's first workgroups
     // NampModelW.reserved == 2 with an x3 image: plain bf16 products on its hi half (mixed-precision training)
     if (x3 && w->reserved == 2) hipLaunchKernelGGL(edge_features_kernel<2>, grid, dim3(e.nwaves * 64), FEAT_LDS, s, a);
     else if (x3) hipLaunchKernelGGL(edge_features_kernel<1>, grid, dim3(e.nwaves * 64), FEAT_LDS, s, a);
@@ -1208,6 +1209,31 @@ int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, cons
   }
   CHECK_LAUNCH();
   return NAMP_OK;
+}
+
+int namp_featurize(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                   const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                   const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
+                   size_t ws_bytes, int B, int L, void* stream) {
+  return featurize_impl(w, X, X_m, mask, R_idx, chain_labels, protein_mask, dna_mask, rna_mask, top_k, ref_atom, E_idx, E, h_E, ws, ws_bytes, B, L,
+                        nullptr, stream);
+}
+
+// namp_featurize + namp_decoding_order in the same launches: the sort depends on (mask, chain_mask, randn) only and its first consumer is the
+// decoder, so its B_order workgroups ride in front of the edge-feature launch (one more launch, or a side stream with two cross-stream
+// hand-overs, cost score() from coordinates ~12 us at 1,000 residues).
+int namp_featurize_ordered(const NampModelW* w, const float* X, const int32_t* X_m, const int32_t* mask, const int32_t* R_idx,
+                           const int32_t* chain_labels, const int32_t* protein_mask, const int32_t* dna_mask,
+                           const int32_t* rna_mask, int top_k, int ref_atom, int32_t* E_idx, float* E, float* h_E, void* ws,
+                           size_t ws_bytes, int B, int L, const float* order_mask, const float* order_chain_mask, const float* randn,
+                           int64_t* order64, int32_t* order32, int32_t* rank32, int B_order, void* stream) {
+  if (!order_mask || !randn || !rank32) return fail(NAMP_EINVAL, "namp_featurize_ordered: null mask / randn / rank");
+  REQUIRE(B_order >= 1 && B >= 1 && B_order % B == 0 && L >= 1 && L <= 8192, "namp_featurize_ordered: bad dims B_order=%d B=%d L=%d (L <= 8192)", B_order, B, L);
+  int P2 = 2;
+  while (P2 < L) P2 <<= 1;
+  const OrderJob o = {order_mask, order_chain_mask, randn, order64, order32, rank32, B_order, B, L, P2};
+  return featurize_impl(w, X, X_m, mask, R_idx, chain_labels, protein_mask, dna_mask, rna_mask, top_k, ref_atom, E_idx, E, h_E, ws, ws_bytes, B, L,
+                        &o, stream);
 }
 
 // Sampler workspace for a model of n_dec decoder layers: Pfw[L] + Pa0 on the encoder side; Pa[L-1] + Pv[L-1] + h[L] on the sample-stream
@@ -1368,8 +1394,8 @@ int namp_decoding_order(const float* mask, const float* chain_mask, const float*
   while (P2 < L) P2 <<= 1;
   int rc = ensure_attributes();
   if (rc) return rc;
-  hipLaunchKernelGGL(decoding_order_kernel, dim3(B), dim3(P2 >= 1024 ? 512 : 256), (size_t)P2 * 8, (hipStream_t)stream, mask, chain_mask, randn,
-                     B_mask, L, P2, order64, order32, rank32);
+  const OrderJob o = {mask, chain_mask, randn, order64, order32, rank32, B, B_mask, L, P2};
+  hipLaunchKernelGGL(decoding_order_kernel, dim3(B), dim3(P2 >= 1024 ? 512 : 256), (size_t)P2 * 8, (hipStream_t)stream, o);
   CHECK_LAUNCH();
   return NAMP_OK;
 }

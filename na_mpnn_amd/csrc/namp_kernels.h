@@ -3606,6 +3606,61 @@ static __global__ __launch_bounds__(256) void knn_select_kernel(const float* __r
   for (int k = tid; k < K; k += 256) E_idx[(long)row * K + k] = (int32_t)(sel[k] & 0x7fffffffu);
 }
 
+// ---- decoding order on the device (round 6; namp_order.h's kernel and, folded into the featuriser's edge-feature launch, its first workgroups) ----
+// order[b] = argsort((mask * chain_mask + 1e-4) * |randn|) and its inverse permutation (model_utils.py:389-390; na_model_utils.py:623): one workgroup
+// per stream, bitonic sort of (key, index) pairs in LDS (ascending key, ties by index; a NaN key sorts last).  The keys are the same fp32 operations
+// torch runs.  Any workgroup size that is a multiple of 64; P2 * 8 bytes of LDS.
+struct OrderJob {
+  const float* mask; const float* chain_mask; const float* randn;    // [B_mask][L], [B_mask][L] or null, [B][L]
+  int64_t* order64; int32_t* order32; int32_t* rank32;               // [B][L]; either order may be null
+  int B, B_mask, L, P2;                                              // B == 0: no job
+};
+static __device__ __forceinline__ void decoding_order_body(const OrderJob o, const int b, char* smem) {
+  float* key = (float*)smem;
+  int* idx = (int*)(smem + (size_t)o.P2 * 4);
+  const int bm = b % o.B_mask, L = o.L, P2 = o.P2;
+  for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+    float k = __builtin_inff();
+    if (i < L) {
+      const float cm = o.mask[(long)bm * L + i] * (o.chain_mask ? o.chain_mask[(long)bm * L + i] : 1.0f);
+      k = (cm + 0.0001f) * fabsf(o.randn[(long)b * L + i]);
+    }
+    key[i] = k; idx[i] = i;
+  }
+  __syncthreads();
+  // a before b: smaller key; NaN after everything; ties (and NaN pairs) by index; padding entries (index >= L) carry +inf and larger indices
+  auto before = [](const float ka, const int ia, const float kb, const int ib) {
+    const bool na = ka != ka, nb = kb != kb;
+    if (na != nb) return nb;
+    if (!na && ka != kb) return ka < kb;
+    return ia < ib;
+  };
+  // Compare-exchanges of stride <= 64 stay inside one wave's 128-entry block (thread t of a wave handles pair t of ITS block), and a wave's LDS
+  // accesses execute in program order: those sub-stages need no workgroup barrier, only the larger strides do (15 barriers instead of 78 at 4,096
+  // entries; none below 256) — the barriers were half of the launch (20 us at L = 1,000, 46 us at a 13 x 2,400 batch).
+  for (int size = 2; size <= P2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (P2 >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));            // index with bit `stride` clear
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const float ka = key[lo], kb = key[hi];
+        const int ia = idx[lo], ib = idx[hi];
+        if (before(kb, ib, ka, ia) == up) { key[lo] = kb; key[hi] = ka; idx[lo] = ib; idx[hi] = ia; }
+      }
+      if (stride > 64 || (stride == 1 && size < P2 && size >= 64)) __syncthreads();     // next sub-stage crosses waves (or the next stage opens with a stride > 64)
+      else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    const int v = idx[i];
+    if (o.order64) o.order64[(long)b * L + i] = v;
+    if (o.order32) o.order32[(long)b * L + i] = v;
+    o.rank32[(long)b * L + v] = i;
+  }
+}
+
 #ifdef FEAT_STAMPS
 // -DFEAT_STAMPS (tools/feat_stamps.py): per workgroup of the last edge_features launch: s_memrealtime (100 MHz, one clock for the chip) at entry, behind the set-up, at the end; residue
 // block, part, chunks walked, HW_ID
@@ -3640,6 +3695,8 @@ struct FeatArgs {
   int nparts;
   float* pbuf[4];
   const int32_t* order;                           // feat_rank_blocks' output (nparts > 1)
+  OrderJob ord;                                   // ord.B > 0: the launch's first ord.B workgroups sort the decoding orders (independent of the features;
+                                                  // a launch of its own cost score() ~12 us of cross-stream hand-over at 1,000 residues)
 };
 
 #define FEAT_CHUNK_BYTES (6 * 8 * 64 * 16)        // 6 k-tiles x 8 tn x 1 KiB
@@ -3657,10 +3714,12 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
   const int m = lane & 15, g = lane >> 4;
   const int npw = nwaves / a.TPN;
   const int node_l = wave / a.TPN, kt = wave - node_l * a.TPN;
+  if ((int)blockIdx.x < a.ord.B) { decoding_order_body(a.ord, blockIdx.x, smem); return; }      // (workgroup-uniform; first in dispatch order)
+  const int bx0 = (int)blockIdx.x - a.ord.B, ngrid = (int)gridDim.x - a.ord.B;
 #ifdef FEAT_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int blk = blockIdx.x, part = 0, myparts = 1;
+  int blk = bx0, part = 0, myparts = 1;
   if (a.nparts > 1) {
     // One complex, at most a round of the chip unsplit: the launch lasts as long as its longest workgroup — a block of residues that holds a
     // nucleotide walks 39-54 atom-pair chunks, a protein block ~10.  Long blocks (feat_rank_blocks) are taken by nparts workgroups, each
@@ -3672,7 +3731,7 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
     // us, but +22 us in the neighbour search for its per-row device-scope fences; three / four parts: 116-120 us.  The launch's sum of
     // workgroup durations / 256 CUs is 70 us unsplit and 79 us in two parts: second-round workgroups of ~35 us behind 86 us parts.)  (Tried: one workgroup per CU popping the same items from a
     // counter — no surplus, greedy packing: the same 151 us per call at 1,000 residues, with spilled scalars around the item loop.)
-    const int P = a.nparts, nblk = (int)gridDim.x / P, bx = blockIdx.x;
+    const int P = a.nparts, nblk = ngrid / P, bx = bx0;
     const int n_long = a.order[256];
     int slot_i = bx / P;
     if (bx < n_long * P) { part = bx - slot_i * P; myparts = P; }
@@ -3992,8 +4051,8 @@ __global__ __launch_bounds__(768) void edge_features_kernel(const FeatArgs a) {
     }
   }
 #ifdef FEAT_STAMPS
-  if (tid == 0 && blockIdx.x < 1024) {
-    unsigned long long* o = g_feat_stamps[blockIdx.x];
+  if (tid == 0 && bx0 < 1024) {
+    unsigned long long* o = g_feat_stamps[bx0];
     o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = blk; o[4] = part | (myparts << 8); o[5] = st_chunks;
     o[6] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, 4)); o[7] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));
   }

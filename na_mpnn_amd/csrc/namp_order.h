@@ -1,59 +1,11 @@
 #pragma once
 #include "namp_kernels.h"
 
-// ---- decoding order on the device (round 6) ------------------------------------------------------------------------------------------
-// order[b] = argsort((mask * chain_mask + 1e-4) * |randn|) and its inverse permutation (model_utils.py:389-390; na_model_utils.py:623):
-// one workgroup per stream, bitonic sort of (key, index) pairs in LDS (ascending key, ties by index; a NaN key sorts last).  The keys are
-// the same fp32 operations torch runs.  Replaces ~15 stock launches per score() / sample() call (mul, add, abs, mul, the segmented sort's
-// launches and copies, arange, scatter).
-static __global__ __launch_bounds__(512) void decoding_order_kernel(const float* __restrict__ mask, const float* __restrict__ chain_mask,
-                                                                    const float* __restrict__ randn, int B_mask, int L, int P2,
-                                                                    int64_t* __restrict__ order64, int32_t* __restrict__ order32,
-                                                                    int32_t* __restrict__ rank32) {
+// ---- decoding order on the device (round 6): decoding_order_body (namp_kernels.h) as a launch of its own — one workgroup per stream.  Replaces
+// ~15 stock launches per score() / sample() call (mul, add, abs, mul, the segmented sort's launches and copies, arange, scatter).
+static __global__ __launch_bounds__(512) void decoding_order_kernel(const OrderJob o) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* key = (float*)smem;
-  int* idx = (int*)(smem + (size_t)P2 * 4);
-  const int b = blockIdx.x, bm = b % B_mask;
-  for (int i = threadIdx.x; i < P2; i += blockDim.x) {
-    float k = __builtin_inff();
-    if (i < L) {
-      const float cm = mask[(long)bm * L + i] * (chain_mask ? chain_mask[(long)bm * L + i] : 1.0f);
-      k = (cm + 0.0001f) * fabsf(randn[(long)b * L + i]);
-    }
-    key[i] = k; idx[i] = i;
-  }
-  __syncthreads();
-  // a before b: smaller key; NaN after everything; ties (and NaN pairs) by index; padding entries (index >= L) carry +inf and larger indices
-  auto before = [](const float ka, const int ia, const float kb, const int ib) {
-    const bool na = ka != ka, nb = kb != kb;
-    if (na != nb) return nb;
-    if (!na && ka != kb) return ka < kb;
-    return ia < ib;
-  };
-  // Compare-exchanges of stride <= 64 stay inside one wave's 128-entry block (thread t of a wave handles pair t of ITS block), and a wave's LDS
-  // accesses execute in program order: those sub-stages need no workgroup barrier, only the larger strides do (15 barriers instead of 78 at 4,096
-  // entries; none below 256) — the barriers were half of the launch (20 us at L = 1,000, 46 us at a 13 x 2,400 batch).
-  for (int size = 2; size <= P2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < (P2 >> 1); t += blockDim.x) {
-        const int lo = 2 * t - (t & (stride - 1));            // index with bit `stride` clear
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const float ka = key[lo], kb = key[hi];
-        const int ia = idx[lo], ib = idx[hi];
-        if (before(kb, ib, ka, ia) == up) { key[lo] = kb; key[hi] = ka; idx[lo] = ib; idx[hi] = ia; }
-      }
-      if (stride > 64 || (stride == 1 && size < P2 && size >= 64)) __syncthreads();     // next sub-stage crosses waves (or the next stage opens with a stride > 64)
-      else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    const int v = idx[i];
-    if (order64) order64[(long)b * L + i] = v;
-    if (order32) order32[(long)b * L + i] = v;
-    rank32[(long)b * L + v] = i;
-  }
+  decoding_order_body(o, blockIdx.x, smem);
 }
 
 

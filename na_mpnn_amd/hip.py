@@ -114,6 +114,8 @@ _PROTOTYPES = {
     "namp_featurize_split_bytes": (sz, [i32, i32, i32]),
     "namp_featurize": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
                              vp, sz, i32, i32, vp]),
+    "namp_featurize_ordered": (i32, [C.POINTER(NampModelW), c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, i32, i32, c_ip, c_fp, c_fp,
+                                     vp, sz, i32, i32, c_fp, c_fp, c_fp, vp, c_ip, c_ip, i32, vp]),
     "namp_decoder_sample": (i32, [C.POINTER(NampModelW), c_fp, c_fp, c_ip, c_ip, c_ip, c_ip, c_ip, c_fp, c_ip, c_ip, c_fp, c_ip,
                                   c_ip, c_ip, c_fp, c_fp,
                                   C.c_float, C.c_uint64, c_ip, c_fp, c_fp, vp, sz, i32, i32, i32, i32, vp]),

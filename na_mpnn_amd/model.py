@@ -289,6 +289,15 @@ class ProteinMPNN(nn.Module):
             # them).  The calling stream waits for it at once — a wait in the stream, not on the host —, so everything enqueued later is ordered
             # behind it... which would serialise again: the wait is therefore deferred to `wait_order()` (score / sample / forward call it
             # right before their decoder launch).
+            self._order_job = None
+            if defer and self.order_fold:
+                # The sort depends on (mask, chain_mask, randn) only and its first consumer is the decoder: the featuriser call that follows
+                # (score / forward / sample) takes it along as the first workgroups of its edge-feature launch (namp_featurize_ordered); a caller
+                # that never featurises gets it from `wait_order()`.  (A side stream, below, cost two cross-stream hand-overs: ~12 us per score().)
+                self._order_job = (m, cm, r, order, order32, rank, Br, Bm, L)
+                self._order32 = (order, order32)
+                self._order_event = None
+                return order, rank
             main = torch.cuda.current_stream(mask.device)
             side = self._side_stream(mask.device) if (defer and self.order_side_stream) else main
             if side is not main:
@@ -316,6 +325,12 @@ class ProteinMPNN(nn.Module):
 
     def wait_order(self):
         """Order the calling stream behind the decoding-order launch of the last `order_and_rank` (no host synchronisation)."""
+        job = getattr(self, "_order_job", None)
+        if job is not None:                                     # no featuriser call took the sort along: here, in the calling stream
+            m, cm, r, order, order32, rank, Br, Bm, L = job
+            self._order_job = None
+            hip.check(hip.lib().namp_decoding_order(m.data_ptr(), hip.ptr(cm), r.data_ptr(), order.data_ptr(), order32.data_ptr(), rank.data_ptr(),
+                                                    Br, Bm, L, hip.current_stream()), "decoding_order")
         ev = getattr(self, "_order_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -384,9 +399,18 @@ class ProteinMPNN(nn.Module):
                          dtype=torch.uint8, device=dev)
         dna_m, rna_m = self._na_masks(fd)
         t = [self._as(fd[k], "i32") for k in ("X_m", "mask", "R_idx", "chain_labels", "protein_mask")] + [self._as(dna_m, "i32"), self._as(rna_m, "i32")]
-        hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
-                                    int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
-                                    ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
+        job = getattr(self, "_order_job", None)
+        if job is not None and job[7] == B and job[8] == L and job[0].device == dev:
+            om, ocm, orn, order, order32, rank, Br = job[:7]      # the pending decoding-order sort rides in the edge-feature launch
+            self._order_job = None
+            hip.check(Lb.namp_featurize_ordered(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
+                                                int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
+                                                ws.data_ptr(), ws.numel(), B, L, om.data_ptr(), hip.ptr(ocm), orn.data_ptr(), order.data_ptr(),
+                                                order32.data_ptr(), rank.data_ptr(), Br, hip.current_stream()), "featurize_ordered")
+        else:
+            hip.check(Lb.namp_featurize(W.model(), X.data_ptr(), *[x.data_ptr() for x in t], int(self.k_neighbors),
+                                        int(self.atom_dict[self.na_ref_atom]), E_idx.data_ptr(), hip.ptr(E), hip.ptr(hE),
+                                        ws.data_ptr(), ws.numel(), B, L, hip.current_stream()), "featurize")
         # no host sync: the int32 temporaries and the workspace come from torch's stream-ordered caching allocator, so
         # their blocks are only reused by work enqueued AFTER these launches on the same stream
         return self._node_features(fd), E, hE, E_idx
@@ -538,6 +562,8 @@ class ProteinMPNN(nn.Module):
     reference_sample_mask_quirk = True
     # the decoding-order sort on a side stream beside the featuriser launches (False: in the calling stream; A/B switch)
     order_side_stream = os.environ.get("NAMP_ORDER_SIDE", "1") != "0"
+    # the decoding-order sort inside the featuriser's edge-feature launch (False: a launch of its own, on the side stream if enabled; A/B switch)
+    order_fold = os.environ.get("NAMP_ORDER_FOLD", "1") != "0"
     # decode the plain sampling branch by dependency level (False: the one-launch sequential walk; same results)
     sample_level_parallel = True
     # ... as ONE persistent launch walking the levels (no host read-back, warm L2); False: one launch per level
@@ -576,7 +602,7 @@ class ProteinMPNN(nn.Module):
         early = None
         o32_pair = getattr(self, "_order32", None)
         if (not symmetric and "pair_bias" not in fd and self.sample_level_parallel and self.sample_level_walk and self.order_side_stream
-                and getattr(self, "_order_event", None) is not None and o32_pair is not None and o32_pair[0] is order
+                and getattr(self, "_order_job", None) is None and o32_pair is not None and o32_pair[0] is order
                 and order.shape[0] == B_dec and L <= 16000 and E_idx.dtype == torch.int32 and E_idx.is_contiguous()
                 and hip.lib().namp_decoder_sample_walk_grid(B_dec, L, K) > 0):
             Lb_ = hip.lib()
